@@ -1,0 +1,53 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+
+import numpy as np
+import torch
+
+from morpheus_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REL_FLOOR = 1e-3   # rel = |a-b| / max(|b|, REL_FLOOR)   (SURVEY 8d "state the floor")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def max_rel(a, b, floor=REL_FLOOR):
+    a = torch.as_tensor(a).detach().double().reshape(-1).cpu()
+    b = torch.as_tensor(b).detach().double().reshape(-1).cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(((a - b).abs() / b.abs().clamp(min=floor)).max())
+
+
+def assert_close(a, b, tol, what="", floor=REL_FLOOR):
+    r = max_rel(a, b, floor)
+    assert r <= tol, f"{what}: max rel err {r:.3e} > {tol:.1e}"
+
+
+def probe_points(n, stream=300, scale=1.15):
+    return synth.hash_tensor((n, 3), stream, scale)
+
+
+def grad_digest_check(named_grads, golden, prefix, tol, skip=()):
+    """Compare per-tensor grad norm / sum / 64 strided samples with the golden digest."""
+    checked = 0
+    for k, g in named_grads.items():
+        if any(s in k for s in skip):
+            continue
+        key = prefix + "|grad|" + k
+        if key + "|norm" not in golden:
+            continue
+        g = g.detach().reshape(-1).double().cpu()
+        gn = float(golden[key + "|norm"])
+        scale = max(gn, 1e-12)
+        assert abs(float(g.norm()) - gn) <= tol * max(gn, 1e-8) + 1e-12, f"{k} norm {float(g.norm())} vs {gn}"
+        idx = torch.linspace(0, g.numel() - 1, min(64, g.numel())).long()
+        smp = torch.from_numpy(golden[key + "|samples"]).double()
+        # samples are compared relative to the tensor's RMS-per-element scale (atomics reorder sums)
+        rms = scale / np.sqrt(g.numel())
+        err = float((g[idx] - smp).abs().max())
+        assert err <= tol * max(float(smp.abs().max()), rms) * 4 + 1e-12, f"{k} samples err {err}"
+        checked += 1
+    return checked
