@@ -1,0 +1,149 @@
+/*
+ * morpheus_hip.h -- C ABI of libmorpheus_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in native boundary for the render_rays hot path of HengyiWang/MorpheuS.
+ * Every entry point takes raw device pointers + sizes + an explicit hipStream_t
+ * (passed as void*), returns an int status (0 = ok), never throws, never
+ * allocates or frees, keeps no thread-local or global mutable state (forward
+ * and backward arrive on different host threads), and launches only on the
+ * stream it is given (the reference launched on the legacy default stream --
+ * gridencoder.cu:386 -- a defect this ABI deliberately does not reproduce).
+ * All buffers are caller-owned, contiguous, fp32 unless stated.
+ *
+ * Reference interfaces replaced (file:line under the reference tree):
+ *   mh_grid_encode_fwd / _bwd   external/encoders/gridencoder/src/gridencoder.h:12-13,
+ *                               bindings.cpp:5-10, python callers grid.py:61,91
+ *   mh_composite_fwd / _bwd     nerfacc.render_weight_from_density + accumulate_along_rays,
+ *                               call sites morpheus.py:675-685 (third-party, un-vendored)
+ *   mh_sample_uniform           nerfacc OccGridEstimator.sampling call site morpheus.py:628-638
+ *                               (benchmark sampler of SURVEY 8d; marcher is next-tier)
+ *   mh_generate_rays            datasets/utils.py:28-65 + datasets/dataset.py:363-366
+ *   mh_warp_* / mh_field_*      models/model.py:412-437 (warp), :273-307 (get_sigma_albedo),
+ *                               models/decoders.py:59-64, models/encodings.py:35-57,
+ *                               models/density.py:22-31 -- plain PyTorch in the reference
+ *   mh_mlp_wgrad                the weight-gradient GEMMs autograd ran for those MLPs
+ */
+#ifndef MORPHEUS_HIP_H
+#define MORPHEUS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
+#define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
+
+#define MH_ABI_VERSION 1
+#define MH_MAX_LEVELS 32
+#define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
+
+int mh_abi_version(void);
+const char *mh_status_string(int status);
+
+/* ---- multiresolution hash grid (D=3, C=2, linear, align_corners=false, gridtype=hash) --------
+ * x:        [M,3] world coordinates; u = (x + bound) / (2*bound) is formed in-kernel
+ * emb:      [rows,2] table;  offsets_host: [L+1] HOST ints;  res_host: [L] HOST ints
+ *           (res_l = (uint32)ceil(exp2f(l*S)*H) evaluated in float32 by the caller)
+ * out:      [M, L*2] point-major, level-major/channel-minor inside a point (grid.py:64)
+ * n_levels: levels >= n_levels are written as zero (grid.py:42,53)
+ * Out-of-range points give zeros and zero gradients (gridencoder.cu:105-130, :279-284). */
+int mh_grid_encode_fwd(const float *x, const float *emb, const int32_t *offsets_host,
+                       const int32_t *res_host, float *out, int64_t M, int32_t L, int32_t n_levels,
+                       float bound, void *stream);
+/* grad: [M, L*2]; grad_emb: [rows,2] ACCUMULATED into (caller zeroes it, as grid.py:84 does);
+ * grad_x: NULL or [M,3], receives d/dx (the 1/(2*bound) chain factor included).  The slope uses
+ * the kernel's dy_dx definition, which ignores the border clamp (gridencoder.cu:205-247). */
+int mh_grid_encode_bwd(const float *grad, const float *x, const float *emb,
+                       const int32_t *offsets_host, const int32_t *res_host, float *grad_emb,
+                       float *grad_x, int64_t M, int32_t L, int32_t n_levels, float bound, void *stream);
+
+/* ---- packed transmittance compositor -------------------------------------------------------
+ * Samples of ray r are the contiguous range [ray_start[r], ray_start[r]+ray_cnt[r]) of the packed
+ * arrays, ordered by t.  w_i = exp(-sum_{j<i} sigma_j dt_j) * (1 - exp(-sigma_i dt_i)).
+ * weights [M]; opacity [N]; depth [N] = sum w * (ts+te)/2; color [N,3] = sum w * rgb. */
+int mh_composite_fwd(const float *sigma, const float *t_starts, const float *t_ends, const float *rgb,
+                     const int32_t *ray_start, const int32_t *ray_cnt, float *weights, float *opacity,
+                     float *depth, float *color, int32_t N, void *stream);
+/* g_weights may be NULL.  Outputs d_sigma [M], d_rgb [M,3]. */
+int mh_composite_bwd(const float *sigma, const float *t_starts, const float *t_ends, const float *rgb,
+                     const int32_t *ray_start, const int32_t *ray_cnt, const float *weights,
+                     const float *g_weights, const float *g_opacity, const float *g_depth,
+                     const float *g_color, float *d_sigma, float *d_rgb, int32_t N, void *stream);
+
+/* ---- ray generation + uniform stratified sampler ------------------------------------------- */
+/* K = fx,fy,cx,cy; c2w: [4,4] row-major HOST floats; rays_o/rays_d: [H*W,3] (OpenGL, un-normalised) */
+int mh_generate_rays(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
+                     float *rays_o, float *rays_d, void *stream);
+/* AABB slab clip to [-bound,bound]^3, S bins of (t_far-t_near)/(S+1), comb shifted by jitter*dt.
+ * Outputs (length N*S, ray-major): ray_idx int32, t_starts, t_ends, xyz [N*S,3] = o + d*(ts+te)/2;
+ * and ray_start/ray_cnt [N] int32. */
+int mh_sample_uniform(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, int32_t S,
+                      float bound, int32_t *ray_idx, float *t_starts, float *t_ends, float *xyz,
+                      int32_t *ray_start, int32_t *ray_cnt, void *stream);
+
+/* ---- fused tiny-MLP evaluators on fp32 MFMA (v_mfma_f32_32x32x2_f32) -------------------------
+ * Weight operands are PRE-PACKED by the host into the MFMA A-fragment order (see
+ * morpheus_amd/packing.py): for layer l, tile mt, k-quad q: float4 per lane.  `wpack` is the
+ * concatenation of all layers of the net(s); layer geometry is fixed by the kernel.
+ * Activation scratch ("acts") is written by the forward when save != 0 and consumed by the
+ * backward: per 32-point tile, per layer, feature-major [F][32] fp32.
+ *
+ * mh_warp_fwd: deform = deform_net([freq(x), code]), topo = topo_net(same)
+ *   x [M,3]; slot [M] int32 -> row of bias0 (per-frame first-layer bias  W0[:,39:87].code + b0,
+ *   computed by the caller; one row per distinct frame time); bias0_{d,t}: [n_slots,128];
+ *   n_bands: frequency bands kept (progressive max_level), 0..6;
+ *   out_deform [M,3]; out_topo [M,2];  acts: NULL or scratch of mh_warp_acts_floats(M) floats. */
+int64_t mh_mlp_tiles(int64_t M);        /* 32-point tiles the kernels touch: 4 * ceil(M/128) */
+int64_t mh_warp_acts_floats(int64_t M);
+int64_t mh_warp_dpre_floats(int64_t M);
+int64_t mh_warp_wpack_floats(void);   /* per net, forward pack */
+int64_t mh_warp_wpackT_floats(void);  /* per net, transposed pack */
+int mh_warp_fwd(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t,
+                const float *wpack_d, const float *wpack_t, const float *bias_d, const float *bias_t,
+                int32_t n_bands, float *out_deform, float *out_topo, float *acts, int64_t M, void *stream);
+/* backward-data: consumes g_deform [M,3], g_topo [M,2] (either may be NULL = zero), acts from the
+ * forward and the TRANSPOSED packs; writes g_x [M,3] (d/dx through the frequency encoding) and
+ * dpre scratch (same geometry as acts) for mh_mlp_wgrad. */
+int mh_warp_bwd_data(const float *x, const float *g_deform, const float *g_topo, const float *wpackT_d,
+                     const float *wpackT_t, int32_t n_bands, const float *acts, float *dpre, float *g_x,
+                     int64_t M, void *stream);
+
+/* mh_field_fwd: canonical field  sdf_net([freq(xc), hash, topo]) -> sdf, sigma (Laplace), geo;
+ *               color_net([hash_c, geo]) -> sigmoid -> albedo.
+ *   xc [M,3]; feat_s / feat_c [M,32] (hash features); topo NULL or [M,2]; beta: DEVICE scalar = |beta_p|+1e-4
+ *   (a pointer, so the host never synchronises to read the learnable beta);
+ *   with_color = 0 skips color_net (FD-normal taps, occupancy queries). */
+int64_t mh_field_acts_floats(int64_t M);
+int64_t mh_field_dpre_floats(int64_t M);
+int64_t mh_field_wpack_floats(void);
+int64_t mh_field_wpackT_floats(void);
+int mh_field_fwd(const float *xc, const float *feat_s, const float *feat_c, const float *topo,
+                 const float *wpack, const float *bias, const float *beta, int32_t n_bands, int32_t with_color,
+                 float *sdf, float *sigma, float *albedo, float *acts, int64_t M, void *stream);
+/* backward-data: g_sdf, g_sigma [M], g_albedo [M,3] (any may be NULL) -> g_xc [M,3] (freq path only;
+ * the hash path's d/dx comes from mh_grid_encode_bwd), g_feat_s, g_feat_c [M,32], g_topo [M,2],
+ * g_beta_partial [mh_mlp_tiles(M)] (per-tile partial sums of dL/dbeta), dpre scratch.
+ * sdf / albedo are the forward's outputs (Laplace and sigmoid derivatives are formed from them). */
+int mh_field_bwd_data(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
+                      const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
+                      int32_t n_bands, int32_t with_color, const float *acts, float *dpre, float *g_xc,
+                      float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial, int64_t M,
+                      void *stream);
+
+/* weight gradients: for `n_layers` layers described by HOST arrays (offsets in floats into
+ * acts/dpre tiles, feature counts padded to multiples of 32):
+ *   dW_l[out][in] = sum_pts dpre_l[out][pt] * act_l[in][pt],  db_l[out] = sum_pts dpre_l[out][pt]
+ * written as per-chunk partials  dw_part [n_chunks, sum_l out_l*in_l], db_part [n_chunks, sum_l out_l]
+ * (caller reduces over chunks).  tile_floats = floats per 32-point tile in acts (resp. dpre). */
+int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                 int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
+                 const int32_t *in_feats_host, const int32_t *out_feats_host, float *dw_part, float *db_part,
+                 int32_t n_chunks, int64_t n_tiles, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MORPHEUS_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI declared in include/morpheus_hip.h.
+
+The product path has no CPU fallback: if the library is missing or a call fails this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from .build import SO
+
+_P = ctypes.c_void_p
+_I32, _I64, _F = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+_SIGS = {
+    "mh_abi_version": (ctypes.c_int, []),
+    "mh_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "mh_grid_encode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
+    "mh_grid_encode_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
+    "mh_composite_fwd": (ctypes.c_int, [_P] * 10 + [_I32, _P]),
+    "mh_composite_bwd": (ctypes.c_int, [_P] * 13 + [_I32, _P]),
+    "mh_generate_rays": (ctypes.c_int, [_F, _F, _F, _F, _P, _I32, _I32, _P, _P, _P]),
+    "mh_sample_uniform": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "mh_mlp_tiles": (_I64, [_I64]),
+    "mh_warp_acts_floats": (_I64, [_I64]),
+    "mh_warp_dpre_floats": (_I64, [_I64]),
+    "mh_warp_wpack_floats": (_I64, []),
+    "mh_warp_wpackT_floats": (_I64, []),
+    "mh_field_acts_floats": (_I64, [_I64]),
+    "mh_field_dpre_floats": (_I64, [_I64]),
+    "mh_field_wpack_floats": (_I64, []),
+    "mh_field_wpackT_floats": (_I64, []),
+    "mh_warp_fwd": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _I64, _P]),
+    "mh_warp_bwd_data": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
+    "mh_field_fwd": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
+    "mh_field_bwd_data": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 7 + [_I64, _P]),
+    "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _I64, _P]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class MorpheusHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmorpheus_hip.so; never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise MorpheusHipError(
+                f"{SO} not found: build it with `python -m morpheus_amd.build` (hipcc, gfx950). "
+                "The hot path has no CPU/PyTorch fallback by design.")
+        lib = ctypes.CDLL(SO)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.mh_abi_version() != 1:
+            raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI takes contiguous buffers"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise MorpheusHipError(f"{what}: {load().mh_status_string(status).decode()} (status {status})")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MorpheusHipError("morpheus_amd ops run on an MI355X only (tensor is on %s); there is no CPU path"
+                                   % t.device)

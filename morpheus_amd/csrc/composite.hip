@@ -1,0 +1,184 @@
+// Packed transmittance compositor (Laplace-density volume integration), forward + backward.
+//
+// Semantics: nerfacc.render_weight_from_density + accumulate_along_rays as called at
+// reference morpheus.py:675-685 (third-party, un-vendored; published 0.5.x definition):
+//   alpha_i = 1 - exp(-sigma_i * (te_i - ts_i));  T_i = exp(-sum_{j<i in ray} sigma_j dt_j);  w = T * alpha
+//   opacity = sum w;  depth = sum w * (ts+te)/2;  color = sum w * rgb
+// Design: one wavefront per ray.  The ray's packed samples are walked in chunks of 64; the
+// exclusive prefix of sigma*dt is a 6-step wave scan plus a scalar carry, and the five per-ray
+// accumulators are reduced across the wave once at the end -- no cross-ray running sum is ever
+// formed (a global cumsum loses ~1e-4 here), no atomics, no index_add.
+#include "common.h"
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float n = __shfl_up(v, o);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_rev_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float n = __shfl_down(v, o);
+        if (lane + o < 64) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float *__restrict__ sigma, const float *__restrict__ ts,
+                                                            const float *__restrict__ te, const float *__restrict__ rgb,
+                                                            const int32_t *__restrict__ ray_start,
+                                                            const int32_t *__restrict__ ray_cnt, float *__restrict__ weights,
+                                                            float *__restrict__ opacity, float *__restrict__ depth,
+                                                            float *__restrict__ color, int N) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= N) return;
+    const int64_t start = ray_start[ray];
+    const int cnt = ray_cnt[ray];
+    float carry = 0.f, a_o = 0.f, a_d = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+    for (int base = 0; base < cnt; base += 64) {
+        const int k = base + lane;
+        const bool on = k < cnt;
+        const int64_t i = start + k;
+        float s0 = 0.f, s1 = 0.f, sd = 0.f;
+        if (on) {
+            s0 = ts[i];
+            s1 = te[i];
+            sd = sigma[i] * (s1 - s0);
+        }
+        const float incl = wave_incl_scan(sd, lane);
+        const float excl = carry + (incl - sd);
+        const float w = on ? expf(-excl) * (1.0f - expf(-sd)) : 0.f;
+        if (on) {
+            weights[i] = w;
+            a_o += w;
+            a_d += w * ((s0 + s1) * 0.5f);
+            if (rgb) {
+                a_r += w * rgb[i * 3 + 0];
+                a_g += w * rgb[i * 3 + 1];
+                a_b += w * rgb[i * 3 + 2];
+            }
+        }
+        carry += __shfl(incl, 63);
+    }
+    a_o = wave_sum(a_o);
+    a_d = wave_sum(a_d);
+    a_r = wave_sum(a_r);
+    a_g = wave_sum(a_g);
+    a_b = wave_sum(a_b);
+    if (lane == 0) {
+        opacity[ray] = a_o;
+        depth[ray] = a_d;
+        if (color) {
+            color[ray * 3 + 0] = a_r;
+            color[ray * 3 + 1] = a_g;
+            color[ray * 3 + 2] = a_b;
+        }
+    }
+}
+
+// dL/dsigma_i = dt_i * ( g_i * T_i * (1 - alpha_i)  -  sum_{j>i} g_j * w_j ),
+//   g_j = gW_j + gO + gD * tmid_j + gC . rgb_j ;   dL/drgb_i = w_i * gC
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float *__restrict__ sigma, const float *__restrict__ ts, const float *__restrict__ te,
+    const float *__restrict__ rgb, const int32_t *__restrict__ ray_start, const int32_t *__restrict__ ray_cnt,
+    const float *__restrict__ weights, const float *__restrict__ g_weights, const float *__restrict__ g_opacity,
+    const float *__restrict__ g_depth, const float *__restrict__ g_color, float *__restrict__ d_sigma,
+    float *__restrict__ d_rgb, int N) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= N) return;
+    const int64_t start = ray_start[ray];
+    const int cnt = ray_cnt[ray];
+    const float gO = g_opacity ? g_opacity[ray] : 0.f;
+    const float gD = g_depth ? g_depth[ray] : 0.f;
+    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f;
+    if (g_color && rgb) {
+        gC0 = g_color[ray * 3 + 0];
+        gC1 = g_color[ray * 3 + 1];
+        gC2 = g_color[ray * 3 + 2];
+    }
+    // pass 1 (forward): exclusive prefix of sigma*dt parked in d_sigma (each lane re-reads only
+    // what it wrote itself)
+    float carry = 0.f;
+    for (int base = 0; base < cnt; base += 64) {
+        const int k = base + lane;
+        const bool on = k < cnt;
+        const int64_t i = start + k;
+        const float sd = on ? sigma[i] * (te[i] - ts[i]) : 0.f;
+        const float incl = wave_incl_scan(sd, lane);
+        if (on) d_sigma[i] = carry + (incl - sd);
+        carry += __shfl(incl, 63);
+    }
+    // pass 2 (reverse): suffix sums of g*w
+    float tail = 0.f;
+    const int nchunk = (cnt + 63) / 64;
+    for (int c = nchunk - 1; c >= 0; c--) {
+        const int k = c * 64 + lane;
+        const bool on = k < cnt;
+        const int64_t i = start + k;
+        float gw = 0.f, dt = 0.f, g = 0.f, sd = 0.f, excl = 0.f, w = 0.f;
+        if (on) {
+            const float s0 = ts[i], s1 = te[i];
+            dt = s1 - s0;
+            sd = sigma[i] * dt;
+            excl = d_sigma[i];
+            w = weights[i];
+            g = gO + gD * ((s0 + s1) * 0.5f);
+            if (g_weights) g += g_weights[i];
+            if (rgb && g_color) {
+                const float r0 = rgb[i * 3 + 0], r1 = rgb[i * 3 + 1], r2 = rgb[i * 3 + 2];
+                g += gC0 * r0 + gC1 * r1 + gC2 * r2;
+                d_rgb[i * 3 + 0] = w * gC0;
+                d_rgb[i * 3 + 1] = w * gC1;
+                d_rgb[i * 3 + 2] = w * gC2;
+            } else if (d_rgb) {
+                d_rgb[i * 3 + 0] = 0.f;
+                d_rgb[i * 3 + 1] = 0.f;
+                d_rgb[i * 3 + 2] = 0.f;
+            }
+            gw = g * w;
+        }
+        const float rincl = wave_rev_incl_scan(gw, lane);
+        const float suffix = tail + (rincl - gw);
+        if (on) d_sigma[i] = dt * (g * expf(-(excl + sd)) - suffix);
+        tail += __shfl(rincl, 0);
+    }
+}
+
+extern "C" int mh_composite_fwd(const float *sigma, const float *t_starts, const float *t_ends, const float *rgb,
+                                const int32_t *ray_start, const int32_t *ray_cnt, float *weights, float *opacity,
+                                float *depth, float *color, int32_t N, void *stream) {
+    if (N == 0) return MH_OK;
+    if (N < 0 || !sigma || !t_starts || !t_ends || !ray_start || !ray_cnt || !weights || !opacity || !depth)
+        return MH_ERR_ARG;
+    if ((rgb == nullptr) != (color == nullptr)) return MH_ERR_ARG;
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, mh_stream(stream), sigma, t_starts,
+                       t_ends, rgb, ray_start, ray_cnt, weights, opacity, depth, color, (int)N);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_composite_bwd(const float *sigma, const float *t_starts, const float *t_ends, const float *rgb,
+                                const int32_t *ray_start, const int32_t *ray_cnt, const float *weights,
+                                const float *g_weights, const float *g_opacity, const float *g_depth,
+                                const float *g_color, float *d_sigma, float *d_rgb, int32_t N, void *stream) {
+    if (N == 0) return MH_OK;
+    if (N < 0 || !sigma || !t_starts || !t_ends || !ray_start || !ray_cnt || !weights || !d_sigma) return MH_ERR_ARG;
+    if (rgb && !d_rgb) return MH_ERR_ARG;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, mh_stream(stream), sigma, t_starts,
+                       t_ends, rgb, ray_start, ray_cnt, weights, g_weights, g_opacity, g_depth, g_color, d_sigma,
+                       d_rgb, (int)N);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}

@@ -1,0 +1,748 @@
+// Fused tiny-MLP evaluators on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// Replaces, for the render_rays hot path, what the reference runs as ~150 separate PyTorch ops:
+//   warp            models/model.py:412-437  (freq-enc + deform code -> deform_net, topo_net)
+//   get_sigma_albedo models/model.py:273-307 (freq-enc + hash + topo -> sdf_net -> Laplace sigma;
+//                                             hash_c + geo -> color_net -> sigmoid)
+//   MLP.forward     models/decoders.py:59-64 ; FreqEncoder_torch models/encodings.py:35-57 ;
+//   LaplaceDensity  models/density.py:22-31
+//
+// Design (CDNA4-first):
+//  * A wavefront owns a tile of 32 sample points for the whole network.  With the 32x32x2 fp32
+//    MFMA the accumulator layout is  D[row = (r&3)+8(r>>2)+4(lane>>5)][col = lane&31]  and the B
+//    operand of the NEXT layer wants  B[k = lane>>5][col = lane&31]: choosing the k-pairing
+//    (row, row+4) makes every accumulator register directly the next layer's B operand -- the
+//    activations never leave the register file between layers (no LDS transpose, no HBM round
+//    trip; the reference materialises [M,128] per layer).  The matching k-permutation is baked
+//    into the host-side packing of the weight (A) operands (morpheus_amd/packing.py).
+//  * Weights are staged per layer into LDS once per 128-point block in A-fragment order, read
+//    back with conflict-free ds_read_b128 (one read feeds 4 MFMAs per output tile).
+//  * fp32 in / fp32 accumulate: bitwise a k-ordered fmaf chain, so parity with the PyTorch
+//    reference is round-off only (summation order differs).
+//  * Forward (training) parks post-ReLU activations per 32-point tile feature-major [F][32] --
+//    the layout the weight-gradient MFMA wants (K = points) -- instead of recomputing the
+//    forward in backward: 128 MACs per stored float makes the store cheaper than the recompute.
+//  * Backward is two kernels: backward-data (same register-resident chain with transposed packs,
+//    writes dPre tiles) and mh_mlp_wgrad (dW = dPre . act^T as MFMA over the point axis, per-chunk
+//    partials reduced by the caller; no atomics anywhere).
+#include "common.h"
+
+#define TILE 32
+#define BLOCK_PTS 128
+
+// ---- per-tile scratch geometry (floats) -------------------------------------------------------
+// warp acts : H0 [64 rows: 2kk+h, 40 used] | deform H1..H5 [5 x 128] | topo H1..H5 [5 x 128]
+// warp dpre : deform dPre0..4 [5 x 128], dPre5 [32] | topo same
+#define WARP_ACT_ROWS (64 + 2 * 640)
+#define WARP_DPRE_ROWS (2 * 672)
+#define WARP_NET_WPACK (5120 + 4 * 16384 + 4096)       // fwd pack floats per net
+#define WARP_NET_WPACKT (4096 /*T5*/ + 4 * 16384 + 8192 /*T0: MT=2,KS=64*/)
+#define WARP_NET_BIAS (4 * 128 + 32)
+// field acts: S0 [96: 2kk+h, 80 used] | S1 [64] | S2 [64] | C0 [64: 2kk+h] | C1 [64] | C2 [64]
+// field dpre: P0 [64] | P1 [64] | P2 [64] | Q0 [64] | Q1 [64] | Q2 [32]
+#define FIELD_ACT_ROWS (96 + 64 * 5)
+#define FIELD_DPRE_ROWS (64 * 5 + 32)
+#define FIELD_WPACK (5120 + 4096 * 4 + 2048)
+#define FIELD_WPACKT (2048 /*TC2*/ + 4096 /*TC1*/ + 4096 /*TC0*/ + 4096 /*TS2*/ + 4096 /*TS1*/ + 6144 /*TS0 MT=3*/)
+#define FIELD_BIAS (64 * 5 + 32)
+
+__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__shared__ f32x4 lds_w[4096];  // 64 KB: one layer's A fragments  [mt][q][lane] float4
+
+__device__ __forceinline__ void stage_weights(const float *__restrict__ g, int n_f4) {
+    __syncthreads();  // everyone is done reading the previous layer
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(g);
+    for (int i = threadIdx.x; i < n_f4; i += blockDim.x) lds_w[i] = src[i];
+    __syncthreads();
+}
+
+template <int MT>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[MT], const float *__restrict__ bias, int h) {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + 32 * t + 8 * r4 + 4 * h);
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = v[c];
+        }
+}
+
+template <int MT>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT]) {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+}
+
+// acc[mt] += W_tile[mt] . bin   (KS k-steps of 2)
+template <int KS, int MT>
+__device__ __forceinline__ void mfma_layer(const float (&bin)[KS], f32x16 (&acc)[MT], int lane) {
+    static_assert(KS % 4 == 0, "k-steps come in quads");
+#pragma unroll
+    for (int q = 0; q < KS / 4; q++) {
+        f32x4 a[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) a[t] = lds_w[(t * (KS / 4) + q) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], bin[4 * q + j], acc[t], 0, 0, 0);
+    }
+}
+
+template <int MT, bool RELU>
+__device__ __forceinline__ void acc_to_bin(const f32x16 (&acc)[MT], float (&bin)[16 * MT]) {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) bin[16 * t + r] = RELU ? fmaxf(acc[t][r], 0.f) : acc[t][r];
+}
+
+// feature-major tile store: row = 32t + acc_row(r,h)
+template <int MT>
+__device__ __forceinline__ void store_acc_rows(float *__restrict__ tile, const float (&v)[16 * MT], int pt, int h) {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) tile[(32 * t + acc_row(r, h)) * TILE + pt] = v[16 * t + r];
+}
+template <int MT>
+__device__ __forceinline__ void load_acc_rows(const float *__restrict__ tile, float (&v)[16 * MT], int pt, int h) {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[16 * t + r] = tile[(32 * t + acc_row(r, h)) * TILE + pt];
+}
+// k-step ordered store: row = 2kk + h
+template <int KS>
+__device__ __forceinline__ void store_kk_rows(float *__restrict__ tile, const float (&v)[KS], int pt, int h) {
+#pragma unroll
+    for (int k = 0; k < KS; k++) tile[(2 * k + h) * TILE + pt] = v[k];
+}
+
+// frequency encoding of one point as B operands: k-step kk<18 = (band kk/3, dim kk%3): sin on
+// lanes 0-31, cos on lanes 32-63; kk 18 = (x0 | x1); kk 19 = (x2 | 0).   encodings.py:35-57
+__device__ __forceinline__ void enc_bin(const float (&x)[3], int h, int n_bands, float *__restrict__ bin /*[20]*/,
+                                        float *__restrict__ dsc /*[18] d(feature)/dx or null*/) {
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        const int band = k / 3, dim = k % 3;
+        const float f = (float)(1 << band);
+        float s, c;
+        sincosf(x[dim] * f, &s, &c);
+        const bool on = band < n_bands;
+        bin[k] = on ? (h ? c : s) : 0.f;
+        if (dsc) dsc[k] = on ? (h ? -f * s : f * c) : 0.f;
+    }
+    bin[18] = h ? x[1] : x[0];
+    bin[19] = h ? 0.f : x[2];
+}
+
+// =====================================================================================
+// warp: deform_net + topo_net
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ slot,
+                                                          const float *__restrict__ bias0_d, const float *__restrict__ bias0_t,
+                                                          const float *__restrict__ wpack_d, const float *__restrict__ wpack_t,
+                                                          const float *__restrict__ bias_d, const float *__restrict__ bias_t,
+                                                          int n_bands, float *__restrict__ out_deform,
+                                                          float *__restrict__ out_topo, float *__restrict__ acts, int64_t M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const int64_t pc = p < M ? p : M - 1;
+    float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
+    const int sl = slot ? slot[pc] : 0;
+    float *tile = acts ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
+
+    float bin0[20];
+    enc_bin(xv, h, n_bands, bin0, nullptr);
+    if (tile) {
+        store_kk_rows<20>(tile, bin0, pt, h);
+#pragma unroll
+        for (int k = 20; k < 32; k++) tile[(2 * k + h) * TILE + pt] = 0.f;  // pad rows 40..63
+    }
+    for (int net = 0; net < 2; net++) {
+        const float *wp = net ? wpack_t : wpack_d;
+        const float *bs = net ? bias_t : bias_d;
+        const float *b0 = (net ? bias0_t : bias0_d) + (int64_t)sl * 128;
+        float *ht = tile ? tile + (64 + net * 640) * TILE : nullptr;
+        f32x16 acc[4];
+        float bin[64];
+        // layer 0: 40 -> 128, bias row chosen by the point's frame slot
+        stage_weights(wp, 1280);
+        acc_bias<4>(acc, b0, h);
+        mfma_layer<20, 4>(bin0, acc, lane);
+        acc_to_bin<4, true>(acc, bin);
+        if (ht) store_acc_rows<4>(ht, bin, pt, h);
+        wp += 5120;
+        // layers 1..4: 128 -> 128
+        for (int l = 1; l <= 4; l++) {
+            stage_weights(wp, 4096);
+            acc_bias<4>(acc, bs + (l - 1) * 128, h);
+            mfma_layer<64, 4>(bin, acc, lane);
+            acc_to_bin<4, true>(acc, bin);
+            if (ht) store_acc_rows<4>(ht + l * 128 * TILE, bin, pt, h);
+            wp += 16384;
+        }
+        // layer 5: 128 -> 3 | 2 (one padded tile)
+        stage_weights(wp, 1024);
+        f32x16 o[1];
+        acc_bias<1>(o, bs + 4 * 128, h);
+        mfma_layer<64, 1>(bin, o, lane);
+        if (h == 0 && p < M) {
+            if (net == 0) {
+                out_deform[p * 3 + 0] = o[0][0];
+                out_deform[p * 3 + 1] = o[0][1];
+                out_deform[p * 3 + 2] = o[0][2];
+            } else {
+                out_topo[p * 2 + 0] = o[0][0];
+                out_topo[p * 2 + 1] = o[0][1];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restrict__ x, const float *__restrict__ g_deform,
+                                                          const float *__restrict__ g_topo, const float *__restrict__ wpackT_d,
+                                                          const float *__restrict__ wpackT_t, int n_bands,
+                                                          const float *__restrict__ acts, float *__restrict__ dpre,
+                                                          float *__restrict__ g_x, int64_t M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const bool live = p < M;
+    const int64_t pc = live ? p : M - 1;
+    float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
+    const float *atile = acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE);
+    float *dtile = dpre + tile_id * (int64_t)(WARP_DPRE_ROWS * TILE);
+    float encb[20], dsc[18];
+    enc_bin(xv, h, n_bands, encb, dsc);
+    float gx[3] = {0.f, 0.f, 0.f};
+
+    for (int net = 0; net < 2; net++) {
+        const float *wt = net ? wpackT_t : wpackT_d;
+        const float *g = net ? g_topo : g_deform;
+        const int nout = net ? 2 : 3;
+        const float *ht = atile + (64 + net * 640) * TILE;
+        float *dt = dtile + net * 672 * TILE;
+        // dPre5: rows 0..nout-1 carry the incoming gradient (no activation on the last layer)
+        float d5[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) d5[r] = 0.f;
+        if (g && live && h == 0) {
+            d5[0] = g[p * nout + 0];
+            d5[1] = g[p * nout + 1];
+            if (nout == 3) d5[2] = g[p * nout + 2];
+        }
+        store_acc_rows<1>(dt + 640 * TILE, d5, pt, h);
+        // dH5 = W5^T dPre5
+        f32x16 acc[4];
+        float dbin[64], hv[64];
+        stage_weights(wt, 1024);
+        acc_zero<4>(acc);
+        mfma_layer<16, 4>(d5, acc, lane);
+        wt += 4096;
+        for (int l = 4; l >= 0; l--) {
+            // output of layer l is H_{l+1}; mask by its ReLU and park dPre_l
+            load_acc_rows<4>(ht + l * 128 * TILE, hv, pt, h);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+            store_acc_rows<4>(dt + l * 128 * TILE, dbin, pt, h);
+            if (l > 0) {
+                stage_weights(wt, 4096);
+                acc_zero<4>(acc);
+                mfma_layer<64, 4>(dbin, acc, lane);
+                wt += 16384;
+            } else {
+                // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5)
+                stage_weights(wt, 2048);
+                f32x16 e[2];
+                acc_zero<2>(e);
+                mfma_layer<64, 2>(dbin, e, lane);
+#pragma unroll
+                for (int k = 0; k < 18; k++) {
+                    const float de = k < 16 ? e[0][k] : e[1][k - 16];
+                    gx[k % 3] += de * dsc[k];
+                }
+                // kk 18: (x0 | x1), kk 19: (x2 | -)
+                if (h == 0) {
+                    gx[0] += e[1][2];
+                    gx[2] += e[1][3];
+                } else {
+                    gx[1] += e[1][2];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
+    if (g_x && live && h == 0) {
+        g_x[p * 3 + 0] = gx[0];
+        g_x[p * 3 + 1] = gx[1];
+        g_x[p * 3 + 2] = gx[2];
+    }
+}
+
+// =====================================================================================
+// canonical field: sdf_net (+ Laplace density) and color_net
+// =====================================================================================
+__device__ __forceinline__ float laplace_sigma(float s, float beta) {
+    // density.py:22-31: (1/beta) * (0.5 + 0.5 * sign(s) * expm1(-|s|/beta))
+    const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+}
+
+__global__ __launch_bounds__(256, 2) void field_fwd_kernel(const float *__restrict__ xc, const float *__restrict__ feat_s,
+                                                           const float *__restrict__ feat_c, const float *__restrict__ topo,
+                                                           const float *__restrict__ wpack, const float *__restrict__ bias,
+                                                           const float *__restrict__ beta_p, int n_bands, int with_color, float *__restrict__ sdf,
+                                                           float *__restrict__ sigma, float *__restrict__ albedo,
+                                                           float *__restrict__ acts, int64_t M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const bool live = p < M;
+    const int64_t pc = live ? p : M - 1;
+    float xv[3] = {xc[pc * 3 + 0], xc[pc * 3 + 1], xc[pc * 3 + 2]};
+    float *tile = acts ? acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE) : nullptr;
+
+    float bin0[40];
+    enc_bin(xv, h, n_bands, bin0, nullptr);
+    {
+        const f32x4 *fs = reinterpret_cast<const f32x4 *>(feat_s + pc * 32 + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v = fs[q];
+#pragma unroll
+            for (int c = 0; c < 4; c++) bin0[20 + 4 * q + c] = v[c];
+        }
+    }
+    bin0[36] = topo ? topo[pc * 2 + h] : 0.f;
+    bin0[37] = bin0[38] = bin0[39] = 0.f;
+    if (tile) {
+        store_kk_rows<40>(tile, bin0, pt, h);
+#pragma unroll
+        for (int k = 40; k < 48; k++) tile[(2 * k + h) * TILE + pt] = 0.f;  // pad rows 80..95
+    }
+    const float *wp = wpack;
+    f32x16 acc[2];
+    float bin[32];
+    // sdf L0: 73 -> 64
+    stage_weights(wp, 1280);
+    acc_bias<2>(acc, bias, h);
+    mfma_layer<40, 2>(bin0, acc, lane);
+    acc_to_bin<2, true>(acc, bin);
+    if (tile) store_acc_rows<2>(tile + 96 * TILE, bin, pt, h);
+    wp += 5120;
+    // sdf L1: 64 -> 64
+    stage_weights(wp, 1024);
+    acc_bias<2>(acc, bias + 64, h);
+    mfma_layer<32, 2>(bin, acc, lane);
+    acc_to_bin<2, true>(acc, bin);
+    if (tile) store_acc_rows<2>(tile + 160 * TILE, bin, pt, h);
+    wp += 4096;
+    // sdf L2: 64 -> [geo(32) | sdf], no activation
+    stage_weights(wp, 1024);
+    acc_bias<2>(acc, bias + 128, h);
+    mfma_layer<32, 2>(bin, acc, lane);
+    wp += 4096;
+    if (h == 0 && live) {
+        const float s = acc[1][0];
+        sdf[p] = s;
+        if (sigma) sigma[p] = laplace_sigma(s, *beta_p);
+    }
+    if (!with_color) return;
+    // color L0: [hash_c(32) | geo(32)] -> 64
+    float binc[32];
+    {
+        const f32x4 *fc = reinterpret_cast<const f32x4 *>(feat_c + pc * 32 + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v = fc[q];
+#pragma unroll
+            for (int c = 0; c < 4; c++) binc[4 * q + c] = v[c];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) binc[16 + r] = acc[0][r];
+    }
+    if (tile) store_kk_rows<32>(tile + 224 * TILE, binc, pt, h);
+    stage_weights(wp, 1024);
+    acc_bias<2>(acc, bias + 192, h);
+    mfma_layer<32, 2>(binc, acc, lane);
+    acc_to_bin<2, true>(acc, bin);
+    if (tile) store_acc_rows<2>(tile + 288 * TILE, bin, pt, h);
+    wp += 4096;
+    // color L1
+    stage_weights(wp, 1024);
+    acc_bias<2>(acc, bias + 256, h);
+    mfma_layer<32, 2>(bin, acc, lane);
+    acc_to_bin<2, true>(acc, bin);
+    if (tile) store_acc_rows<2>(tile + 352 * TILE, bin, pt, h);
+    wp += 4096;
+    // color L2: 64 -> 3, sigmoid
+    stage_weights(wp, 512);
+    f32x16 o[1];
+    acc_bias<1>(o, bias + 320, h);
+    mfma_layer<32, 1>(bin, o, lane);
+    if (h == 0 && live) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) albedo[p * 3 + c] = 1.0f / (1.0f + expf(-o[0][c]));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void field_bwd_kernel(
+    const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ albedo,
+    const float *__restrict__ g_sdf, const float *__restrict__ g_sigma, const float *__restrict__ g_albedo,
+    const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands, int with_color, const float *__restrict__ acts,
+    float *__restrict__ dpre, float *__restrict__ g_xc, float *__restrict__ g_feat_s, float *__restrict__ g_feat_c,
+    float *__restrict__ g_topo, float *__restrict__ g_beta_partial, int64_t M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const bool live = p < M;
+    const int64_t pc = live ? p : M - 1;
+    float xv[3] = {xc[pc * 3 + 0], xc[pc * 3 + 1], xc[pc * 3 + 2]};
+    const float *atile = acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE);
+    float *dtile = dpre + tile_id * (int64_t)(FIELD_DPRE_ROWS * TILE);
+    float encb[20], dsc[18];
+    enc_bin(xv, h, n_bands, encb, dsc);
+    const float beta = *beta_p;
+
+    const float *wt = wpackT;
+    f32x16 acc[2];
+    float dbin[32], hv[32];
+    float dgeo[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) dgeo[r] = 0.f;
+
+    if (with_color) {
+        // dQ2 = g_albedo * a * (1 - a)
+        float d2[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) d2[r] = 0.f;
+        if (g_albedo && live && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float a = albedo[p * 3 + c];
+                d2[c] = g_albedo[p * 3 + c] * a * (1.0f - a);
+            }
+        }
+        store_acc_rows<1>(dtile + 320 * TILE, d2, pt, h);
+        stage_weights(wt, 512);  // TC2: MT=2, KS=16
+        acc_zero<2>(acc);
+        mfma_layer<16, 2>(d2, acc, lane);
+        wt += 2048;
+        // mask C2 -> dQ1
+        load_acc_rows<2>(atile + 352 * TILE, hv, pt, h);
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+        store_acc_rows<2>(dtile + 256 * TILE, dbin, pt, h);
+        stage_weights(wt, 1024);  // TC1
+        acc_zero<2>(acc);
+        mfma_layer<32, 2>(dbin, acc, lane);
+        wt += 4096;
+        // mask C1 -> dQ0
+        load_acc_rows<2>(atile + 288 * TILE, hv, pt, h);
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+        store_acc_rows<2>(dtile + 192 * TILE, dbin, pt, h);
+        stage_weights(wt, 1024);  // TC0: tile0 -> hash_c (16h + r), tile1 -> geo (acc layout)
+        acc_zero<2>(acc);
+        mfma_layer<32, 2>(dbin, acc, lane);
+        wt += 4096;
+        if (g_feat_c && live) {
+            f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_c + p * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = acc[0][4 * q + c];
+                o[q] = v;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) dgeo[r] = acc[1][r];
+    } else {
+        wt += 2048 + 4096 + 4096;
+    }
+    // dP2 = [dgeo | d sdf]
+    float gs = 0.f, gbeta = 0.f;
+    if (live && h == 0) {
+        const float s = sdf[p];
+        if (g_sdf) gs = g_sdf[p];
+        if (g_sigma) {
+            const float gsg = g_sigma[p];
+            const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+            const float a = fabsf(s) / beta;
+            const float ex = expf(-a);
+            gs += gsg * (-(0.5f / (beta * beta)) * sg * sg * ex);
+            // d sigma / d beta
+            gbeta = gsg * (-(1.0f / (beta * beta)) * (0.5f + 0.5f * sg * expm1f(-a)) +
+                           (1.0f / beta) * (0.5f * sg * ex * (fabsf(s) / (beta * beta))));
+        }
+    }
+    if (g_beta_partial) {
+        float tot = gbeta;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (lane == 0) g_beta_partial[tile_id] = tot;
+    }
+    {
+        float d2[32];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            d2[r] = dgeo[r];
+            d2[16 + r] = 0.f;
+        }
+        d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
+        store_acc_rows<2>(dtile + 128 * TILE, d2, pt, h);
+        stage_weights(wt, 1024);  // TS2
+        acc_zero<2>(acc);
+        mfma_layer<32, 2>(d2, acc, lane);
+        wt += 4096;
+    }
+    // mask S2 -> dP1
+    load_acc_rows<2>(atile + 160 * TILE, hv, pt, h);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+    store_acc_rows<2>(dtile + 64 * TILE, dbin, pt, h);
+    stage_weights(wt, 1024);  // TS1
+    acc_zero<2>(acc);
+    mfma_layer<32, 2>(dbin, acc, lane);
+    wt += 4096;
+    // mask S1 -> dP0
+    load_acc_rows<2>(atile + 96 * TILE, hv, pt, h);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+    store_acc_rows<2>(dtile, dbin, pt, h);
+    // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
+    stage_weights(wt, 1536);  // TS0: MT=3, KS=32
+    f32x16 e[3];
+    acc_zero<3>(e);
+    mfma_layer<32, 3>(dbin, e, lane);
+    float gx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        const float de = k < 16 ? e[0][k] : e[1][k - 16];
+        gx[k % 3] += de * dsc[k];
+    }
+    if (h == 0) {
+        gx[0] += e[1][2];
+        gx[2] += e[1][3];
+    } else {
+        gx[1] += e[1][2];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
+    if (live) {
+        if (g_xc && h == 0) {
+            g_xc[p * 3 + 0] = gx[0];
+            g_xc[p * 3 + 1] = gx[1];
+            g_xc[p * 3 + 2] = gx[2];
+        }
+        if (g_topo) g_topo[p * 2 + h] = e[1][4];
+        if (g_feat_s) {
+            f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_s + p * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = e[2][4 * q + c];
+                o[q] = v;
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// weight gradients: dW[out][in] = sum_pt dPre[out][pt] * act[in][pt]  (MFMA, K = points)
+// one wave per 32-row out tile; block = OT waves sharing the act tiles through L1
+// =====================================================================================
+template <int IT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                    int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                                    int dpre_off, int out_pad, float *__restrict__ dw_part,
+                                                    float *__restrict__ db_part, int64_t dw_stride, int64_t db_stride,
+                                                    int64_t dw_off, int64_t db_off, int64_t n_tiles, int n_chunks) {
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int64_t per = (n_tiles + n_chunks - 1) / n_chunks;
+    const int64_t t0 = chunk * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    f32x16 acc[IT];
+    acc_zero<IT>(acc);
+    float bsum = 0.f;
+    for (int64_t t = t0; t < t1; t++) {
+        const f32x4 *a = reinterpret_cast<const f32x4 *>(dpre + t * dpre_tile_floats + dpre_off +
+                                                          (int64_t)(32 * mt + i) * TILE + 16 * h);
+        f32x4 av[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) av[j] = a[j];
+        f32x4 bv[IT][4];
+#pragma unroll
+        for (int n = 0; n < IT; n++) {
+            const f32x4 *b = reinterpret_cast<const f32x4 *>(acts + t * acts_tile_floats + act_off +
+                                                              (int64_t)(32 * n + i) * TILE + 16 * h);
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[n][j] = b[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                bsum += av[j][q];
+#pragma unroll
+                for (int n = 0; n < IT; n++)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][q], bv[n][j][q], acc[n], 0, 0, 0);
+            }
+    }
+    // D[row = out (acc_row), col = in (lane&31)]
+    float *dw = dw_part + chunk * dw_stride + dw_off;
+    const int in_pad = 32 * IT;
+#pragma unroll
+    for (int n = 0; n < IT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, h)) * in_pad + 32 * n + i] = acc[n][r];
+    bsum += __shfl_xor(bsum, 32);
+    if (h == 0) db_part[chunk * db_stride + db_off + 32 * mt + i] = bsum;
+}
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+static inline int64_t n_tiles_for(int64_t M) { return ((M + BLOCK_PTS - 1) / BLOCK_PTS) * 4; }
+
+extern "C" int64_t mh_warp_acts_floats(int64_t M) { return n_tiles_for(M) * (int64_t)(WARP_ACT_ROWS * TILE); }
+extern "C" int64_t mh_warp_dpre_floats(int64_t M) { return n_tiles_for(M) * (int64_t)(WARP_DPRE_ROWS * TILE); }
+extern "C" int64_t mh_warp_wpack_floats(void) { return WARP_NET_WPACK; }
+extern "C" int64_t mh_warp_wpackT_floats(void) { return WARP_NET_WPACKT; }
+extern "C" int64_t mh_field_acts_floats(int64_t M) { return n_tiles_for(M) * (int64_t)(FIELD_ACT_ROWS * TILE); }
+extern "C" int64_t mh_field_dpre_floats(int64_t M) { return n_tiles_for(M) * (int64_t)(FIELD_DPRE_ROWS * TILE); }
+extern "C" int64_t mh_field_wpack_floats(void) { return FIELD_WPACK; }
+extern "C" int64_t mh_field_wpackT_floats(void) { return FIELD_WPACKT; }
+extern "C" int64_t mh_mlp_tiles(int64_t M) { return n_tiles_for(M); }
+
+extern "C" int mh_warp_fwd(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t,
+                           const float *wpack_d, const float *wpack_t, const float *bias_d, const float *bias_t,
+                           int32_t n_bands, float *out_deform, float *out_topo, float *acts, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !x || !bias0_d || !bias0_t || !wpack_d || !wpack_t || !bias_d || !bias_t || !out_deform || !out_topo ||
+        n_bands < 0 || n_bands > 6)
+        return MH_ERR_ARG;
+    const int64_t blocks = (M + BLOCK_PTS - 1) / BLOCK_PTS;
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), x, slot, bias0_d, bias0_t,
+                       wpack_d, wpack_t, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_warp_bwd_data(const float *x, const float *g_deform, const float *g_topo, const float *wpackT_d,
+                                const float *wpackT_t, int32_t n_bands, const float *acts, float *dpre, float *g_x,
+                                int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !x || !wpackT_d || !wpackT_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
+    const int64_t blocks = (M + BLOCK_PTS - 1) / BLOCK_PTS;
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), x, g_deform, g_topo,
+                       wpackT_d, wpackT_t, (int)n_bands, acts, dpre, g_x, M);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_field_fwd(const float *xc, const float *feat_s, const float *feat_c, const float *topo,
+                            const float *wpack, const float *bias, const float *beta, int32_t n_bands, int32_t with_color,
+                            float *sdf, float *sigma, float *albedo, float *acts, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !xc || !feat_s || !wpack || !bias || !sdf || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
+    if (with_color && (!feat_c || !albedo)) return MH_ERR_ARG;
+    const int64_t blocks = (M + BLOCK_PTS - 1) / BLOCK_PTS;
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    hipLaunchKernelGGL(field_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), xc, feat_s, feat_c, topo,
+                       wpack, bias, beta, (int)n_bands, (int)with_color, sdf, sigma, albedo, acts, M);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
+                                 const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
+                                 int32_t n_bands, int32_t with_color, const float *acts, float *dpre, float *g_xc,
+                                 float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial, int64_t M,
+                                 void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !xc || !sdf || !wpackT || !acts || !dpre || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
+    if (with_color && !albedo) return MH_ERR_ARG;
+    const int64_t blocks = (M + BLOCK_PTS - 1) / BLOCK_PTS;
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), xc, sdf, albedo, g_sdf,
+                       g_sigma, g_albedo, wpackT, beta, (int)n_bands, (int)with_color, acts, dpre, g_xc, g_feat_s, g_feat_c,
+                       g_topo, g_beta_partial, M);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                            int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
+                            const int32_t *in_feats_host, const int32_t *out_feats_host, float *dw_part, float *db_part,
+                            int32_t n_chunks, int64_t n_tiles, void *stream) {
+    if (n_tiles == 0 || n_layers == 0) return MH_OK;
+    if (!acts || !dpre || !act_off_host || !dpre_off_host || !in_feats_host || !out_feats_host || !dw_part || !db_part ||
+        n_layers < 0 || n_chunks <= 0 || n_tiles < 0)
+        return MH_ERR_ARG;
+    int64_t dw_stride = 0, db_stride = 0;
+    for (int l = 0; l < n_layers; l++) {
+        const int in = in_feats_host[l], out = out_feats_host[l];
+        if (in <= 0 || out <= 0 || (in % 32) || (out % 32) || in > 128 || out > 128) return MH_ERR_ARG;
+        dw_stride += (int64_t)in * out;
+        db_stride += out;
+    }
+    int64_t dw_off = 0, db_off = 0;
+    for (int l = 0; l < n_layers; l++) {
+        const int in = in_feats_host[l], out = out_feats_host[l];
+        const dim3 grid((unsigned)n_chunks), block((unsigned)(out / 32) * 64);
+#define WG_LAUNCH(IT)                                                                                              \
+    hipLaunchKernelGGL(wgrad_kernel<IT>, grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats,          \
+                       dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, dw_part, db_part,       \
+                       dw_stride, db_stride, dw_off, db_off, n_tiles, (int)n_chunks)
+        switch (in / 32) {
+            case 1: WG_LAUNCH(1); break;
+            case 2: WG_LAUNCH(2); break;
+            case 3: WG_LAUNCH(3); break;
+            default: WG_LAUNCH(4); break;
+        }
+#undef WG_LAUNCH
+        MH_CHECK_LAUNCH();
+        dw_off += (int64_t)in * out;
+        db_off += out;
+    }
+    return MH_OK;
+}
+
+extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }
+extern "C" const char *mh_status_string(int status) {
+    switch (status) {
+        case MH_OK: return "ok";
+        case MH_ERR_ARG: return "invalid argument (null pointer, bad size or unsupported configuration)";
+        case MH_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
+        default: return "unknown status";
+    }
+}

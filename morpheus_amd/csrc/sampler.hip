@@ -1,0 +1,110 @@
+// Ray generation + uniform stratified sampler.
+//
+// Ray generation: reference datasets/utils.py:28-65 (OpenGL pinhole, directions NOT normalised)
+// and datasets/dataset.py:363-366 (rays_d = sum_k dirs_k * R[:,k]; rays_o = c2w[:3,3]).
+// Sampler: replaces the nerfacc OccGridEstimator.sampling call site (morpheus.py:628-638) with the
+// benchmark sampler of SURVEY 8(d); definition shared with oracle/field.py:uniform_samples:
+//   slab clip to [-bound,bound]^3 -> [t_near>=0, t_far];  dt = (t_far - t_near) / (S+1);
+//   ts_i = t_near + (i + u) * dt;  te_i = t_near + (i + 1 + u) * dt;   misses -> zero-width samples.
+// Arithmetic uses explicit round-to-nearest mul/add/div (no FMA contraction) so the packed
+// samples are bit-identical to the oracle's -- samples are *inputs* to every parity test.
+#include "common.h"
+
+// HIP's __fadd_rn/__fmul_rn are plain operators; without this the compiler fuses them into FMAs.
+#pragma clang fp contract(off)
+
+struct Pose {
+    float r[9];
+    float t[3];
+};
+
+__global__ __launch_bounds__(256) void generate_rays_kernel(float fx, float fy, float cx, float cy, Pose pose, int H,
+                                                            int W, float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int j = idx / W, i = idx - j * W;
+    const float d0 = __fdiv_rn(__fsub_rn(__fadd_rn((float)i, 0.5f), cx), fx);
+    const float d1 = -__fdiv_rn(__fsub_rn(__fadd_rn((float)j, 0.5f), cy), fy);
+    const float d2 = -1.0f;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float v = __fadd_rn(__fadd_rn(__fmul_rn(d0, pose.r[a * 3 + 0]), __fmul_rn(d1, pose.r[a * 3 + 1])),
+                            __fmul_rn(d2, pose.r[a * 3 + 2]));
+        rays_d[idx * 3 + a] = v;
+        rays_o[idx * 3 + a] = pose.t[a];
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_uniform_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                             const float *__restrict__ jitter, int N, int S, float bound,
+                                                             int32_t *__restrict__ ray_idx, float *__restrict__ t_starts,
+                                                             float *__restrict__ t_ends, float *__restrict__ xyz,
+                                                             int32_t *__restrict__ ray_start, int32_t *__restrict__ ray_cnt) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * S;
+    if (gid >= total) return;
+    const int r = (int)(gid / S);
+    const int i = (int)(gid - (int64_t)r * S);
+    float o[3], d[3];
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o[a] = rays_o[r * 3 + a];
+        d[a] = rays_d[r * 3 + a];
+        const float ta = __fdiv_rn(__fsub_rn(-bound, o[a]), d[a]);
+        const float tb = __fdiv_rn(__fsub_rn(bound, o[a]), d[a]);
+        tmin = fmaxf(tmin, fminf(ta, tb));
+        tmax = fminf(tmax, fmaxf(ta, tb));
+    }
+    tmin = fmaxf(tmin, 0.0f);
+    const bool hit = tmax > tmin;
+    if (!hit) {
+        tmin = 0.f;
+        tmax = 0.f;
+    }
+    const float dt = __fdiv_rn(__fsub_rn(tmax, tmin), (float)(S + 1));
+    const float u = jitter[r];
+    const float ts = __fadd_rn(tmin, __fmul_rn(__fadd_rn((float)i, u), dt));
+    const float te = __fadd_rn(tmin, __fmul_rn(__fadd_rn(__fadd_rn((float)i, 1.0f), u), dt));
+    ray_idx[gid] = r;
+    t_starts[gid] = ts;
+    t_ends[gid] = te;
+    if (xyz) {
+        const float tm = __fdiv_rn(__fadd_rn(ts, te), 2.0f);
+#pragma unroll
+        for (int a = 0; a < 3; a++) xyz[gid * 3 + a] = __fadd_rn(o[a], __fmul_rn(d[a], tm));
+    }
+    if (i == 0) {
+        ray_start[r] = (int32_t)((int64_t)r * S);
+        ray_cnt[r] = S;
+    }
+}
+
+extern "C" int mh_generate_rays(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
+                                float *rays_o, float *rays_d, void *stream) {
+    if (!c2w_host || !rays_o || !rays_d || H <= 0 || W <= 0) return MH_ERR_ARG;
+    Pose p;
+    for (int a = 0; a < 3; a++) {
+        for (int b = 0; b < 3; b++) p.r[a * 3 + b] = c2w_host[a * 4 + b];
+        p.t[a] = c2w_host[a * 4 + 3];
+    }
+    const int n = H * W;
+    hipLaunchKernelGGL(generate_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, mh_stream(stream), fx, fy, cx, cy, p,
+                       (int)H, (int)W, rays_o, rays_d);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_sample_uniform(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, int32_t S,
+                                 float bound, int32_t *ray_idx, float *t_starts, float *t_ends, float *xyz,
+                                 int32_t *ray_start, int32_t *ray_cnt, void *stream) {
+    if (N == 0) return MH_OK;
+    if (!rays_o || !rays_d || !jitter || !ray_idx || !t_starts || !t_ends || !ray_start || !ray_cnt || N < 0 || S <= 0)
+        return MH_ERR_ARG;
+    const int64_t total = (int64_t)N * S;
+    if (total > 0x7fffffffLL) return MH_ERR_ARG;
+    hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mh_stream(stream),
+                       rays_o, rays_d, jitter, (int)N, (int)S, bound, ray_idx, t_starts, t_ends, xyz, ray_start, ray_cnt);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}

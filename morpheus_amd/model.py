@@ -1,0 +1,363 @@
+"""`scene_representation` -- drop-in for the reference's models.model.scene_representation.
+
+Same constructor keywords, method names, parameter-group names and state_dict keys as
+/root/reference/models/model.py:31-533 (keys listed in SURVEY.md C.10), so morpheus.py's
+optimisation loop, EMA, checkpoints and LR schedule address it unchanged.  Underneath, the deform
+field, canonical field and hash grids run on the HIP kernels of libmorpheus_hip.so through
+morpheus_amd.ops; there is no PyTorch fallback for those (CPU tensors raise).
+
+Only the configuration every shipped YAML uses is wired to the fused kernels
+(use_t=False, use_app=False, use_joint=True, color_grid=True, encode_topo=False); other switches
+raise NotImplementedError instead of silently taking a slow path.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def safe_normalize(x: torch.Tensor, eps: float = 1e-20) -> torch.Tensor:
+    """utils.py:70-71."""
+    return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=eps))
+
+
+# ------------------------------------------------------------------------------------ small modules
+class PoseArray(nn.Module):
+    """Per-frame 6-DoF pose correction, Euler angles -> R (models/pose.py:4-64)."""
+
+    def __init__(self, num_frames: int):
+        super().__init__()
+        self.num_frames = num_frames
+        self.data = nn.Parameter(torch.zeros(num_frames, 6))
+
+    def get_translations(self, ids):
+        t = self.data[:, 3:6][ids]
+        return t[None] if t.dim() == 1 else t
+
+    def get_rotation_matrices(self, ids):
+        r = self.data[:, 0:3][ids]
+        if r.dim() == 1:
+            r = r[None]
+        ca, cb, cg = torch.cos(r[:, 0]), torch.cos(r[:, 1]), torch.cos(r[:, 2])
+        sa, sb, sg = torch.sin(r[:, 0]), torch.sin(r[:, 1]), torch.sin(r[:, 2])
+        cols = [torch.stack([ca * cb, sa * cb, -sb], -1),
+                torch.stack([ca * sb * sg - sa * cg, sa * sb * sg + ca * cg, cb * sg], -1),
+                torch.stack([ca * sb * cg + sa * sg, sa * sb * cg - ca * sg, cb * cg], -1)]
+        return torch.stack(cols, -1)
+
+
+class MultiCode(nn.Module):
+    """Multi-resolution 1-D code grid, linear in time (models/deform_code.py:5-43)."""
+
+    def __init__(self, sizes, c):
+        super().__init__()
+        self.volumes = nn.ParameterList([nn.Parameter(torch.randn(1, c, s, 1)) for s in sizes])
+
+    def sample(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.reshape(-1).clamp(0, 1)
+        out = []
+        for vol in self.volumes:
+            v = vol[0, :, :, 0]
+            size = v.shape[1]
+            r = ((t * 2 - 1) + 1) / 2 * (size - 1)
+            r0 = torch.floor(r)
+            fr = (r - r0)[None]
+            i0 = r0.long().clamp(0, size - 1)
+            i1 = (i0 + 1).clamp(0, size - 1)
+            out.append((v[:, i0] * (1 - fr) + v[:, i1] * fr).t())
+        return torch.cat(out, -1)
+
+    def get_code(self, level=-1):
+        return self.volumes[level].squeeze().permute(1, 0)
+
+
+class _WNLinear(nn.Module):
+    """Linear with the legacy weight_norm parametrisation: W = g * v / ||v|| (decoders.py:51-52)."""
+
+    def __init__(self, din, dout):
+        super().__init__()
+        lin = nn.Linear(din, dout)
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        v = lin.weight.detach().clone()
+        self.weight_g = nn.Parameter(v.norm(dim=1, keepdim=True))
+        self.weight_v = nn.Parameter(v)
+
+    def effective(self):
+        return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
+
+
+class _PlainLinear(nn.Module):
+    def __init__(self, din, dout):
+        super().__init__()
+        lin = nn.Linear(din, dout)
+        self.weight = nn.Parameter(lin.weight.detach().clone())
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+
+    def effective(self):
+        return self.weight
+
+
+class MLP(nn.Module):
+    """Parameter container with the reference's layout `net.{l}.{weight_g,weight_v|weight,bias}`
+    (decoders.py:9-64, incl. the geometric initialisation of :25-43)."""
+
+    def __init__(self, dim_in, dim_out, dim_hidden, num_layers, bias=True, geo_init=False, geo_bias=0.5,
+                 weight_norm=True):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_hidden, self.num_layers = dim_in, dim_out, dim_hidden, num_layers
+        layers = []
+        for l in range(num_layers):
+            i = dim_in if l == 0 else dim_hidden
+            o = dim_out if l == num_layers - 1 else dim_hidden
+            lin = _WNLinear(i, o) if weight_norm else _PlainLinear(i, o)
+            if geo_init:
+                assert not weight_norm
+                with torch.no_grad():
+                    if l == num_layers - 1:
+                        lin.weight.normal_(math.sqrt(math.pi) / math.sqrt(i), 1e-4)
+                        lin.bias.fill_(-geo_bias)
+                    elif l == 0:
+                        lin.bias.zero_()
+                        lin.weight[:, 3:].zero_()
+                        lin.weight[:, :3].normal_(0.0, math.sqrt(2) / math.sqrt(o))
+                    else:
+                        lin.bias.zero_()
+                        lin.weight.normal_(0.0, math.sqrt(2) / math.sqrt(o))
+            layers.append(lin)
+        self.net = nn.ModuleList(layers)
+
+    def weights(self) -> List[torch.Tensor]:
+        return [l.effective() for l in self.net]
+
+    def biases(self) -> List[torch.Tensor]:
+        return [l.bias for l in self.net]
+
+    def forward(self, x):
+        """Plain PyTorch evaluation -- only for nets that are NOT on the hot path (bg_net)."""
+        for l, lin in enumerate(self.net):
+            x = torch.addmm(lin.bias, x, lin.effective().t())
+            if l != self.num_layers - 1:
+                x = torch.relu(x)
+        return x
+
+
+class GridEncoder(nn.Module):
+    """Multires hash grid with the reference's table sizing (grid.py:104-147) on the HIP kernels."""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=15,
+                 desired_resolution=128):
+        super().__init__()
+        assert input_dim == 3 and level_dim == 2, "HIP encoder is specialised to D=3, C=2"
+        self.num_levels, self.level_dim, self.base_resolution = num_levels, level_dim, base_resolution
+        self.per_level_scale = float(np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1)))
+        self.output_dim = num_levels * level_dim
+        offs, total = [], 0
+        for i in range(num_levels):
+            res = int(np.ceil(base_resolution * self.per_level_scale ** i))      # float64, grid.py:129
+            n = int(np.ceil(min(2 ** log2_hashmap_size, res ** input_dim) / 8) * 8)
+            offs.append(total)
+            total += n
+        offs.append(total)
+        self.register_buffer("offsets", torch.tensor(offs, dtype=torch.int32))
+        self._offsets_np = np.asarray(offs, dtype=np.int32)
+        self._res_np = ops.level_resolutions(num_levels, self.per_level_scale, base_resolution)
+        self.n_params = total * level_dim
+        self.embeddings = nn.Parameter(torch.empty(total, level_dim).uniform_(-1e-4, 1e-4))
+
+    def forward(self, inputs, bound=1, max_level=None):
+        return ops.grid_encode(inputs, self.embeddings, self._offsets_np, self._res_np, float(bound), max_level)
+
+
+class LaplaceDensity(nn.Module):
+    """VolSDF density, learnable beta (models/density.py:17-31)."""
+
+    def __init__(self, beta=0.1, beta_min=1e-4):
+        super().__init__()
+        self.beta = nn.Parameter(torch.tensor(float(beta)))
+        self.beta_min = beta_min
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min
+
+    def forward(self, sdf, beta=None):
+        beta = self.get_beta() if beta is None else beta
+        return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
+def _freq_encode_torch(x, n_freqs=6, max_level=None):
+    """encodings.py:35-57, plain torch -- used only off the hot path (background net)."""
+    keep = n_freqs if max_level is None else int(max_level * n_freqs)
+    parts = [x]
+    for i in range(keep):
+        parts += [torch.sin(x * float(2 ** i)), torch.cos(x * float(2 ** i))]
+    if keep < n_freqs:
+        parts.append(x.new_zeros(*x.shape[:-1], (n_freqs - keep) * 2 * x.shape[-1]))
+    return torch.cat(parts, -1)
+
+
+# ------------------------------------------------------------------------------------ the model
+class scene_representation(nn.Module):
+    def __init__(self, config, bound, max_level=None, num_layers=3, num_layers_t=6, hidden_dim=64, hidden_dim_t=128,
+                 hidden_dim_tpo=128, num_layers_bg=2, geo_dim=32, deform_dim=16, hidden_dim_bg=32, amb_dim=2,
+                 num_frames=None, use_app=False, use_t=False, color_grid=True, use_joint=False, encode_topo=False,
+                 encode_deform=True):
+        super().__init__()
+        if use_app or use_t or encode_topo or not color_grid or not use_joint or not encode_deform:
+            raise NotImplementedError("fused HIP path covers the shipped configuration only: use_t=False, "
+                                      "use_app=False, use_joint=True, color_grid=True, encode_topo=False")
+        if (num_layers, num_layers_t, hidden_dim, hidden_dim_t, hidden_dim_tpo, geo_dim, deform_dim, amb_dim) != \
+                (3, 6, 64, 128, 128, 32, 16, 2):
+            raise NotImplementedError("kernel geometry is fixed to the reference defaults (model.py:36-44)")
+        self.config, self.bound, self.max_level = config, float(bound), max_level
+        self.num_layers, self.hidden_dim, self.geo_dim, self.num_frames = num_layers, hidden_dim, geo_dim, num_frames
+        self.use_t, self.use_app, self.use_joint = use_t, use_app, use_joint
+        self.encode_topo, self.encode_deform = encode_topo, encode_deform
+        self.in_dim_t, self.in_dim_amb, self.in_dim_deform, self.in_dim_xyz = 0, amb_dim, 39, 39
+        self.deform_dim, self.app_dim = 3 * deform_dim, 0
+        self.encoder_t = self.encoder_topo = self.app_code = None
+
+        self.pose_array = PoseArray(num_frames)
+        self.deform_code = MultiCode([num_frames // 8, num_frames // 4, num_frames], deform_dim)
+        self.deform_net = MLP(self.in_dim_deform + self.deform_dim, 3, hidden_dim_t, num_layers_t)
+        self.topo_net = MLP(self.in_dim_deform + self.deform_dim, amb_dim, hidden_dim_tpo, num_layers_t)
+        self.encoder = GridEncoder()
+        self.encoder_c = GridEncoder()
+        self.in_dim = self.in_dim_c = self.encoder.output_dim
+        self.sdf_net = MLP(self.in_dim + self.in_dim_amb + self.in_dim_xyz, 1 + geo_dim, hidden_dim, num_layers,
+                           geo_init=True, geo_bias=0.4, weight_norm=False)
+        self.color_net = MLP(self.in_dim_c + geo_dim, 3, hidden_dim, num_layers)
+        if self.config["model"]["bg_radius"] > 0:
+            self.in_dim_bg, self.in_dim_bg_t = 39, 13
+            self.bg_net = MLP(self.in_dim_bg + self.in_dim_bg_t, 3, hidden_dim_bg, num_layers_bg)
+        self.sdf2density = LaplaceDensity(0.1)
+        self._frame_slots = None   # optional (t [M,1] object, t_unique [F], slot [M] int32) hint set by the renderer
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _n_bands(self) -> int:
+        return 6 if self.max_level is None else int(self.max_level * 6)
+
+    def _slots(self, t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """distinct frame times and per-sample slot ids.  The renderer supplies them without a host
+        sync (a batch row is one frame); otherwise fall back to torch.unique."""
+        if self._frame_slots is not None and self._frame_slots[0] is t:
+            return self._frame_slots[1], self._frame_slots[2]
+        tu, inv = torch.unique(t.reshape(-1), return_inverse=True)
+        return tu, inv.to(torch.int32)
+
+    def _warp_params(self, net: MLP):
+        w, b = net.weights(), net.biases()
+        return [w[0][:, :39]] + w[1:] + b, w[0][:, 39:], b[0]
+
+    # -- public API (names/signatures of the reference) ----------------------------------------
+    def get_deform_code(self, t, app=False):
+        if app:
+            raise NotImplementedError("use_app=False in every shipped config")
+        return self.deform_code.sample(t)
+
+    def get_RT(self, frame_ids):
+        ids = frame_ids.squeeze()
+        return self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)
+
+    def pose_optimisation(self, rays_o, rays_d, frame_ids):
+        ids = frame_ids.squeeze()
+        R, t = self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)
+        return rays_o + t, (rays_d[..., None, :] * R).sum(-1)
+
+    def warp(self, x, t):
+        """-> deform [M,3], topo [M,2], app_code (None)   (model.py:412-437)."""
+        tu, slot = self._slots(t)
+        code = self.deform_code.sample(tu[:, None])                       # [F,48], F = distinct frames
+        pd, wcode_d, b0_d = self._warp_params(self.deform_net)
+        pt, wcode_t, b0_t = self._warp_params(self.topo_net)
+        bias0_d = torch.addmm(b0_d, code, wcode_d.t())                    # per-frame first-layer bias
+        bias0_t = torch.addmm(b0_t, code, wcode_t.t())
+        deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), pd, pt)
+        return deform, topo, None
+
+    def get_topo(self, x, t):
+        return self.warp(x, t)[1]
+
+    def get_sigma_albedo(self, x, topo=None, app_code=None, return_color=True):
+        feat_s = self.encoder(x, bound=self.bound, max_level=self.max_level)
+        feat_c = self.encoder_c(x, bound=self.bound, max_level=self.max_level) if return_color else None
+        params = self.sdf_net.weights() + self.color_net.weights() + self.sdf_net.biases() + self.color_net.biases()
+        sdf, sigma, albedo = ops.field_mlp(x, feat_s, feat_c, topo, self.sdf2density.get_beta(), self._n_bands(),
+                                           return_color, params)
+        return sdf, sigma, (albedo if return_color else None)
+
+    def get_params_all(self, lr):
+        groups = [
+            {"name": "encoder_sdf", "params": self.encoder.parameters(), "lr": lr},
+            {"name": "encoder_color", "params": self.encoder_c.parameters(), "lr": lr},
+            {"name": "decoder_sdf", "params": self.sdf_net.parameters(), "lr": lr},
+            {"name": "decoder_topo", "params": self.topo_net.parameters(), "lr": lr},
+            {"name": "decoder_color", "params": self.color_net.parameters(), "lr": lr},
+            {"name": "density", "params": self.sdf2density.parameters(), "lr": lr / 2.0},
+            {"name": "decoder_deform", "params": self.deform_net.parameters(), "lr": lr},
+            {"name": "code_deform", "params": self.deform_code.parameters(), "lr": lr},
+            {"name": "pose", "params": self.pose_array.parameters(), "lr": lr / 10.0},
+        ]
+        if self.config["model"]["bg_radius"] > 0:
+            groups.append({"name": "decoder_bg", "params": self.bg_net.parameters(), "lr": lr})
+        return groups
+
+    def finite_difference_normal(self, x, epsilon=2e-3, topo=None):
+        """6 clamped taps of the SDF (model.py:367-385)."""
+        cols = []
+        for k in range(3):
+            e = x.new_zeros(1, 3)
+            e[0, k] = epsilon
+            sp = self.get_sigma_albedo((x + e).clamp(-self.bound, self.bound), topo=topo, return_color=False)[0]
+            sn = self.get_sigma_albedo((x - e).clamp(-self.bound, self.bound), topo=topo, return_color=False)[0]
+            cols.append(0.5 * (sp - sn) / epsilon)
+        return torch.stack(cols, -1)
+
+    def normal(self, x, t=None, cano=False, topo=None):
+        if t is not None and not cano:
+            deform, topo, _ = self.warp(x, t)
+            x = x + deform
+        raw = self.finite_difference_normal(x, topo=topo)
+        return torch.nan_to_num(safe_normalize(raw)), raw
+
+    def background(self, d, t):
+        h = torch.cat([_freq_encode_torch(d, 6, None), _freq_encode_torch(t, 6, self.max_level)], -1)
+        return torch.sigmoid(self.bg_net(h))
+
+    def density(self, x, t=None, cano=False, allow_shape=False, return_color=True):
+        topo = None
+        if not (cano or t is None):
+            if isinstance(t, float):
+                t = t * torch.ones(x.shape[0], 1, device=x.device)
+            if x.shape[0] != t.shape[0]:
+                if not allow_shape:
+                    raise Exception("Shape inconsistent!!!")
+                t = t[0, 0] * torch.ones(x.shape[0], 1, device=x.device)
+            deform, topo, _ = self.warp(x, t)
+            x = x + deform
+        sdf, sigma, albedo = self.get_sigma_albedo(x, topo=topo, return_color=return_color)
+        return {"sdf": sdf, "sigma": sigma, "albedo": albedo}
+
+    def forward(self, x, t, light_dir=None, ratio=1, shading="albedo", cano=False, return_color=True):
+        deform = topo = None
+        xc = x
+        if not cano:
+            deform, topo, _ = self.warp(x, t)
+            xc = x + deform
+        sdf, sigma, albedo = self.get_sigma_albedo(xc, topo, None, return_color)
+        if shading == "albedo":
+            return sdf, sigma, albedo, None, deform, None
+        normal, raw = self.normal(x, topo=topo)        # un-warped x, warped point's topo (model.py:515-521)
+        lam = ratio + (1 - ratio) * (normal * light_dir).sum(-1).clamp(min=0)
+        if shading == "textureless":
+            color = lam.unsqueeze(-1).repeat(1, 3)
+        elif shading == "normal":
+            color = (normal + 1) / 2
+        else:
+            color = albedo * lam.unsqueeze(-1)
+        return sdf, sigma, color, normal, deform, raw

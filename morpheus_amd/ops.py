@@ -1,0 +1,327 @@
+"""torch.autograd wrappers over the C ABI (include/morpheus_hip.h).
+
+Each Function allocates its outputs/workspaces as torch tensors (the reference's ownership model,
+external/encoders/gridencoder/grid.py:50,56,84,87), hands raw device pointers plus torch's CURRENT
+stream to libmorpheus_hip.so and returns.  There is no CPU or PyTorch fallback: a CPU tensor or a
+missing library raises MorpheusHipError.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_gpu, stream
+from .packing import field_packer, warp_packer
+
+WGRAD_CHUNKS = 256
+
+
+def _i32arr(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ------------------------------------------------------------------------------------ hash grid
+def level_resolutions(L: int, per_level_scale: float, base: int) -> np.ndarray:
+    """res_l = (uint32)ceil(exp2f(l*S)*H) in float32, S = (float)log2(per_level_scale)
+    (gridencoder.cu:133, grid.py:39).  Host-computed so no device libm is involved."""
+    S = np.float32(np.log2(per_level_scale))
+    l = np.arange(L, dtype=np.float32)
+    return np.ceil(np.exp2(l * S).astype(np.float32) * np.float32(base)).astype(np.int32)
+
+
+def effective_levels(max_level, L: int) -> int:
+    """grid.py:42."""
+    return L if max_level is None else max(min(int(math.ceil(max_level * L)), L), 1)
+
+
+class _GridEncode(torch.autograd.Function):
+    """grid.py:25-96 (_grid_encode) on the HIP kernels; no dy_dx tensor is materialised."""
+
+    @staticmethod
+    def forward(ctx, x, emb, offsets_np, res_np, n_levels, bound):
+        require_gpu(x, emb)
+        lib = _lib.load()
+        x = x.detach().contiguous().float()
+        embc = emb.detach().contiguous()
+        M, L = x.shape[0], len(res_np)
+        out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
+        o_np, o_p = _i32arr(offsets_np)
+        r_np, r_p = _i32arr(res_np)
+        check(lib.mh_grid_encode_fwd(ptr(x), ptr(embc), o_p, r_p, ptr(out), M, L, n_levels, float(bound), stream()),
+              "mh_grid_encode_fwd")
+        ctx.save_for_backward(x, embc)
+        ctx.meta = (o_np, r_np, n_levels, float(bound), L)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib = _lib.load()
+        x, emb = ctx.saved_tensors
+        o_np, r_np, n_levels, bound, L = ctx.meta
+        grad = grad.contiguous()
+        M = x.shape[0]
+        g_emb = torch.zeros_like(emb)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(lib.mh_grid_encode_bwd(ptr(grad), ptr(x), ptr(emb), o_np.ctypes.data_as(ctypes.c_void_p),
+                                     r_np.ctypes.data_as(ctypes.c_void_p), ptr(g_emb), ptr(g_x), M, L, n_levels, bound,
+                                     stream()), "mh_grid_encode_bwd")
+        return g_x, g_emb, None, None, None, None
+
+
+def grid_encode(x, emb, offsets_np, res_np, bound, max_level=None):
+    """x [..,3] in world units -> [.., L*2] (grid.py:152-169)."""
+    L = len(res_np)
+    lead = list(x.shape[:-1])
+    out = _GridEncode.apply(x.reshape(-1, 3), emb, offsets_np, res_np, effective_levels(max_level, L), bound)
+    return out.view(lead + [L * 2])
+
+
+# ------------------------------------------------------------------------------------ compositor
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigma, t_starts, t_ends, rgb, ray_start, ray_cnt):
+        require_gpu(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt)
+        lib = _lib.load()
+        sigma, t_starts, t_ends = sigma.detach().contiguous(), t_starts.contiguous(), t_ends.contiguous()
+        rgbc = rgb.detach().contiguous()
+        N, M = ray_start.shape[0], sigma.shape[0]
+        dev = sigma.device
+        weights = torch.empty(M, device=dev)
+        opacity, depth = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        color = torch.empty(N, 3, device=dev)
+        check(lib.mh_composite_fwd(ptr(sigma), ptr(t_starts), ptr(t_ends), ptr(rgbc), ptr(ray_start), ptr(ray_cnt),
+                                   ptr(weights), ptr(opacity), ptr(depth), ptr(color), N, stream()), "mh_composite_fwd")
+        ctx.save_for_backward(sigma, t_starts, t_ends, rgbc, ray_start, ray_cnt, weights)
+        return weights, opacity, depth, color
+
+    @staticmethod
+    def backward(ctx, g_w, g_o, g_d, g_c):
+        lib = _lib.load()
+        sigma, ts, te, rgb, ray_start, ray_cnt, weights = ctx.saved_tensors
+        N = ray_start.shape[0]
+        c = lambda t: None if t is None else t.contiguous()
+        d_sigma = torch.empty_like(sigma)
+        d_rgb = torch.empty_like(rgb)
+        check(lib.mh_composite_bwd(ptr(sigma), ptr(ts), ptr(te), ptr(rgb), ptr(ray_start), ptr(ray_cnt), ptr(weights),
+                                   ptr(c(g_w)), ptr(c(g_o)), ptr(c(g_d)), ptr(c(g_c)), ptr(d_sigma), ptr(d_rgb), N,
+                                   stream()), "mh_composite_bwd")
+        return d_sigma, None, None, d_rgb, None, None
+
+
+def composite(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt):
+    """-> weights [M], opacity [N], depth [N], color [N,3]  (morpheus.py:675-685)."""
+    return _Composite.apply(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt)
+
+
+def packed_info(ray_indices: torch.Tensor, n_rays: int):
+    """(ray_start, ray_cnt) int32 from sorted packed ray indices (no host sync)."""
+    cnt = torch.bincount(ray_indices, minlength=n_rays)
+    start = torch.cumsum(cnt, 0) - cnt
+    return start.to(torch.int32), cnt.to(torch.int32)
+
+
+# ------------------------------------------------------------------------------------ sampler / rays
+def generate_rays(fx, fy, cx, cy, c2w, H, W, device):
+    lib = _lib.load()
+    c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(4, 4))
+    o = torch.empty(H * W, 3, device=device)
+    d = torch.empty(H * W, 3, device=device)
+    require_gpu(o)
+    check(lib.mh_generate_rays(float(fx), float(fy), float(cx), float(cy), c2w.ctypes.data_as(ctypes.c_void_p), H, W,
+                               ptr(o), ptr(d), stream()), "mh_generate_rays")
+    return o, d
+
+
+def sample_uniform(rays_o, rays_d, jitter, S: int, bound: float, with_xyz: bool = False):
+    """-> ray_idx int32 [N*S], t_starts, t_ends, xyz|None, ray_start, ray_cnt (no_grad, like morpheus.py:628)."""
+    require_gpu(rays_o, rays_d, jitter)
+    lib = _lib.load()
+    o, d, j = rays_o.detach().contiguous(), rays_d.detach().contiguous(), jitter.contiguous()
+    N, dev = o.shape[0], o.device
+    ri = torch.empty(N * S, dtype=torch.int32, device=dev)
+    ts, te = torch.empty(N * S, device=dev), torch.empty(N * S, device=dev)
+    xyz = torch.empty(N * S, 3, device=dev) if with_xyz else None
+    rs, rc = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+    check(lib.mh_sample_uniform(ptr(o), ptr(d), ptr(j), N, S, float(bound), ptr(ri), ptr(ts), ptr(te), ptr(xyz), ptr(rs),
+                                ptr(rc), stream()), "mh_sample_uniform")
+    return ri, ts, te, xyz, rs, rc
+
+
+# ------------------------------------------------------------------------------------ fused MLPs
+def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev):
+    n_layers = len(act_off)
+    dw_len = int(sum(i * o for i, o in zip(in_pad, out_pad)))
+    db_len = int(sum(out_pad))
+    chunks = int(min(WGRAD_CHUNKS, max(1, n_tiles)))
+    dw_part = torch.empty(chunks, dw_len, device=dev)
+    db_part = torch.empty(chunks, db_len, device=dev)
+    a_np, a_p = _i32arr(act_off)
+    d_np, d_p = _i32arr(dpre_off)
+    i_np, i_p = _i32arr(in_pad)
+    o_np, o_p = _i32arr(out_pad)
+    check(lib.mh_mlp_wgrad(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(dw_part),
+                           ptr(db_part), chunks, n_tiles, stream()), "mh_mlp_wgrad")
+    return dw_part.sum(0), db_part.sum(0)
+
+
+WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640, 2 * 672
+FIELD_ACT_ROWS, FIELD_DPRE_ROWS = 96 + 64 * 5, 64 * 5 + 32
+
+
+class _WarpMLP(torch.autograd.Function):
+    """deform_net + topo_net on [freq(x), per-slot code bias]  (model.py:412-437).
+
+    params = 12 tensors per net, deform first:  W0x [128,39], W1..W4 [128,128], W5 [n_out,128],
+    b0 (unused here: it lives in bias0), b1..b4 [128], b5 [n_out]  -- natural, effective weights.
+    bias0_{d,t} [n_slots,128] = code_slot @ W0[:,39:].T + b0, built by the caller in torch so that
+    autograd carries the gradient on to the deform code, W0's code columns and b0.
+    """
+
+    @staticmethod
+    def forward(ctx, x, slot, bias0_d, bias0_t, n_bands, *params):
+        require_gpu(x, bias0_d, bias0_t, *params)
+        lib = _lib.load()
+        assert len(params) == 24
+        pd, pt_ = params[:12], params[12:]
+        pk_d, pk_t = warp_packer(3), warp_packer(2)
+        wd, wdT = pk_d.pack([p.detach() for p in pd[:6]])
+        wt, wtT = pk_t.pack([p.detach() for p in pt_[:6]])
+        bd = pk_d.pack_biases([p.detach() for p in pd[6:]], skip_first=True)
+        bt = pk_t.pack_biases([p.detach() for p in pt_[6:]], skip_first=True)
+        x = x.detach().contiguous().float()
+        M, dev = x.shape[0], x.device
+        need_grad = any(ctx.needs_input_grad)
+        acts = torch.empty(lib.mh_warp_acts_floats(M), device=dev) if need_grad else None
+        deform, topo = torch.empty(M, 3, device=dev), torch.empty(M, 2, device=dev)
+        b0d, b0t = bias0_d.detach().contiguous(), bias0_t.detach().contiguous()
+        slot_c = None if slot is None else slot.contiguous()
+        check(lib.mh_warp_fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(wd), ptr(wt), ptr(bd), ptr(bt), n_bands,
+                              ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
+        ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
+        ctx.n_bands, ctx.n_slots = n_bands, bias0_d.shape[0]
+        return deform, topo
+
+    @staticmethod
+    def backward(ctx, g_deform, g_topo):
+        lib = _lib.load()
+        x, slot, wdT, wtT, acts = ctx.saved_tensors
+        M, dev = x.shape[0], x.device
+        n_tiles = lib.mh_mlp_tiles(M)
+        dpre = torch.empty(lib.mh_warp_dpre_floats(M), device=dev)
+        g_x = torch.empty(M, 3, device=dev)
+        c = lambda t: None if t is None else t.contiguous()
+        check(lib.mh_warp_bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts),
+                                   ptr(dpre), ptr(g_x), M, stream()), "mh_warp_bwd_data")
+        act_off, dpre_off, in_pad, out_pad = [], [], [], []
+        for net in range(2):
+            for l in range(6):
+                act_off.append(0 if l == 0 else (64 + net * 640 + (l - 1) * 128) * 32)
+                dpre_off.append((net * 672 + l * 128) * 32)
+                in_pad.append(64 if l == 0 else 128)
+                out_pad.append(32 if l == 5 else 128)
+        dw_raw, db_raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, act_off, dpre_off, in_pad,
+                                out_pad, n_tiles, dev)
+        pk_d, pk_t = warp_packer(3), warp_packer(2)
+        gw_d, gb_d = pk_d.unpack_grads(dw_raw[:pk_d.raw_dw], db_raw[:pk_d.raw_db])
+        gw_t, gb_t = pk_t.unpack_grads(dw_raw[pk_d.raw_dw:], db_raw[pk_d.raw_db:])
+        # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
+        if ctx.n_slots == 1:
+            g_b0d, g_b0t = gb_d[0][None], gb_t[0][None]
+        else:
+            dp = dpre.view(n_tiles, WARP_DPRE_ROWS, 32)
+            per_pt_d = dp[:, 0:128, :].permute(0, 2, 1).reshape(-1, 128)[:M]
+            per_pt_t = dp[:, 672:800, :].permute(0, 2, 1).reshape(-1, 128)[:M]
+            idx = slot.long()
+            g_b0d = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_d)
+            g_b0t = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_t)
+        zero_b0 = lambda g: torch.zeros_like(g)   # b0 itself gets its gradient through bias0
+        grads_d = gw_d + [zero_b0(gb_d[0])] + gb_d[1:]
+        grads_t = gw_t + [zero_b0(gb_t[0])] + gb_t[1:]
+        return (g_x, None, g_b0d, g_b0t, None, *grads_d, *grads_t)
+
+
+def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, params_d: Sequence[torch.Tensor], params_t: Sequence[torch.Tensor]):
+    return _WarpMLP.apply(x, slot, bias0_d, bias0_t, n_bands, *params_d, *params_t)
+
+
+class _FieldMLP(torch.autograd.Function):
+    """sdf_net (+Laplace density) and color_net on [freq(xc), hash, topo] / [hash_c, geo]
+    (model.py:273-307, density.py:22-31).
+
+    params: Ws0 [64,73], Ws1 [64,64], Ws2 [33,64], Wc0 [64,64], Wc1 [64,64], Wc2 [3,64],
+            bs0, bs1, bs2, bc0, bc1, bc2   (natural, effective weights)
+    beta: 0-dim device tensor = |beta_param| + 1e-4 (stays on the device: no host sync).
+    """
+
+    @staticmethod
+    def forward(ctx, xc, feat_s, feat_c, topo, beta, n_bands, with_color, *params):
+        require_gpu(xc, feat_s, feat_c, topo, beta, *params)
+        lib = _lib.load()
+        assert len(params) == 12
+        pk = field_packer()
+        w, wT = pk.pack([p.detach() for p in params[:6]])
+        b = pk.pack_biases([p.detach() for p in params[6:]], skip_first=False)
+        xc = xc.detach().contiguous().float()
+        M, dev = xc.shape[0], xc.device
+        fs = feat_s.detach().contiguous()
+        fc = None if feat_c is None else feat_c.detach().contiguous()
+        tp = None if topo is None else topo.detach().contiguous()
+        beta_c = beta.detach().reshape(1).contiguous().float()
+        need_grad = any(ctx.needs_input_grad)
+        acts = torch.empty(lib.mh_field_acts_floats(M), device=dev) if need_grad else None
+        sdf, sigma = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        albedo = torch.empty(M, 3, device=dev) if with_color else None
+        check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands,
+                               int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()),
+              "mh_field_fwd")
+        ctx.save_for_backward(xc, wT, beta_c, acts, sdf, albedo)
+        ctx.cfg = (n_bands, bool(with_color), topo is not None, feat_c is not None)
+        if albedo is None:
+            albedo = torch.zeros(0, device=dev)
+            ctx.mark_non_differentiable(albedo)
+        return sdf, sigma, albedo
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_sigma, g_albedo):
+        lib = _lib.load()
+        xc, wT, beta_c, acts, sdf, albedo = ctx.saved_tensors
+        n_bands, with_color, has_topo, has_fc = ctx.cfg
+        M, dev = xc.shape[0], xc.device
+        n_tiles = lib.mh_mlp_tiles(M)
+        dpre = torch.empty(lib.mh_field_dpre_floats(M), device=dev)
+        if not with_color:
+            g_albedo = None   # colour rows of the scratch are neither written nor read on this path
+        g_xc = torch.empty(M, 3, device=dev)
+        g_fs = torch.empty(M, 32, device=dev)
+        g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
+        g_tp = torch.empty(M, 2, device=dev)
+        g_bp = torch.empty(n_tiles, device=dev)
+        c = lambda t: None if t is None else t.contiguous()
+        check(lib.mh_field_bwd_data(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)),
+                                    ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color),
+                                    ptr(acts), ptr(dpre), ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), M,
+                                    stream()), "mh_field_bwd_data")
+        pk = field_packer()
+        act_rows = [0, 96, 160, 224, 288, 352]
+        dpre_rows = [0, 64, 128, 192, 256, 320]
+        n_l = 6 if with_color else 3
+        dw_raw, db_raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32,
+                                [r * 32 for r in act_rows[:n_l]], [r * 32 for r in dpre_rows[:n_l]], pk.wg_in[:n_l],
+                                pk.wg_out[:n_l], n_tiles, dev)
+        if not with_color:
+            dw_raw = torch.cat([dw_raw, dw_raw.new_zeros(pk.raw_dw - dw_raw.numel())])
+            db_raw = torch.cat([db_raw, db_raw.new_zeros(pk.raw_db - db_raw.numel())])
+        gw, gb = pk.unpack_grads(dw_raw, db_raw)
+        g_beta = g_bp.sum().reshape(())
+        return (g_xc, g_fs, g_fc, g_tp if has_topo else None, g_beta, None, None, *gw, *gb)
+
+
+def field_mlp(xc, feat_s, feat_c, topo, beta, n_bands, with_color, params: Sequence[torch.Tensor]):
+    """-> sdf [M], sigma [M], albedo [M,3] (empty when with_color is False)."""
+    return _FieldMLP.apply(xc, feat_s, feat_c, topo, beta, n_bands, with_color, *params)

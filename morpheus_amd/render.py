@@ -1,0 +1,217 @@
+"""`render_rays` with the reference's signature and result keys (morpheus.py:558-794).
+
+`HotPathRenderer` plays the role of the `self` that MorpheuS.render_rays closes over: it owns
+`model` (scene_representation), `config` (the YAML dict), `occupancy_grid` (anything with a
+nerfacc-style `.sampling(rays_o, rays_d, ...) -> (ray_indices, t_starts, t_ends)`) and
+`num_frames`.  A maintainer wires it into morpheus.py by delegating MorpheuS.render_rays to
+`HotPathRenderer.render_rays`.
+
+Covered: the eval outputs (image, depth, sdf, weights, weights_sum, normal, deform, normal_raw) and
+the deterministic training extras (loss_orient, loss_code, sdf_loss, fs_loss, normal_image).  The
+randomised regularisers of morpheus.py:714-783 (normal perturbation / smoothness) reuse the same
+model entry points and are implemented here on top of them.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .model import safe_normalize, scene_representation
+
+
+class UniformSampler:
+    """Benchmark sampler of SURVEY 8(d) behind nerfacc's `.sampling` call shape: S equal bins per
+    ray inside the AABB with one stratified jitter per ray (csrc/sampler.hip)."""
+
+    def __init__(self, n_samples: int, bound: float, jitter: Optional[torch.Tensor] = None):
+        self.n_samples, self.bound, self.jitter = n_samples, float(bound), jitter
+        self.packed = None
+
+    def sampling(self, rays_o, rays_d, sigma_fn=None, render_step_size=None, alpha_thre=0, stratified=True,
+                 cone_angle=0.0, early_stop_eps=0):
+        n = rays_o.shape[0]
+        if self.jitter is not None:
+            u = self.jitter
+        elif stratified:
+            u = torch.rand(n, device=rays_o.device)
+        else:
+            u = torch.full((n,), 0.5, device=rays_o.device)
+        ri, ts, te, _, rs, rc = ops.sample_uniform(rays_o, rays_d, u, self.n_samples, self.bound)
+        self.packed = (rs, rc)
+        return ri, ts, te
+
+
+class PresetSampler:
+    """Feeds fixed packed samples (parity runs treat samples as inputs)."""
+
+    def __init__(self, ray_indices, t_starts, t_ends):
+        self.samples = (ray_indices, t_starts, t_ends)
+        self.packed = None
+
+    def sampling(self, rays_o, rays_d, **kw):
+        return self.samples
+
+
+def sdf_losses(z_vals, target_d, pred_sdf, trunc, mask=None):
+    """Free-space and near-surface SDF losses on packed samples (utils.py:91-113)."""
+    pred = pred_sdf[..., None]
+    depth_mask = target_d > 0.0
+    front = (z_vals < (target_d - trunc)) | ((target_d < 0.0) & (z_vals < 3.5))
+    bnd = target_d - z_vals
+    bnd = torch.where((target_d[:, 0] < 0.0)[:, None], torch.full_like(bnd, 10.0), bnd)
+    smask = (bnd.abs() <= trunc) & depth_mask
+    if mask is not None:
+        smask = smask & (mask > 0.5)
+    n = front.sum(-1) + smask.sum(-1) + 1e-8
+    nd = torch.count_nonzero(target_d)
+    fs = torch.max(torch.exp(-5.0 * pred) - 1.0, pred - bnd).clamp(min=0.0) * front
+    fs = (fs.sum(-1) / n).sum() / nd
+    sl = ((torch.abs(pred - bnd) * smask).sum(-1) / n).sum() / nd
+    return fs, sl
+
+
+class HotPathRenderer:
+    def __init__(self, model: scene_representation, config: dict, occupancy_grid, num_frames: int,
+                 frame_batched: bool = True):
+        self.model, self.config, self.occupancy_grid, self.num_frames = model, config, occupancy_grid, num_frames
+        # frame_batched: each row of the [B, N, .] ray tensors is ONE frame (how the reference's dataset
+        # builds every batch) -> per-frame deform-code bias without a host sync.
+        self.frame_batched = frame_batched
+
+    # -- helpers of morpheus.py:518-556
+    def get_ortho_normal_dir(self, normals):
+        n = torch.nn.functional.normalize(normals, dim=-1)
+        u = torch.nn.functional.normalize(n[..., [1, 0, 2]] * torch.tensor([1.0, -1.0, 0.0], device=n.device), dim=-1)
+        v = torch.cross(n, u, dim=-1)
+        phi = torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
+        return torch.cos(phi) * u + torch.sin(phi) * v
+
+    def get_normal_smoothness_loss(self, rays_o, rays_d, rays_t, depth):
+        trunc = self.config["train"]["trunc"]
+        npts = int(trunc * 100 + 1)
+        off = torch.linspace(-0.5 * trunc, 0.5 * trunc, npts)
+        off = off + 0.01 * torch.rand_like(off)
+        pts = (depth + off[:, None].to(depth))[..., None] * rays_d[None] + rays_o[None]
+        pts = pts.view(-1, 3)
+        tt = rays_t[None].repeat(npts, 1, 1).view(-1, 1)
+        keep = torch.linalg.norm(pts, ord=2, dim=-1) < 1.1
+        pts, tt = pts[keep], tt[keep]
+        n1, _ = self.model.normal(pts, t=tt)
+        w = self.get_ortho_normal_dir(n1)
+        n2, _ = self.model.normal(pts + w * self.config["train"]["smoothness_std"], t=tt)
+        return torch.mean(torch.square(n1 - n2))
+
+    # -- the hot path
+    def render_rays(self, rays_o, rays_d, rays_t, rays_id, H, W, perturb=True, bg_color=None, ambient_ratio=1.0,
+                    light_d=None, shading="albedo", real_view=True, cano=False, rays_depth=None, rays_mask=None,
+                    optimize_pose=False):
+        model, cfg = self.model, self.config
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        rays_t = rays_t.contiguous().view(-1, 1)
+        rays_id = rays_id.contiguous().view(-1, 1)
+        if not cano and optimize_pose:
+            rays_o, rays_d = model.pose_optimisation(rays_o, rays_d, rays_id)
+        if rays_depth is not None:
+            rays_depth = rays_depth.contiguous().view(-1, 1)
+        if rays_mask is not None:
+            rays_mask = rays_mask.contiguous().view(-1, 1)
+        N = rays_o.shape[0]
+        results = {}
+
+        with torch.no_grad():
+            ray_indices, t_starts_, t_ends_ = self.occupancy_grid.sampling(
+                rays_o, rays_d, sigma_fn=None, render_step_size=cfg["render"]["step_size"], alpha_thre=0,
+                stratified=True, cone_angle=0.0, early_stop_eps=0)
+        if light_d is None:
+            light_d = safe_normalize(rays_o + torch.randn(3, device=rays_o.device))
+        ray_indices = ray_indices.long()
+        t_starts, t_ends = t_starts_[..., None], t_ends_[..., None]
+        t_positions = (t_starts + t_ends) / 2.0
+        xyzs = rays_o[ray_indices] + rays_d[ray_indices] * t_positions
+        time_step = rays_t[ray_indices]
+        t_dirs = safe_normalize(rays_d[ray_indices])
+
+        if xyzs.shape[0] == 0:
+            # the reference falls into a NameError here; return the white image it intended
+            results.update(image=torch.ones([*prefix, 3], device=rays_o.device),
+                           depth=torch.zeros([*prefix], device=rays_o.device), sdf=None, weights=None,
+                           weights_sum=None, normal=None, deform=None, normal_raw=None)
+            return results
+
+        # per-frame deform-code slots without a device->host sync
+        if not cano and self.frame_batched and len(prefix) == 2:
+            B, n_per = prefix
+            slot_ray = torch.arange(B, device=rays_o.device, dtype=torch.int32).repeat_interleave(n_per)
+            model._frame_slots = (time_step, rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray[ray_indices].contiguous())
+        try:
+            sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, light_d[ray_indices],
+                                                                   ratio=ambient_ratio, shading=shading, cano=cano)
+        finally:
+            model._frame_slots = None
+
+        packed = getattr(self.occupancy_grid, "packed", None)
+        ray_start, ray_cnt = packed if packed is not None else ops.packed_info(ray_indices, N)
+        weights, opacity, depth, rgb_acc = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), rgbs,
+                                                         ray_start, ray_cnt)
+        opacity, depth = opacity[:, None], depth[:, None]
+        if bg_color is None:
+            if cfg["model"]["bg_radius"] > 0 and cano and (not real_view):
+                bg_color = model.background(rays_d, rays_t)
+            else:
+                bg_color = 1
+        image = (rgb_acc + (1 - opacity) * bg_color).view(*prefix, 3)
+        depth = depth.view(*prefix)
+        results.update(image=image, depth=depth, sdf=sdf, weights=weights, weights_sum=opacity, normal=normals,
+                       deform=deform, normal_raw=normal_raw)
+
+        if model.training:
+            tr = cfg["train"]
+            if tr["ori_weight"] > 0 and normals is not None and (not real_view):
+                lo = weights.detach() * (normals * t_dirs).sum(-1).clamp(min=0) ** 2
+                results["loss_orient"] = lo.sum(-1).mean()
+            if tr["normal_smooth_3d"] > 0 and normals is not None:
+                if tr["normal_dir"]:
+                    xyzs_p = xyzs + self.get_ortho_normal_dir(normals) * tr["smoothness_std"]
+                else:
+                    xyzs_p = xyzs + torch.randn_like(xyzs) * tr["smoothness_std"]
+                if tr["topo_none"]:
+                    normals_p, _ = model.normal(xyzs_p, topo=None, cano=cano)
+                else:
+                    normals_p, _ = model.normal(xyzs_p, topo=model.get_topo(xyzs_p, t=time_step), cano=cano)
+                results["loss_normal_perturb"] = (normals - normals_p).abs().mean()
+                if tr["normal_smooth_3d_t"] > 0:
+                    tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
+                    normals_pt, _ = model.normal(xyzs, topo=model.get_topo(xyzs, t=tt), cano=cano)
+                    results["loss_normal_perturb_t"] = (normals - normals_pt).abs().mean()
+                if tr["deform_smooth"] > 0 and not cano:
+                    deform_p, _, _ = model.warp(xyzs_p, t=time_step)
+                    results["loss_deform_perturb"] = (deform - deform_p).abs().mean()
+            if (tr["deform_smooth_t"] > 0 or tr["topo_smooth_t"] > 0) and not cano:
+                tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
+                deform_pt, topo_pt, _ = model.warp(xyzs, t=tt)
+                topo_now = model.get_topo(xyzs, t=time_step)      # the reference reads an undefined `topo` here
+                results["loss_deform_perturb_t"] = (deform - deform_pt).abs().mean()
+                results["loss_topo_perturb_t"] = (topo_now - topo_pt).abs().mean()
+            if tr["code_reg"] > 0 and not cano:
+                t0 = time_step[:1]
+                code = model.get_deform_code(t0)
+                cp = model.get_deform_code(t0 - 1 / self.num_frames)
+                cn = model.get_deform_code(t0 + 1 / self.num_frames)
+                results["loss_code"] = torch.square(2 * code - cp - cn).mean()
+            if tr["normal_smooth_2d"] > 0 and normals is not None and (not real_view):
+                _, _, _, nimg = ops.composite(sigmas.detach(), t_starts_.contiguous(), t_ends_.contiguous(),
+                                              (normals + 1) / 2, ray_start, ray_cnt)
+                results["normal_image"] = nimg
+            if tr["normal_smoothness"] > 0:
+                results["normal_reg"] = self.get_normal_smoothness_loss(rays_o, rays_d, rays_t, depth)
+            if rays_depth is not None:
+                t_gt = rays_depth[ray_indices]
+                t_mask = None if rays_mask is None else rays_mask[ray_indices]
+                fs_loss, sdf_loss = sdf_losses(t_positions, t_gt, sdf, tr["trunc"], mask=t_mask)
+                results["sdf_loss"], results["fs_loss"] = sdf_loss, fs_loss
+        return results

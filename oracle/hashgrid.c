@@ -20,6 +20,10 @@
  * align_corners = False, gridtype = hash: the only configuration the model
  * instantiates (models/model.py:144-157).
  *
+ * Arithmetic follows what nvcc emits for the reference kernel under its default -fmad=true:
+ * `u*res - 0.5` and the `+= w * value` accumulations are single-rounding FMAs (explicit fmaf
+ * here and in csrc/hashgrid.hip, with contraction otherwise disabled on both sides).
+ *
  * Per-level resolutions are supplied by the caller (host-computed float32
  * ceil(exp2f(l*S)*H), gridencoder.cu:133) so that oracle and HIP kernel share
  * one table instead of two libm's.
@@ -63,7 +67,7 @@ void oracle_grid_forward(const float *u, const float *emb, const int32_t *offset
             float pos[3];
             uint32_t pg[3];
             for (int d = 0; d < 3; d++) {
-                float p = fminf(fmaxf(x[d] * (float)res - 0.5f, 0.0f), (float)(res - 1));
+                float p = fminf(fmaxf(fmaf(x[d], (float)res, -0.5f), 0.0f), (float)(res - 1));
                 pg[d] = (uint32_t)floorf(p);
                 pos[d] = p - (float)pg[d];
             }
@@ -81,7 +85,7 @@ void oracle_grid_forward(const float *u, const float *emb, const int32_t *offset
                     }
                 }
                 uint32_t row = og_index(T, res, pl);
-                for (int c = 0; c < C; c++) o[c] += w * g[(size_t)row * C + c];
+                for (int c = 0; c < C; c++) o[c] = fmaf(w, g[(size_t)row * C + c], o[c]);
             }
             if (dydx) {
                 float *dd = dydx + ((b * L + l) * 3) * C;
@@ -147,7 +151,7 @@ void oracle_grid_backward(const float *grad, const float *u, const int32_t *offs
             float pos[3];
             uint32_t pg[3];
             for (int d = 0; d < 3; d++) {
-                float p = fminf(fmaxf(x[d] * (float)res - 0.5f, 0.0f), (float)(res - 1));
+                float p = fminf(fmaxf(fmaf(x[d], (float)res, -0.5f), 0.0f), (float)(res - 1));
                 pg[d] = (uint32_t)floorf(p);
                 pos[d] = p - (float)pg[d];
             }

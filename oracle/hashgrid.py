@@ -28,7 +28,7 @@ def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "hashgrid.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fopenmp", "-shared",
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-mfma", "-fopenmp", "-shared",
                                "-fPIC", "-o", _SO, src, "-lm"])
     return _SO
 

@@ -69,7 +69,7 @@ def test_model_forward_modes(kind):
                 f = of.OracleField(p, 1.01, ml)
                 sdf, sig, col, nrm, dfm, raw = f.forward(x, t, light, ratio=0.3, shading=shading, cano=cano)
                 key = f"{kind}_{ml_tag}_{shading}_{'cano' if cano else 'deform'}"
-                assert_close(sdf, g[key + "|sdf"], TOL, key + " sdf")
+                assert_close(sdf, g[key + "|sdf"], TOL, key + " sdf", floor=1e-2)
                 assert_close(sig, g[key + "|sigma"], 5e-4, key + " sigma (exp(-sdf/beta): x10 gain on sdf round-off)")
                 assert_close(col, g[key + "|color"], TOL if shading == "albedo" else 3e-3, key + " color")
                 if nrm is not None:
