@@ -60,6 +60,24 @@ int mh_grid_encode_bwd(const float *grad, const float *x, const float *emb,
                        const int32_t *offsets_host, const int32_t *res_host, float *grad_emb,
                        float *grad_x, int64_t M, int32_t L, int32_t n_levels, float bound, void *stream);
 
+/* Brick-binned backward (the fast path; same results as mh_grid_encode_bwd up to summation order).
+ * mh_grid_bin_points counting-sorts the points into 16^3 spatial bricks of the box:
+ *   workspace: int32[mh_grid_bin_workspace_ints()] scratch; perm: int32[M] point ids grouped by brick
+ *   (out-of-box points last); brick_start: int32[mh_grid_bin_index_ints()] = offsets into perm followed
+ *   by the work-item table (bricks holding more than 1024 points are split over several workgroups).
+ * One binning serves every encoder evaluated at the same x (sdf and colour tables).
+ * mh_grid_encode_bwd_binned: one workgroup per brick accumulates all levels in LDS, then flushes the
+ * touched vertices with one global atomic each. L must be 16. grad_x (optional) is fully written. */
+int64_t mh_grid_bin_workspace_ints(void);
+int32_t mh_grid_bin_bricks(void);
+int32_t mh_grid_bin_index_ints(void);
+int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_t *workspace, int32_t *perm,
+                       int32_t *brick_start, void *stream);
+int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *emb,
+                              const int32_t *offsets_host, const int32_t *res_host, const int32_t *perm,
+                              const int32_t *brick_start, float *grad_emb, float *grad_x, int64_t M,
+                              int32_t L, int32_t n_levels, float bound, void *stream);
+
 /* ---- packed transmittance compositor -------------------------------------------------------
  * Samples of ray r are the contiguous range [ray_start[r], ray_start[r]+ray_cnt[r]) of the packed
  * arrays, ordered by t.  w_i = exp(-sum_{j<i} sigma_j dt_j) * (1 - exp(-sigma_i dt_i)).

@@ -19,6 +19,11 @@ _SIGS = {
     "mh_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mh_grid_encode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_grid_encode_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
+    "mh_grid_bin_workspace_ints": (_I64, []),
+    "mh_grid_bin_bricks": (_I32, []),
+    "mh_grid_bin_index_ints": (_I32, []),
+    "mh_grid_bin_points": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P, _P]),
+    "mh_grid_encode_bwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_composite_fwd": (ctypes.c_int, [_P] * 10 + [_I32, _P]),
     "mh_composite_bwd": (ctypes.c_int, [_P] * 13 + [_I32, _P]),
     "mh_generate_rays": (ctypes.c_int, [_F, _F, _F, _F, _P, _I32, _I32, _P, _P, _P]),

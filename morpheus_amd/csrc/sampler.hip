@@ -6,11 +6,14 @@
 // benchmark sampler of SURVEY 8(d); definition shared with oracle/field.py:uniform_samples:
 //   slab clip to [-bound,bound]^3 -> [t_near>=0, t_far];  dt = (t_far - t_near) / (S+1);
 //   ts_i = t_near + (i + u) * dt;  te_i = t_near + (i + 1 + u) * dt;   misses -> zero-width samples.
-// Arithmetic uses explicit round-to-nearest mul/add/div (no FMA contraction) so the packed
+// Arithmetic is un-contracted round-to-nearest mul/add/div (no FMA) so the packed
 // samples are bit-identical to the oracle's -- samples are *inputs* to every parity test.
 #include "common.h"
 
-// HIP's __fadd_rn/__fmul_rn are plain operators; without this the compiler fuses them into FMAs.
+// No FMA contraction in this file: every mul/add/div below is a separate IEEE round-to-nearest
+// operation, exactly the sequence torch executes on the CPU for the oracle.  (HIP's __fadd_rn /
+// __fmul_rn are inline header functions compiled BEFORE this pragma and still get fused, so
+// plain operators are used instead.)
 #pragma clang fp contract(off)
 
 struct Pose {
@@ -23,13 +26,12 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(float fx, float fy, 
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * W) return;
     const int j = idx / W, i = idx - j * W;
-    const float d0 = __fdiv_rn(__fsub_rn(__fadd_rn((float)i, 0.5f), cx), fx);
-    const float d1 = -__fdiv_rn(__fsub_rn(__fadd_rn((float)j, 0.5f), cy), fy);
+    const float d0 = (((float)i + 0.5f) - cx) / fx;
+    const float d1 = -((((float)j + 0.5f) - cy) / fy);
     const float d2 = -1.0f;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        float v = __fadd_rn(__fadd_rn(__fmul_rn(d0, pose.r[a * 3 + 0]), __fmul_rn(d1, pose.r[a * 3 + 1])),
-                            __fmul_rn(d2, pose.r[a * 3 + 2]));
+        float v = (d0 * pose.r[a * 3 + 0] + d1 * pose.r[a * 3 + 1]) + d2 * pose.r[a * 3 + 2];
         rays_d[idx * 3 + a] = v;
         rays_o[idx * 3 + a] = pose.t[a];
     }
@@ -51,8 +53,8 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(const float *__rest
     for (int a = 0; a < 3; a++) {
         o[a] = rays_o[r * 3 + a];
         d[a] = rays_d[r * 3 + a];
-        const float ta = __fdiv_rn(__fsub_rn(-bound, o[a]), d[a]);
-        const float tb = __fdiv_rn(__fsub_rn(bound, o[a]), d[a]);
+        const float ta = (-bound - o[a]) / d[a];
+        const float tb = (bound - o[a]) / d[a];
         tmin = fmaxf(tmin, fminf(ta, tb));
         tmax = fminf(tmax, fmaxf(ta, tb));
     }
@@ -62,17 +64,17 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(const float *__rest
         tmin = 0.f;
         tmax = 0.f;
     }
-    const float dt = __fdiv_rn(__fsub_rn(tmax, tmin), (float)(S + 1));
+    const float dt = (tmax - tmin) / (float)(S + 1);
     const float u = jitter[r];
-    const float ts = __fadd_rn(tmin, __fmul_rn(__fadd_rn((float)i, u), dt));
-    const float te = __fadd_rn(tmin, __fmul_rn(__fadd_rn(__fadd_rn((float)i, 1.0f), u), dt));
+    const float ts = tmin + ((float)i + u) * dt;
+    const float te = tmin + (((float)i + 1.0f) + u) * dt;
     ray_idx[gid] = r;
     t_starts[gid] = ts;
     t_ends[gid] = te;
     if (xyz) {
-        const float tm = __fdiv_rn(__fadd_rn(ts, te), 2.0f);
+        const float tm = (ts + te) / 2.0f;
 #pragma unroll
-        for (int a = 0; a < 3; a++) xyz[gid * 3 + a] = __fadd_rn(o[a], __fmul_rn(d[a], tm));
+        for (int a = 0; a < 3; a++) xyz[gid * 3 + a] = o[a] + d[a] * tm;
     }
     if (i == 0) {
         ray_start[r] = (int32_t)((int64_t)r * S);

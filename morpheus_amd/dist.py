@@ -1,0 +1,80 @@
+"""Data-parallel ray sharding: one process per GPU, replicated parameters, ONE all-reduce per step.
+
+The reference has no distributed code at all; this is the build's addition.  Rays (or
+frames) are independent given the parameters, so the only exchange on the path is the gradient sum.
+All gradients live in ONE flat fp32 bucket (~1.86 M elements = 7.45 MB for the snoopy model: two
+3.2 MB hash tables + MLPs + codes + poses); `p.grad` are views into it, so backward accumulates in
+place and a single RCCL all-reduce over xGMI moves everything -- at this size the collective is
+latency-bound (~13 MB per GPU on a ring), which is why it is one call and not one per parameter.
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT) -> (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class GradBucket:
+    """Flat gradient bucket with `p.grad` views; `allreduce_mean()` is the whole exchange step."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def rebind(self):
+        """Re-attach views (call if something replaced p.grad, e.g. zero_grad(set_to_none=True))."""
+        o = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat[o:o + p.numel()].data_ptr():
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def allreduce_mean(self):
+        if not getattr(self, "_checked", False):
+            # autograd accumulates in place into an existing .grad; verify once that the views held
+            o = 0
+            for p in self.params:
+                assert p.grad is not None and p.grad.data_ptr() == self.flat[o:o + p.numel()].data_ptr(), \
+                    "a parameter's .grad was replaced; call rebind() after zero_grad(set_to_none=True)"
+                o += p.numel()
+            self._checked = True
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+
+def shard_rays(n_rays: int, rank: int, world: int):
+    """Contiguous block of a frame's rays for this rank (single-frame strong split)."""
+    per = (n_rays + world - 1) // world
+    lo = min(rank * per, n_rays)
+    return lo, min(lo + per, n_rays)

@@ -284,8 +284,13 @@ class scene_representation(nn.Module):
         return self.warp(x, t)[1]
 
     def get_sigma_albedo(self, x, topo=None, app_code=None, return_color=True):
-        feat_s = self.encoder(x, bound=self.bound, max_level=self.max_level)
-        feat_c = self.encoder_c(x, bound=self.bound, max_level=self.max_level) if return_color else None
+        if return_color:
+            # both tables share the sample points: one autograd node, one brick binning in backward
+            feat_s, feat_c = ops.grid_encode_multi(x, (self.encoder.embeddings, self.encoder_c.embeddings),
+                                                   self.encoder._offsets_np, self.encoder._res_np, self.bound,
+                                                   self.max_level)
+        else:
+            feat_s, feat_c = self.encoder(x, bound=self.bound, max_level=self.max_level), None
         params = self.sdf_net.weights() + self.color_net.weights() + self.sdf_net.biases() + self.color_net.biases()
         sdf, sigma, albedo = ops.field_mlp(x, feat_s, feat_c, topo, self.sdf2density.get_beta(), self._n_bands(),
                                            return_color, params)

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -19,6 +20,39 @@ from ._lib import check, ptr, require_gpu, stream
 from .packing import field_packer, warp_packer
 
 WGRAD_CHUNKS = 256
+
+
+class KernelTimer:
+    """Optional per-C-ABI-call timing with events recorded on the launch stream (torch's current
+    stream, which is the one handed to the library).  Used by bench.py for the roofline numbers."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self, enabled: bool):
+        self.enabled, self.records = enabled, {}
+
+    def start(self):
+        if not self.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name: str, e0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.setdefault(name, []).append((e0, e1))
+
+    def summary(self):
+        """name -> (calls, total_ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.records.items()}
+
+
+TIMER = KernelTimer()
 
 
 def _i32arr(a):
@@ -40,46 +74,96 @@ def effective_levels(max_level, L: int) -> int:
     return L if max_level is None else max(min(int(math.ceil(max_level * L)), L), 1)
 
 
+def _bin_points(lib, x, bound):
+    """Counting-sort the points into 16^3 bricks (shared by every table evaluated at x)."""
+    M, dev = x.shape[0], x.device
+    ws = torch.empty(lib.mh_grid_bin_workspace_ints(), dtype=torch.int32, device=dev)
+    perm = torch.empty(M, dtype=torch.int32, device=dev)
+    bstart = torch.empty(lib.mh_grid_bin_index_ints(), dtype=torch.int32, device=dev)
+    _e = TIMER.start()
+    check(lib.mh_grid_bin_points(ptr(x), M, bound, ptr(ws), ptr(perm), ptr(bstart), stream()), "mh_grid_bin_points")
+    TIMER.stop("mh_grid_bin_points", _e)
+    return perm, bstart
+
+
+GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B switch: per-point global atomics
+
+
 class _GridEncode(torch.autograd.Function):
-    """grid.py:25-96 (_grid_encode) on the HIP kernels; no dy_dx tensor is materialised."""
+    """grid.py:25-96 (_grid_encode) on the HIP kernels, for one or several tables evaluated at the
+    same points (sdf + colour encoders share x: one index computation pattern, one binning).
+    No dy_dx tensor is materialised; backward recomputes corner weights."""
 
     @staticmethod
-    def forward(ctx, x, emb, offsets_np, res_np, n_levels, bound):
-        require_gpu(x, emb)
+    def forward(ctx, x, offsets_np, res_np, n_levels, bound, *embs):
+        require_gpu(x, *embs)
         lib = _lib.load()
         x = x.detach().contiguous().float()
-        embc = emb.detach().contiguous()
         M, L = x.shape[0], len(res_np)
-        out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
         o_np, o_p = _i32arr(offsets_np)
         r_np, r_p = _i32arr(res_np)
-        check(lib.mh_grid_encode_fwd(ptr(x), ptr(embc), o_p, r_p, ptr(out), M, L, n_levels, float(bound), stream()),
-              "mh_grid_encode_fwd")
-        ctx.save_for_backward(x, embc)
+        outs, saved = [], []
+        for emb in embs:
+            embc = emb.detach().contiguous()
+            out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
+            _e = TIMER.start()
+            check(lib.mh_grid_encode_fwd(ptr(x), ptr(embc), o_p, r_p, ptr(out), M, L, n_levels, float(bound), stream()),
+                  "mh_grid_encode_fwd")
+            TIMER.stop("mh_grid_encode_fwd", _e)
+            outs.append(out)
+            saved.append(embc)
+        ctx.save_for_backward(x, *saved)
         ctx.meta = (o_np, r_np, n_levels, float(bound), L)
-        return out
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, *grads):
         lib = _lib.load()
-        x, emb = ctx.saved_tensors
+        x, *embs = ctx.saved_tensors
         o_np, r_np, n_levels, bound, L = ctx.meta
-        grad = grad.contiguous()
+        o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
         M = x.shape[0]
-        g_emb = torch.zeros_like(emb)
-        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        check(lib.mh_grid_encode_bwd(ptr(grad), ptr(x), ptr(emb), o_np.ctypes.data_as(ctypes.c_void_p),
-                                     r_np.ctypes.data_as(ctypes.c_void_p), ptr(g_emb), ptr(g_x), M, L, n_levels, bound,
-                                     stream()), "mh_grid_encode_bwd")
-        return g_x, g_emb, None, None, None, None
+        need_dx = ctx.needs_input_grad[0]
+        g_x_total, g_embs = None, []
+        binned = None
+        for emb, grad in zip(embs, grads):
+            if grad is None:
+                g_embs.append(None)
+                continue
+            grad = grad.contiguous()
+            g_emb = torch.zeros_like(emb)
+            g_x = torch.empty_like(x) if need_dx else None
+            if M > 0 and not GRID_BWD_NAIVE and L == 16:
+                if binned is None:
+                    binned = _bin_points(lib, x, bound)
+                _e = TIMER.start()
+                check(lib.mh_grid_encode_bwd_binned(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(binned[0]), ptr(binned[1]),
+                                                    ptr(g_emb), ptr(g_x), M, L, n_levels, bound, stream()),
+                      "mh_grid_encode_bwd_binned")
+                TIMER.stop("mh_grid_encode_bwd_binned", _e)
+            else:
+                _e = TIMER.start()
+                check(lib.mh_grid_encode_bwd(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(g_emb), ptr(g_x), M, L, n_levels,
+                                             bound, stream()), "mh_grid_encode_bwd")
+                TIMER.stop("mh_grid_encode_bwd", _e)
+            g_embs.append(g_emb)
+            if need_dx:
+                g_x_total = g_x if g_x_total is None else g_x_total + g_x
+        return (g_x_total, None, None, None, None, *g_embs)
 
 
 def grid_encode(x, emb, offsets_np, res_np, bound, max_level=None):
     """x [..,3] in world units -> [.., L*2] (grid.py:152-169)."""
     L = len(res_np)
     lead = list(x.shape[:-1])
-    out = _GridEncode.apply(x.reshape(-1, 3), emb, offsets_np, res_np, effective_levels(max_level, L), bound)
+    (out,) = _GridEncode.apply(x.reshape(-1, 3), offsets_np, res_np, effective_levels(max_level, L), bound, emb)
     return out.view(lead + [L * 2])
+
+
+def grid_encode_multi(x, embs, offsets_np, res_np, bound, max_level=None):
+    """Several tables with identical level geometry at the same points -> tuple of [M, L*2]."""
+    L = len(res_np)
+    return _GridEncode.apply(x.reshape(-1, 3), offsets_np, res_np, effective_levels(max_level, L), bound, *embs)
 
 
 # ------------------------------------------------------------------------------------ compositor
@@ -95,8 +179,10 @@ class _Composite(torch.autograd.Function):
         weights = torch.empty(M, device=dev)
         opacity, depth = torch.empty(N, device=dev), torch.empty(N, device=dev)
         color = torch.empty(N, 3, device=dev)
+        _e = TIMER.start()
         check(lib.mh_composite_fwd(ptr(sigma), ptr(t_starts), ptr(t_ends), ptr(rgbc), ptr(ray_start), ptr(ray_cnt),
                                    ptr(weights), ptr(opacity), ptr(depth), ptr(color), N, stream()), "mh_composite_fwd")
+        TIMER.stop("mh_composite_fwd", _e)
         ctx.save_for_backward(sigma, t_starts, t_ends, rgbc, ray_start, ray_cnt, weights)
         return weights, opacity, depth, color
 
@@ -108,9 +194,11 @@ class _Composite(torch.autograd.Function):
         c = lambda t: None if t is None else t.contiguous()
         d_sigma = torch.empty_like(sigma)
         d_rgb = torch.empty_like(rgb)
+        _e = TIMER.start()
         check(lib.mh_composite_bwd(ptr(sigma), ptr(ts), ptr(te), ptr(rgb), ptr(ray_start), ptr(ray_cnt), ptr(weights),
                                    ptr(c(g_w)), ptr(c(g_o)), ptr(c(g_d)), ptr(c(g_c)), ptr(d_sigma), ptr(d_rgb), N,
                                    stream()), "mh_composite_bwd")
+        TIMER.stop("mh_composite_bwd", _e)
         return d_sigma, None, None, d_rgb, None, None
 
 
@@ -133,8 +221,10 @@ def generate_rays(fx, fy, cx, cy, c2w, H, W, device):
     o = torch.empty(H * W, 3, device=device)
     d = torch.empty(H * W, 3, device=device)
     require_gpu(o)
+    _e = TIMER.start()
     check(lib.mh_generate_rays(float(fx), float(fy), float(cx), float(cy), c2w.ctypes.data_as(ctypes.c_void_p), H, W,
                                ptr(o), ptr(d), stream()), "mh_generate_rays")
+    TIMER.stop("mh_generate_rays", _e)
     return o, d
 
 
@@ -148,13 +238,15 @@ def sample_uniform(rays_o, rays_d, jitter, S: int, bound: float, with_xyz: bool 
     ts, te = torch.empty(N * S, device=dev), torch.empty(N * S, device=dev)
     xyz = torch.empty(N * S, 3, device=dev) if with_xyz else None
     rs, rc = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+    _e = TIMER.start()
     check(lib.mh_sample_uniform(ptr(o), ptr(d), ptr(j), N, S, float(bound), ptr(ri), ptr(ts), ptr(te), ptr(xyz), ptr(rs),
                                 ptr(rc), stream()), "mh_sample_uniform")
+    TIMER.stop("mh_sample_uniform", _e)
     return ri, ts, te, xyz, rs, rc
 
 
 # ------------------------------------------------------------------------------------ fused MLPs
-def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev):
+def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag):
     n_layers = len(act_off)
     dw_len = int(sum(i * o for i, o in zip(in_pad, out_pad)))
     db_len = int(sum(out_pad))
@@ -165,8 +257,10 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     d_np, d_p = _i32arr(dpre_off)
     i_np, i_p = _i32arr(in_pad)
     o_np, o_p = _i32arr(out_pad)
+    _e = TIMER.start()
     check(lib.mh_mlp_wgrad(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(dw_part),
                            ptr(db_part), chunks, n_tiles, stream()), "mh_mlp_wgrad")
+    TIMER.stop("mh_mlp_wgrad[" + tag + "]", _e)
     return dw_part.sum(0), db_part.sum(0)
 
 
@@ -201,8 +295,10 @@ class _WarpMLP(torch.autograd.Function):
         deform, topo = torch.empty(M, 3, device=dev), torch.empty(M, 2, device=dev)
         b0d, b0t = bias0_d.detach().contiguous(), bias0_t.detach().contiguous()
         slot_c = None if slot is None else slot.contiguous()
+        _e = TIMER.start()
         check(lib.mh_warp_fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(wd), ptr(wt), ptr(bd), ptr(bt), n_bands,
                               ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
+        TIMER.stop("mh_warp_fwd", _e)
         ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
         ctx.n_bands, ctx.n_slots = n_bands, bias0_d.shape[0]
         return deform, topo
@@ -216,8 +312,10 @@ class _WarpMLP(torch.autograd.Function):
         dpre = torch.empty(lib.mh_warp_dpre_floats(M), device=dev)
         g_x = torch.empty(M, 3, device=dev)
         c = lambda t: None if t is None else t.contiguous()
+        _e = TIMER.start()
         check(lib.mh_warp_bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts),
                                    ptr(dpre), ptr(g_x), M, stream()), "mh_warp_bwd_data")
+        TIMER.stop("mh_warp_bwd_data", _e)
         act_off, dpre_off, in_pad, out_pad = [], [], [], []
         for net in range(2):
             for l in range(6):
@@ -226,7 +324,7 @@ class _WarpMLP(torch.autograd.Function):
                 in_pad.append(64 if l == 0 else 128)
                 out_pad.append(32 if l == 5 else 128)
         dw_raw, db_raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, act_off, dpre_off, in_pad,
-                                out_pad, n_tiles, dev)
+                                out_pad, n_tiles, dev, "warp")
         pk_d, pk_t = warp_packer(3), warp_packer(2)
         gw_d, gb_d = pk_d.unpack_grads(dw_raw[:pk_d.raw_dw], db_raw[:pk_d.raw_db])
         gw_t, gb_t = pk_t.unpack_grads(dw_raw[pk_d.raw_dw:], db_raw[pk_d.raw_db:])
@@ -277,9 +375,10 @@ class _FieldMLP(torch.autograd.Function):
         acts = torch.empty(lib.mh_field_acts_floats(M), device=dev) if need_grad else None
         sdf, sigma = torch.empty(M, device=dev), torch.empty(M, device=dev)
         albedo = torch.empty(M, 3, device=dev) if with_color else None
+        _e = TIMER.start()
         check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands,
-                               int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()),
-              "mh_field_fwd")
+                               int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd")
+        TIMER.stop("mh_field_fwd", _e)
         ctx.save_for_backward(xc, wT, beta_c, acts, sdf, albedo)
         ctx.cfg = (n_bands, bool(with_color), topo is not None, feat_c is not None)
         if albedo is None:
@@ -303,17 +402,19 @@ class _FieldMLP(torch.autograd.Function):
         g_tp = torch.empty(M, 2, device=dev)
         g_bp = torch.empty(n_tiles, device=dev)
         c = lambda t: None if t is None else t.contiguous()
+        _e = TIMER.start()
         check(lib.mh_field_bwd_data(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)),
                                     ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color),
                                     ptr(acts), ptr(dpre), ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), M,
                                     stream()), "mh_field_bwd_data")
+        TIMER.stop("mh_field_bwd_data", _e)
         pk = field_packer()
         act_rows = [0, 96, 160, 224, 288, 352]
         dpre_rows = [0, 64, 128, 192, 256, 320]
         n_l = 6 if with_color else 3
         dw_raw, db_raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32,
                                 [r * 32 for r in act_rows[:n_l]], [r * 32 for r in dpre_rows[:n_l]], pk.wg_in[:n_l],
-                                pk.wg_out[:n_l], n_tiles, dev)
+                                pk.wg_out[:n_l], n_tiles, dev, "field")
         if not with_color:
             dw_raw = torch.cat([dw_raw, dw_raw.new_zeros(pk.raw_dw - dw_raw.numel())])
             db_raw = torch.cat([db_raw, db_raw.new_zeros(pk.raw_db - db_raw.numel())])

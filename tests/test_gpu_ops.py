@@ -103,12 +103,12 @@ def test_composite_forward_backward_ragged():
     assert torch.equal(rc.cpu(), torch.from_numpy(cnt).int())
     w_g, o_g, d_g, c_g = ops.composite(sg, ts.to(DEV), te.to(DEV), rg, rs, rc)
     loss(w_g, o_g, d_g, c_g, DEV).backward()
-    assert_close(w_g, w_o, 1e-5, "weights", floor=1e-4)
+    assert_close(w_g, w_o, 1e-4, "weights (wave scan vs fp64 cumsum)", floor=1e-4)
     assert_close(o_g, o_o, 1e-5, "opacity", floor=1e-3)
     assert_close(d_g, d_o, 1e-5, "depth", floor=1e-3)
     assert_close(c_g, c_o, 1e-5, "color", floor=1e-3)
     assert_close(sg.grad, so.grad, 1e-4, "d sigma", floor=1e-4)
-    assert_close(rg.grad, ro.grad, 1e-5, "d rgb", floor=1e-4)
+    assert_close(rg.grad, ro.grad, 2e-4, "d rgb (= w * g: inherits the weights' scan round-off)", floor=1e-4)
 
 
 def test_sampler_and_raygen_bit_exact():

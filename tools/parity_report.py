@@ -1,0 +1,94 @@
+"""GPU-box tool: HIP path vs the CPU oracle on identical inputs -- per-output and per-parameter-gradient
+errors, printed as JSON (feeds DESIGN.md's parity table; not part of the product path)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from morpheus_amd import harness, synth  # noqa: E402
+from oracle import field as of  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b, floor):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float(((a - b).abs() / b.abs().clamp(min=floor)).max())
+
+
+def nrm(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def leaf(kind):
+    return {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in synth.make_state(kind).items()}
+
+
+def model_probe(kind, shading, cano):
+    n = 2048
+    x = synth.hash_tensor((n, 3), 330, 1.15)
+    t = torch.full((n, 1), 37 / 200)
+    light = of.safe_normalize(synth.hash_tensor((n, 3), 331, 1.0))
+    p = leaf(kind)
+    f = of.OracleField(p, 1.01, None)
+    so, go, co, _, do, _ = f.forward(x, t, light, ratio=0.3, shading=shading, cano=cano)
+    ((co ** 2).sum() + 0.01 * (go ** 2).mean() + (so ** 2).sum()).backward()
+    m = harness.build_model(kind, DEV).eval()
+    sg, gg, cg, _, dg, _ = m(x.to(DEV), t.to(DEV), light.to(DEV), ratio=0.3, shading=shading, cano=cano)
+    ((cg ** 2).sum() + 0.01 * (gg ** 2).mean() + (sg ** 2).sum()).backward()
+    out = dict(case=f"model_probe {kind} {shading} {'cano' if cano else 'deform'}", sdf=rel(sg, so, 1e-2),
+               sigma=rel(gg, go, 1e-2), color=rel(cg, co, 1e-2))
+    grads = {}
+    for k, prm in m.named_parameters():
+        if prm.grad is not None and p[k].grad is not None:
+            grads[k] = nrm(prm.grad, p[k].grad)
+    out["grad_rel_l2_max"] = max(grads.values())
+    out["grad_rel_l2_worst"] = sorted(grads.items(), key=lambda kv: -kv[1])[:6]
+    return out
+
+
+def render_case(kind, hw, S, cano, nray=None):
+    o, d, t, rid = synth.frame_rays(25, hw, hw)
+    if nray:
+        o, d, t, rid = o[:, :nray], d[:, :nray], t[:, :nray], rid[:, :nray]
+    N = o.shape[1]
+    jit = synth.ray_jitter(N)
+    smp = of.uniform_samples(o[0], d[0], jit, S, 1.01)
+    light = of.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    timg, tdep = synth.targets(N)
+    p = leaf(kind)
+    f = of.OracleField(p, 1.01, None)
+    ro = of.render_rays(f, o, d, t, rid, smp, ambient_ratio=1.0, light_d=light, shading="albedo", cano=cano)
+    (((ro["image"][0] - timg) ** 2).mean() + ((ro["depth"][0] - tdep) ** 2).mean()).backward()
+    m = harness.build_model(kind, DEV).eval()
+    rend = harness.make_renderer(m, S, jitter=jit.to(DEV))
+    rg = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, ambient_ratio=1.0, light_d=light.to(DEV),
+                          shading="albedo", cano=cano)
+    (((rg["image"][0] - timg.to(DEV)) ** 2).mean() + ((rg["depth"][0] - tdep.to(DEV)) ** 2).mean()).backward()
+    out = dict(case=f"render {kind} {N}x{S} {'cano' if cano else 'deform'}", image=rel(rg["image"], ro["image"], 1e-2),
+               depth=rel(rg["depth"], ro["depth"], 5e-2), sdf=rel(rg["sdf"], ro["sdf"], 1e-2),
+               opacity=rel(rg["weights_sum"], ro["weights_sum"], 1e-2))
+    grads = {}
+    for k, prm in m.named_parameters():
+        if prm.grad is not None and p[k].grad is not None:
+            grads[k] = nrm(prm.grad, p[k].grad)
+    out["grad_rel_l2_max"] = max(grads.values())
+    out["grad_rel_l2_worst"] = sorted(grads.items(), key=lambda kv: -kv[1])[:4]
+    return out
+
+
+if __name__ == "__main__":
+    rows = []
+    for kind in ("a", "b"):
+        rows.append(model_probe(kind, "albedo", False))
+        rows.append(model_probe(kind, "albedo", True))
+        rows.append(render_case(kind, 32, 64, False))
+        rows.append(render_case(kind, 32, 64, True))
+        rows.append(render_case(kind, 128, 128, False, nray=512))
+    for r in rows:
+        print(json.dumps(r))
