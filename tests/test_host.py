@@ -1,0 +1,187 @@
+"""CPU (no GPU): host-side logic of the product path -- the C-ABI library loads and exports every
+symbol the header declares, the product path refuses CPU tensors (no fallback), state_dict /
+parameter-group compatibility with the reference, the MFMA packing maps, level tables."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from morpheus_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from morpheus_amd import _lib, build
+    build.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from morpheus_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "morpheus_hip.h")).read()
+    declared = set(re.findall(r"\b(mh_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(os.path.join(ROOT, "morpheus_amd", "_build", "libmorpheus_hip.so"))
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/morpheus_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.mh_abi_version() == 1
+    assert lib.mh_status_string(1).decode().startswith("invalid argument")
+    # size queries are pure host functions
+    assert lib.mh_mlp_tiles(1) == 4 and lib.mh_mlp_tiles(129) == 8
+    assert lib.mh_warp_acts_floats(128) == 4 * (64 + 2 * 640) * 32
+    assert lib.mh_field_dpre_floats(128) == 4 * (64 * 5 + 32) * 32
+    assert lib.mh_grid_bin_bricks() == 4096 and lib.mh_grid_bin_index_ints() == 2 * 4096 + 4
+
+
+def test_argument_validation_without_gpu(lib):
+    """status codes, never exceptions or launches, for bad arguments"""
+    assert lib.mh_grid_encode_fwd(None, None, None, None, None, 10, 16, 16, 1.01, None) == 1
+    assert lib.mh_grid_encode_fwd(None, None, None, None, None, 0, 16, 16, 1.01, None) == 0      # empty input is fine
+    assert lib.mh_composite_fwd(*([None] * 10), 0, None) == 0
+    assert lib.mh_composite_fwd(*([None] * 10), 5, None) == 1
+    assert lib.mh_warp_fwd(*([None] * 8), 6, None, None, None, 128, None) == 1
+    assert lib.mh_field_fwd(*([None] * 7), 7, 1, None, None, None, None, 128, None) == 1        # n_bands > 6
+
+
+def test_no_cpu_fallback():
+    from morpheus_amd import harness, ops
+    from morpheus_amd._lib import MorpheusHipError
+    model = harness.build_model("a", "cpu")
+    x = torch.zeros(8, 3)
+    with pytest.raises(MorpheusHipError):
+        model(x, torch.zeros(8, 1))
+    with pytest.raises(MorpheusHipError):
+        model.encoder(x, bound=1.01)
+    with pytest.raises(MorpheusHipError):
+        ops.composite(torch.zeros(4), torch.zeros(4), torch.ones(4), torch.zeros(4, 3), torch.zeros(1, dtype=torch.int32),
+                      torch.full((1,), 4, dtype=torch.int32))
+    # nothing under morpheus_amd/ imports the oracle
+    for fn in os.listdir(os.path.join(ROOT, "morpheus_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "morpheus_amd", fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_state_dict_and_param_groups_match_reference_layout():
+    from morpheus_amd import harness
+    model = harness.build_model("b", "cpu")
+    want = synth.make_state("b")
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(want.keys()), set(sd.keys()) ^ set(want.keys())
+    for k, v in want.items():
+        assert sd[k].shape == v.shape and sd[k].dtype == v.dtype, k
+        assert torch.equal(sd[k], v), k
+    groups = model.get_params_all(5e-4)
+    assert [g["name"] for g in groups] == ["encoder_sdf", "encoder_color", "decoder_sdf", "decoder_topo", "decoder_color",
+                                           "density", "decoder_deform", "code_deform", "pose", "decoder_bg"]
+    lrs = {g["name"]: g["lr"] for g in groups}
+    assert lrs["density"] == 2.5e-4 and lrs["pose"] == 5e-5
+    n_in_groups = sum(p.numel() for g in model.get_params_all(1.0) for p in g["params"])
+    assert n_in_groups == sum(p.numel() for p in model.parameters())
+    assert float(model.sdf2density.get_beta()) == pytest.approx(0.1001)
+    assert model.encoder._res_np.tolist() == [16, 19, 22, 25, 28, 32, 37, 43, 49, 56, 64, 74, 85, 98, 112, 128]
+    # unsupported switches fail loudly instead of silently taking another path
+    from morpheus_amd.model import scene_representation
+    with pytest.raises(NotImplementedError):
+        scene_representation(model.config, 1.01, num_frames=200, use_t=True, use_joint=True)
+
+
+def _mfma_emulate(wpack, KS, MT, bin_lanes):
+    """numpy model of csrc/mlp.hip:mfma_layer -- v_mfma_f32_32x32x2_f32 semantics:
+    A[i][k] from lane i+32k, B[k][j] from lane j+32k, D[row][col] in lane col+32*((row>>2)&1), reg (row&3)+4*(row>>3)."""
+    wp = wpack.reshape(MT, KS // 4, 64, 4)
+    acc = np.zeros((64, MT, 16), dtype=np.float64)
+    for mt in range(MT):
+        D = np.zeros((32, 32))
+        for kk in range(KS):
+            a = wp[mt, kk // 4, :, kk % 4]
+            b = bin_lanes[:, kk]
+            A = np.stack([a[:32], a[32:]], 1)           # [32 rows, k=2]
+            B = np.stack([b[:32], b[32:]], 0)           # [k=2, 32 cols]
+            D += A @ B
+        for lane in range(64):
+            for r in range(16):
+                acc[lane, mt, r] = D[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31]
+    return acc
+
+
+def test_packing_maps_reproduce_a_linear_layer():
+    """Forward pack of a 128->128 hidden layer + the accumulator-as-B-operand convention == W @ h."""
+    from morpheus_amd import packing
+    pk = packing.warp_packer(3)
+    rng = np.random.RandomState(0)
+    Ws = [rng.randn(s.out_dim, s.in_dim).astype(np.float32) for s in pk.specs]
+    wp, wpT = pk.pack([torch.from_numpy(w) for w in Ws])
+    wp, wpT = wp.numpy(), wpT.numpy()
+    assert wp.shape[0] == 74752 and wpT.shape[0] == 77824
+    # layer 1 (offset 5120): input h in accumulator layout
+    h = rng.randn(128, 32)                                  # [feature, point]
+    km = packing.kmap_acc(4)
+    bin_lanes = np.zeros((64, 64))
+    for lane in range(64):
+        for kk in range(64):
+            bin_lanes[lane, kk] = h[km[kk, lane >> 5], lane & 31]
+    acc = _mfma_emulate(wp[5120:5120 + 16384], 64, 4, bin_lanes)
+    want = Ws[1].astype(np.float64) @ h
+    for lane in (0, 5, 31, 32, 63):
+        for t in range(4):
+            for r in range(16):
+                row = 32 * t + packing.acc_row(r, lane >> 5)
+                assert abs(acc[lane, t, r] - want[row, lane & 31]) < 1e-4
+    # transposed pack of the same layer (T1 is the 5th block of the backward stream): W^T @ g
+    g = rng.randn(128, 32)
+    for lane in range(64):
+        for kk in range(64):
+            bin_lanes[lane, kk] = g[km[kk, lane >> 5], lane & 31]
+    off_T1 = 4096 + 3 * 16384
+    accT = _mfma_emulate(wpT[off_T1:off_T1 + 16384], 64, 4, bin_lanes)
+    wantT = Ws[1].astype(np.float64).T @ g
+    for lane in (0, 17, 40, 63):
+        for t in range(4):
+            for r in range(16):
+                row = 32 * t + packing.acc_row(r, lane >> 5)
+                assert abs(accT[lane, t, r] - wantT[row, lane & 31]) < 1e-4
+
+
+def test_packing_first_layers_and_gradient_unpack():
+    from morpheus_amd import packing
+    # every natural weight appears exactly once in the forward pack and once in the transposed pack
+    for pk in (packing.warp_packer(3), packing.warp_packer(2), packing.field_packer()):
+        for idx in (pk.fwd_index, pk.bwd_index):
+            cnt = np.bincount(idx[idx < pk.n_weights], minlength=pk.n_weights)
+            assert (cnt == 1).all(), (cnt != 1).sum()
+        # dW / db gather indices are a bijection onto the natural layout
+        assert pk.dw_index.shape[0] == pk.n_weights and len(np.unique(pk.dw_index)) == pk.n_weights
+        assert pk.db_index.shape[0] == pk.n_biases and len(np.unique(pk.db_index)) == pk.n_biases
+        assert pk.dw_index.max() < pk.raw_dw and pk.db_index.max() < pk.raw_db
+    # frequency-encoding k-steps cover the reference's 39-vector exactly once
+    enc = packing.kmap_enc20()
+    assert sorted(enc[enc >= 0].tolist()) == list(range(39))
+    # field: sdf layer-0 k-steps cover the 73 inputs, colour layer-0 the 64 inputs
+    s0, c0 = packing.field_specs()[0], packing.field_specs()[3]
+    assert sorted(s0.kmap[s0.kmap >= 0].tolist()) == list(range(73))
+    assert sorted(c0.kmap[c0.kmap >= 0].tolist()) == list(range(64))
+
+
+def test_level_tables_agree_with_oracle():
+    from morpheus_amd import ops
+    from oracle.hashgrid import effective_levels, level_resolutions
+    _, s = synth.grid_offsets()
+    assert ops.level_resolutions(16, s, 16).tolist() == level_resolutions(16, s, 16).tolist()
+    for ml in (None, 0.01, 0.5, 0.75, 1.0):
+        assert ops.effective_levels(ml, 16) == effective_levels(ml, 16)
+
+
+def test_config_schema_matches_reference_keys():
+    from morpheus_amd import harness
+    cfg = harness.load_config("snoopy")
+    assert set(cfg) == {"data", "exp", "render", "train", "model", "guidance"}
+    assert cfg["render"]["step_size"] == 0.01 and cfg["model"]["use_joint"] is True and cfg["exp"]["fp16"] is False
+    for k in ("trunc", "normal_smoothness", "normal_smooth_3d", "code_reg", "ori_weight", "topo_none", "smoothness_std"):
+        assert k in cfg["train"]

@@ -85,7 +85,7 @@ def test_model_forward_modes(kind):
         p = leaf_state(kind)
         f = of.OracleField(p, 1.01, ml)
         d = f.density(x, t)
-        assert_close(d["sdf"], g[f"{kind}_{ml_tag}_density|sdf"], TOL, "density sdf")
+        assert_close(d["sdf"], g[f"{kind}_{ml_tag}_density|sdf"], TOL, "density sdf", floor=1e-2)
         assert_close(d["albedo"], g[f"{kind}_{ml_tag}_density|albedo"], TOL, "density albedo")
         assert_close(f.normal(x, t)[1], g[f"{kind}_{ml_tag}_normal_warped|raw"], 3e-3, "normal raw", floor=5e-2)
         assert_close(f.warp(x, t)[1], g[f"{kind}_{ml_tag}_warp|topo"], TOL, "topo")
