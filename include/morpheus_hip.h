@@ -151,15 +151,19 @@ int mh_field_bwd_data(const float *xc, const float *sdf, const float *albedo, co
                       float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial, int64_t M,
                       void *stream);
 
-/* weight gradients: for `n_layers` layers described by HOST arrays (offsets in floats into
- * acts/dpre tiles, feature counts padded to multiples of 32):
+/* weight gradients: for `n_layers` (<= 16) layers described by HOST arrays (offsets in floats into the
+ * acts / dpre tiles, feature counts padded to multiples of 32):
  *   dW_l[out][in] = sum_pts dpre_l[out][pt] * act_l[in][pt],  db_l[out] = sum_pts dpre_l[out][pt]
- * written as per-chunk partials  dw_part [n_chunks, sum_l out_l*in_l], db_part [n_chunks, sum_l out_l]
- * (caller reduces over chunks).  tile_floats = floats per 32-point tile in acts (resp. dpre). */
+ * One MFMA launch per layer writes per-chunk partials into `workspace`
+ * (mh_mlp_wgrad_workspace_floats(...) floats), one reduction launch sums them into
+ *   dw_raw [sum_l out_l*in_l]  followed contiguously by  db_raw [sum_l out_l]   (db_raw == dw_raw + sum_l out_l*in_l)
+ * in tile-row order (the caller maps rows back to the natural layout, morpheus_amd/packing.py). */
+int64_t mh_mlp_wgrad_workspace_floats(int32_t n_layers, const int32_t *in_feats_host,
+                                      const int32_t *out_feats_host, int64_t n_tiles);
 int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
                  int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                 const int32_t *in_feats_host, const int32_t *out_feats_host, float *dw_part, float *db_part,
-                 int32_t n_chunks, int64_t n_tiles, void *stream);
+                 const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
+                 float *db_raw, int64_t n_tiles, void *stream);
 
 #ifdef __cplusplus
 }

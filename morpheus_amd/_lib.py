@@ -41,7 +41,8 @@ _SIGS = {
     "mh_warp_bwd_data": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_field_fwd": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_field_bwd_data": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 7 + [_I64, _P]),
-    "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _I64, _P]),
+    "mh_mlp_wgrad_workspace_floats": (_I64, [_I32, _P, _P, _I64]),
+    "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -575,55 +575,141 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 
 // =====================================================================================
 // weight gradients: dW[out][in] = sum_pt dPre[out][pt] * act[in][pt]  (MFMA, K = points)
-// one wave per 32-row out tile; block = OT waves sharing the act tiles through L1
+// one wave per 32-row out tile; a block = OT waves sharing the act tiles through L1.  Fragments of
+// tile t+1 are fetched into a second register set while tile t's MFMAs issue (the operands come
+// straight from HBM: 2.15 GB per 128x128 layer at the benchmark size).
 // =====================================================================================
 template <int IT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
-                                                    int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
-                                                    int dpre_off, int out_pad, float *__restrict__ dw_part,
-                                                    float *__restrict__ db_part, int64_t dw_stride, int64_t db_stride,
-                                                    int64_t dw_off, int64_t db_off, int64_t n_tiles, int n_chunks) {
+struct WgFrag {
+    f32x4 a[4];
+    f32x4 b[IT][4];
+};
+
+template <int IT>
+__device__ __forceinline__ void wg_load(WgFrag<IT> &f, const float *__restrict__ acts, const float *__restrict__ dpre,
+                                        int64_t t, int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                        int dpre_off, int mt, int i, int h) {
+    const f32x4 *a = reinterpret_cast<const f32x4 *>(dpre + t * dpre_tile_floats + dpre_off + (int64_t)(32 * mt + i) * TILE + 16 * h);
+#pragma unroll
+    for (int j = 0; j < 4; j++) f.a[j] = a[j];
+#pragma unroll
+    for (int n = 0; n < IT; n++) {
+        const f32x4 *b = reinterpret_cast<const f32x4 *>(acts + t * acts_tile_floats + act_off + (int64_t)(32 * n + i) * TILE + 16 * h);
+#pragma unroll
+        for (int j = 0; j < 4; j++) f.b[n][j] = b[j];
+    }
+}
+
+// Same loads, but issued through inline asm so that hipcc neither waits for them nor re-rolls the software
+// pipeline (cdna_hip_programming.md 5.7): the caller owns the s_waitcnt vmcnt(N) accounting.
+template <int IT>
+__device__ __forceinline__ void wg_load_async(WgFrag<IT> &f, const float *__restrict__ acts, const float *__restrict__ dpre,
+                                              int64_t t, int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                              int dpre_off, int mt, int i, int h) {
+    const float *a = dpre + t * dpre_tile_floats + dpre_off + (int64_t)(32 * mt + i) * TILE + 16 * h;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.a[0]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.a[1]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.a[2]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.a[3]) : "v"(a) : "memory");
+#pragma unroll
+    for (int n = 0; n < IT; n++) {
+        const float *b = acts + t * acts_tile_floats + act_off + (int64_t)(32 * n + i) * TILE + 16 * h;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.b[n][0]) : "v"(b) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.b[n][1]) : "v"(b) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.b[n][2]) : "v"(b) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.b[n][3]) : "v"(b) : "memory");
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wg_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);  // keep register-only MFMAs below the wait (guide rule 18)
+}
+
+template <int IT>
+__device__ __forceinline__ void wg_mma(const WgFrag<IT> &f, f32x16 (&acc)[IT], float &bsum) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bsum += f.a[j][q];
+#pragma unroll
+            for (int n = 0; n < IT; n++)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j][q], f.b[n][j][q], acc[n], 0, 0, 0);
+        }
+}
+
+template <int IT>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                       int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                                       int dpre_off, int out_pad, float *__restrict__ dw_part,
+                                                       float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int chunk = blockIdx.x;
-    const int64_t per = (n_tiles + n_chunks - 1) / n_chunks;
-    const int64_t t0 = chunk * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    // tiles are dealt round-robin: at any instant the resident workgroups read NEIGHBOURING tiles (172 KB apart,
+    // spread over all HBM channels) rather than addresses a fixed 2^20-multiple apart (channel camping)
+    const int64_t st = n_chunks;
     f32x16 acc[IT];
     acc_zero<IT>(acc);
     float bsum = 0.f;
-    for (int64_t t = t0; t < t1; t++) {
-        const f32x4 *a = reinterpret_cast<const f32x4 *>(dpre + t * dpre_tile_floats + dpre_off +
-                                                          (int64_t)(32 * mt + i) * TILE + 16 * h);
-        f32x4 av[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) av[j] = a[j];
-        f32x4 bv[IT][4];
-#pragma unroll
-        for (int n = 0; n < IT; n++) {
-            const f32x4 *b = reinterpret_cast<const f32x4 *>(acts + t * acts_tile_floats + act_off +
-                                                              (int64_t)(32 * n + i) * TILE + 16 * h);
-#pragma unroll
-            for (int j = 0; j < 4; j++) bv[n][j] = b[j];
+    WgFrag<IT> f0;
+    // Two register sets, software-pipelined by hand: tile k+1's 4+4*IT loads are in flight while tile k's MFMAs
+    // issue.  The loads are inline asm with counted waits because hipcc re-rolls a C++-level double buffer into
+    // load -> vmcnt(0) -> MFMA (checked in the .s).  Index-clamped prefetches past the end are harmless re-reads.
+    constexpr int NL = 4 + 4 * IT;  // loads per tile
+    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
+    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
+#define WG_TILE(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
+    if (n_my > 0) {
+        WgFrag<IT> f1;
+        wg_load_async<IT>(f0, acts, dpre, chunk, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h);
+        for (int64_t k = 0; k < n_my; k += 2) {
+            wg_load_async<IT>(f1, acts, dpre, WG_TILE(k + 1), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h);
+            wg_wait<NL>();  // f0 landed (everything but the NL loads just issued)
+            wg_mma<IT>(f0, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
+            wg_load_async<IT>(f0, acts, dpre, WG_TILE(k + 2), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h);
+            wg_wait<NL>();  // f1 landed
+            if (k + 1 < n_my) wg_mma<IT>(f1, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                bsum += av[j][q];
-#pragma unroll
-                for (int n = 0; n < IT; n++)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][q], bv[n][j][q], acc[n], 0, 0, 0);
-            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // D[row = out (acc_row), col = in (lane&31)]
-    float *dw = dw_part + chunk * dw_stride + dw_off;
+#undef WG_TILE
+    // D[row = out (acc_row), col = in (lane&31)];  partial of this chunk: [out_pad][32*IT]
     const int in_pad = 32 * IT;
+    float *dw = dw_part + (int64_t)chunk * out_pad * in_pad;
 #pragma unroll
     for (int n = 0; n < IT; n++)
 #pragma unroll
         for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, h)) * in_pad + 32 * n + i] = acc[n][r];
     bsum += __shfl_xor(bsum, 32);
-    if (h == 0) db_part[chunk * db_stride + db_off + 32 * mt + i] = bsum;
+    if (h == 0) db_part[(int64_t)chunk * out_pad + 32 * mt + i] = bsum;
+}
+
+// sum the per-chunk partials of every layer in one launch
+#define WG_MAX_LAYERS 16
+struct WgReduce {
+    int32_t n;
+    int32_t chunks[2 * WG_MAX_LAYERS];
+    int32_t len[2 * WG_MAX_LAYERS];
+    int64_t part_off[2 * WG_MAX_LAYERS];
+    int64_t out_off[2 * WG_MAX_LAYERS];
+    int64_t first[2 * WG_MAX_LAYERS + 1];  // prefix of len: element ranges of the launch
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, WgReduce d) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.first[d.n]) return;
+    int s = 0;
+    while (e >= d.first[s + 1]) s++;
+    const int64_t j = e - d.first[s];
+    const float *p = part + d.part_off[s] + j;
+    float acc = 0.f;
+    for (int c = 0; c < d.chunks[s]; c++) acc += p[(int64_t)c * d.len[s]];
+    out[d.out_off[s] + j] = acc;
 }
 
 // =====================================================================================
@@ -700,29 +786,57 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
     return MH_OK;
 }
 
+static inline int wg_chunks(int out_pad, int64_t n_tiles) {
+    // ~2048 waves per launch (2 per SIMD) whatever the number of output tiles
+    int64_t c = 2048 / (out_pad / 32);
+    if (c > n_tiles) c = n_tiles;
+    return (int)(c < 1 ? 1 : c);
+}
+
+extern "C" int64_t mh_mlp_wgrad_workspace_floats(int32_t n_layers, const int32_t *in_feats_host,
+                                                 const int32_t *out_feats_host, int64_t n_tiles) {
+    int64_t tot = 0;
+    for (int l = 0; l < n_layers; l++)
+        tot += (int64_t)wg_chunks(out_feats_host[l], n_tiles) * ((int64_t)in_feats_host[l] * out_feats_host[l] + out_feats_host[l]);
+    return tot;
+}
+
 extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
                             int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                            const int32_t *in_feats_host, const int32_t *out_feats_host, float *dw_part, float *db_part,
-                            int32_t n_chunks, int64_t n_tiles, void *stream) {
+                            const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
+                            float *db_raw, int64_t n_tiles, void *stream) {
     if (n_tiles == 0 || n_layers == 0) return MH_OK;
-    if (!acts || !dpre || !act_off_host || !dpre_off_host || !in_feats_host || !out_feats_host || !dw_part || !db_part ||
-        n_layers < 0 || n_chunks <= 0 || n_tiles < 0)
+    if (!acts || !dpre || !act_off_host || !dpre_off_host || !in_feats_host || !out_feats_host || !workspace || !dw_raw ||
+        !db_raw || n_layers < 0 || n_layers > WG_MAX_LAYERS || n_tiles < 0)
         return MH_ERR_ARG;
-    int64_t dw_stride = 0, db_stride = 0;
     for (int l = 0; l < n_layers; l++) {
         const int in = in_feats_host[l], out = out_feats_host[l];
         if (in <= 0 || out <= 0 || (in % 32) || (out % 32) || in > 128 || out > 128) return MH_ERR_ARG;
-        dw_stride += (int64_t)in * out;
-        db_stride += out;
     }
-    int64_t dw_off = 0, db_off = 0;
+    // workspace: [dW partials of layer 0 | 1 | ...][db partials of layer 0 | 1 | ...]; outputs: dw_raw | db_raw
+    WgReduce rd;
+    rd.n = 2 * n_layers;
+    int64_t woff = 0, dw_out = 0, db_out = 0;
+    int64_t dw_poff[WG_MAX_LAYERS], db_poff[WG_MAX_LAYERS];
+    for (int l = 0; l < n_layers; l++) {
+        dw_poff[l] = woff;
+        woff += (int64_t)wg_chunks(out_feats_host[l], n_tiles) * in_feats_host[l] * out_feats_host[l];
+    }
+    for (int l = 0; l < n_layers; l++) {
+        db_poff[l] = woff;
+        woff += (int64_t)wg_chunks(out_feats_host[l], n_tiles) * out_feats_host[l];
+    }
+    int64_t dw_total = 0;
+    for (int l = 0; l < n_layers; l++) dw_total += (int64_t)in_feats_host[l] * out_feats_host[l];
+    rd.first[0] = 0;
     for (int l = 0; l < n_layers; l++) {
         const int in = in_feats_host[l], out = out_feats_host[l];
-        const dim3 grid((unsigned)n_chunks), block((unsigned)(out / 32) * 64);
-#define WG_LAUNCH(IT)                                                                                              \
-    hipLaunchKernelGGL(wgrad_kernel<IT>, grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats,          \
-                       dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, dw_part, db_part,       \
-                       dw_stride, db_stride, dw_off, db_off, n_tiles, (int)n_chunks)
+        const int chunks = wg_chunks(out, n_tiles);
+        const dim3 grid((unsigned)chunks), block((unsigned)(out / 32) * 64);
+#define WG_LAUNCH(IT)                                                                                         \
+    hipLaunchKernelGGL(wgrad_kernel<IT>, grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats,     \
+                       dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, workspace + dw_poff[l], \
+                       workspace + db_poff[l], n_tiles, chunks)
         switch (in / 32) {
             case 1: WG_LAUNCH(1); break;
             case 2: WG_LAUNCH(2); break;
@@ -731,9 +845,25 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
         }
 #undef WG_LAUNCH
         MH_CHECK_LAUNCH();
-        dw_off += (int64_t)in * out;
-        db_off += out;
+        // reduction segments: dW of layer l, then (second half) db of layer l; both outputs live in ONE buffer:
+        // out = dw_raw for e < dw_total, db_raw is addressed relative to dw_raw via out_off (caller passes them contiguous)
+        rd.chunks[l] = chunks;
+        rd.len[l] = in * out;
+        rd.part_off[l] = dw_poff[l];
+        rd.out_off[l] = dw_out;
+        dw_out += (int64_t)in * out;
+        rd.chunks[n_layers + l] = chunks;
+        rd.len[n_layers + l] = out;
+        rd.part_off[n_layers + l] = db_poff[l];
+        rd.out_off[n_layers + l] = dw_total + db_out;
+        db_out += out;
     }
+    for (int s = 0; s < rd.n; s++) rd.first[s + 1] = rd.first[s] + rd.len[s];
+    if (db_raw != dw_raw + dw_total) return MH_ERR_ARG;  // dw_raw and db_raw must be one contiguous buffer
+    const int64_t total = rd.first[rd.n];
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mh_stream(stream), workspace,
+                       dw_raw, rd);
+    MH_CHECK_LAUNCH();
     return MH_OK;
 }
 

@@ -19,7 +19,6 @@ from . import _lib
 from ._lib import check, ptr, require_gpu, stream
 from .packing import field_packer, warp_packer
 
-WGRAD_CHUNKS = 256
 
 
 class KernelTimer:
@@ -250,18 +249,18 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     n_layers = len(act_off)
     dw_len = int(sum(i * o for i, o in zip(in_pad, out_pad)))
     db_len = int(sum(out_pad))
-    chunks = int(min(WGRAD_CHUNKS, max(1, n_tiles)))
-    dw_part = torch.empty(chunks, dw_len, device=dev)
-    db_part = torch.empty(chunks, db_len, device=dev)
     a_np, a_p = _i32arr(act_off)
     d_np, d_p = _i32arr(dpre_off)
     i_np, i_p = _i32arr(in_pad)
     o_np, o_p = _i32arr(out_pad)
+    ws = torch.empty(lib.mh_mlp_wgrad_workspace_floats(n_layers, i_p, o_p, n_tiles), device=dev)
+    raw = torch.empty(dw_len + db_len, device=dev)
+    dw_raw, db_raw = raw[:dw_len], raw[dw_len:]
     _e = TIMER.start()
-    check(lib.mh_mlp_wgrad(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(dw_part),
-                           ptr(db_part), chunks, n_tiles, stream()), "mh_mlp_wgrad")
+    check(lib.mh_mlp_wgrad(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw),
+                           ptr(db_raw), n_tiles, stream()), "mh_mlp_wgrad")
     TIMER.stop("mh_mlp_wgrad[" + tag + "]", _e)
-    return dw_part.sum(0), db_part.sum(0)
+    return dw_raw, db_raw
 
 
 WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640, 2 * 672
