@@ -33,7 +33,7 @@ def run(x, tag):
     t_bin = timeit(lambda: lib.mh_grid_bin_points(x.data_ptr(), M, 1.01, ws.data_ptr(), perm.data_ptr(), bs.data_ptr(), st))
     cnt = (bs[1:4098] - bs[:4097]).cpu()
     print(f"[{tag}] M={M} bin {t_bin:.3f} ms; bricks nonempty {(cnt[:4096] > 0).sum().item()}, max {cnt[:4096].max().item()}, mean(nonempty) {cnt[:4096][cnt[:4096] > 0].float().mean().item():.0f}, oob {cnt[4096].item()}")
-    for nl in (1, 4, 8, 12, 16):
+    for nl in (16,):
         for dx in (False, True):
             t = timeit(lambda: lib.mh_grid_encode_bwd_binned(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), perm.data_ptr(), bs.data_ptr(), g_emb.data_ptr(), g_x.data_ptr() if dx else None, M, 16, nl, 1.01, st))
             print(f"   binned n_levels={nl:2d} dx={int(dx)}: {t:.3f} ms")
