@@ -50,10 +50,22 @@ __device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) 
 
 __shared__ f32x4 lds_w[4096];  // 64 KB: one layer's A fragments  [mt][q][lane] float4
 
-__device__ __forceinline__ void stage_weights(const float *__restrict__ g, int n_f4) {
+// Weight staging by LDS-DMA (global_load_lds_dwordx4): the packed layout is lane-linear ([tile][quad][lane] float4),
+// exactly the "wave-uniform LDS base + lane*16" destination the instruction wants, so a layer is N_F4/256 DMA
+// instructions per thread, all in flight together, with no VGPR round trip and no ds_write pass.  N_F4 is a
+// compile-time constant: with a run-time trip count hipcc emits load -> s_waitcnt vmcnt(0) -> ds_write per
+// iteration, i.e. 16 serial L2 round trips per layer -- as long as the layer's whole MFMA phase (seen in the .s).
+template <int N_F4>
+__device__ __forceinline__ void stage_weights(const float *__restrict__ g) {
+    static_assert(N_F4 % 256 == 0, "whole rounds of the 256-thread block");
     __syncthreads();  // everyone is done reading the previous layer
     const f32x4 *src = reinterpret_cast<const f32x4 *>(g);
-    for (int i = threadIdx.x; i < n_f4; i += blockDim.x) lds_w[i] = src[i];
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N_F4 / 256; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * 256 + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_w + k * 256 + wave * 64), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
         f32x16 acc[4];
         float bin[64];
         // layer 0: 40 -> 128, bias row chosen by the point's frame slot
-        stage_weights(wp, 1280);
+        stage_weights<1280>(wp);
         acc_bias<4>(acc, b0, h);
         mfma_layer<20, 4>(bin0, acc, lane);
         acc_to_bin<4, true>(acc, bin);
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
         wp += 5120;
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
-            stage_weights(wp, 4096);
+            stage_weights<4096>(wp);
             acc_bias<4>(acc, bs + (l - 1) * 128, h);
             mfma_layer<64, 4>(bin, acc, lane);
             acc_to_bin<4, true>(acc, bin);
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
             wp += 16384;
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
-        stage_weights(wp, 1024);
+        stage_weights<1024>(wp);
         f32x16 o[1];
         acc_bias<1>(o, bs + 4 * 128, h);
         mfma_layer<64, 1>(bin, o, lane);
@@ -222,8 +234,6 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
     float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
     const float *atile = acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE);
     float *dtile = dpre + tile_id * (int64_t)(WARP_DPRE_ROWS * TILE);
-    float encb[20], dsc[18];
-    enc_bin(xv, h, n_bands, encb, dsc);
     float gx[3] = {0.f, 0.f, 0.f};
 
     for (int net = 0; net < 2; net++) {
@@ -244,30 +254,41 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
         store_acc_rows<1>(dt + 640 * TILE, d5, pt, h);
         // dH5 = W5^T dPre5
         f32x16 acc[4];
-        float dbin[64], hv[64];
-        stage_weights(wt, 1024);
+        float dbin[64];
+        stage_weights<1024>(wt);
         acc_zero<4>(acc);
         mfma_layer<16, 4>(d5, acc, lane);
         wt += 4096;
         for (int l = 4; l >= 0; l--) {
             // output of layer l is H_{l+1}; mask by its ReLU and park dPre_l
-            load_acc_rows<4>(ht + l * 128 * TILE, hv, pt, h);
+            // one 32-row tile at a time (16 loads in flight, not 64): the kernel sits at the 256-VGPR limit
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < 4; t++) {
+                float hv[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
-            store_acc_rows<4>(dt + l * 128 * TILE, dbin, pt, h);
+                for (int r = 0; r < 16; r++) hv[r] = ht[(l * 128 + 32 * t + acc_row(r, h)) * TILE + pt];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = hv[r] > 0.f ? acc[t][r] : 0.f;
+                    dbin[16 * t + r] = v;
+                    dt[(l * 128 + 32 * t + acc_row(r, h)) * TILE + pt] = v;
+                }
+            }
             if (l > 0) {
-                stage_weights(wt, 4096);
+                stage_weights<4096>(wt);
                 acc_zero<4>(acc);
                 mfma_layer<64, 4>(dbin, acc, lane);
                 wt += 16384;
             } else {
                 // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5)
-                stage_weights(wt, 2048);
+                stage_weights<2048>(wt);
                 f32x16 e[2];
                 acc_zero<2>(e);
                 mfma_layer<64, 2>(dbin, e, lane);
+                // the encoding derivatives are (re)computed here, once per net, instead of living in 38 registers
+                // across the whole layer chain (the kernel sits at the 256-VGPR limit)
+                float encb[20], dsc[18];
+                enc_bin(xv, h, n_bands, encb, dsc);
 #pragma unroll
                 for (int k = 0; k < 18; k++) {
                     const float de = k < 16 ? e[0][k] : e[1][k - 16];
@@ -338,21 +359,21 @@ __global__ __launch_bounds__(256, 2) void field_fwd_kernel(const float *__restri
     f32x16 acc[2];
     float bin[32];
     // sdf L0: 73 -> 64
-    stage_weights(wp, 1280);
+    stage_weights<1280>(wp);
     acc_bias<2>(acc, bias, h);
     mfma_layer<40, 2>(bin0, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 96 * TILE, bin, pt, h);
     wp += 5120;
     // sdf L1: 64 -> 64
-    stage_weights(wp, 1024);
+    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 64, h);
     mfma_layer<32, 2>(bin, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 160 * TILE, bin, pt, h);
     wp += 4096;
     // sdf L2: 64 -> [geo(32) | sdf], no activation
-    stage_weights(wp, 1024);
+    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 128, h);
     mfma_layer<32, 2>(bin, acc, lane);
     wp += 4096;
@@ -376,21 +397,21 @@ __global__ __launch_bounds__(256, 2) void field_fwd_kernel(const float *__restri
         for (int r = 0; r < 16; r++) binc[16 + r] = acc[0][r];
     }
     if (tile) store_kk_rows<32>(tile + 224 * TILE, binc, pt, h);
-    stage_weights(wp, 1024);
+    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 192, h);
     mfma_layer<32, 2>(binc, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 288 * TILE, bin, pt, h);
     wp += 4096;
     // color L1
-    stage_weights(wp, 1024);
+    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 256, h);
     mfma_layer<32, 2>(bin, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 352 * TILE, bin, pt, h);
     wp += 4096;
     // color L2: 64 -> 3, sigmoid
-    stage_weights(wp, 512);
+    stage_weights<512>(wp);
     f32x16 o[1];
     acc_bias<1>(o, bias + 320, h);
     mfma_layer<32, 1>(bin, o, lane);
@@ -415,8 +436,6 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
     float xv[3] = {xc[pc * 3 + 0], xc[pc * 3 + 1], xc[pc * 3 + 2]};
     const float *atile = acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE);
     float *dtile = dpre + tile_id * (int64_t)(FIELD_DPRE_ROWS * TILE);
-    float encb[20], dsc[18];
-    enc_bin(xv, h, n_bands, encb, dsc);
     const float beta = *beta_p;
 
     const float *wt = wpackT;
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
             }
         }
         store_acc_rows<1>(dtile + 320 * TILE, d2, pt, h);
-        stage_weights(wt, 512);  // TC2: MT=2, KS=16
+        stage_weights<512>(wt);  // TC2: MT=2, KS=16
         acc_zero<2>(acc);
         mfma_layer<16, 2>(d2, acc, lane);
         wt += 2048;
@@ -450,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
         store_acc_rows<2>(dtile + 256 * TILE, dbin, pt, h);
-        stage_weights(wt, 1024);  // TC1
+        stage_weights<1024>(wt);  // TC1
         acc_zero<2>(acc);
         mfma_layer<32, 2>(dbin, acc, lane);
         wt += 4096;
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
         store_acc_rows<2>(dtile + 192 * TILE, dbin, pt, h);
-        stage_weights(wt, 1024);  // TC0: tile0 -> hash_c (16h + r), tile1 -> geo (acc layout)
+        stage_weights<1024>(wt);  // TC0: tile0 -> hash_c (16h + r), tile1 -> geo (acc layout)
         acc_zero<2>(acc);
         mfma_layer<32, 2>(dbin, acc, lane);
         wt += 4096;
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
         }
         d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
         store_acc_rows<2>(dtile + 128 * TILE, d2, pt, h);
-        stage_weights(wt, 1024);  // TS2
+        stage_weights<1024>(wt);  // TS2
         acc_zero<2>(acc);
         mfma_layer<32, 2>(d2, acc, lane);
         wt += 4096;
@@ -523,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
     store_acc_rows<2>(dtile + 64 * TILE, dbin, pt, h);
-    stage_weights(wt, 1024);  // TS1
+    stage_weights<1024>(wt);  // TS1
     acc_zero<2>(acc);
     mfma_layer<32, 2>(dbin, acc, lane);
     wt += 4096;
@@ -535,10 +554,12 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
         for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
     store_acc_rows<2>(dtile, dbin, pt, h);
     // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
-    stage_weights(wt, 1536);  // TS0: MT=3, KS=32
+    stage_weights<1536>(wt);  // TS0: MT=3, KS=32
     f32x16 e[3];
     acc_zero<3>(e);
     mfma_layer<32, 3>(dbin, e, lane);
+    float encb[20], dsc[18];
+    enc_bin(xv, h, n_bands, encb, dsc);
     float gx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 18; k++) {
