@@ -98,7 +98,7 @@ def main():
     rend = harness.make_renderer(model, S, jitter=jitter)
     light = torch.nn.functional.normalize(o[0] + torch.tensor([0.3, -0.2, 0.5], device=dev), dim=-1)
     timg, tdep = [v.to(dev) for v in synth.targets(N)]
-    opt = torch.optim.Adam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
+    opt = torch.optim.Adam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15, fused=True)
     bucket = mdist.GradBucket(model.parameters())
 
     def step():

@@ -103,6 +103,26 @@ class _PlainLinear(nn.Module):
         return self.weight
 
 
+def wn_effective_batched(layers) -> List[torch.Tensor]:
+    """Effective weights W = g * v / ||v|| of many weight-normed layers with few kernel launches: layers of equal
+    shape are stacked (8 of the 12 warp layers are 128x128) so the norm / divide / multiply run once per shape
+    group instead of once per layer -- ~90 fewer tiny launches per step, forward and backward."""
+    out = [None] * len(layers)
+    groups = {}
+    for i, l in enumerate(layers):
+        groups.setdefault(tuple(l.weight_v.shape), []).append(i)
+    for shape, idx in groups.items():
+        if len(idx) == 1:
+            out[idx[0]] = layers[idx[0]].effective()
+            continue
+        v = torch.stack([layers[i].weight_v for i in idx])            # [k, out, in]
+        g = torch.stack([layers[i].weight_g for i in idx])            # [k, out, 1]
+        w = v * (g / v.norm(dim=2, keepdim=True))
+        for j, i in enumerate(idx):
+            out[i] = w[j]
+    return out
+
+
 class MLP(nn.Module):
     """Parameter container with the reference's layout `net.{l}.{weight_g,weight_v|weight,bias}`
     (decoders.py:9-64, incl. the geometric initialisation of :25-43)."""
@@ -250,8 +270,8 @@ class scene_representation(nn.Module):
         tu, inv = torch.unique(t.reshape(-1), return_inverse=True)
         return tu, inv.to(torch.int32)
 
-    def _warp_params(self, net: MLP):
-        w, b = net.weights(), net.biases()
+    def _warp_params(self, net: MLP, w):
+        b = net.biases()
         return [w[0][:, :39]] + w[1:] + b, w[0][:, 39:], b[0]
 
     # -- public API (names/signatures of the reference) ----------------------------------------
@@ -273,8 +293,9 @@ class scene_representation(nn.Module):
         """-> deform [M,3], topo [M,2], app_code (None)   (model.py:412-437)."""
         tu, slot = self._slots(t)
         code = self.deform_code.sample(tu[:, None])                       # [F,48], F = distinct frames
-        pd, wcode_d, b0_d = self._warp_params(self.deform_net)
-        pt, wcode_t, b0_t = self._warp_params(self.topo_net)
+        w_all = wn_effective_batched(list(self.deform_net.net) + list(self.topo_net.net))
+        pd, wcode_d, b0_d = self._warp_params(self.deform_net, w_all[:6])
+        pt, wcode_t, b0_t = self._warp_params(self.topo_net, w_all[6:])
         bias0_d = torch.addmm(b0_d, code, wcode_d.t())                    # per-frame first-layer bias
         bias0_t = torch.addmm(b0_t, code, wcode_t.t())
         deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), pd, pt)
@@ -291,7 +312,8 @@ class scene_representation(nn.Module):
                                                    self.max_level)
         else:
             feat_s, feat_c = self.encoder(x, bound=self.bound, max_level=self.max_level), None
-        params = self.sdf_net.weights() + self.color_net.weights() + self.sdf_net.biases() + self.color_net.biases()
+        params = self.sdf_net.weights() + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
+            self.color_net.biases()
         sdf, sigma, albedo = ops.field_mlp(x, feat_s, feat_c, topo, self.sdf2density.get_beta(), self._n_bands(),
                                            return_color, params)
         return sdf, sigma, (albedo if return_color else None)

@@ -134,7 +134,6 @@ class HotPathRenderer:
         t_positions = (t_starts + t_ends) / 2.0
         xyzs = rays_o[ray_indices] + rays_d[ray_indices] * t_positions
         time_step = rays_t[ray_indices]
-        t_dirs = safe_normalize(rays_d[ray_indices])
 
         if xyzs.shape[0] == 0:
             # the reference falls into a NameError here; return the white image it intended
@@ -149,8 +148,10 @@ class HotPathRenderer:
             slot_ray = torch.arange(B, device=rays_o.device, dtype=torch.int32).repeat_interleave(n_per)
             model._frame_slots = (time_step, rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray[ray_indices].contiguous())
         try:
-            sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, light_d[ray_indices],
-                                                                   ratio=ambient_ratio, shading=shading, cano=cano)
+            # per-sample light directions are only read by the shaded modes (model.py:515-531)
+            t_light = light_d[ray_indices] if shading != "albedo" else None
+            sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, t_light, ratio=ambient_ratio,
+                                                                   shading=shading, cano=cano)
         finally:
             model._frame_slots = None
 
@@ -172,6 +173,7 @@ class HotPathRenderer:
         if model.training:
             tr = cfg["train"]
             if tr["ori_weight"] > 0 and normals is not None and (not real_view):
+                t_dirs = safe_normalize(rays_d[ray_indices])
                 lo = weights.detach() * (normals * t_dirs).sum(-1).clamp(min=0) ** 2
                 results["loss_orient"] = lo.sum(-1).mean()
             if tr["normal_smooth_3d"] > 0 and normals is not None:
