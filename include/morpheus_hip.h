@@ -103,6 +103,17 @@ int mh_sample_uniform(const float *rays_o, const float *rays_d, const float *jit
                       float bound, int32_t *ray_idx, float *t_starts, float *t_ends, float *xyz,
                       int32_t *ray_start, int32_t *ray_cnt, void *stream);
 
+/* Occupancy-grid marcher (nerfacc OccGridEstimator.sampling call shape, morpheus.py:628-638): fixed `step`,
+ * one jitter per ray (NULL = none), binary grid [R,R,R] uint8 over the AABB [-bound,bound]^3.  Interval k of a ray:
+ * ts = t_near + u*step + k*step, te = min(ts+step, t_far), kept iff the cell of its midpoint is occupied.
+ * Pass 1 writes ray_cnt [N]; the caller scans it into ray_start [N] (exclusive) and allocates; pass 2 fills
+ * the packed ray_idx / t_starts / t_ends. */
+int mh_march_count(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step, float bound,
+                   int32_t R, const uint8_t *binary, int32_t *ray_cnt, void *stream);
+int mh_march_fill(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step, float bound,
+                  int32_t R, const uint8_t *binary, const int32_t *ray_start, int32_t *ray_idx, float *t_starts,
+                  float *t_ends, void *stream);
+
 /* ---- fused tiny-MLP evaluators on fp32 MFMA (v_mfma_f32_32x32x2_f32) -------------------------
  * Weight operands are PRE-PACKED by the host into the MFMA A-fragment order (see
  * morpheus_amd/packing.py): for layer l, tile mt, k-quad q: float4 per lane.  `wpack` is the

@@ -82,6 +82,83 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(const float *__rest
     }
 }
 
+// ---- occupancy-grid ray marcher ----------------------------------------------------------------
+// Stands where nerfacc's OccGridEstimator.sampling stands in the reference (morpheus.py:628-638: fixed
+// render_step_size, one stratified near-plane jitter per ray, alpha_thre = 0, early_stop_eps = 0, sigma_fn =
+// None => the output depends only on the rays and the binary grid).  nerfacc's source is not in the reference
+// tree, so the interval placement is defined here (and mirrored by oracle/field.py:march_samples):
+//   [t_near, t_far] = slab clip to the AABB, t_near >= 0;   t0 = t_near + u * step;
+//   interval k: ts = t0 + k*step, te = min(ts + step, t_far), kept while ts < t_far and only if the grid cell
+//   containing the interval's midpoint is occupied.
+// Two passes (count, fill) around an exclusive scan of the per-ray counts: the packed layout is ragged.
+struct MarchRay {
+    float o[3], d[3];
+    float t0, tfar;
+};
+
+__device__ __forceinline__ MarchRay march_setup(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                const float *__restrict__ jitter, int r, float step, float bound) {
+    MarchRay m;
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        m.o[a] = rays_o[r * 3 + a];
+        m.d[a] = rays_d[r * 3 + a];
+        const float ta = (-bound - m.o[a]) / m.d[a];
+        const float tb = (bound - m.o[a]) / m.d[a];
+        tmin = fmaxf(tmin, fminf(ta, tb));
+        tmax = fminf(tmax, fmaxf(ta, tb));
+    }
+    tmin = fmaxf(tmin, 0.0f);
+    if (!(tmax > tmin)) {
+        tmin = 0.f;
+        tmax = 0.f;
+    }
+    m.t0 = tmin + (jitter ? jitter[r] : 0.0f) * step;
+    m.tfar = tmax;
+    return m;
+}
+
+__device__ __forceinline__ bool march_occupied(const MarchRay &m, float ts, float te, float bound, int R,
+                                               const uint8_t *__restrict__ binary) {
+    const float tm = (ts + te) / 2.0f;
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float x = m.o[a] + m.d[a] * tm;
+        const float u = (x + bound) / (2.0f * bound);
+        c[a] = min(max((int)floorf(u * (float)R), 0), R - 1);
+    }
+    return binary[((int64_t)c[0] * R + c[1]) * R + c[2]] != 0;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(64) void march_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                   const float *__restrict__ jitter, int N, float step, float bound, int R,
+                                                   const uint8_t *__restrict__ binary, int32_t *__restrict__ ray_cnt,
+                                                   const int32_t *__restrict__ ray_start, int32_t *__restrict__ ray_idx,
+                                                   float *__restrict__ t_starts, float *__restrict__ t_ends) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const MarchRay m = march_setup(rays_o, rays_d, jitter, r, step, bound);
+    int n = 0;
+    const int64_t base = FILL ? ray_start[r] : 0;
+    for (int k = 0;; k++) {
+        const float ts = m.t0 + (float)k * step;
+        if (!(ts < m.tfar)) break;
+        const float te = fminf(ts + step, m.tfar);
+        if (march_occupied(m, ts, te, bound, R, binary)) {
+            if (FILL) {
+                ray_idx[base + n] = r;
+                t_starts[base + n] = ts;
+                t_ends[base + n] = te;
+            }
+            n++;
+        }
+    }
+    if (!FILL) ray_cnt[r] = n;
+}
+
 extern "C" int mh_generate_rays(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
                                 float *rays_o, float *rays_d, void *stream) {
     if (!c2w_host || !rays_o || !rays_d || H <= 0 || W <= 0) return MH_ERR_ARG;
@@ -107,6 +184,30 @@ extern "C" int mh_sample_uniform(const float *rays_o, const float *rays_d, const
     if (total > 0x7fffffffLL) return MH_ERR_ARG;
     hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mh_stream(stream),
                        rays_o, rays_d, jitter, (int)N, (int)S, bound, ray_idx, t_starts, t_ends, xyz, ray_start, ray_cnt);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_march_count(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step,
+                              float bound, int32_t R, const uint8_t *binary, int32_t *ray_cnt, void *stream) {
+    if (N == 0) return MH_OK;
+    if (!rays_o || !rays_d || !binary || !ray_cnt || N < 0 || R <= 0 || !(step > 0.f) || !(bound > 0.f)) return MH_ERR_ARG;
+    hipLaunchKernelGGL(march_kernel<false>, dim3((N + 63) / 64), dim3(64), 0, mh_stream(stream), rays_o, rays_d, jitter,
+                       (int)N, step, bound, (int)R, binary, ray_cnt, (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (float *)nullptr, (float *)nullptr);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_march_fill(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step,
+                             float bound, int32_t R, const uint8_t *binary, const int32_t *ray_start, int32_t *ray_idx,
+                             float *t_starts, float *t_ends, void *stream) {
+    if (N == 0) return MH_OK;
+    if (!rays_o || !rays_d || !binary || !ray_start || !ray_idx || !t_starts || !t_ends || N < 0 || R <= 0 || !(step > 0.f) ||
+        !(bound > 0.f))
+        return MH_ERR_ARG;
+    hipLaunchKernelGGL(march_kernel<true>, dim3((N + 63) / 64), dim3(64), 0, mh_stream(stream), rays_o, rays_d, jitter, (int)N,
+                       step, bound, (int)R, binary, (int32_t *)nullptr, ray_start, ray_idx, t_starts, t_ends);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

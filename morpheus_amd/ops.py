@@ -244,6 +244,34 @@ def sample_uniform(rays_o, rays_d, jitter, S: int, bound: float, with_xyz: bool 
     return ri, ts, te, xyz, rs, rc
 
 
+def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.Tensor):
+    """Occupancy-grid marcher -> (ray_idx int32 [M], t_starts [M], t_ends [M], ray_start [N], ray_cnt [N]).
+    The only host sync on the path: M = total sample count is needed to size the packed arrays
+    (nerfacc synchronises at the same point)."""
+    require_gpu(rays_o, rays_d, jitter, binary)
+    lib = _lib.load()
+    o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+    j = None if jitter is None else jitter.contiguous()
+    assert binary.dtype == torch.uint8 and binary.is_contiguous() and binary.dim() == 3
+    N, R, dev = o.shape[0], binary.shape[0], o.device
+    cnt = torch.empty(N, dtype=torch.int32, device=dev)
+    _e = TIMER.start()
+    check(lib.mh_march_count(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), ptr(cnt), stream()),
+          "mh_march_count")
+    TIMER.stop("mh_march_count", _e)
+    csum = torch.cumsum(cnt, 0, dtype=torch.int32)
+    start = (csum - cnt).contiguous()
+    M = int(csum[-1].item()) if N > 0 else 0
+    ri = torch.empty(M, dtype=torch.int32, device=dev)
+    ts, te = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    if M > 0:
+        _e = TIMER.start()
+        check(lib.mh_march_fill(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), ptr(start), ptr(ri),
+                                ptr(ts), ptr(te), stream()), "mh_march_fill")
+        TIMER.stop("mh_march_fill", _e)
+    return ri, ts, te, start, cnt
+
+
 # ------------------------------------------------------------------------------------ fused MLPs
 def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag):
     n_layers = len(act_off)

@@ -161,3 +161,46 @@ def test_full_size_properties():
     c1, c2 = torch.rand(M, 3, device=DEV), torch.rand(M, 3, device=DEV)
     f = lambda c: ops.composite(sig, ts, te, c, rs, rc)[3]
     assert_close(f(0.3 * c1 + 0.7 * c2), 0.3 * f(c1) + 0.7 * f(c2), 1e-5, "linearity", floor=1e-3)
+
+
+def test_render_with_occupancy_marcher_ragged():
+    """The reference's call shape end to end: OccupancyGrid.sampling (ragged, fixed step 0.01) -> render_rays.
+    HIP vs the CPU oracle on the oracle-marched samples (bit-identical to the HIP marcher's), values and gradients."""
+    from morpheus_amd import harness
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.render import HotPathRenderer
+    hw = 24
+    o, d, t, rid = synth.frame_rays(25, hw, hw)
+    N = o.shape[1]
+    jit = synth.ray_jitter(N)
+    c = (torch.arange(128).float() + 0.5) / 128 * 2.02 - 1.01
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    ball = ((X ** 2 + Y ** 2 + Z ** 2).sqrt() < 0.7).to(torch.uint8).contiguous()
+    light = of.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    timg, tdep = synth.targets(N)
+    # oracle
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in synth.make_state("b").items()}
+    f = of.OracleField(p, 1.01, None)
+    smp = of.march_samples(o[0], d[0], jit, 0.01, 1.01, ball)
+    assert smp[0].numel() > 20000 and len(torch.unique(torch.bincount(smp[0], minlength=N))) > 5      # genuinely ragged
+    ro = of.render_rays(f, o, d, t, rid, smp, ambient_ratio=1.0, light_d=light, shading="albedo")
+    (((ro["image"][0] - timg) ** 2).mean() + ((ro["depth"][0] - tdep) ** 2).mean()).backward()
+    # HIP
+    model = harness.build_model("b", DEV).eval()
+    grid = OccupancyGrid([-1.01] * 3 + [1.01] * 3, 128).to(DEV)
+    grid.set_binary(ball.to(DEV))
+    grid.fixed_jitter = jit.to(DEV)
+    rend = HotPathRenderer(model, model.config, grid, 200)
+    rg = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, ambient_ratio=1.0, light_d=light.to(DEV),
+                          shading="albedo")
+    assert rg["sdf"].shape[0] == smp[0].numel()
+    (((rg["image"][0] - timg.to(DEV)) ** 2).mean() + ((rg["depth"][0] - tdep.to(DEV)) ** 2).mean()).backward()
+    assert_close(rg["image"], ro["image"], TOL, "image", floor=FLOOR)
+    assert_close(rg["depth"], ro["depth"], TOL, "depth", floor=DEPTH_FLOOR)
+    assert_close(rg["sdf"], ro["sdf"], TOL, "sdf", floor=FLOOR)
+    assert_close(rg["weights_sum"], ro["weights_sum"], TOL, "opacity", floor=FLOOR)
+    worst = 0.0
+    for k, prm in model.named_parameters():
+        if prm.grad is not None and p[k].grad is not None and float(p[k].grad.norm()) > 0:
+            worst = max(worst, float((prm.grad.cpu().double() - p[k].grad.double()).norm() / p[k].grad.double().norm()))
+    assert worst < 5e-4, worst
