@@ -662,7 +662,7 @@ __device__ __forceinline__ void wg_mma(const WgFrag<IT> &f, f32x16 (&acc)[IT], f
 }
 
 template <int IT>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                        int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
                                                        int dpre_off, int out_pad, float *__restrict__ dw_part,
                                                        float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
@@ -676,28 +676,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const float *__restrict__
     acc_zero<IT>(acc);
     float bsum = 0.f;
     WgFrag<IT> f0;
-    // Two register sets, software-pipelined by hand: tile k+1's 4+4*IT loads are in flight while tile k's MFMAs
-    // issue.  The loads are inline asm with counted waits because hipcc re-rolls a C++-level double buffer into
-    // load -> vmcnt(0) -> MFMA (checked in the .s).  Index-clamped prefetches past the end are harmless re-reads.
+    // Three register sets, software-pipelined by hand, ONE wave per SIMD: two tiles' loads (2 x (4+4*IT) x 1 KB per
+    // wave) are in flight while a third tile's 16*IT MFMAs issue.  Two design facts measured on gfx950
+    // (tools/micro/mfma_rate.hip): (i) two waves issuing fp32 MFMAs with changing operands on one SIMD reach only 105
+    // TFLOP/s chip-wide, one wave alone reaches 156, so this kernel wants exactly one wave per SIMD and hides latency by
+    // prefetch depth instead of occupancy; (ii) the loads must be inline asm with counted s_waitcnt -- hipcc re-rolls a
+    // C++-level multi-buffer loop into load -> vmcnt(0) -> MFMA.  Index-clamped prefetches past the end re-read a tile.
     constexpr int NL = 4 + 4 * IT;  // loads per tile
     const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
     const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
 #define WG_TILE(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
+#define WG_LOAD(f, k) wg_load_async<IT>(f, acts, dpre, WG_TILE(k), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h)
     if (n_my > 0) {
-        WgFrag<IT> f1;
-        wg_load_async<IT>(f0, acts, dpre, chunk, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h);
-        for (int64_t k = 0; k < n_my; k += 2) {
-            wg_load_async<IT>(f1, acts, dpre, WG_TILE(k + 1), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h);
-            wg_wait<NL>();  // f0 landed (everything but the NL loads just issued)
+        WgFrag<IT> f1, f2;
+        WG_LOAD(f0, 0);
+        WG_LOAD(f1, 1);
+        for (int64_t k = 0; k < n_my; k += 3) {
+            WG_LOAD(f2, k + 2);
+            wg_wait<2 * NL>();  // f0 landed
             wg_mma<IT>(f0, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
-            wg_load_async<IT>(f0, acts, dpre, WG_TILE(k + 2), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h);
-            wg_wait<NL>();  // f1 landed
+            WG_LOAD(f0, k + 3);
+            wg_wait<2 * NL>();  // f1 landed
             if (k + 1 < n_my) wg_mma<IT>(f1, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
+            WG_LOAD(f1, k + 4);
+            wg_wait<2 * NL>();  // f2 landed
+            if (k + 2 < n_my) wg_mma<IT>(f2, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#undef WG_LOAD
 #undef WG_TILE
     // D[row = out (acc_row), col = in (lane&31)];  partial of this chunk: [out_pad][32*IT]
     const int in_pad = 32 * IT;
@@ -808,8 +818,8 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
 }
 
 static inline int wg_chunks(int out_pad, int64_t n_tiles) {
-    // ~2048 waves per launch (2 per SIMD) whatever the number of output tiles
-    int64_t c = 2048 / (out_pad / 32);
+    // 1024 waves per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
+    int64_t c = 1024 / (out_pad / 32);
     if (c > n_tiles) c = n_tiles;
     return (int)(c < 1 ? 1 : c);
 }
