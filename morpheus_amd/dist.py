@@ -24,10 +24,14 @@ def init_from_env(backend: str | None = None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MORPHEUS_DIST_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks
+            backend = os.environ.get("MORPHEUS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     return rank, local, world
 
 
