@@ -66,7 +66,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg3b"],
+                    help="cfg3: deform field, albedo (headline); cfg2: canonical only; cfg3b: deform + albedo_normal "
+                         "shading (FD normals: the reference's real-view training mode, SURVEY 8d optional case)")
     ap.add_argument("--rays", type=int, default=128 * 128)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,7 +105,8 @@ def main():
 
     def step():
         bucket.zero()
-        res = rend.render_rays(o, d, t, rid, hw, hw, ambient_ratio=1.0, light_d=light, shading="albedo", cano=cano)
+        res = rend.render_rays(o, d, t, rid, hw, hw, ambient_ratio=1.0, light_d=light,
+                               shading="albedo_normal" if args.workload == "cfg3b" else "albedo", cano=cano)
         loss = harness.bench_loss(res, timg, tdep)
         loss.backward()
         bucket.allreduce_mean()
@@ -174,7 +177,8 @@ def main():
         "metric": "rays/sec (fwd+bwd, 128 samples/ray)", "value": round(total_rays / elapsed, 1), "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("snoopy.yaml full deform field" if not cano else "snoopy.yaml canonical field only")
+        "config": {"workload": ("snoopy.yaml full deform field" + (" + FD normals (albedo_normal)" if args.workload == "cfg3b" else "")
+                                if not cano else "snoopy.yaml canonical field only")
                    + f", {N} rays x {S} samples per GPU, fwd+bwd+Adam ({args.workload})",
                    "rays_per_gpu": N, "samples_per_ray": S, "parallelism": f"dp{world} (rays/frames sharded, "
                    f"one {bucket.nbytes / 1e6:.2f} MB gradient all-reduce per step)", "weights": "closed-form state b",

@@ -204,3 +204,57 @@ def test_render_with_occupancy_marcher_ragged():
         if prm.grad is not None and p[k].grad is not None and float(p[k].grad.norm()) > 0:
             worst = max(worst, float((prm.grad.cpu().double() - p[k].grad.double()).norm() / p[k].grad.double().norm()))
     assert worst < 5e-4, worst
+
+
+def test_training_regularisers_wiring():
+    """The in-render regularisers of morpheus.py:708-792 on the HIP path.  They draw random perturbations, so the
+    comparison with the oracle pins the perturbation to zero (smoothness_std = 0, topo_none = True):
+      loss_normal_perturb = mean |normal(x; topo) - normal(x; topo=None)|   and   loss_orient, loss_code
+    and then the default config (all regularisers on, random perturbations) must run, give finite losses and reach
+    every parameter group with finite gradients."""
+    from morpheus_amd import harness
+    hw, S = 16, 32
+    o, d, t, rid = synth.frame_rays(25, hw, hw)
+    N = o.shape[1]
+    jit = synth.ray_jitter(N)
+    smp = of.uniform_samples(o[0], d[0], jit, S, 1.01)
+    light = of.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    # --- oracle, zero perturbation
+    p = {k: v for k, v in synth.make_state("b").items()}
+    f = of.OracleField(p, 1.01, None)
+    ri, ts, te = smp
+    xyz = o[0][ri] + d[0][ri] * ((ts + te) / 2)[:, None]
+    tstep = t[0][ri]
+    sdf, sig, col, nrm, dfm, raw = f.forward(xyz, tstep, light[ri], ratio=0.3, shading="lambertian")
+    nrm_none, _ = f.normal(xyz, topo=None)
+    want_perturb = (nrm - nrm_none).abs().mean()
+    w, _, _ = of.render_weights(ts, te, sig, ri, N)
+    tdirs = of.safe_normalize(d[0][ri])
+    want_orient = (w * (nrm * tdirs).sum(-1).clamp(min=0) ** 2).sum(-1).mean()
+    # --- HIP
+    model = harness.build_model("b", DEV).train()
+    cfg = model.config
+    cfg["train"]["smoothness_std"] = 0.0
+    cfg["train"]["normal_smoothness"] = 0.0
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    res = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, ambient_ratio=0.3, light_d=light.to(DEV),
+                           shading="lambertian", real_view=False)
+    assert_close(res["loss_normal_perturb"], want_perturb, 2e-2, "loss_normal_perturb (FD normals)", floor=1e-3)
+    assert_close(res["loss_orient"], want_orient, 2e-2, "loss_orient", floor=1e-4)
+    assert "loss_code" in res and "normal_reg" not in res
+    # --- default config: everything on, random perturbations
+    model = harness.build_model("b", DEV).train()
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    dep = synth.hash_tensor((1, N, 1), 400, 0.3, 1.5).to(DEV)
+    res = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, ambient_ratio=0.3, light_d=light.to(DEV),
+                           shading="lambertian", real_view=True, rays_depth=dep, rays_mask=torch.ones_like(dep),
+                           optimize_pose=True)
+    keys = ("loss_normal_perturb", "loss_code", "normal_reg", "sdf_loss", "fs_loss")
+    for k in keys:
+        assert k in res and torch.isfinite(res[k]).all(), k
+    total = (res["image"] ** 2).mean() + sum(res[k] for k in keys)
+    total.backward()
+    for name, prm in model.named_parameters():
+        if "bg_net" in name:
+            continue
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
