@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one whole step (render fwd+bwd, all-reduce excluded, Adam) in a HIP graph and replay it; "
+                         "disables the per-kernel event timers")
     args = ap.parse_args()
 
     from morpheus_amd import dist as mdist
@@ -100,7 +103,8 @@ def main():
     rend = harness.make_renderer(model, S, jitter=jitter)
     light = torch.nn.functional.normalize(o[0] + torch.tensor([0.3, -0.2, 0.5], device=dev), dim=-1)
     timg, tdep = [v.to(dev) for v in synth.targets(N)]
-    opt = torch.optim.Adam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15, fused=True)
+    opt = torch.optim.Adam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15, fused=True,
+                           capturable=args.graph)
     bucket = mdist.GradBucket(model.parameters())
 
     def step():
@@ -115,7 +119,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ops.TIMER.reset(enabled=(rank == 0 and not args.no_kernel_timers))
+    graph = None
+    if args.graph:
+        assert world == 1, "--graph captures the single-GPU step"
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()                                   # warm the allocator on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_g = step()
+        eager_step = step
+
+        def step():                                  # noqa: F811 -- replay the captured step
+            graph.replay()
+            return loss_g
+    ops.TIMER.reset(enabled=(rank == 0 and not args.no_kernel_timers and graph is None))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

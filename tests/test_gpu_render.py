@@ -258,3 +258,35 @@ def test_training_regularisers_wiring():
         if "bg_net" in name:
             continue
         assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+
+
+def test_two_frames_in_one_batch():
+    """B = 2 frames flattened into one render_rays call (how cfg5 / a multi-frame batch reaches the path,
+    morpheus.py:596-600): per-frame deform codes are selected per sample through the slot table, and their
+    gradients are segment-summed per frame."""
+    from morpheus_amd import harness
+    hw, S = 16, 48
+    fr = [synth.frame_rays(fid, hw, hw) for fid in (0, 25)]
+    o, d, t, rid = [torch.cat([f[k] for f in fr], 0) for k in range(4)]          # [2, N, .]
+    N = o.shape[1]
+    jit = synth.ray_jitter(2 * N)
+    smp = of.uniform_samples(o.reshape(-1, 3), d.reshape(-1, 3), jit, S, 1.01)
+    light = of.safe_normalize(o.reshape(-1, 3) + torch.tensor([0.3, -0.2, 0.5]))
+    timg, tdep = synth.targets(2 * N)
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in synth.make_state("b").items()}
+    f = of.OracleField(p, 1.01, None)
+    ro = of.render_rays(f, o, d, t, rid, smp, ambient_ratio=1.0, light_d=light, shading="albedo")
+    (((ro["image"].reshape(-1, 3) - timg) ** 2).mean() + ((ro["depth"].reshape(-1) - tdep) ** 2).mean()).backward()
+    model = harness.build_model("b", DEV).eval()
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    rg = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, ambient_ratio=1.0, light_d=light.to(DEV),
+                          shading="albedo")
+    (((rg["image"].reshape(-1, 3) - timg.to(DEV)) ** 2).mean() + ((rg["depth"].reshape(-1) - tdep.to(DEV)) ** 2).mean()).backward()
+    assert rg["image"].shape == (2, N, 3) and rg["depth"].shape == (2, N)
+    assert_close(rg["image"], ro["image"], TOL, "image", floor=FLOOR)
+    assert_close(rg["depth"], ro["depth"], TOL, "depth", floor=DEPTH_FLOOR)
+    assert_close(rg["deform"], ro["deform"], TOL, "deform", floor=1e-3)
+    for k in ("deform_code.volumes.0", "deform_code.volumes.2", "deform_net.net.0.bias", "deform_net.net.0.weight_v",
+              "topo_net.net.0.weight_g", "encoder.embeddings"):
+        gg, go = dict(model.named_parameters())[k].grad.cpu().double(), p[k].grad.double()
+        assert float((gg - go).norm() / go.norm()) < 5e-4, k
