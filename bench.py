@@ -175,17 +175,37 @@ def main():
             ktab[name]["tflops"] = round(flops[name] / (avg_ms * 1e-3) / 1e12, 2)
             if dominant is None:
                 dominant = name
+    def pmc_traffic(kernel_symbol):
+        """HBM bytes per launch measured by the committed rocprofv3 --pmc passes of this same command
+        (profiles/r01_pmc_summary.csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB units)."""
+        try:
+            import csv
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")) as f:
+                for row in csv.DictReader(f):
+                    if row["k"] == kernel_symbol:
+                        return round((float(row["hbm_read_MB_per_launch"]) + float(row["hbm_write_MB_per_launch"])) * 1024 * 1024)
+        except Exception:      # noqa: BLE001
+            pass
+        return None
+
+    symbol = {"mh_warp_fwd": "warp_fwd_kernel", "mh_warp_bwd_data": "warp_bwd_kernel", "mh_field_fwd": "field_fwd_kernel",
+              "mh_field_bwd_data": "field_bwd_kernel"}
     roofline = None
     if dominant is not None:
         ach = flops[dominant] / (ktab[dominant]["avg_ms"] * 1e-3) / 1e12
         roofline = dict(kernel=dominant, bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        traffic=pmc_traffic(symbol.get(dominant, "")) if (N * S == 128 * 128 * 128 and not cano) else None,
+                        traffic_note="HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), not a live "
+                                     "measurement; null when the workload differs from the profiled one",
                         flops_per_launch=flops[dominant], avg_launch_ms=ktab[dominant]["avg_ms"])
     roof_hash = None
     if "mh_grid_encode_fwd" in ktab:
         gb = GRID_FWD_BYTES * M / (ktab["mh_grid_encode_fwd"]["avg_ms"] * 1e-3) / 1e9
         roof_hash = dict(kernel="grid_fwd_kernel", bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                         frac=round(gb / HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=GRID_FWD_BYTES * M,
+                         frac=round(gb / HBM_PEAK_GBS, 4),
+                         traffic=pmc_traffic("grid_fwd_kernel") if (N * S == 128 * 128 * 128) else None,
+                         bytes_per_launch=GRID_FWD_BYTES * M,
                          note="algorithmic bytes; both 3.2 MB tables are L2/MALL resident, so gathers are "
                               "cache-served (SURVEY 8d caveat)")
         bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
