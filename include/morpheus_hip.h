@@ -135,7 +135,8 @@ int mh_warp_fwd(const float *x, const int32_t *slot, const float *bias0_d, const
                 const float *wpack_d, const float *wpack_t, const float *bias_d, const float *bias_t,
                 int32_t n_bands, float *out_deform, float *out_topo, float *acts, int64_t M, void *stream);
 /* backward-data: consumes g_deform [M,3], g_topo [M,2] (either may be NULL = zero), acts from the
- * forward and the TRANSPOSED packs; writes g_x [M,3] (d/dx through the frequency encoding) and
+ * forward and the TRANSPOSED packs; writes g_x [M,3] (d/dx through the frequency encoding; pass NULL when the
+ * sample positions carry no gradient and the first-layer transposed GEMM is skipped) and
  * dpre scratch (same geometry as acts) for mh_mlp_wgrad. */
 int mh_warp_bwd_data(const float *x, const float *g_deform, const float *g_topo, const float *wpackT_d,
                      const float *wpackT_t, int32_t n_bands, const float *acts, float *dpre, float *g_x,

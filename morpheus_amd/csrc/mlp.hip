@@ -279,8 +279,10 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
                 acc_zero<4>(acc);
                 mfma_layer<64, 4>(dbin, acc, lane);
                 wt += 16384;
-            } else {
-                // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5)
+            } else if (g_x) {
+                // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5).  Skipped when nobody asks
+                // for d/dx (sample positions without gradient: every step that does not optimise the camera pose) --
+                // 128 of the net's 1216 MFMAs
                 stage_weights<2048>(wt);
                 f32x16 e[2];
                 acc_zero<2>(e);

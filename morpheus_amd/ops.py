@@ -337,7 +337,7 @@ class _WarpMLP(torch.autograd.Function):
         M, dev = x.shape[0], x.device
         n_tiles = lib.mh_mlp_tiles(M)
         dpre = torch.empty(lib.mh_warp_dpre_floats(M), device=dev)
-        g_x = torch.empty(M, 3, device=dev)
+        g_x = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL -> the kernel skips the W0^T stage
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
         check(lib.mh_warp_bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts),
