@@ -106,6 +106,45 @@ __device__ __forceinline__ void mfma_layer(const float (&bin)[KS], f32x16 (&acc)
     }
 }
 
+// Same contraction with the layer's A fragments at an arbitrary LDS address (resident-weight kernels below).
+template <int KS, int MT>
+__device__ __forceinline__ void mfma_layer_at(const f32x4 *__restrict__ w, const float (&bin)[KS], f32x16 (&acc)[MT],
+                                              int lane) {
+    static_assert(KS % 4 == 0, "k-steps come in quads");
+#pragma unroll
+    for (int q = 0; q < KS / 4; q++) {
+        f32x4 a[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) a[t] = w[(t * (KS / 4) + q) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], bin[4 * q + j], acc[t], 0, 0, 0);
+    }
+}
+
+// The field networks are small enough (94 KB fwd / 98 KB transposed) to keep EVERY layer's fragments in LDS for the
+// life of a persistent block: one staging pass per block, then no barrier at all between layers or tiles.
+#define FIELD_THREADS 512
+extern __shared__ f32x4 lds_res[];
+template <int N_F4>
+__device__ __forceinline__ void stage_resident(const float *__restrict__ g, int dst_f4) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(g);
+    constexpr int R = (N_F4 + FIELD_THREADS - 1) / FIELD_THREADS;
+    f32x4 v[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = k * FIELD_THREADS + threadIdx.x;
+        if (i < N_F4) v[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = k * FIELD_THREADS + threadIdx.x;
+        if (i < N_F4) lds_res[dst_f4 + i] = v[k];
+    }
+}
+
 template <int MT, bool RELU>
 __device__ __forceinline__ void acc_to_bin(const f32x16 (&acc)[MT], float (&bin)[16 * MT]) {
 #pragma unroll
@@ -324,15 +363,21 @@ __device__ __forceinline__ float laplace_sigma(float s, float beta) {
     return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
 }
 
-__global__ __launch_bounds__(256, 2) void field_fwd_kernel(const float *__restrict__ xc, const float *__restrict__ feat_s,
+__global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float *__restrict__ xc, const float *__restrict__ feat_s,
                                                            const float *__restrict__ feat_c, const float *__restrict__ topo,
                                                            const float *__restrict__ wpack, const float *__restrict__ bias,
                                                            const float *__restrict__ beta_p, int n_bands, int with_color, float *__restrict__ sdf,
                                                            float *__restrict__ sigma, float *__restrict__ albedo,
-                                                           float *__restrict__ acts, int64_t M) {
+                                                           float *__restrict__ acts, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
-    const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    if (with_color)
+        stage_resident<FIELD_WPACK / 4>(wpack, 0);
+    else
+        stage_resident<(5120 + 2 * 4096) / 4>(wpack, 0);
+    __syncthreads();
+    for (int64_t tile_id = (int64_t)blockIdx.x * (FIELD_THREADS / 64) + wave; tile_id < n_tiles;
+         tile_id += (int64_t)gridDim.x * (FIELD_THREADS / 64)) {
     const int64_t p = tile_id * TILE + pt;
     const bool live = p < M;
     const int64_t pc = live ? p : M - 1;
@@ -357,34 +402,31 @@ __global__ __launch_bounds__(256, 2) void field_fwd_kernel(const float *__restri
 #pragma unroll
         for (int k = 40; k < 48; k++) tile[(2 * k + h) * TILE + pt] = 0.f;  // pad rows 80..95
     }
-    const float *wp = wpack;
+    const f32x4 *wp = lds_res;
     f32x16 acc[2];
     float bin[32];
     // sdf L0: 73 -> 64
-    stage_weights<1280>(wp);
     acc_bias<2>(acc, bias, h);
-    mfma_layer<40, 2>(bin0, acc, lane);
+    mfma_layer_at<40, 2>(wp, bin0, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 96 * TILE, bin, pt, h);
-    wp += 5120;
+    wp += 1280;
     // sdf L1: 64 -> 64
-    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 64, h);
-    mfma_layer<32, 2>(bin, acc, lane);
+    mfma_layer_at<32, 2>(wp, bin, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 160 * TILE, bin, pt, h);
-    wp += 4096;
+    wp += 1024;
     // sdf L2: 64 -> [geo(32) | sdf], no activation
-    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 128, h);
-    mfma_layer<32, 2>(bin, acc, lane);
-    wp += 4096;
+    mfma_layer_at<32, 2>(wp, bin, acc, lane);
+    wp += 1024;
     if (h == 0 && live) {
         const float s = acc[1][0];
         sdf[p] = s;
         if (sigma) sigma[p] = laplace_sigma(s, *beta_p);
     }
-    if (!with_color) return;
+    if (!with_color) continue;
     // color L0: [hash_c(32) | geo(32)] -> 64
     float binc[32];
     {
@@ -399,48 +441,51 @@ __global__ __launch_bounds__(256, 2) void field_fwd_kernel(const float *__restri
         for (int r = 0; r < 16; r++) binc[16 + r] = acc[0][r];
     }
     if (tile) store_kk_rows<32>(tile + 224 * TILE, binc, pt, h);
-    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 192, h);
-    mfma_layer<32, 2>(binc, acc, lane);
+    mfma_layer_at<32, 2>(wp, binc, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 288 * TILE, bin, pt, h);
-    wp += 4096;
+    wp += 1024;
     // color L1
-    stage_weights<1024>(wp);
     acc_bias<2>(acc, bias + 256, h);
-    mfma_layer<32, 2>(bin, acc, lane);
+    mfma_layer_at<32, 2>(wp, bin, acc, lane);
     acc_to_bin<2, true>(acc, bin);
     if (tile) store_acc_rows<2>(tile + 352 * TILE, bin, pt, h);
-    wp += 4096;
+    wp += 1024;
     // color L2: 64 -> 3, sigmoid
-    stage_weights<512>(wp);
     f32x16 o[1];
     acc_bias<1>(o, bias + 320, h);
-    mfma_layer<32, 1>(bin, o, lane);
+    mfma_layer_at<32, 1>(wp, bin, o, lane);
     if (h == 0 && live) {
 #pragma unroll
         for (int c = 0; c < 3; c++) albedo[p * 3 + c] = 1.0f / (1.0f + expf(-o[0][c]));
     }
+    }  // tile loop
 }
 
-__global__ __launch_bounds__(256, 2) void field_bwd_kernel(
+__global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
     const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ albedo,
     const float *__restrict__ g_sdf, const float *__restrict__ g_sigma, const float *__restrict__ g_albedo,
     const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands, int with_color, const float *__restrict__ acts,
     float *__restrict__ dpre, float *__restrict__ g_xc, float *__restrict__ g_feat_s, float *__restrict__ g_feat_c,
-    float *__restrict__ g_topo, float *__restrict__ g_beta_partial, int64_t M) {
+    float *__restrict__ g_topo, float *__restrict__ g_beta_partial, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
-    const int64_t tile_id = (int64_t)blockIdx.x * 4 + wave;
+    if (with_color)
+        stage_resident<FIELD_WPACKT / 4>(wpackT, 0);
+    else
+        stage_resident<(2 * 4096 + 6144) / 4>(wpackT + 2048 + 2 * 4096, (2048 + 2 * 4096) / 4);
+    __syncthreads();
+    const float beta = *beta_p;
+    for (int64_t tile_id = (int64_t)blockIdx.x * (FIELD_THREADS / 64) + wave; tile_id < n_tiles;
+         tile_id += (int64_t)gridDim.x * (FIELD_THREADS / 64)) {
     const int64_t p = tile_id * TILE + pt;
     const bool live = p < M;
     const int64_t pc = live ? p : M - 1;
     float xv[3] = {xc[pc * 3 + 0], xc[pc * 3 + 1], xc[pc * 3 + 2]};
     const float *atile = acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE);
     float *dtile = dpre + tile_id * (int64_t)(FIELD_DPRE_ROWS * TILE);
-    const float beta = *beta_p;
-
-    const float *wt = wpackT;
+    const f32x4 *wt = lds_res;
     f32x16 acc[2];
     float dbin[32], hv[32];
     float dgeo[16];
@@ -460,10 +505,9 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
             }
         }
         store_acc_rows<1>(dtile + 320 * TILE, d2, pt, h);
-        stage_weights<512>(wt);  // TC2: MT=2, KS=16
-        acc_zero<2>(acc);
-        mfma_layer<16, 2>(d2, acc, lane);
-        wt += 2048;
+            acc_zero<2>(acc);
+        mfma_layer_at<16, 2>(wt, d2, acc, lane);
+        wt += 512;
         // mask C2 -> dQ1
         load_acc_rows<2>(atile + 352 * TILE, hv, pt, h);
 #pragma unroll
@@ -471,10 +515,9 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
         store_acc_rows<2>(dtile + 256 * TILE, dbin, pt, h);
-        stage_weights<1024>(wt);  // TC1
-        acc_zero<2>(acc);
-        mfma_layer<32, 2>(dbin, acc, lane);
-        wt += 4096;
+            acc_zero<2>(acc);
+        mfma_layer_at<32, 2>(wt, dbin, acc, lane);
+        wt += 1024;
         // mask C1 -> dQ0
         load_acc_rows<2>(atile + 288 * TILE, hv, pt, h);
 #pragma unroll
@@ -482,10 +525,9 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
         store_acc_rows<2>(dtile + 192 * TILE, dbin, pt, h);
-        stage_weights<1024>(wt);  // TC0: tile0 -> hash_c (16h + r), tile1 -> geo (acc layout)
-        acc_zero<2>(acc);
-        mfma_layer<32, 2>(dbin, acc, lane);
-        wt += 4096;
+            acc_zero<2>(acc);
+        mfma_layer_at<32, 2>(wt, dbin, acc, lane);
+        wt += 1024;
         if (g_feat_c && live) {
             f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_c + p * 32 + 16 * h);
 #pragma unroll
@@ -499,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++) dgeo[r] = acc[1][r];
     } else {
-        wt += 2048 + 4096 + 4096;
+        wt += (2048 + 4096 + 4096) / 4;
     }
     // dP2 = [dgeo | d sdf]
     float gs = 0.f, gbeta = 0.f;
@@ -532,10 +574,9 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
         }
         d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
         store_acc_rows<2>(dtile + 128 * TILE, d2, pt, h);
-        stage_weights<1024>(wt);  // TS2
-        acc_zero<2>(acc);
-        mfma_layer<32, 2>(d2, acc, lane);
-        wt += 4096;
+            acc_zero<2>(acc);
+        mfma_layer_at<32, 2>(wt, d2, acc, lane);
+        wt += 1024;
     }
     // mask S2 -> dP1
     load_acc_rows<2>(atile + 160 * TILE, hv, pt, h);
@@ -544,10 +585,9 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
     store_acc_rows<2>(dtile + 64 * TILE, dbin, pt, h);
-    stage_weights<1024>(wt);  // TS1
     acc_zero<2>(acc);
-    mfma_layer<32, 2>(dbin, acc, lane);
-    wt += 4096;
+    mfma_layer_at<32, 2>(wt, dbin, acc, lane);
+    wt += 1024;
     // mask S1 -> dP0
     load_acc_rows<2>(atile + 96 * TILE, hv, pt, h);
 #pragma unroll
@@ -556,10 +596,9 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
         for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
     store_acc_rows<2>(dtile, dbin, pt, h);
     // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
-    stage_weights<1536>(wt);  // TS0: MT=3, KS=32
     f32x16 e[3];
     acc_zero<3>(e);
-    mfma_layer<32, 3>(dbin, e, lane);
+    mfma_layer_at<32, 3>(wt, dbin, e, lane);
     float encb[20], dsc[18];
     enc_bin(xv, h, n_bands, encb, dsc);
     float gx[3] = {0.f, 0.f, 0.f};
@@ -594,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void field_bwd_kernel(
             }
         }
     }
+    }  // tile loop
 }
 
 // =====================================================================================
@@ -788,16 +828,24 @@ extern "C" int mh_warp_bwd_data(const float *x, const float *g_deform, const flo
     return MH_OK;
 }
 
+// persistent field kernels: one 8-wave block per CU (the resident weights take 94-98 KB of its LDS)
+static inline unsigned field_blocks(int64_t n_tiles) {
+    const int64_t need = (n_tiles + FIELD_THREADS / 64 - 1) / (FIELD_THREADS / 64);
+    return (unsigned)(need < 256 ? need : 256);
+}
+
 extern "C" int mh_field_fwd(const float *xc, const float *feat_s, const float *feat_c, const float *topo,
                             const float *wpack, const float *bias, const float *beta, int32_t n_bands, int32_t with_color,
                             float *sdf, float *sigma, float *albedo, float *acts, int64_t M, void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !xc || !feat_s || !wpack || !bias || !sdf || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && (!feat_c || !albedo)) return MH_ERR_ARG;
-    const int64_t blocks = (M + BLOCK_PTS - 1) / BLOCK_PTS;
-    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
-    hipLaunchKernelGGL(field_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), xc, feat_s, feat_c, topo,
-                       wpack, bias, beta, (int)n_bands, (int)with_color, sdf, sigma, albedo, acts, M);
+    const int64_t n_tiles = n_tiles_for(M);  // dead tail tiles are processed too: wgrad reads every scratch tile
+    const size_t lds = (size_t)FIELD_WPACK * sizeof(float);
+    if (hipFuncSetAttribute((const void *)field_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MH_ERR_LAUNCH;
+    hipLaunchKernelGGL(field_fwd_kernel, dim3(field_blocks(n_tiles)), dim3(FIELD_THREADS), lds, mh_stream(stream), xc, feat_s,
+                       feat_c, topo, wpack, bias, beta, (int)n_bands, (int)with_color, sdf, sigma, albedo, acts, M, n_tiles);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
@@ -810,11 +858,13 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
     if (M == 0) return MH_OK;
     if (M < 0 || !xc || !sdf || !wpackT || !acts || !dpre || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && !albedo) return MH_ERR_ARG;
-    const int64_t blocks = (M + BLOCK_PTS - 1) / BLOCK_PTS;
-    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
-    hipLaunchKernelGGL(field_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), xc, sdf, albedo, g_sdf,
-                       g_sigma, g_albedo, wpackT, beta, (int)n_bands, (int)with_color, acts, dpre, g_xc, g_feat_s, g_feat_c,
-                       g_topo, g_beta_partial, M);
+    const int64_t n_tiles = n_tiles_for(M);  // dead tail tiles are processed too: wgrad reads every scratch tile
+    const size_t lds = (size_t)FIELD_WPACKT * sizeof(float);
+    if (hipFuncSetAttribute((const void *)field_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return MH_ERR_LAUNCH;
+    hipLaunchKernelGGL(field_bwd_kernel, dim3(field_blocks(n_tiles)), dim3(FIELD_THREADS), lds, mh_stream(stream), xc, sdf,
+                       albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, (int)n_bands, (int)with_color, acts, dpre, g_xc, g_feat_s,
+                       g_feat_c, g_topo, g_beta_partial, M, n_tiles);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
