@@ -195,22 +195,25 @@ def main():
         ach = flops[dominant] / (ktab[dominant]["avg_ms"] * 1e-3) / 1e12
         roofline = dict(kernel=dominant, bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=pmc_traffic(symbol.get(dominant, "")) if (N * S == 128 * 128 * 128 and not cano) else None,
+                        traffic=pmc_traffic(symbol.get(dominant, "")) if (N * S == 128 * 128 * 128 and args.workload == "cfg3") else None,
                         traffic_note="HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), not a live "
                                      "measurement; null when the workload differs from the profiled one",
                         flops_per_launch=flops[dominant], avg_launch_ms=ktab[dominant]["avg_ms"])
     roof_hash = None
     if "mh_grid_encode_fwd" in ktab:
-        gb = GRID_FWD_BYTES * M / (ktab["mh_grid_encode_fwd"]["avg_ms"] * 1e-3) / 1e9
+        # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b), averaged over launches
+        enc_points = (2 * M + (6 * M if args.workload == "cfg3b" else 0))
+        pts_per_launch = enc_points / ktab["mh_grid_encode_fwd"]["calls_per_step"]
+        gb = GRID_FWD_BYTES * pts_per_launch / (ktab["mh_grid_encode_fwd"]["avg_ms"] * 1e-3) / 1e9
         roof_hash = dict(kernel="grid_fwd_kernel", bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=round(gb / HBM_PEAK_GBS, 4),
-                         traffic=pmc_traffic("grid_fwd_kernel") if (N * S == 128 * 128 * 128) else None,
-                         bytes_per_launch=GRID_FWD_BYTES * M,
+                         traffic=pmc_traffic("grid_fwd_kernel") if (N * S == 128 * 128 * 128 and args.workload != "cfg3b") else None,
+                         bytes_per_launch=round(GRID_FWD_BYTES * pts_per_launch),
                          note="algorithmic bytes; both 3.2 MB tables are L2/MALL resident, so gathers are "
                               "cache-served (SURVEY 8d caveat)")
         bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
         if bwd_name in ktab:
-            gbb = GRID_BWD_BYTES * M / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9
+            gbb = GRID_BWD_BYTES * (enc_points / ktab[bwd_name]["calls_per_step"]) / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9
             roof_hash["bwd_kernel"] = bwd_name
             roof_hash["bwd_achieved"] = round(gbb, 1)
             roof_hash["bwd_frac"] = round(gbb / HBM_PEAK_GBS, 4)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Copy the judged summaries of the latest GPU run from gpurun_out/ (scratch) into profiles/ (tracked).
+
+  python tools/collect_profiles.py [round-tag, default r01]
+
+Inputs (written by tools/gpu/round.sh and tools/gpu/pmc.sh on the GPU box):
+  gpurun_out/bench.log, bench_cfg2.log, bench_cfg3b.log   -> profiles/<tag>_bench_<workload>.json (the JSON line)
+  gpurun_out/prof/runc/*_kernel_stats.csv                  -> profiles/<tag>_bench_cfg3_kernel_stats.csv
+  gpurun_out/prof_cfg3b/runc/*_kernel_stats.csv            -> profiles/<tag>_bench_cfg3b_kernel_stats.csv
+  gpurun_out/parity.log                                    -> profiles/<tag>_parity_report.jsonl
+  gpurun_out/pmc_{sq,fetch,write}/runc/*_counter_collection.csv -> profiles/<tag>_pmc_summary.csv
+PMC units / corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE are KB; FETCH_SIZE
+is doubled on gfx950; every counter comes from its own rocprofv3 pass with --kernel-trace only.
+"""
+import csv
+import glob
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+PROF = os.path.join(ROOT, "profiles")
+
+
+def latest(pattern):
+    files = glob.glob(os.path.join(OUT, pattern))
+    return max(files, key=os.path.getmtime) if files else None
+
+
+def json_line(path):
+    if not path or not os.path.exists(path):
+        return None
+    for line in open(path):
+        if line.startswith("{"):
+            return line
+    return None
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.split(r"[<(]", name)[0]
+
+
+def pmc_summary(tag):
+    per = defaultdict(lambda: defaultdict(list))
+    for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        f = latest(f"{d}/runc/*_counter_collection.csv")
+        if not f:
+            return False
+        for row in csv.DictReader(open(f)):
+            per[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    mean = lambda v: sum(v) / len(v) if v else 0.0
+    cols = ["k", "hbm_read_MB_per_launch", "hbm_write_MB_per_launch", "mfma_busy_frac", "l2_hit_rate", "SQ_WAVE_CYCLES",
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"]
+    with open(os.path.join(PROF, f"{tag}_pmc_summary.csv"), "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(cols)
+        for k in sorted(per):
+            c = per[k]
+            if not k or k.startswith(("at::", "__amd", "Cijk_")) or "rocprim" in k or "anonymous" in k:
+                continue
+            hit, miss = mean(c["TCC_HIT_sum"]), mean(c["TCC_MISS_sum"])
+            # GRBM_GUI_ACTIVE sums the 8 XCDs' clocks, SQ_VALU_MFMA_BUSY_CYCLES the 1024 SIMDs': busy fraction = busy / (gui * 128)
+            busy, gui = mean(c["SQ_VALU_MFMA_BUSY_CYCLES"]), 128.0 * mean(c["GRBM_GUI_ACTIVE"])
+            w.writerow([k, round(2.0 * mean(c["FETCH_SIZE"]) / 1024.0, 4), round(mean(c["WRITE_SIZE"]) / 1024.0, 4),
+                        round(busy / gui, 4) if gui else 0.0, round(hit / (hit + miss), 4) if hit + miss else 0.0,
+                        round(mean(c["SQ_WAVE_CYCLES"]), 4), round(mean(c["SQ_WAIT_ANY"]), 4),
+                        round(mean(c["SQ_WAIT_INST_ANY"]), 4), round(mean(c["GRBM_GUI_ACTIVE"]), 4)])
+    return True
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(PROF, exist_ok=True)
+    for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b")):
+        line = json_line(os.path.join(OUT, log))
+        if line:
+            open(os.path.join(PROF, f"{tag}_bench_{wl}.json"), "w").write(line)
+            print("bench", wl)
+    for d, wl in (("prof", "cfg3"), ("prof_cfg3b", "cfg3b")):
+        f = latest(f"{d}/runc/*_kernel_stats.csv")
+        if f:
+            shutil.copy(f, os.path.join(PROF, f"{tag}_bench_{wl}_kernel_stats.csv"))
+            print("kernel stats", wl, os.path.basename(f))
+    p = os.path.join(OUT, "parity.log")
+    if os.path.exists(p):
+        lines = [l for l in open(p) if l.startswith("{")]
+        if lines:
+            open(os.path.join(PROF, f"{tag}_parity_report.jsonl"), "w").writelines(lines)
+            print("parity", len(lines), "records")
+    print("pmc summary", pmc_summary(tag))
+
+
+if __name__ == "__main__":
+    main()
