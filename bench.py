@@ -81,6 +81,7 @@ def main():
 
     from morpheus_amd import dist as mdist
     from morpheus_amd import harness, ops, synth
+    from morpheus_amd.optim import FlatAdam
     import torch.distributed as dist
 
     rank, local, world = mdist.init_from_env()
@@ -103,9 +104,15 @@ def main():
     rend = harness.make_renderer(model, S, jitter=jitter)
     light = torch.nn.functional.normalize(o[0] + torch.tensor([0.3, -0.2, 0.5], device=dev), dim=-1)
     timg, tdep = [v.to(dev) for v in synth.targets(N)]
-    opt = torch.optim.Adam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15, fused=True,
-                           capturable=args.graph)
-    bucket = mdist.GradBucket(model.parameters())
+    if args.graph:
+        # a captured step freezes by-value kernel arguments (step count, learning rates): keep torch's capturable Adam
+        opt = torch.optim.Adam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15, fused=True,
+                               capturable=True)
+        bucket = mdist.GradBucket(model.parameters())
+    else:
+        # Adam of morpheus.py:154-155 over one flat bucket: one mh_adam_step launch per step, gradients in opt.bucket
+        opt = FlatAdam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
+        bucket = opt.bucket
 
     def step():
         bucket.zero()

@@ -178,6 +178,15 @@ int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats,
                  const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
                  float *db_raw, int64_t n_tiles, void *stream);
 
+/* ---- optimiser step over the flat parameter bucket (the step after the path) ---- */
+/* Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9,0.99), eps=1e-15).step() of morpheus.py:154-155,
+ * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned;
+ * param groups are contiguous segments: seg_end_host[s] = exclusive end offset of group s (last == n), seg_lr_host[s]
+ * its learning rate (HOST arrays, n_segs <= 16).  step = 1-based step count (bias correction). */
+int mh_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
+                 const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps, int64_t step,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+// Adam over ONE flat fp32 parameter bucket: the step after the hot path.
+//
+// Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9, 0.99), eps=1e-15) of the reference
+// (morpheus.py:154-155) as it is stepped at morpheus.py:1401-1424: no weight decay, no amsgrad.  The reference's
+// optimiser walks ~60 parameter tensors in 10 groups (the two 3.2 MB hash tables included); here every parameter,
+// gradient and moment lives in one flat buffer (morpheus_amd/optim.py), so a step is one launch streaming
+// 7 x 7.45 MB.  Groups are contiguous segments of the bucket; their learning rates travel by value.
+//   m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// -- the operation order of torch's fused Adam kernel, so the two agree to fp32 round-off.
+#include "common.h"
+
+#define ADAM_MAX_SEGS 16
+struct AdamSegs {
+    int n;
+    int64_t end[ADAM_MAX_SEGS];
+    float step_size[ADAM_MAX_SEGS];  // lr / (1 - b1^t)
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps,
+                                                   float bc2_sqrt, int64_t n) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    const int cnt = (n - i0) < 4 ? (int)(n - i0) : 4;
+    float pv[4], gv[4], mv[4], vv[4];
+    if (cnt == 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p + i0), b = *reinterpret_cast<const f32x4 *>(g + i0);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(m + i0), d = *reinterpret_cast<const f32x4 *>(v + i0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) pv[k] = a[k], gv[k] = b[k], mv[k] = c[k], vv[k] = d[k];
+    } else {
+        for (int k = 0; k < cnt; k++) pv[k] = p[i0 + k], gv[k] = g[i0 + k], mv[k] = m[i0 + k], vv[k] = v[i0 + k];
+    }
+    int seg = 0;
+    while (seg < segs.n - 1 && i0 >= segs.end[seg]) seg++;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < cnt) {
+            while (seg < segs.n - 1 && i0 + k >= segs.end[seg]) seg++;
+            mv[k] = mv[k] + (gv[k] - mv[k]) * (1.0f - beta1);
+            vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pv[k] -= segs.step_size[seg] * mv[k] / denom;
+        }
+    }
+    if (cnt == 4) {
+        f32x4 a, c, d;
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] = pv[k], c[k] = mv[k], d[k] = vv[k];
+        *reinterpret_cast<f32x4 *>(p + i0) = a;
+        *reinterpret_cast<f32x4 *>(m + i0) = c;
+        *reinterpret_cast<f32x4 *>(v + i0) = d;
+    } else {
+        for (int k = 0; k < cnt; k++) p[i0 + k] = pv[k], m[i0 + k] = mv[k], v[i0 + k] = vv[k];
+    }
+}
+
+extern "C" int mh_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
+                            const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
+                            int64_t step, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || n_segs <= 0 || n_segs > ADAM_MAX_SEGS || !seg_end_host ||
+        !seg_lr_host || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
+        return MH_ERR_ARG;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return MH_ERR_ARG;
+    AdamSegs segs;
+    segs.n = n_segs;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    int64_t prev = 0;
+    for (int s = 0; s < n_segs; s++) {
+        if (seg_end_host[s] < prev || seg_end_host[s] > n) return MH_ERR_ARG;
+        prev = segs.end[s] = seg_end_host[s];
+        segs.step_size[s] = (float)((double)seg_lr_host[s] / bc1);
+    }
+    if (prev != n) return MH_ERR_ARG;
+    const int64_t threads = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, mh_stream(stream), params, grads,
+                       exp_avg, exp_avg_sq, segs, beta1, beta2, eps, (float)sqrt(bc2), n);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}

@@ -39,34 +39,43 @@ class GradBucket:
     """Flat gradient bucket with `p.grad` views; `allreduce_mean()` is the whole exchange step."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        o = 0
-        for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        plist = [p for p in params if p.requires_grad]
+        layout, o = [], 0
+        for p in plist:
+            layout.append((p, o, p.numel()))
             o += p.numel()
+        self._init(layout, o, plist[0].device)
+
+    @classmethod
+    def from_layout(cls, layout, n: int, device):
+        """Bucket with a caller-chosen layout [(param, offset, numel)] of total length n (optim.FlatAdam shares its
+        parameter layout so that one offset addresses parameter, gradient and both moments)."""
+        self = cls.__new__(cls)
+        self._init(list(layout), n, device)
+        return self
+
+    def _init(self, layout, n, device):
+        self._layout = layout
+        self.params: List[torch.nn.Parameter] = [p for p, _, _ in layout]
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self._checked = False
+        self.rebind(force=True)
 
     def zero(self):
         self.flat.zero_()
 
-    def rebind(self):
+    def rebind(self, force: bool = False):
         """Re-attach views (call if something replaced p.grad, e.g. zero_grad(set_to_none=True))."""
-        o = 0
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != self.flat[o:o + p.numel()].data_ptr():
-                p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
+        for p, o, k in self._layout:
+            if force or p.grad is None or p.grad.data_ptr() != self.flat[o:o + k].data_ptr():
+                p.grad = self.flat[o:o + k].view(p.shape)
 
     def allreduce_mean(self):
-        if not getattr(self, "_checked", False):
+        if not self._checked:
             # autograd accumulates in place into an existing .grad; verify once that the views held
-            o = 0
-            for p in self.params:
-                assert p.grad is not None and p.grad.data_ptr() == self.flat[o:o + p.numel()].data_ptr(), \
+            for p, o, k in self._layout:
+                assert p.grad is not None and p.grad.data_ptr() == self.flat[o:o + k].data_ptr(), \
                     "a parameter's .grad was replaced; call rebind() after zero_grad(set_to_none=True)"
-                o += p.numel()
             self._checked = True
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

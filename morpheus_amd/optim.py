@@ -1,0 +1,169 @@
+"""Optimiser step for the hot path's parameters: ONE flat bucket, one HIP launch.
+
+`FlatAdam` stands where the reference builds `Adam(self.model.get_params_all(lr), betas=(0.9, 0.99), eps=1e-15)`
+(morpheus.py:154-155) and is used the same way: `param_groups` keep their `name`/`lr` keys, so
+`update_learning_rate` / `freeze_lr_deform` / `reset_lr_deform` (morpheus.py:472-528), which mutate
+`param_group['lr']` by group name, work unchanged; `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format
+(`step`, `exp_avg`, `exp_avg_sq` per parameter), so the reference's checkpoints (morpheus.py:329-358) interchange.
+
+What is different underneath: parameters, gradients and both moments live in four flat fp32 buffers (1.86 M elements
+= 7.45 MB each for snoopy.yaml; `p.data` / `p.grad` / the state tensors are views), groups are contiguous segments,
+and `step()` is a single `mh_adam_step` launch instead of torch's ~10 multi-tensor launches over ~60 tensors per
+group list.  The gradient buffer is a `dist.GradBucket`, so the data-parallel exchange is the same single all-reduce.
+
+`FlatEMA` mirrors `torch_ema.ExponentialMovingAverage` as the reference uses it (morpheus.py:160-162, 1299-1301,
+1368-1369, 1432-1433: `update()` once per epoch, `store()/copy_to()/restore()` around evaluation).  torch_ema is a
+third-party package that is not in the reference tree (requirements.txt lists it unpinned); its published update rule is
+restated here: decay_t = min(decay, (1 + n) / (10 + n)), shadow -= (1 - decay_t) (shadow - param).
+
+There is no CPU path: `step()` raises if the parameters are not on a GPU or the HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable, List
+
+import torch
+
+from . import _lib
+from ._lib import MorpheusHipError, check, ptr, stream
+from .dist import GradBucket
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        plist: List[torch.nn.Parameter] = [p for g in self.param_groups for p in g["params"]]
+        if not plist:
+            raise ValueError("FlatAdam got an empty parameter list")
+        if len(self.param_groups) > 16:
+            raise NotImplementedError("mh_adam_step takes at most 16 parameter groups")
+        dev = plist[0].device
+        for p in plist:
+            if p.dtype != torch.float32 or p.device != dev or not p.requires_grad:
+                raise NotImplementedError("FlatAdam: fp32 trainable parameters on one device only")
+        for g in self.param_groups:
+            if tuple(g["betas"]) != tuple(self.param_groups[0]["betas"]) or g["eps"] != self.param_groups[0]["eps"]:
+                raise NotImplementedError("FlatAdam: betas/eps are shared by all groups (as in the reference)")
+        # every group starts on a 4-element boundary so that the kernel's float4 lanes never straddle two groups' tensors
+        # needlessly; the pad elements have zero gradient and never move
+        self._views = []
+        off = 0
+        self._seg_end = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                self._views.append((p, off, p.numel()))
+                off += p.numel()
+            off = (off + 3) // 4 * 4
+            self._seg_end.append(off)
+        self.n = off
+        self.flat_p = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        with torch.no_grad():
+            for p, o, k in self._views:
+                self.flat_p[o:o + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + k].view(p.shape)
+        self.bucket = GradBucket.from_layout(self._views, self.n, dev)
+        self._step = 0
+        self._seg_end_c = (ctypes.c_int64 * len(self._seg_end))(*self._seg_end)
+        self._bind_state()
+
+    # ---- torch.optim.Adam-format state -----------------------------------------------------------------------------
+    def _bind_state(self):
+        for p, o, k in self._views:
+            self.state[p] = {"step": torch.tensor(float(self._step)),
+                             "exp_avg": self.exp_avg[o:o + k].view(p.shape),
+                             "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape)}
+
+    def state_dict(self):
+        for p, _, _ in self._views:
+            self.state[p]["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = set()
+        with torch.no_grad():
+            for p, o, k in self._views:
+                st = self.state.get(p, {})
+                if "exp_avg" in st:
+                    self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(float(st["step"])))
+                else:   # torch's Adam creates state lazily: a parameter that never had a gradient has none
+                    self.exp_avg[o:o + k].zero_()
+                    self.exp_avg_sq[o:o + k].zero_()
+        if len(steps) > 1:
+            raise NotImplementedError(f"FlatAdam keeps one step count; checkpoint has {sorted(steps)}")
+        self._step = steps.pop() if steps else 0
+        self._bind_state()
+
+    # ---- stepping ---------------------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        self.bucket.zero()          # the views stay bound: autograd accumulates in place
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FlatAdam.step takes no closure")
+        if not self.flat_p.is_cuda:
+            raise MorpheusHipError("FlatAdam steps on an MI355X only; there is no CPU path")
+        lib = _lib.load()
+        self._step += 1
+        g0 = self.param_groups[0]
+        lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
+        check(lib.mh_adam_step(ptr(self.flat_p), ptr(self.bucket.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
+                               len(self.param_groups), self._seg_end_c, lrs, float(g0["betas"][0]), float(g0["betas"][1]),
+                               float(g0["eps"]), self._step, stream()), "mh_adam_step")
+
+
+class FlatEMA:
+    """Exponential moving average of a FlatAdam bucket (one fused op per update); torch_ema's interface."""
+
+    def __init__(self, optimizer: FlatAdam, decay: float, use_num_updates: bool = True):
+        if not 0.0 <= decay <= 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.opt = optimizer
+        self.decay = decay
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow = optimizer.flat_p.detach().clone()
+        self.collected = None
+
+    @torch.no_grad()
+    def update(self):
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        self.shadow.sub_((self.shadow - self.opt.flat_p).mul_(1.0 - decay))
+
+    @torch.no_grad()
+    def store(self):
+        self.collected = self.opt.flat_p.detach().clone()
+
+    @torch.no_grad()
+    def copy_to(self):
+        self.opt.flat_p.copy_(self.shadow)
+
+    @torch.no_grad()
+    def restore(self):
+        if self.collected is None:
+            raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
+        self.opt.flat_p.copy_(self.collected)
+        self.collected = None
+
+    def state_dict(self):
+        per = lambda flat: None if flat is None else [flat[o:o + k].view(p.shape).clone() for p, o, k in self.opt._views]
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": per(self.shadow),
+                "collected_params": per(self.collected)}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        self.decay, self.num_updates = sd["decay"], sd["num_updates"]
+        for (p, o, k), s in zip(self.opt._views, sd["shadow_params"]):
+            self.shadow[o:o + k].copy_(s.reshape(-1))
+        if sd.get("collected_params") is not None:
+            self.collected = torch.zeros_like(self.shadow)
+            for (p, o, k), s in zip(self.opt._views, sd["collected_params"]):
+                self.collected[o:o + k].copy_(s.reshape(-1))

@@ -288,3 +288,42 @@ def test_occupancy_marcher_bit_exact_and_ragged():
     ri_o, ts_o, te_o = of.march_samples(o, d, jit, 0.01, 1.01, g.binaries.cpu())
     assert torch.equal(ts.cpu(), ts_o) and g.packed[1].sum().item() == ri.numel() > 1000
     assert "occs" in g.state_dict() and "binaries" in g.state_dict()
+
+
+def test_flat_adam_matches_torch_adam():
+    """mh_adam_step vs torch.optim.Adam (the reference's optimiser, morpheus.py:154-155) over several steps with
+    per-group learning rates that change between steps (update_learning_rate), sparse (mostly-zero) table gradients
+    and ragged group sizes."""
+    from morpheus_amd.optim import FlatAdam
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(7)
+    shapes = [[(4099, 2), (64, 73)], [(33,)], [(200, 6), (5,), (1,)]]
+    mk = lambda: [[torch.nn.Parameter((torch.randn(*s, generator=g) * 0.1).to(dev)) for s in grp] for grp in shapes]
+    mine = mk()
+    ref = [[torch.nn.Parameter(p.detach().clone()) for p in grp] for grp in mine]
+    groups = lambda ps: [{"name": f"g{i}", "params": grp, "lr": lr} for i, (grp, lr) in enumerate(zip(ps, (1e-2, 5e-3, 1e-3)))]
+    opt = FlatAdam(groups(mine), betas=(0.9, 0.99), eps=1e-15)
+    ropt = torch.optim.Adam(groups(ref), betas=(0.9, 0.99), eps=1e-15, foreach=False, fused=False)
+    for it in range(6):
+        opt.zero_grad()
+        for gm, gr in zip(mine, ref):
+            for pm, pr in zip(gm, gr):
+                gv = (torch.randn(pm.shape, generator=g) * 10.0 ** float(torch.randint(-6, 1, (1,), generator=g))).to(dev)
+                if pm.shape == (4099, 2):
+                    gv = gv * (torch.rand(4099, 1, generator=g) < 0.05).to(dev)   # hash-table-like: 95 % exact zeros
+                pm.grad.add_(gv)                                                   # accumulates into the flat bucket
+                pr.grad = gv.clone()
+        if it == 3:
+            for o in (opt, ropt):
+                o.param_groups[2]["lr"] = 2e-4
+                o.param_groups[0]["lr"] *= 0.5
+        opt.step()
+        ropt.step()
+        for gm, gr in zip(mine, ref):
+            for pm, pr in zip(gm, gr):
+                # an Adam step moves a parameter by at most ~lr: compare at that scale
+                assert float((pm - pr).abs().max()) <= 1e-2 * 2e-5, (it, tuple(pm.shape))
+    sd = opt.state_dict()
+    assert float(sd["state"][0]["step"]) == 6.0
+    e_m = ropt.state[ref[0][0]]["exp_avg"]
+    assert float((sd["state"][0]["exp_avg"] - e_m).abs().max()) <= 1e-6 * float(e_m.abs().max())
