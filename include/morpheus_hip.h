@@ -178,6 +178,17 @@ int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats,
                  const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
                  float *db_raw, int64_t n_tiles, void *stream);
 
+/* ---- weight-norm parametrisation of every weight-normed layer, one launch each way ---------- */
+/* Replaces nn.utils.weight_norm on the Linear layers of deform_net / topo_net / color_net (models/decoders.py:51-52),
+ * recomputed per forward: W_l[r,:] = v_l[r,:] * g_l[r] / ||v_l[r,:]||, and its backward (dv_l, dg_l from dW_l).
+ * The *_host arguments are HOST arrays (n_layers <= 32) of DEVICE pointers / sizes; v_l, W_l, dW_l, dv_l are
+ * [rows_l, cols_l] row-major, g_l and dg_l are [rows_l].  dw_host[l] may be NULL (no gradient): dv_l = dg_l = 0. */
+int mh_weight_norm_fwd(int32_t n_layers, const float *const *v_host, const float *const *g_host, float *const *w_host,
+                       const int32_t *rows_host, const int32_t *cols_host, void *stream);
+int mh_weight_norm_bwd(int32_t n_layers, const float *const *v_host, const float *const *g_host,
+                       const float *const *dw_host, float *const *dv_host, float *const *dg_host,
+                       const int32_t *rows_host, const int32_t *cols_host, void *stream);
+
 /* ---- optimiser step over the flat parameter bucket (the step after the path) ---- */
 /* Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9,0.99), eps=1e-15).step() of morpheus.py:154-155,
  * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned;

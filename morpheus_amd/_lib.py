@@ -45,6 +45,8 @@ _SIGS = {
     "mh_field_bwd_data": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 7 + [_I64, _P]),
     "mh_mlp_wgrad_workspace_floats": (_I64, [_I32, _P, _P, _I64]),
     "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mh_weight_norm_fwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
+    "mh_weight_norm_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _F, _F, _F, _I64, _P]),
 }
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 SO = os.path.join(OUT_DIR, "libmorpheus_hip.so")
-SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "optim.hip"]
+SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "optim.hip", "wnorm.hip"]
 
 
 def _stale() -> bool:

@@ -104,23 +104,10 @@ class _PlainLinear(nn.Module):
 
 
 def wn_effective_batched(layers) -> List[torch.Tensor]:
-    """Effective weights W = g * v / ||v|| of many weight-normed layers with few kernel launches: layers of equal
-    shape are stacked (8 of the 12 warp layers are 128x128) so the norm / divide / multiply run once per shape
-    group instead of once per layer -- ~90 fewer tiny launches per step, forward and backward."""
-    out = [None] * len(layers)
-    groups = {}
-    for i, l in enumerate(layers):
-        groups.setdefault(tuple(l.weight_v.shape), []).append(i)
-    for shape, idx in groups.items():
-        if len(idx) == 1:
-            out[idx[0]] = layers[idx[0]].effective()
-            continue
-        v = torch.stack([layers[i].weight_v for i in idx])            # [k, out, in]
-        g = torch.stack([layers[i].weight_g for i in idx])            # [k, out, 1]
-        w = v * (g / v.norm(dim=2, keepdim=True))
-        for j, i in enumerate(idx):
-            out[i] = w[j]
-    return out
+    """Effective weights W = g * v / ||v|| of many weight-normed layers: ONE HIP launch forward and one backward
+    (ops.weight_norm_all) instead of ~200 tiny torch launches per training step for the 15 layers' norm / divide /
+    multiply and their autograd graph."""
+    return ops.weight_norm_all([l.weight_v for l in layers], [l.weight_g for l in layers])
 
 
 class MLP(nn.Module):

@@ -453,3 +453,46 @@ class _FieldMLP(torch.autograd.Function):
 def field_mlp(xc, feat_s, feat_c, topo, beta, n_bands, with_color, params: Sequence[torch.Tensor]):
     """-> sdf [M], sigma [M], albedo [M,3] (empty when with_color is False)."""
     return _FieldMLP.apply(xc, feat_s, feat_c, topo, beta, n_bands, with_color, *params)
+
+
+class _WeightNormAll(torch.autograd.Function):
+    """W_l = g_l * v_l / ||v_l||_row for a list of weight-normed layers (decoders.py:51-52), one launch forward and one
+    backward (csrc/wnorm.hip) instead of norm / divide / multiply and their autograd graph per layer."""
+
+    @staticmethod
+    def forward(ctx, n, *vg):
+        vs, gs = vg[:n], vg[n:]
+        require_gpu(*vg)
+        lib = _lib.load()
+        vs_c = [v.detach().contiguous() for v in vs]
+        gs_c = [g.detach().contiguous() for g in gs]
+        ws = [torch.empty_like(v) for v in vs_c]
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+        rows, cols = IA(*[v.shape[0] for v in vs_c]), IA(*[v.shape[1] for v in vs_c])
+        check(lib.mh_weight_norm_fwd(n, PA(*[ptr(v) for v in vs_c]), PA(*[ptr(g) for g in gs_c]), PA(*[ptr(w) for w in ws]),
+                                     rows, cols, stream()), "mh_weight_norm_fwd")
+        ctx.save_for_backward(*vs_c, *gs_c)
+        ctx.n = n
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *gw):
+        n = ctx.n
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        vs, gs = saved[:n], saved[n:]
+        gw_c = [None if g is None else g.contiguous() for g in gw]
+        dvs = [torch.empty_like(v) for v in vs]
+        dgs = [torch.empty_like(g) for g in gs]
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int32 * n
+        rows, cols = IA(*[v.shape[0] for v in vs]), IA(*[v.shape[1] for v in vs])
+        check(lib.mh_weight_norm_bwd(n, PA(*[ptr(v) for v in vs]), PA(*[ptr(g) for g in gs]), PA(*[ptr(g) for g in gw_c]),
+                                     PA(*[ptr(t) for t in dvs]), PA(*[ptr(t) for t in dgs]), rows, cols, stream()),
+              "mh_weight_norm_bwd")
+        return (None, *dvs, *dgs)
+
+
+def weight_norm_all(vs: Sequence[torch.Tensor], gs: Sequence[torch.Tensor]):
+    """Effective weights of weight-normed layers: vs[l] [out,in], gs[l] [out,1] -> list of [out,in]."""
+    assert len(vs) == len(gs) and all(v.dim() == 2 for v in vs)
+    return list(_WeightNormAll.apply(len(vs), *vs, *gs))

@@ -327,3 +327,27 @@ def test_flat_adam_matches_torch_adam():
     assert float(sd["state"][0]["step"]) == 6.0
     e_m = ropt.state[ref[0][0]]["exp_avg"]
     assert float((sd["state"][0]["exp_avg"] - e_m).abs().max()) <= 1e-6 * float(e_m.abs().max())
+
+
+def test_weight_norm_all_matches_torch():
+    """mh_weight_norm_fwd/bwd vs torch._weight_norm (what nn.utils.weight_norm of decoders.py:51-52 evaluates) on the
+    hot path's layer shapes, with one output left unused (NULL gradient)."""
+    from morpheus_amd import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 87), (128, 128), (128, 128), (3, 128), (2, 128), (64, 64), (3, 64)]
+    vs = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    gs = [(torch.rand(s[0], 1, generator=g) + 0.5).to(DEV).requires_grad_(True) for s in shapes]
+    probes = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
+    ws = ops.weight_norm_all(vs, gs)
+    loss = sum((w * p).sum() for i, (w, p) in enumerate(zip(ws, probes)) if i != 2)     # layer 2 gets no gradient
+    loss.backward()
+    for i, (v, gg, w, p) in enumerate(zip(vs, gs, ws, probes)):
+        v2, g2 = v.detach().clone().requires_grad_(True), gg.detach().clone().requires_grad_(True)
+        w2 = torch._weight_norm(v2, g2, 0)
+        assert_close(w, w2, 1e-6, f"W[{i}]", floor=1e-3)
+        if i == 2:
+            assert float(v.grad.abs().max()) == 0.0 and float(gg.grad.abs().max()) == 0.0
+            continue
+        (w2 * p).sum().backward()
+        assert_close(v.grad, v2.grad, 2e-5, f"dv[{i}]", floor=1e-2)
+        assert_close(gg.grad, g2.grad, 2e-5, f"dg[{i}]", floor=1e-2)
