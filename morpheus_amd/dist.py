@@ -36,7 +36,8 @@ def init_from_env(backend: str | None = None):
 
 
 class GradBucket:
-    """Flat gradient bucket with `p.grad` views; `allreduce_mean()` is the whole exchange step."""
+    """Flat gradient bucket; `zero()` ... backward ... `allreduce_mean()` (collect + the one exchange step) is a step.
+    After `collect()` / `allreduce_mean()` every `p.grad` is a view of `flat`."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         plist = [p for p in params if p.requires_grad]
@@ -58,11 +59,30 @@ class GradBucket:
         self._layout = layout
         self.params: List[torch.nn.Parameter] = [p for p, _, _ in layout]
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
-        self._checked = False
         self.rebind(force=True)
 
     def zero(self):
+        """Start a step: clear the bucket and detach `p.grad`, so that autograd hands each parameter its fresh gradient
+        tensor (a pointer move) instead of launching one accumulate-add per parameter into a bound view; `collect()`
+        gathers them with one multi-tensor copy."""
         self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        """Gather the gradients autograd produced into the flat bucket and re-bind `p.grad` to its views."""
+        dst, src = [], []
+        for p, o, k in self._layout:
+            g = p.grad
+            if g is None:
+                p.grad = self.flat[o:o + k].view(p.shape)       # no gradient this step: the zeros of zero()
+            elif g.data_ptr() != self.flat[o:o + k].data_ptr():
+                view = self.flat[o:o + k].view(p.shape)
+                dst.append(view)
+                src.append(g)
+                p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def rebind(self, force: bool = False):
         """Re-attach views (call if something replaced p.grad, e.g. zero_grad(set_to_none=True))."""
@@ -71,12 +91,7 @@ class GradBucket:
                 p.grad = self.flat[o:o + k].view(p.shape)
 
     def allreduce_mean(self):
-        if not self._checked:
-            # autograd accumulates in place into an existing .grad; verify once that the views held
-            for p, o, k in self._layout:
-                assert p.grad is not None and p.grad.data_ptr() == self.flat[o:o + k].data_ptr(), \
-                    "a parameter's .grad was replaced; call rebind() after zero_grad(set_to_none=True)"
-            self._checked = True
+        self.collect()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())

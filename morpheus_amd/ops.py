@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, require_gpu, stream
-from .packing import field_packer, warp_packer
+from .packing import field_joint_packer, field_packer, warp_joint_packer, warp_packer
 
 
 
@@ -288,7 +288,7 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     check(lib.mh_mlp_wgrad(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw),
                            ptr(db_raw), n_tiles, stream()), "mh_mlp_wgrad")
     TIMER.stop("mh_mlp_wgrad[" + tag + "]", _e)
-    return dw_raw, db_raw
+    return raw          # dw_raw | db_raw, tile-row order (packing.JointPacker.unpack_grads maps it back)
 
 
 WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640, 2 * 672
@@ -310,11 +310,11 @@ class _WarpMLP(torch.autograd.Function):
         lib = _lib.load()
         assert len(params) == 24
         pd, pt_ = params[:12], params[12:]
-        pk_d, pk_t = warp_packer(3), warp_packer(2)
-        wd, wdT = pk_d.pack([p.detach() for p in pd[:6]])
-        wt, wtT = pk_t.pack([p.detach() for p in pt_[:6]])
-        bd = pk_d.pack_biases([p.detach() for p in pd[6:]], skip_first=True)
-        bt = pk_t.pack_biases([p.detach() for p in pt_[6:]], skip_first=True)
+        jp = warp_joint_packer()       # both nets' fragments, transposed fragments and bias packs: 2 gathers in all
+        det = lambda ts: [p.detach() for p in ts]
+        fpack, bpack = jp.pack([det(pd[:6]), det(pt_[:6])], [det(pd[6:]), det(pt_[6:])])
+        wd, wt, bd, bt = jp.take(fpack, jp.w[0]), jp.take(fpack, jp.w[1]), jp.take(fpack, jp.b[0]), jp.take(fpack, jp.b[1])
+        wdT, wtT = jp.take(bpack, jp.wT[0]), jp.take(bpack, jp.wT[1])
         x = x.detach().contiguous().float()
         M, dev = x.shape[0], x.device
         need_grad = any(ctx.needs_input_grad)
@@ -350,11 +350,9 @@ class _WarpMLP(torch.autograd.Function):
                 dpre_off.append((net * 672 + l * 128) * 32)
                 in_pad.append(64 if l == 0 else 128)
                 out_pad.append(32 if l == 5 else 128)
-        dw_raw, db_raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, act_off, dpre_off, in_pad,
-                                out_pad, n_tiles, dev, "warp")
-        pk_d, pk_t = warp_packer(3), warp_packer(2)
-        gw_d, gb_d = pk_d.unpack_grads(dw_raw[:pk_d.raw_dw], db_raw[:pk_d.raw_db])
-        gw_t, gb_t = pk_t.unpack_grads(dw_raw[pk_d.raw_dw:], db_raw[pk_d.raw_db:])
+        raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, act_off, dpre_off, in_pad, out_pad, n_tiles,
+                     dev, "warp")
+        (gw_d, gw_t), (gb_d, gb_t) = warp_joint_packer().unpack_grads(raw)
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
             g_b0d, g_b0t = gb_d[0][None], gb_t[0][None]
@@ -389,9 +387,9 @@ class _FieldMLP(torch.autograd.Function):
         require_gpu(xc, feat_s, feat_c, topo, beta, *params)
         lib = _lib.load()
         assert len(params) == 12
-        pk = field_packer()
-        w, wT = pk.pack([p.detach() for p in params[:6]])
-        b = pk.pack_biases([p.detach() for p in params[6:]], skip_first=False)
+        jp = field_joint_packer()
+        fpack, bpack = jp.pack([[p.detach() for p in params[:6]]], [[p.detach() for p in params[6:]]])
+        w, b, wT = jp.take(fpack, jp.w[0]), jp.take(fpack, jp.b[0]), jp.take(bpack, jp.wT[0])
         xc = xc.detach().contiguous().float()
         M, dev = xc.shape[0], xc.device
         fs = feat_s.detach().contiguous()
@@ -438,14 +436,18 @@ class _FieldMLP(torch.autograd.Function):
         pk = field_packer()
         act_rows = [0, 96, 160, 224, 288, 352]
         dpre_rows = [0, 64, 128, 192, 256, 320]
-        n_l = 6 if with_color else 3
-        dw_raw, db_raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32,
-                                [r * 32 for r in act_rows[:n_l]], [r * 32 for r in dpre_rows[:n_l]], pk.wg_in[:n_l],
-                                pk.wg_out[:n_l], n_tiles, dev, "field")
-        if not with_color:
+        if with_color:
+            raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows],
+                         [r * 32 for r in dpre_rows], pk.wg_in, pk.wg_out, n_tiles, dev, "field")
+            (gw,), (gb,) = field_joint_packer().unpack_grads(raw)
+        else:   # FD-normal taps: the sdf net only; the colour net's gradients are zero
+            raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows[:3]],
+                         [r * 32 for r in dpre_rows[:3]], pk.wg_in[:3], pk.wg_out[:3], n_tiles, dev, "field")
+            n_dw = sum(i * o for i, o in zip(pk.wg_in[:3], pk.wg_out[:3]))
+            dw_raw, db_raw = raw[:n_dw], raw[n_dw:]
             dw_raw = torch.cat([dw_raw, dw_raw.new_zeros(pk.raw_dw - dw_raw.numel())])
             db_raw = torch.cat([db_raw, db_raw.new_zeros(pk.raw_db - db_raw.numel())])
-        gw, gb = pk.unpack_grads(dw_raw, db_raw)
+            gw, gb = pk.unpack_grads(dw_raw, db_raw)
         g_beta = g_bp.sum().reshape(())
         return (g_xc, g_fs, g_fc, g_tp if has_topo else None, g_beta, None, None, *gw, *gb)
 

@@ -101,7 +101,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     # ---- stepping ---------------------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):
-        self.bucket.zero()          # the views stay bound: autograd accumulates in place
+        self.bucket.zero()          # clears the bucket and detaches p.grad; step() gathers what backward produced
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -110,6 +110,7 @@ class FlatAdam(torch.optim.Optimizer):
         if not self.flat_p.is_cuda:
             raise MorpheusHipError("FlatAdam steps on an MI355X only; there is no CPU path")
         lib = _lib.load()
+        self.bucket.collect()       # no-op when allreduce_mean() already gathered the gradients
         self._step += 1
         g0 = self.param_groups[0]
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])

@@ -262,7 +262,99 @@ class NetPacker:
         return outw, outb
 
 
-_PACKERS: Dict[str, NetPacker] = {}
+class JointPacker:
+    """Several NetPackers behind ONE gather each way, so that preparing the kernels' operands costs 4 launches per call
+    instead of ~15 per net (the maps are static; only the number of launches changes, not a single value):
+
+      flat in   : [W of net 0 | W of net 1 | ... | b of net 0 | b of net 1 | ... | 0]        (natural, effective)
+      fwd pack  : [A-fragments net 0 | net 1 | ... | bias pack net 0 | net 1 | ...]          -> `w[k]`, `b[k]` slices
+      bwd pack  : [transposed fragments net 0 | net 1 | ...]                                 -> `wT[k]` slices
+      raw grads : [dW tiles net 0 | net 1 | ... | db tiles net 0 | net 1 | ...] (mh_mlp_wgrad's output) ->
+      natural   : [dW net 0 | dW net 1 | ... | db net 0 | db net 1 | ...]
+    """
+
+    def __init__(self, packers: Sequence[NetPacker], skip_first_bias: bool):
+        self.packers = list(packers)
+        nW = sum(p.n_weights for p in self.packers)
+        nB = sum(p.n_biases for p in self.packers)
+        zero = nW + nB
+        fwd, bwd, bias = [], [], []
+        self.w, self.wT, self.b = [], [], []
+        wo, bo, f_off, t_off = 0, nW, 0, 0
+        for p in self.packers:
+            fwd.append(np.where(p.fwd_index == p.n_weights, zero, p.fwd_index + wo))
+            bwd.append(np.where(p.bwd_index == p.n_weights, zero, p.bwd_index + wo))
+            sel = p.bias_index[1:] if skip_first_bias else p.bias_index
+            bi = np.concatenate(sel)
+            bias.append(np.where(bi == p.n_biases, zero, bi + bo))
+            self.w.append((f_off, len(p.fwd_index)))
+            self.wT.append((t_off, len(p.bwd_index)))
+            f_off += len(p.fwd_index)
+            t_off += len(p.bwd_index)
+            wo += p.n_weights
+            bo += p.n_biases
+        for bi in bias:
+            self.b.append((f_off, len(bi)))
+            f_off += len(bi)
+        assert all(o % 4 == 0 for o, _ in self.w + self.wT + self.b), "kernel operands are read as float4"
+        self.fwd_index = np.concatenate(fwd + bias)
+        self.bwd_index = np.concatenate(bwd)
+        self.n_flat = zero + 1
+        # gradients
+        raw_dw = sum(p.raw_dw for p in self.packers)
+        g, dwo, dbo = [], 0, raw_dw
+        for p in self.packers:
+            g.append(p.dw_index + dwo)
+            dwo += p.raw_dw
+        for p in self.packers:
+            g.append(p.db_index + dbo)
+            dbo += p.raw_db
+        self.grad_index = np.concatenate(g)
+        self.raw_len = dbo
+        self._dev: Dict[Tuple[str, int], Dict[str, torch.Tensor]] = {}
+
+    def on(self, device: torch.device) -> Dict[str, torch.Tensor]:
+        key = (device.type, device.index or 0)
+        if key not in self._dev:
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            self._dev[key] = dict(fwd=t(self.fwd_index), bwd=t(self.bwd_index), grad=t(self.grad_index))
+        return self._dev[key]
+
+    def pack(self, weights: Sequence[Sequence[torch.Tensor]], biases: Sequence[Sequence[torch.Tensor]]):
+        """weights[k] / biases[k]: the layers of net k (natural).  -> (fwd pack, bwd pack); slice with self.w/b/wT."""
+        parts = [w.reshape(-1) for net in weights for w in net] + [b.reshape(-1) for net in biases for b in net]
+        flat = torch.cat(parts + [parts[0].new_zeros(1)])
+        assert flat.numel() == self.n_flat
+        m = self.on(flat.device)
+        return flat[m["fwd"]], flat[m["bwd"]]
+
+    @staticmethod
+    def take(buf: torch.Tensor, sl: Tuple[int, int]) -> torch.Tensor:
+        return buf[sl[0]:sl[0] + sl[1]]
+
+    def unpack_grads(self, raw: torch.Tensor):
+        """raw [raw_len] = mh_mlp_wgrad's dw_raw | db_raw -> per net (list of natural dW, list of natural db), views of
+        one gathered buffer."""
+        assert raw.numel() == self.raw_len
+        nat = raw[self.on(raw.device)["grad"]]
+        out_w, out_b, o = [], [], 0
+        for p in self.packers:
+            ws = []
+            for s in p.specs:
+                n = s.out_dim * s.in_dim
+                ws.append(nat[o:o + n].view(s.out_dim, s.in_dim))
+                o += n
+            out_w.append(ws)
+        for p in self.packers:
+            bs = []
+            for s in p.specs:
+                bs.append(nat[o:o + s.out_dim])
+                o += s.out_dim
+            out_b.append(bs)
+        return out_w, out_b
+
+
+_PACKERS: Dict[str, object] = {}
 
 
 def warp_packer(n_out: int) -> NetPacker:
@@ -278,3 +370,16 @@ def field_packer() -> NetPacker:
         # backward consumption order: TC2, TC1, TC0, TS2, TS1, TS0
         _PACKERS["field"] = NetPacker(field_specs(), bwd_order=[5, 4, 3, 2, 1, 0])
     return _PACKERS["field"]
+
+
+def warp_joint_packer() -> JointPacker:
+    if "warp_joint" not in _PACKERS:
+        # b0 of both nets lives in the per-slot bias0 the caller builds (ops._WarpMLP), not in the bias pack
+        _PACKERS["warp_joint"] = JointPacker([warp_packer(3), warp_packer(2)], skip_first_bias=True)
+    return _PACKERS["warp_joint"]
+
+
+def field_joint_packer() -> JointPacker:
+    if "field_joint" not in _PACKERS:
+        _PACKERS["field_joint"] = JointPacker([field_packer()], skip_first_bias=False)
+    return _PACKERS["field_joint"]

@@ -29,6 +29,7 @@ class UniformSampler:
     def __init__(self, n_samples: int, bound: float, jitter: Optional[torch.Tensor] = None):
         self.n_samples, self.bound, self.jitter = n_samples, float(bound), jitter
         self.packed = None
+        self.xyz = None      # sample positions o + d (ts+te)/2 of the last call (same arithmetic as morpheus.py:647)
 
     def sampling(self, rays_o, rays_d, sigma_fn=None, render_step_size=None, alpha_thre=0, stratified=True,
                  cone_angle=0.0, early_stop_eps=0):
@@ -39,8 +40,8 @@ class UniformSampler:
             u = torch.rand(n, device=rays_o.device)
         else:
             u = torch.full((n,), 0.5, device=rays_o.device)
-        ri, ts, te, _, rs, rc = ops.sample_uniform(rays_o, rays_d, u, self.n_samples, self.bound)
-        self.packed = (rs, rc)
+        ri, ts, te, xyz, rs, rc = ops.sample_uniform(rays_o, rays_d, u, self.n_samples, self.bound, with_xyz=True)
+        self.packed, self.xyz = (rs, rc), xyz
         return ri, ts, te
 
 
@@ -132,7 +133,11 @@ class HotPathRenderer:
         ray_indices = ray_indices.long()
         t_starts, t_ends = t_starts_[..., None], t_ends_[..., None]
         t_positions = (t_starts + t_ends) / 2.0
-        xyzs = rays_o[ray_indices] + rays_d[ray_indices] * t_positions
+        xyzs = getattr(self.occupancy_grid, "xyz", None)
+        if xyzs is not None:
+            self.occupancy_grid.xyz = None             # one use: it belongs to the sampling call above
+        if xyzs is None or rays_o.requires_grad or rays_d.requires_grad:   # pose optimisation: positions carry gradients
+            xyzs = rays_o[ray_indices] + rays_d[ray_indices] * t_positions
         time_step = rays_t[ray_indices]
 
         if xyzs.shape[0] == 0:

@@ -56,7 +56,8 @@ def test_gradient_bucket_allreduce_two_ranks():
 
 
 def test_single_process_equivalence():
-    """bucket views: backward accumulates in place, all-reduce is a no-op at world size 1."""
+    """bucket: bound views accumulate in place; after zero() backward hands over fresh tensors that
+    allreduce_mean() gathers; the all-reduce itself is a no-op at world size 1."""
     from morpheus_amd import dist as mdist
     torch.manual_seed(0)
     lin = torch.nn.Linear(4, 2)
@@ -68,6 +69,9 @@ def test_single_process_equivalence():
     assert torch.equal(b.flat, g1)
     assert lin.weight.grad.data_ptr() == b.flat.data_ptr()
     b.zero()
-    assert float(lin.weight.grad.abs().sum()) == 0.0
+    assert lin.weight.grad is None and float(b.flat.abs().sum()) == 0.0
+    lin(x).sum().backward()
+    b.allreduce_mean()
+    assert torch.equal(b.flat, g1) and lin.weight.grad.data_ptr() == b.flat.data_ptr()
     lo, hi = mdist.shard_rays(10, 3, 4)
     assert (lo, hi) == (9, 10) and mdist.shard_rays(10, 0, 4) == (0, 3)

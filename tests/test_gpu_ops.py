@@ -311,7 +311,7 @@ def test_flat_adam_matches_torch_adam():
                 gv = (torch.randn(pm.shape, generator=g) * 10.0 ** float(torch.randint(-6, 1, (1,), generator=g))).to(dev)
                 if pm.shape == (4099, 2):
                     gv = gv * (torch.rand(4099, 1, generator=g) < 0.05).to(dev)   # hash-table-like: 95 % exact zeros
-                pm.grad.add_(gv)                                                   # accumulates into the flat bucket
+                pm.grad = gv.clone()                                               # what backward would hand over
                 pr.grad = gv.clone()
         if it == 3:
             for o in (opt, ropt):

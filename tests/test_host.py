@@ -185,3 +185,57 @@ def test_config_schema_matches_reference_keys():
     assert cfg["render"]["step_size"] == 0.01 and cfg["model"]["use_joint"] is True and cfg["exp"]["fp16"] is False
     for k in ("trunc", "normal_smoothness", "normal_smooth_3d", "code_reg", "ori_weight", "topo_none", "smoothness_std"):
         assert k in cfg["train"]
+
+
+def test_joint_packer_equals_per_net_packers():
+    """One gather each way (JointPacker) produces exactly the per-net packs and gradient un-packs."""
+    from morpheus_amd.packing import field_joint_packer, field_packer, warp_joint_packer, warp_packer
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g)
+
+    def net(n_out):
+        return ([rn(128, 39)] + [rn(128, 128) for _ in range(4)] + [rn(n_out, 128)],
+                [rn(128) for _ in range(5)] + [rn(n_out)])
+    (Wd, Bd), (Wt, Bt) = net(3), net(2)
+    jp, pd, pt = warp_joint_packer(), warp_packer(3), warp_packer(2)
+    f, b = jp.pack([Wd, Wt], [Bd, Bt])
+    for k, (pk, W, B) in enumerate(((pd, Wd, Bd), (pt, Wt, Bt))):
+        w, wT = pk.pack(W)
+        assert torch.equal(jp.take(f, jp.w[k]), w) and torch.equal(jp.take(b, jp.wT[k]), wT)
+        assert torch.equal(jp.take(f, jp.b[k]), pk.pack_biases(B, skip_first=True))
+    raw = rn(jp.raw_len)
+    (gwd, gwt), (gbd, gbt) = jp.unpack_grads(raw)
+    n_dw = pd.raw_dw + pt.raw_dw
+    a, ab = pd.unpack_grads(raw[:pd.raw_dw], raw[n_dw:n_dw + pd.raw_db])
+    c, cb = pt.unpack_grads(raw[pd.raw_dw:n_dw], raw[n_dw + pd.raw_db:])
+    assert all(torch.equal(x, y) for x, y in zip(gwd + gwt + gbd + gbt, a + c + ab + cb))
+    Ws = [rn(64, 73), rn(64, 64), rn(33, 64), rn(64, 64), rn(64, 64), rn(3, 64)]
+    Bs = [rn(64), rn(64), rn(33), rn(64), rn(64), rn(3)]
+    fj, fp = field_joint_packer(), field_packer()
+    f, b = fj.pack([Ws], [Bs])
+    w, wT = fp.pack(Ws)
+    assert torch.equal(fj.take(f, fj.w[0]), w) and torch.equal(fj.take(b, fj.wT[0]), wT)
+    assert torch.equal(fj.take(f, fj.b[0]), fp.pack_biases(Bs, skip_first=False))
+
+
+def test_multicode_sample_matches_per_level_formula():
+    """The all-levels-at-once MultiCode.sample equals the per-level lerp of deform_code.py:20-38 bit for bit."""
+    from morpheus_amd.model import MultiCode
+    torch.manual_seed(1)
+    mc = MultiCode([25, 50, 200], 16)
+    t = torch.tensor([0.0, 7 / 200, 0.5, 199 / 200, 1.3, -0.2, 0.12345])[:, None]
+    got = mc.sample(t)
+    tt = t.reshape(-1).clamp(0, 1)
+    want = []
+    for vol in mc.volumes:
+        v = vol[0, :, :, 0]
+        size = v.shape[1]
+        r = ((tt * 2 - 1) + 1) / 2 * (size - 1)
+        r0 = torch.floor(r)
+        fr = (r - r0)[None]
+        i0 = r0.long().clamp(0, size - 1)
+        i1 = (i0 + 1).clamp(0, size - 1)
+        want.append((v[:, i0] * (1 - fr) + v[:, i1] * fr).t())
+    assert torch.equal(got, torch.cat(want, -1))
+    got.square().sum().backward()
+    assert all(float(v.grad.abs().sum()) > 0 for v in mc.volumes)

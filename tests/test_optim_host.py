@@ -26,12 +26,18 @@ def test_layout_views_and_groups():
     assert a.data_ptr() == opt.flat_p.data_ptr() and c.data_ptr() == opt.flat_p[24:].data_ptr()
     assert a.grad.data_ptr() == opt.bucket.flat.data_ptr() and c.grad.shape == c.shape
     assert [g["name"] for g in opt.param_groups] == ["decoder_sdf", "pose"]     # the keys update_learning_rate uses
-    (a.sum() * 2 + c.sum()).backward()                          # autograd accumulates into the bucket in place
+    opt.zero_grad(set_to_none=True)                             # detaches p.grad: backward hands over fresh tensors
+    assert a.grad is None
+    (a.sum() * 2 + c.sum()).backward()
+    assert a.grad.data_ptr() != opt.bucket.flat.data_ptr() and b.grad is None
+    opt.bucket.allreduce_mean()                                 # single process: collect only, no collective
+    assert a.grad.data_ptr() == opt.bucket.flat.data_ptr() and b.grad.data_ptr() == opt.bucket.flat[15:].data_ptr()
     assert float(opt.bucket.flat[:15].min()) == 2.0 and float(opt.bucket.flat[24:28].max()) == 1.0
-    assert float(opt.bucket.flat[15:22].abs().max()) == 0.0
-    opt.zero_grad(set_to_none=True)
-    assert a.grad is not None and float(opt.bucket.flat.abs().max()) == 0.0
-    opt.bucket.allreduce_mean()                                 # single process: checks the views, no collective
+    assert float(opt.bucket.flat[15:22].abs().max()) == 0.0     # b had no gradient: the zeros of zero()
+    (a.sum() * 3).backward()                                    # a second backward accumulates into the bound view
+    assert float(opt.bucket.flat[:15].max()) == 5.0
+    opt.zero_grad()
+    assert float(opt.bucket.flat.abs().max()) == 0.0
 
 
 def test_state_dict_interchanges_with_torch_adam():
