@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ g
 // fixed point: q = (int64) (v * 2^40 / G),  G = power of two >= max|grad|.  A vertex receives at most 1024
 // terms of magnitude <= 2^40 per chunk (sum < 2^51), every fp32 term is represented to 2^-40 G (i.e.
 // exactly, for all practical purposes), and integer addition commutes: the on-chip stage is exact and
-// order-independent -- more accurate than the float atomics it replaces, and ~25x faster.
+// order-independent -- more accurate than the float atomics it replaces, and ~25x faster.  (ds_add_f64 is also
+// fast, 8.1 cycles, but its same-address rate is 40 vs 26 cycles and the kernel came out 25 % slower with it, even
+// without the max|grad| pre-pass it makes unnecessary: measured, not kept.)
 #define FX_BITS 40
 __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float &from_fx) {
     int e = (int)(maxbits >> 23) + 1;   // biased exponent of the power of two above max|grad|
@@ -316,8 +318,13 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
     from_fx = __uint_as_float((uint32_t)(127 - FX_BITS - 127 + e) << 23);  // 2^((e-127) - 40)
 }
 
+// The main loop is a chain of dependent loads (perm -> x, grad -> LDS atomics) and was latency-bound at 256 lanes: a
+// workgroup is BRK_THREADS = 1024 lanes (64 points x 16 levels in flight per iteration, 16 waves sharing one 73 KB
+// accumulator; two workgroups per CU): 0.66 -> 0.52 ms (1.03 -> 0.87 ms with d/dx).  What is left is the LDS atomic
+// pipe: the 4 points a wave carries share their coarse-level cells, so every ds_add_u64 pays the 4-way same-address rate.
+#define BRK_THREADS 1024
 template <bool NEED_DX>
-__global__ __launch_bounds__(256) void grid_bwd_brick_kernel(const float2 *__restrict__ grad, const float *__restrict__ x,
+__global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float2 *__restrict__ grad, const float *__restrict__ x,
                                                              const float2 *__restrict__ emb, GridMeta meta, BrickMeta bm,
                                                              const int32_t *__restrict__ perm,
                                                              const int32_t *__restrict__ brick_start,
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256) void grid_bwd_brick_kernel(const float2 *__res
     const int brick = lo_b;
     const int start = brick_start[brick] + (w - work_start[brick]) * BRK_CHUNK;
     const int end = min(start + BRK_CHUNK, brick_start[brick + 1]);
-    for (int i = threadIdx.x; i < 2 * BRK_NODES_MAX; i += 256) acc[i] = 0;
+    for (int i = threadIdx.x; i < 2 * BRK_NODES_MAX; i += BRK_THREADS) acc[i] = 0;
     float to_fx, from_fx;
     fx_scales(*gmax_bits, to_fx, from_fx);
     const int l = threadIdx.x & 15, sub = threadIdx.x >> 4;
@@ -359,8 +366,9 @@ __global__ __launch_bounds__(256) void grid_bwd_brick_kernel(const float2 *__res
     }
     __syncthreads();
     const float2 *tab = emb + meta.offsets[l];
-    const int end_r = start + ((end - start + 15) / 16) * 16;
-    for (int i = start + sub; i < end_r; i += 16) {
+    constexpr int PPI = BRK_THREADS / 16;  // points per iteration
+    const int end_r = start + ((end - start + PPI - 1) / PPI) * PPI;
+    for (int i = start + sub; i < end_r; i += PPI) {
         const bool live = i < end;
         const int64_t p = perm[live ? i : end - 1];
         float dx[3] = {0.f, 0.f, 0.f};
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(256) void grid_bwd_brick_kernel(const float2 *__res
         for (int d = 0; d < 3; d++)
             lo2[d] = (int)floorf(fminf(fmaxf(fmaf((float)bxyz[d] / (float)BRK, (float)r, -0.5f), 0.0f), (float)(r - 1)));
         float *ge = grad_emb + (size_t)meta.offsets[lev] * 2;
-        for (int j = threadIdx.x; j < n * n * n; j += 256) {
+        for (int j = threadIdx.x; j < n * n * n; j += BRK_THREADS) {
             const long long qx = acc[2 * (b0 + j)], qy = acc[2 * (b0 + j) + 1];
             if (qx == 0 && qy == 0) continue;
             const float2 v = make_float2((float)qx * from_fx, (float)qy * from_fx);
@@ -542,11 +550,11 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
     if (grad_x) {
         // points outside the box are never visited by a brick: their d/dx is zero
         if (hipMemsetAsync(grad_x, 0, sizeof(float) * 3 * (size_t)M, mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
-        hipLaunchKernelGGL(grid_bwd_brick_kernel<true>, dim3(work_items), dim3(256), 0, mh_stream(stream),
+        hipLaunchKernelGGL(grid_bwd_brick_kernel<true>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
                            reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
                            brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
     } else {
-        hipLaunchKernelGGL(grid_bwd_brick_kernel<false>, dim3(work_items), dim3(256), 0, mh_stream(stream),
+        hipLaunchKernelGGL(grid_bwd_brick_kernel<false>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
                            reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
                            brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
     }

@@ -16,6 +16,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
             if (MODE == 0) atomicAdd(reinterpret_cast<float *>(buf) + a, 1.0f);
             if (MODE == 1) atomicAdd(reinterpret_cast<unsigned *>(buf) + a, 1u);
             if (MODE == 2) atomicAdd(buf + a, 1ull);
+            if (MODE == 4) atomicAdd(reinterpret_cast<double *>(buf) + a, 1.0);
+            if (MODE == 5) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)(reinterpret_cast<float *>(buf) + a), 1.0f, 0, 0, false);
             if (MODE == 3) reinterpret_cast<float *>(buf)[a] += 1.0f;  // plain RMW (racy) as a reference rate
         }
     }
@@ -41,6 +43,8 @@ int main() {
     run<0, 0>("ds_add_f32 conflict-free"); run<0, 1>("ds_add_f32 4-way same addr");
     run<1, 0>("ds_add_u32 conflict-free"); run<1, 1>("ds_add_u32 4-way same addr");
     run<2, 0>("ds_add_u64 conflict-free"); run<2, 1>("ds_add_u64 4-way same addr");
+    run<4, 0>("ds_add_f64 conflict-free"); run<4, 1>("ds_add_f64 4-way same addr");
+    run<5, 0>("ds_faddf builtin conflict-free");
     run<3, 0>("plain f32 RMW");
     return 0;
 }
