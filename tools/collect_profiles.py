@@ -41,7 +41,7 @@ def json_line(path):
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    return re.split(r"[<(]", name)[0]
+    return name.split("(")[0]
 
 
 def pmc_summary(tag):
