@@ -69,6 +69,24 @@ __device__ __forceinline__ void stage_weights(const float *__restrict__ g) {
     __syncthreads();
 }
 
+// Split form of stage_weights for a layer pipeline: stage_issue<N>() right after the barrier that ends layer l's MFMA
+// phase (every wave is done reading lds_w) starts layer l+1's DMA, the layer-l epilogue (ReLU, tile stores) runs under its
+// latency, stage_wait() then covers the DMA and the epilogue's stores together (vmcnt counts both on gfx9).
+template <int N_F4>
+__device__ __forceinline__ void stage_issue(const float *__restrict__ g) {
+    static_assert(N_F4 % 256 == 0, "whole rounds of the 256-thread block");
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(g);
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N_F4 / 256; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * 256 + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_w + k * 256 + wave * 64), 16, 0, 0);
+}
+__device__ __forceinline__ void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 template <int MT>
 __device__ __forceinline__ void acc_bias(f32x16 (&acc)[MT], const float *__restrict__ bias, int h) {
 #pragma unroll
@@ -218,6 +236,8 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
 #pragma unroll
         for (int k = 20; k < 32; k++) tile[(2 * k + h) * TILE + pt] = 0.f;  // pad rows 40..63
     }
+    __syncthreads();
+    stage_issue<1280>(wpack_d);
     for (int net = 0; net < 2; net++) {
         const float *wp = net ? wpack_t : wpack_d;
         const float *bs = net ? bias_t : bias_d;
@@ -226,26 +246,35 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
         f32x16 acc[4];
         float bin[64];
         // layer 0: 40 -> 128, bias row chosen by the point's frame slot
-        stage_weights<1280>(wp);
+        stage_wait();
         acc_bias<4>(acc, b0, h);
         mfma_layer<20, 4>(bin0, acc, lane);
+        __syncthreads();
+        wp += 5120;
+        stage_issue<4096>(wp);
         acc_to_bin<4, true>(acc, bin);
         if (ht) store_acc_rows<4>(ht, bin, pt, h);
-        wp += 5120;
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
-            stage_weights<4096>(wp);
+            stage_wait();
             acc_bias<4>(acc, bs + (l - 1) * 128, h);
             mfma_layer<64, 4>(bin, acc, lane);
+            __syncthreads();
+            wp += 16384;
+            if (l < 4)
+                stage_issue<4096>(wp);
+            else
+                stage_issue<1024>(wp);
             acc_to_bin<4, true>(acc, bin);
             if (ht) store_acc_rows<4>(ht + l * 128 * TILE, bin, pt, h);
-            wp += 16384;
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
-        stage_weights<1024>(wp);
+        stage_wait();
         f32x16 o[1];
         acc_bias<1>(o, bs + 4 * 128, h);
         mfma_layer<64, 1>(bin, o, lane);
+        __syncthreads();
+        if (net == 0) stage_issue<1280>(wpack_t);
         if (h == 0 && p < M) {
             if (net == 0) {
                 out_deform[p * 3 + 0] = o[0][0];

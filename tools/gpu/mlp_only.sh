@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU-box script: MLP operator tests + default bench
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -k "warp or field" 2>&1 | tail -2
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench.log 2>&1
+python - <<'PY'
+import json
+for line in open('gpurun_out/bench.log'):
+    if line.startswith('{'):
+        d=json.loads(line); print(d['value'], d['ms_per_step'])
+        for k,v in list(d['kernels'].items())[:7]: print('   ',k,v['ms_per_step'],v.get('tflops'))
+PY
