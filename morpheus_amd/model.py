@@ -334,15 +334,17 @@ class scene_representation(nn.Module):
         """6 clamped taps of the SDF (model.py:367-385), evaluated as ONE batch of 6M points: one hash-grid pass,
         one sdf-net pass and one brick binning instead of six of each (same arithmetic per tap)."""
         M = x.shape[0]
-        off = x.new_zeros(6, 1, 3)
+        off = x.new_zeros(1, 6, 3)
         for k in range(3):
-            off[2 * k, 0, k] = epsilon
-            off[2 * k + 1, 0, k] = -epsilon
-        taps = (x[None] + off).clamp(-self.bound, self.bound).reshape(6 * M, 3)
-        topo6 = None if topo is None else topo[None].expand(6, M, topo.shape[-1]).reshape(6 * M, -1)
-        sdf = self.get_sigma_albedo(taps, topo=topo6, return_color=False)[0].view(6, M)
-        return torch.stack([0.5 * (sdf[0] - sdf[1]) / epsilon, 0.5 * (sdf[2] - sdf[3]) / epsilon,
-                            0.5 * (sdf[4] - sdf[5]) / epsilon], -1)
+            off[0, 2 * k, k] = epsilon
+            off[0, 2 * k + 1, k] = -epsilon
+        # point-major tap order: a point's six taps sit next to each other, so their hash-corner gathers hit the same
+        # cache lines (the taps lie within 2 eps of each other) and they fall into the same backward brick
+        taps = (x[:, None] + off).clamp(-self.bound, self.bound).reshape(6 * M, 3)
+        topo6 = None if topo is None else topo[:, None].expand(M, 6, topo.shape[-1]).reshape(6 * M, -1)
+        sdf = self.get_sigma_albedo(taps, topo=topo6, return_color=False)[0].view(M, 6)
+        return torch.stack([0.5 * (sdf[:, 0] - sdf[:, 1]) / epsilon, 0.5 * (sdf[:, 2] - sdf[:, 3]) / epsilon,
+                            0.5 * (sdf[:, 4] - sdf[:, 5]) / epsilon], -1)
 
     def normal(self, x, t=None, cano=False, topo=None):
         if t is not None and not cano:
