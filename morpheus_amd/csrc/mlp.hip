@@ -26,6 +26,7 @@
 //    writes dPre tiles) and mh_mlp_wgrad (dW = dPre . act^T as MFMA over the point axis, per-chunk
 //    partials reduced by the caller; no atomics anywhere).
 #include "common.h"
+#include <stdlib.h>
 
 #define TILE 32
 #define BLOCK_PTS 128
@@ -86,6 +87,22 @@ __device__ __forceinline__ void stage_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
+
+#ifdef MH_PHASE_TRACE
+// phase trace for tools/phase_trace.py (never compiled into the product library): wave 0 of every 64th workgroup
+// stamps s_memtime at the phase boundaries of warp_fwd_kernel
+__device__ long long mh_trace[256 * 64];
+#define MH_STAMP(slot)                                                                     \
+    do {                                                                                   \
+        if ((threadIdx.x == 0) && (blockIdx.x % 64 == 0) && (blockIdx.x / 64 < 256))       \
+            mh_trace[(blockIdx.x / 64) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+extern "C" int mh_trace_read(long long *dst_host) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(mh_trace), sizeof(long long) * 256 * 64) == hipSuccess ? 0 : 2;
+}
+#else
+#define MH_STAMP(slot) do { } while (0)
+#endif
 
 template <int MT>
 __device__ __forceinline__ void acc_bias(f32x16 (&acc)[MT], const float *__restrict__ bias, int h) {
@@ -236,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
 #pragma unroll
         for (int k = 20; k < 32; k++) tile[(2 * k + h) * TILE + pt] = 0.f;  // pad rows 40..63
     }
+    MH_STAMP(0);
     __syncthreads();
     stage_issue<1280>(wpack_d);
     for (int net = 0; net < 2; net++) {
@@ -247,33 +265,46 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
         float bin[64];
         // layer 0: 40 -> 128, bias row chosen by the point's frame slot
         stage_wait();
+        MH_STAMP(1 + (net * 6 + 0) * 5 + 0);
         acc_bias<4>(acc, b0, h);
         mfma_layer<20, 4>(bin0, acc, lane);
+        MH_STAMP(1 + (net * 6 + 0) * 5 + 1);
         __syncthreads();
+        MH_STAMP(1 + (net * 6 + 0) * 5 + 2);
         wp += 5120;
         stage_issue<4096>(wp);
+        MH_STAMP(1 + (net * 6 + 0) * 5 + 3);
         acc_to_bin<4, true>(acc, bin);
         if (ht) store_acc_rows<4>(ht, bin, pt, h);
+        MH_STAMP(1 + (net * 6 + 0) * 5 + 4);
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
             stage_wait();
+            MH_STAMP(1 + (net * 6 + l) * 5 + 0);
             acc_bias<4>(acc, bs + (l - 1) * 128, h);
             mfma_layer<64, 4>(bin, acc, lane);
+            MH_STAMP(1 + (net * 6 + l) * 5 + 1);
             __syncthreads();
+            MH_STAMP(1 + (net * 6 + l) * 5 + 2);
             wp += 16384;
             if (l < 4)
                 stage_issue<4096>(wp);
             else
                 stage_issue<1024>(wp);
+            MH_STAMP(1 + (net * 6 + l) * 5 + 3);
             acc_to_bin<4, true>(acc, bin);
             if (ht) store_acc_rows<4>(ht + l * 128 * TILE, bin, pt, h);
+            MH_STAMP(1 + (net * 6 + l) * 5 + 4);
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
         stage_wait();
+        MH_STAMP(1 + (net * 6 + 5) * 5 + 0);
         f32x16 o[1];
         acc_bias<1>(o, bs + 4 * 128, h);
         mfma_layer<64, 1>(bin, o, lane);
+        MH_STAMP(1 + (net * 6 + 5) * 5 + 1);
         __syncthreads();
+        MH_STAMP(1 + (net * 6 + 5) * 5 + 2);
         if (net == 0) stage_issue<1280>(wpack_t);
         if (h == 0 && p < M) {
             if (net == 0) {
@@ -285,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
                 out_topo[p * 2 + 1] = o[0][1];
             }
         }
+        MH_STAMP(1 + (net * 6 + 5) * 5 + 4);
     }
 }
 
@@ -859,8 +891,16 @@ extern "C" int mh_warp_fwd(const float *x, const int32_t *slot, const float *bia
         return MH_ERR_ARG;
     const int64_t blocks = (M + BLOCK_PTS - 1) / BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), x, slot, bias0_d, bias0_t,
-                       wpack_d, wpack_t, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M);
+#ifdef MH_PHASE_TRACE
+    // trace build only: MH_TRACE_DYNLDS=<bytes> of unused dynamic LDS limits the workgroups per CU (occupancy experiments)
+    const char *dl = getenv("MH_TRACE_DYNLDS");
+    const size_t dyn_lds = dl ? (size_t)atoi(dl) : 0;
+    if (dyn_lds) hipFuncSetAttribute((const void *)warp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+#else
+    const size_t dyn_lds = 0;
+#endif
+    hipLaunchKernelGGL(warp_fwd_kernel, dim3((unsigned)blocks), dim3(256), dyn_lds, mh_stream(stream), x, slot, bias0_d,
+                       bias0_t, wpack_d, wpack_t, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
