@@ -264,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
         f32x16 acc[4];
         float bin[64];
         // layer 0: 40 -> 128, bias row chosen by the point's frame slot
+        acc_bias<4>(acc, b0, h);   // bias loads are issued BEFORE the wait: their latency hides under the DMA's
         stage_wait();
         MH_STAMP(1 + (net * 6 + 0) * 5 + 0);
-        acc_bias<4>(acc, b0, h);
         mfma_layer<20, 4>(bin0, acc, lane);
         MH_STAMP(1 + (net * 6 + 0) * 5 + 1);
         __syncthreads();
@@ -279,9 +279,9 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
         MH_STAMP(1 + (net * 6 + 0) * 5 + 4);
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
+            acc_bias<4>(acc, bs + (l - 1) * 128, h);
             stage_wait();
             MH_STAMP(1 + (net * 6 + l) * 5 + 0);
-            acc_bias<4>(acc, bs + (l - 1) * 128, h);
             mfma_layer<64, 4>(bin, acc, lane);
             MH_STAMP(1 + (net * 6 + l) * 5 + 1);
             __syncthreads();
@@ -297,10 +297,10 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
             MH_STAMP(1 + (net * 6 + l) * 5 + 4);
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
-        stage_wait();
-        MH_STAMP(1 + (net * 6 + 5) * 5 + 0);
         f32x16 o[1];
         acc_bias<1>(o, bs + 4 * 128, h);
+        stage_wait();
+        MH_STAMP(1 + (net * 6 + 5) * 5 + 0);
         mfma_layer<64, 1>(bin, o, lane);
         MH_STAMP(1 + (net * 6 + 5) * 5 + 1);
         __syncthreads();
