@@ -32,9 +32,12 @@
 #define BLOCK_PTS 128
 
 // ---- per-tile scratch geometry (floats) -------------------------------------------------------
-// warp acts : H0 [64 rows: 2kk+h, 40 used] | deform H1..H5 [5 x 128] | topo H1..H5 [5 x 128]
+// warp acts : H0 [64 rows: 2kk+h, 40 used] | deform H1..H5 [5 x 128] | topo H1..H5 [5 x 128] | ReLU sign masks
+//             [net][layer][lane][2] uint32 (bit 16t+r of the lane's 64 outputs): backward-data reads 8 bytes per lane and
+//             layer instead of re-loading the 256-byte activation column (the activations stay parked for the wgrad GEMM)
 // warp dpre : deform dPre0..4 [5 x 128], dPre5 [32] | topo same
-#define WARP_ACT_ROWS (64 + 2 * 640)
+#define WARP_HID_ROWS (64 + 2 * 640)        // activations proper
+#define WARP_ACT_ROWS (WARP_HID_ROWS + 40)  // + ReLU masks: 10 layers x 64 lanes x 2 dwords = 40 rows of 32
 #define WARP_DPRE_ROWS (2 * 672)
 #define WARP_NET_WPACK (5120 + 4 * 16384 + 4096)       // fwd pack floats per net
 #define WARP_NET_WPACKT (4096 /*T5*/ + 4 * 16384 + 8192 /*T0: MT=2,KS=64*/)
@@ -188,6 +191,17 @@ __device__ __forceinline__ void acc_to_bin(const f32x16 (&acc)[MT], float (&bin)
         for (int r = 0; r < 16; r++) bin[16 * t + r] = RELU ? fmaxf(acc[t][r], 0.f) : acc[t][r];
 }
 
+// ReLU mask of a lane's 64 post-activation values, bit 16t+r <-> bin[16t+r] > 0
+__device__ __forceinline__ uint2 relu_mask64(const float (&bin)[64]) {
+    uint32_t m0 = 0, m1 = 0;
+#pragma unroll
+    for (int j = 31; j >= 0; j--) {
+        m0 = (m0 << 1) | (bin[j] > 0.f ? 1u : 0u);
+        m1 = (m1 << 1) | (bin[32 + j] > 0.f ? 1u : 0u);
+    }
+    return make_uint2(m0, m1);
+}
+
 // feature-major tile store: row = 32t + acc_row(r,h)
 template <int MT>
 __device__ __forceinline__ void store_acc_rows(float *__restrict__ tile, const float (&v)[16 * MT], int pt, int h) {
@@ -253,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
 #pragma unroll
         for (int k = 20; k < 32; k++) tile[(2 * k + h) * TILE + pt] = 0.f;  // pad rows 40..63
     }
+    uint2 *mk = tile ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
     MH_STAMP(0);
     __syncthreads();
     stage_issue<1280>(wpack_d);
@@ -275,7 +290,10 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
         stage_issue<4096>(wp);
         MH_STAMP(1 + (net * 6 + 0) * 5 + 3);
         acc_to_bin<4, true>(acc, bin);
-        if (ht) store_acc_rows<4>(ht, bin, pt, h);
+        if (ht) {
+            store_acc_rows<4>(ht, bin, pt, h);
+            mk[(net * 5 + 0) * 64 + lane] = relu_mask64(bin);
+        }
         MH_STAMP(1 + (net * 6 + 0) * 5 + 4);
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
@@ -293,7 +311,10 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
                 stage_issue<1024>(wp);
             MH_STAMP(1 + (net * 6 + l) * 5 + 3);
             acc_to_bin<4, true>(acc, bin);
-            if (ht) store_acc_rows<4>(ht + l * 128 * TILE, bin, pt, h);
+            if (ht) {
+                store_acc_rows<4>(ht + l * 128 * TILE, bin, pt, h);
+                mk[(net * 5 + l) * 64 + lane] = relu_mask64(bin);
+            }
             MH_STAMP(1 + (net * 6 + l) * 5 + 4);
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
@@ -340,8 +361,12 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
         const float *wt = net ? wpackT_t : wpackT_d;
         const float *g = net ? g_topo : g_deform;
         const int nout = net ? 2 : 3;
-        const float *ht = atile + (64 + net * 640) * TILE;
         float *dt = dtile + net * 672 * TILE;
+        // ReLU masks of the net's five hidden layers: 8 bytes per lane and layer, all fetched up front
+        const uint2 *mk = reinterpret_cast<const uint2 *>(atile + WARP_HID_ROWS * TILE) + net * 5 * 64 + lane;
+        uint2 msk[5];
+#pragma unroll
+        for (int l = 0; l < 5; l++) msk[l] = mk[l * 64];
         // dPre5: rows 0..nout-1 carry the incoming gradient (no activation on the last layer)
         float d5[16];
 #pragma unroll
@@ -360,16 +385,14 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
         mfma_layer<16, 4>(d5, acc, lane);
         wt += 4096;
         for (int l = 4; l >= 0; l--) {
-            // output of layer l is H_{l+1}; mask by its ReLU and park dPre_l
-            // one 32-row tile at a time (16 loads in flight, not 64): the kernel sits at the 256-VGPR limit
+            // output of layer l is H_{l+1}; mask by its ReLU (sign bits parked by the forward kernel) and park dPre_l
+            const uint2 m = msk[l];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                float hv[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) hv[r] = ht[(l * 128 + 32 * t + acc_row(r, h)) * TILE + pt];
+                const uint32_t mw = (t < 2 ? m.x : m.y) >> (16 * (t & 1));
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float v = hv[r] > 0.f ? acc[t][r] : 0.f;
+                    const float v = ((mw >> r) & 1u) ? acc[t][r] : 0.f;
                     dbin[16 * t + r] = v;
                     dt[(l * 128 + 32 * t + acc_row(r, h)) * TILE + pt] = v;
                 }

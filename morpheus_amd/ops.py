@@ -291,7 +291,7 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     return raw          # dw_raw | db_raw, tile-row order (packing.JointPacker.unpack_grads maps it back)
 
 
-WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640, 2 * 672
+WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640 + 40, 2 * 672     # csrc/mlp.hip: activations + 40 rows of ReLU masks
 FIELD_ACT_ROWS, FIELD_DPRE_ROWS = 96 + 64 * 5, 64 * 5 + 32
 
 
