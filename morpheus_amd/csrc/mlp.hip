@@ -42,9 +42,10 @@
 #define WARP_NET_WPACK (5120 + 4 * 16384 + 4096)       // fwd pack floats per net
 #define WARP_NET_WPACKT (4096 /*T5*/ + 4 * 16384 + 8192 /*T0: MT=2,KS=64*/)
 #define WARP_NET_BIAS (4 * 128 + 32)
-// field acts: S0 [96: 2kk+h, 80 used] | S1 [64] | S2 [64] | C0 [64: 2kk+h] | C1 [64] | C2 [64]
+// field acts: S0 [96: 2kk+h, 80 used] | S1 [64] | S2 [64] | C0 [64: 2kk+h] | C1 [64] | C2 [64] | ReLU masks [4][64 lanes]
 // field dpre: P0 [64] | P1 [64] | P2 [64] | Q0 [64] | Q1 [64] | Q2 [32]
-#define FIELD_ACT_ROWS (96 + 64 * 5)
+#define FIELD_HID_ROWS (96 + 64 * 5)
+#define FIELD_ACT_ROWS (FIELD_HID_ROWS + 8)  // + ReLU masks of S1, S2, C1, C2: 4 x 64 lanes x 1 dword = 8 rows of 32
 #define FIELD_DPRE_ROWS (64 * 5 + 32)
 #define FIELD_WPACK (5120 + 4096 * 4 + 2048)
 #define FIELD_WPACKT (2048 /*TC2*/ + 4096 /*TC1*/ + 4096 /*TC0*/ + 4096 /*TS2*/ + 4096 /*TS1*/ + 6144 /*TS0 MT=3*/)
@@ -200,6 +201,13 @@ __device__ __forceinline__ uint2 relu_mask64(const float (&bin)[64]) {
         m1 = (m1 << 1) | (bin[32 + j] > 0.f ? 1u : 0u);
     }
     return make_uint2(m0, m1);
+}
+
+__device__ __forceinline__ uint32_t relu_mask32(const float (&bin)[32]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 31; j >= 0; j--) m = (m << 1) | (bin[j] > 0.f ? 1u : 0u);
+    return m;
 }
 
 // feature-major tile store: row = 32t + acc_row(r,h)
@@ -493,13 +501,19 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
     acc_bias<2>(acc, bias, h);
     mfma_layer_at<40, 2>(wp, bin0, acc, lane);
     acc_to_bin<2, true>(acc, bin);
-    if (tile) store_acc_rows<2>(tile + 96 * TILE, bin, pt, h);
+    if (tile) {
+        store_acc_rows<2>(tile + 96 * TILE, bin, pt, h);
+        reinterpret_cast<uint32_t *>(tile + FIELD_HID_ROWS * TILE)[0 * 64 + lane] = relu_mask32(bin);
+    }
     wp += 1280;
     // sdf L1: 64 -> 64
     acc_bias<2>(acc, bias + 64, h);
     mfma_layer_at<32, 2>(wp, bin, acc, lane);
     acc_to_bin<2, true>(acc, bin);
-    if (tile) store_acc_rows<2>(tile + 160 * TILE, bin, pt, h);
+    if (tile) {
+        store_acc_rows<2>(tile + 160 * TILE, bin, pt, h);
+        reinterpret_cast<uint32_t *>(tile + FIELD_HID_ROWS * TILE)[1 * 64 + lane] = relu_mask32(bin);
+    }
     wp += 1024;
     // sdf L2: 64 -> [geo(32) | sdf], no activation
     acc_bias<2>(acc, bias + 128, h);
@@ -528,13 +542,19 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
     acc_bias<2>(acc, bias + 192, h);
     mfma_layer_at<32, 2>(wp, binc, acc, lane);
     acc_to_bin<2, true>(acc, bin);
-    if (tile) store_acc_rows<2>(tile + 288 * TILE, bin, pt, h);
+    if (tile) {
+        store_acc_rows<2>(tile + 288 * TILE, bin, pt, h);
+        reinterpret_cast<uint32_t *>(tile + FIELD_HID_ROWS * TILE)[2 * 64 + lane] = relu_mask32(bin);
+    }
     wp += 1024;
     // color L1
     acc_bias<2>(acc, bias + 256, h);
     mfma_layer_at<32, 2>(wp, bin, acc, lane);
     acc_to_bin<2, true>(acc, bin);
-    if (tile) store_acc_rows<2>(tile + 352 * TILE, bin, pt, h);
+    if (tile) {
+        store_acc_rows<2>(tile + 352 * TILE, bin, pt, h);
+        reinterpret_cast<uint32_t *>(tile + FIELD_HID_ROWS * TILE)[3 * 64 + lane] = relu_mask32(bin);
+    }
     wp += 1024;
     // color L2: 64 -> 3, sigmoid
     f32x16 o[1];
@@ -571,7 +591,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
     float *dtile = dpre + tile_id * (int64_t)(FIELD_DPRE_ROWS * TILE);
     const f32x4 *wt = lds_res;
     f32x16 acc[2];
-    float dbin[32], hv[32];
+    float dbin[32];
     float dgeo[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) dgeo[r] = 0.f;
@@ -593,21 +613,21 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
         mfma_layer_at<16, 2>(wt, d2, acc, lane);
         wt += 512;
         // mask C2 -> dQ1
-        load_acc_rows<2>(atile + 352 * TILE, hv, pt, h);
+        {
+            const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[3 * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+            for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
+        }
         store_acc_rows<2>(dtile + 256 * TILE, dbin, pt, h);
             acc_zero<2>(acc);
         mfma_layer_at<32, 2>(wt, dbin, acc, lane);
         wt += 1024;
         // mask C1 -> dQ0
-        load_acc_rows<2>(atile + 288 * TILE, hv, pt, h);
+        {
+            const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[2 * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+            for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
+        }
         store_acc_rows<2>(dtile + 192 * TILE, dbin, pt, h);
             acc_zero<2>(acc);
         mfma_layer_at<32, 2>(wt, dbin, acc, lane);
@@ -663,21 +683,21 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
         wt += 1024;
     }
     // mask S2 -> dP1
-    load_acc_rows<2>(atile + 160 * TILE, hv, pt, h);
+    {
+        const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[1 * 64 + lane];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+        for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
+    }
     store_acc_rows<2>(dtile + 64 * TILE, dbin, pt, h);
     acc_zero<2>(acc);
     mfma_layer_at<32, 2>(wt, dbin, acc, lane);
     wt += 1024;
     // mask S1 -> dP0
-    load_acc_rows<2>(atile + 96 * TILE, hv, pt, h);
+    {
+        const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[0 * 64 + lane];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dbin[16 * t + r] = hv[16 * t + r] > 0.f ? acc[t][r] : 0.f;
+        for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
+    }
     store_acc_rows<2>(dtile, dbin, pt, h);
     // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
     f32x16 e[3];

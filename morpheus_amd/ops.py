@@ -292,7 +292,7 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
 
 
 WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640 + 40, 2 * 672     # csrc/mlp.hip: activations + 40 rows of ReLU masks
-FIELD_ACT_ROWS, FIELD_DPRE_ROWS = 96 + 64 * 5, 64 * 5 + 32
+FIELD_ACT_ROWS, FIELD_DPRE_ROWS = 96 + 64 * 5 + 8, 64 * 5 + 32   # activations + 8 rows of ReLU masks
 
 
 class _WarpMLP(torch.autograd.Function):
