@@ -118,8 +118,10 @@ int mh_march_fill(const float *rays_o, const float *rays_d, const float *jitter,
  * Weight operands are PRE-PACKED by the host into the MFMA A-fragment order (see
  * morpheus_amd/packing.py): for layer l, tile mt, k-quad q: float4 per lane.  `wpack` is the
  * concatenation of all layers of the net(s); layer geometry is fixed by the kernel.
- * Activation scratch ("acts") is written by the forward when save != 0 and consumed by the
- * backward: per 32-point tile, per layer, feature-major [F][32] fp32.
+ * Activation scratch ("acts") is written by the forward when acts != NULL and consumed by the
+ * backward: per 32-point tile, per layer, feature-major [F][32] fp32 (the weight-gradient GEMM's operand),
+ * followed by the hidden layers' ReLU sign masks (one bit per lane and output row) that backward-data reads
+ * instead of the activations themselves.
  *
  * mh_warp_fwd: deform = deform_net([freq(x), code]), topo = topo_net(same)
  *   x [M,3]; slot [M] int32 -> row of bias0 (per-frame first-layer bias  W0[:,39:87].code + b0,
