@@ -290,3 +290,53 @@ def test_two_frames_in_one_batch():
               "topo_net.net.0.weight_g", "encoder.embeddings"):
         gg, go = dict(model.named_parameters())[k].grad.cpu().double(), p[k].grad.double()
         assert float((gg - go).norm() / go.norm()) < 5e-4, k
+
+
+def test_training_steps_track_the_oracle():
+    """End to end through everything a step touches: render fwd+bwd (HIP), weight-norm backward, gradient un-packing,
+    the flat gradient bucket and mh_adam_step -- against the oracle rendered on the CPU and stepped by torch.optim.Adam
+    with the reference's groups (lr, density lr/2, pose lr/10; morpheus.py:154-155, model.py:309-333).
+    Adam turns a gradient into ~+-lr whatever its size, so individual near-zero-gradient entries may differ; the LOSS
+    trajectory is the robust end-to-end observable: it must agree to 1e-3 relative over three steps and decrease."""
+    from morpheus_amd import harness
+    from morpheus_amd.optim import FlatAdam
+    hw, S, lr = 16, 32, 2e-3
+    o, d, t, rid = synth.frame_rays(25, hw, hw)
+    N = o.shape[1]
+    jit = synth.ray_jitter(N)
+    light = of.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    timg, tdep = synth.targets(N)
+    smp = of.uniform_samples(o[0], d[0], jit, S, 1.01)
+    # HIP side
+    model = harness.build_model("b", DEV).train()
+    for k in ("normal_smoothness", "normal_smooth_3d", "code_reg", "ori_weight"):
+        model.config["train"][k] = 0.0
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    opt = FlatAdam(model.get_params_all(lr), betas=(0.9, 0.99), eps=1e-15)
+    gpu_args = [v.to(DEV) for v in (o, d, t, rid)]
+    losses_hip = []
+    for _ in range(3):
+        opt.zero_grad()
+        res = rend.render_rays(*gpu_args, hw, hw, ambient_ratio=1.0, light_d=light.to(DEV), shading="albedo")
+        loss = harness.bench_loss(res, timg.to(DEV), tdep.to(DEV))
+        loss.backward()
+        opt.bucket.allreduce_mean()
+        opt.step()
+        losses_hip.append(float(loss.detach()))
+    # oracle side
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in synth.make_state("b").items()}
+    scale = lambda k: 0.5 if k.startswith("sdf2density") else (0.1 if k.startswith("pose_array") else 1.0)
+    ropt = torch.optim.Adam([{"params": [v], "lr": lr * scale(k)} for k, v in p.items() if v.is_floating_point()],
+                            betas=(0.9, 0.99), eps=1e-15)
+    losses_ref = []
+    for _ in range(3):
+        ropt.zero_grad()
+        f = of.OracleField(p, 1.01, None)
+        ro = of.render_rays(f, o, d, t, rid, smp, ambient_ratio=1.0, light_d=light, shading="albedo")
+        lo = ((ro["image"][0] - timg) ** 2).mean() + ((ro["depth"][0] - tdep) ** 2).mean()
+        lo.backward()
+        ropt.step()
+        losses_ref.append(float(lo.detach()))
+    for a, b in zip(losses_hip, losses_ref):
+        assert abs(a - b) <= 1e-3 * abs(b), (losses_hip, losses_ref)
+    assert losses_hip[2] < losses_hip[0]
