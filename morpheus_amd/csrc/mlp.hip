@@ -23,8 +23,12 @@
 //    the layout the weight-gradient MFMA wants (K = points) -- instead of recomputing the
 //    forward in backward: 128 MACs per stored float makes the store cheaper than the recompute.
 //  * Backward is two kernels: backward-data (same register-resident chain with transposed packs,
-//    writes dPre tiles) and mh_mlp_wgrad (dW = dPre . act^T as MFMA over the point axis, per-chunk
-//    partials reduced by the caller; no atomics anywhere).
+//    ReLU derivative from sign masks the forward parks next to the activations, writes dPre tiles) and
+//    mh_mlp_wgrad (dW = dPre . act^T as MFMA over the point axis, per-chunk partials summed by a
+//    reduction launch; no atomics anywhere).
+//  * The kernels are ISSUE-bound: on gfx950 one wave's VALU / store / DMA instructions do not issue under
+//    the co-resident wave's fp32 MFMAs (tools/phase_trace.py), so every non-MFMA instruction of the layer
+//    loop is paid in full and the design effort goes into having few of them.
 #include "common.h"
 #include <stdlib.h>
 
@@ -823,11 +827,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__
     float bsum = 0.f;
     WgFrag<IT> f0;
     // Three register sets, software-pipelined by hand, ONE wave per SIMD: two tiles' loads (2 x (4+4*IT) x 1 KB per
-    // wave) are in flight while a third tile's 16*IT MFMAs issue.  Two design facts measured on gfx950
-    // (tools/micro/mfma_rate.hip): (i) two waves issuing fp32 MFMAs with changing operands on one SIMD reach only 105
-    // TFLOP/s chip-wide, one wave alone reaches 156, so this kernel wants exactly one wave per SIMD and hides latency by
-    // prefetch depth instead of occupancy; (ii) the loads must be inline asm with counted s_waitcnt -- hipcc re-rolls a
-    // C++-level multi-buffer loop into load -> vmcnt(0) -> MFMA.  Index-clamped prefetches past the end re-read a tile.
+    // wave) are in flight while a third tile's 16*IT MFMAs issue.  Two design facts measured on gfx950: (i) a second
+    // wave on the SIMD does not hide a wave's non-MFMA issue time, only memory latency (tools/phase_trace.py; 8.5 ms at
+    // two waves per SIMD vs 6.4 at one, for the warp nets), so this kernel wants exactly one wave per SIMD and hides
+    // latency by prefetch depth instead of occupancy; (ii) the loads must be inline asm with counted s_waitcnt -- hipcc
+    // re-rolls a C++-level multi-buffer loop into load -> vmcnt(0) -> MFMA -- and their 3 x (4+4*IT) x 4 destination
+    // registers must all be architectural VGPRs (240 of 256 at IT = 4: there is no room for a second out-tile per wave).
+    // Index-clamped prefetches past the end re-read a tile.
     constexpr int NL = 4 + 4 * IT;  // loads per tile
     const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
     const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
