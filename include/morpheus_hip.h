@@ -68,7 +68,9 @@ int mh_grid_encode_bwd(const float *grad, const float *x, const float *emb,
  *   few scratch words used by the backward (max |grad| for its fixed-point on-chip accumulation).
  * One binning serves every encoder evaluated at the same x (sdf and colour tables).
  * mh_grid_encode_bwd_binned: one workgroup per brick accumulates all levels in LDS, then flushes the
- * touched vertices with one global atomic each. L must be 16. grad_x (optional) is fully written. */
+ * touched vertices with one global atomic each. L must be 16. grad_x (optional) is fully written.
+ * gmax_bits: NULL, or a DEVICE word holding max |grad| as raw float bits (the producer of `grad` may compute it on
+ * the fly, see mh_field_bwd_data); NULL costs one extra pass over `grad`. */
 int64_t mh_grid_bin_workspace_ints(void);
 int32_t mh_grid_bin_bricks(void);
 int32_t mh_grid_bin_index_ints(void);
@@ -77,7 +79,7 @@ int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_t *workspac
 int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *emb,
                               const int32_t *offsets_host, const int32_t *res_host, const int32_t *perm,
                               const int32_t *brick_start, float *grad_emb, float *grad_x, int64_t M,
-                              int32_t L, int32_t n_levels, float bound, void *stream);
+                              int32_t L, int32_t n_levels, float bound, const uint32_t *gmax_bits, void *stream);
 
 /* ---- packed transmittance compositor -------------------------------------------------------
  * Samples of ray r are the contiguous range [ray_start[r], ray_start[r]+ray_cnt[r]) of the packed
@@ -159,12 +161,14 @@ int mh_field_fwd(const float *xc, const float *feat_s, const float *feat_c, cons
 /* backward-data: g_sdf, g_sigma [M], g_albedo [M,3] (any may be NULL) -> g_xc [M,3] (freq path only;
  * the hash path's d/dx comes from mh_grid_encode_bwd), g_feat_s, g_feat_c [M,32], g_topo [M,2],
  * g_beta_partial [mh_mlp_tiles(M)] (per-tile partial sums of dL/dbeta), dpre scratch.
- * sdf / albedo are the forward's outputs (Laplace and sigmoid derivatives are formed from them). */
+ * sdf / albedo are the forward's outputs (Laplace and sigmoid derivatives are formed from them).
+ * gmax_bits: NULL, or 2 DEVICE words zeroed by the caller that receive max |g_feat_s| and max |g_feat_c| as raw float
+ * bits (atomicMax) -- what mh_grid_encode_bwd_binned needs for its fixed-point accumulation. */
 int mh_field_bwd_data(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
                       const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
                       int32_t n_bands, int32_t with_color, const float *acts, float *dpre, float *g_xc,
-                      float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial, int64_t M,
-                      void *stream);
+                      float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial, uint32_t *gmax_bits,
+                      int64_t M, void *stream);
 
 /* weight gradients: for `n_layers` (<= 16) layers described by HOST arrays (offsets in floats into the
  * acts / dpre tiles, feature counts padded to multiples of 32):

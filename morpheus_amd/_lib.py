@@ -23,7 +23,7 @@ _SIGS = {
     "mh_grid_bin_bricks": (_I32, []),
     "mh_grid_bin_index_ints": (_I32, []),
     "mh_grid_bin_points": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P, _P]),
-    "mh_grid_encode_bwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
+    "mh_grid_encode_bwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _P]),
     "mh_composite_fwd": (ctypes.c_int, [_P] * 10 + [_I32, _P]),
     "mh_composite_bwd": (ctypes.c_int, [_P] * 13 + [_I32, _P]),
     "mh_generate_rays": (ctypes.c_int, [_F, _F, _F, _F, _P, _I32, _I32, _P, _P, _P]),
@@ -42,7 +42,7 @@ _SIGS = {
     "mh_warp_fwd": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_warp_bwd_data": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_field_fwd": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
-    "mh_field_bwd_data": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 7 + [_I64, _P]),
+    "mh_field_bwd_data": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 8 + [_I64, _P]),
     "mh_mlp_wgrad_workspace_floats": (_I64, [_I32, _P, _P, _I64]),
     "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mh_weight_norm_fwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P]),

@@ -542,7 +542,7 @@ extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_
 extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *emb, const int32_t *offsets_host,
                                          const int32_t *res_host, const int32_t *perm, const int32_t *brick_start,
                                          float *grad_emb, float *grad_x, int64_t M, int32_t L, int32_t n_levels,
-                                         float bound, void *stream) {
+                                         float bound, const uint32_t *gmax_bits, void *stream) {
     if (M == 0) return MH_OK;
     if (!grad || !x || !emb || !grad_emb || !perm || !brick_start || M < 0 || n_levels < 0 || n_levels > L || L != 16 ||
         !(bound > 0.f))
@@ -561,10 +561,15 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
     if (off > BRK_NODES_MAX) return MH_ERR_ARG;
     // upper bound on sum_b ceil(cnt_b / BRK_CHUNK); surplus workgroups exit at once
     const unsigned work_items = (unsigned)(NBRK + M / BRK_CHUNK + 1);
-    // max|grad| -> scratch word behind the work-item table
-    uint32_t *gmax = reinterpret_cast<uint32_t *>(const_cast<int32_t *>(brick_start)) + (2 * NBRK + 4);
-    if (hipMemsetAsync(gmax, 0, sizeof(uint32_t), mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
-    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, mh_stream(stream), grad, M * (int64_t)L * 2, gmax);
+    // max|grad| (float bits): supplied by the producer of `grad` (mh_field_bwd_data computes it on the fly), else
+    // reduced here into the scratch word behind the work-item table
+    const uint32_t *gmax = gmax_bits;
+    if (!gmax) {
+        uint32_t *own = reinterpret_cast<uint32_t *>(const_cast<int32_t *>(brick_start)) + (2 * NBRK + 4);
+        if (hipMemsetAsync(own, 0, sizeof(uint32_t), mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
+        hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, mh_stream(stream), grad, M * (int64_t)L * 2, own);
+        gmax = own;
+    }
     if (grad_x) {
         // points outside the box are never visited by a brick: their d/dx is zero
         if (hipMemsetAsync(grad_x, 0, sizeof(float) * 3 * (size_t)M, mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;

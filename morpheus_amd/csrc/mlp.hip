@@ -576,9 +576,10 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
     const float *__restrict__ g_sdf, const float *__restrict__ g_sigma, const float *__restrict__ g_albedo,
     const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands, int with_color, const float *__restrict__ acts,
     float *__restrict__ dpre, float *__restrict__ g_xc, float *__restrict__ g_feat_s, float *__restrict__ g_feat_c,
-    float *__restrict__ g_topo, float *__restrict__ g_beta_partial, int64_t M, int64_t n_tiles) {
+    float *__restrict__ g_topo, float *__restrict__ g_beta_partial, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
+    uint32_t max_s = 0, max_c = 0;  // running max |feature gradient| (float bits) for the hash-grid backward's fixed point
     if (with_color)
         stage_resident<FIELD_WPACKT / 4>(wpackT, 0);
     else
@@ -645,6 +646,8 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
                 for (int c = 0; c < 4; c++) v[c] = acc[0][4 * q + c];
                 o[q] = v;
             }
+#pragma unroll
+            for (int r = 0; r < 16; r++) max_c = max(max_c, __float_as_uint(fabsf(acc[0][r])));
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) dgeo[r] = acc[1][r];
@@ -739,9 +742,23 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
                 for (int c = 0; c < 4; c++) v[c] = e[2][4 * q + c];
                 o[q] = v;
             }
+#pragma unroll
+            for (int r = 0; r < 16; r++) max_s = max(max_s, __float_as_uint(fabsf(e[2][r])));
         }
     }
     }  // tile loop
+    if (gmax) {
+        // one pair of atomics per wave for the whole launch (the blocks are persistent)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
+            max_c = max(max_c, (uint32_t)__shfl_xor((int)max_c, o));
+        }
+        if (lane == 0) {
+            if (max_s) atomicMax(gmax + 0, max_s);
+            if (max_c) atomicMax(gmax + 1, max_c);
+        }
+    }
 }
 
 // =====================================================================================
@@ -992,8 +1009,8 @@ extern "C" int mh_field_fwd(const float *xc, const float *feat_s, const float *f
 extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
                                  const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
                                  int32_t n_bands, int32_t with_color, const float *acts, float *dpre, float *g_xc,
-                                 float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial, int64_t M,
-                                 void *stream) {
+                                 float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial,
+                                 uint32_t *gmax_bits, int64_t M, void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !xc || !sdf || !wpackT || !acts || !dpre || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && !albedo) return MH_ERR_ARG;
@@ -1003,7 +1020,7 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
         return MH_ERR_LAUNCH;
     hipLaunchKernelGGL(field_bwd_kernel, dim3(field_blocks(n_tiles)), dim3(FIELD_THREADS), lds, mh_stream(stream), xc, sdf,
                        albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, (int)n_bands, (int)with_color, acts, dpre, g_xc, g_feat_s,
-                       g_feat_c, g_topo, g_beta_partial, M, n_tiles);
+                       g_feat_c, g_topo, g_beta_partial, gmax_bits, M, n_tiles);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

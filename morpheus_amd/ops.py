@@ -85,6 +85,31 @@ def _bin_points(lib, x, bound):
     return perm, bstart
 
 
+class _GradMaxHint:
+    """max |grad| of a feature-gradient tensor, computed on the fly by the kernel that produced it (mh_field_bwd_data)
+    and handed to the hash-grid backward, which needs it for its fixed-point accumulation -- autograd only carries the
+    tensor, so the device word travels beside it keyed by the tensor's address; a miss just means the grid backward
+    reduces max |grad| itself (one more pass over the gradient)."""
+
+    def __init__(self):
+        self._by_ptr = {}
+
+    def put(self, tensor, words, index):
+        if tensor is not None:
+            self._by_ptr = {k: v for k, v in self._by_ptr.items() if v[0] is words}   # keep only the current producer's
+            self._by_ptr[tensor.data_ptr()] = (words, index, tensor.numel(), torch._C._current_graph_task_id())
+
+    def take(self, grad):
+        """device address of the word, or None; valid only inside the backward pass that produced the hint"""
+        hit = self._by_ptr.pop(grad.data_ptr(), None)
+        if hit is None or hit[2] != grad.numel() or hit[3] != torch._C._current_graph_task_id() or hit[3] < 0:
+            return None
+        return hit[0].data_ptr() + 4 * hit[1]
+
+
+_GMAX = _GradMaxHint()
+
+
 GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B switch: per-point global atomics
 
 
@@ -137,7 +162,7 @@ class _GridEncode(torch.autograd.Function):
                     binned = _bin_points(lib, x, bound)
                 _e = TIMER.start()
                 check(lib.mh_grid_encode_bwd_binned(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(binned[0]), ptr(binned[1]),
-                                                    ptr(g_emb), ptr(g_x), M, L, n_levels, bound, stream()),
+                                                    ptr(g_emb), ptr(g_x), M, L, n_levels, bound, _GMAX.take(grad), stream()),
                       "mh_grid_encode_bwd_binned")
                 TIMER.stop("mh_grid_encode_bwd_binned", _e)
             else:
@@ -426,13 +451,16 @@ class _FieldMLP(torch.autograd.Function):
         g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
         g_tp = torch.empty(M, 2, device=dev)
         g_bp = torch.empty(n_tiles, device=dev)
+        gmax = torch.zeros(2, dtype=torch.int32, device=dev)     # max |g_fs|, max |g_fc| as float bits
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
         check(lib.mh_field_bwd_data(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)),
                                     ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color),
-                                    ptr(acts), ptr(dpre), ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), M,
-                                    stream()), "mh_field_bwd_data")
+                                    ptr(acts), ptr(dpre), ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax),
+                                    M, stream()), "mh_field_bwd_data")
         TIMER.stop("mh_field_bwd_data", _e)
+        _GMAX.put(g_fs, gmax, 0)
+        _GMAX.put(g_fc, gmax, 1)
         pk = field_packer()
         act_rows = [0, 96, 160, 224, 288, 352]
         dpre_rows = [0, 64, 128, 192, 256, 320]
