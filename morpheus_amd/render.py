@@ -130,17 +130,29 @@ class HotPathRenderer:
                 stratified=True, cone_angle=0.0, early_stop_eps=0)
         if light_d is None:
             light_d = safe_normalize(rays_o + torch.randn(3, device=rays_o.device))
-        ray_indices = ray_indices.long()
+        M_samples = ray_indices.shape[0]
+        single_frame = (not cano) and self.frame_batched and len(prefix) == 2 and prefix[0] == 1
+        ray_idx32 = ray_indices
+        _long = []
+
+        def ri_long():          # int64 indices for torch gathers, built only if something asks for them
+            if not _long:
+                _long.append(ray_idx32.long())
+            return _long[0]
+
         t_starts, t_ends = t_starts_[..., None], t_ends_[..., None]
-        t_positions = (t_starts + t_ends) / 2.0
         xyzs = getattr(self.occupancy_grid, "xyz", None)
         if xyzs is not None:
             self.occupancy_grid.xyz = None             # one use: it belongs to the sampling call above
+        t_positions = None
+        if xyzs is None or rays_o.requires_grad or rays_d.requires_grad or rays_depth is not None:
+            t_positions = (t_starts + t_ends) / 2.0
         if xyzs is None or rays_o.requires_grad or rays_d.requires_grad:   # pose optimisation: positions carry gradients
-            xyzs = rays_o[ray_indices] + rays_d[ray_indices] * t_positions
-        time_step = rays_t[ray_indices]
+            xyzs = rays_o[ri_long()] + rays_d[ri_long()] * t_positions
+        # a batch row is one frame: with a single row every sample shares rays_t[0] -- no gather needed
+        time_step = rays_t[:1].expand(M_samples, 1) if single_frame else rays_t[ri_long()]
 
-        if xyzs.shape[0] == 0:
+        if M_samples == 0:
             # the reference falls into a NameError here; return the white image it intended
             results.update(image=torch.ones([*prefix, 3], device=rays_o.device),
                            depth=torch.zeros([*prefix], device=rays_o.device), sdf=None, weights=None,
@@ -148,20 +160,22 @@ class HotPathRenderer:
             return results
 
         # per-frame deform-code slots without a device->host sync
-        if not cano and self.frame_batched and len(prefix) == 2:
+        if single_frame:
+            model._frame_slots = (time_step, rays_t[:1, 0].contiguous(), None)     # one slot: the kernel needs no index
+        elif not cano and self.frame_batched and len(prefix) == 2:
             B, n_per = prefix
             slot_ray = torch.arange(B, device=rays_o.device, dtype=torch.int32).repeat_interleave(n_per)
-            model._frame_slots = (time_step, rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray[ray_indices].contiguous())
+            model._frame_slots = (time_step, rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray[ri_long()].contiguous())
         try:
             # per-sample light directions are only read by the shaded modes (model.py:515-531)
-            t_light = light_d[ray_indices] if shading != "albedo" else None
+            t_light = light_d[ri_long()] if shading != "albedo" else None
             sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, t_light, ratio=ambient_ratio,
                                                                    shading=shading, cano=cano)
         finally:
             model._frame_slots = None
 
         packed = getattr(self.occupancy_grid, "packed", None)
-        ray_start, ray_cnt = packed if packed is not None else ops.packed_info(ray_indices, N)
+        ray_start, ray_cnt = packed if packed is not None else ops.packed_info(ri_long(), N)
         weights, opacity, depth, rgb_acc = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), rgbs,
                                                          ray_start, ray_cnt)
         opacity, depth = opacity[:, None], depth[:, None]
@@ -178,7 +192,7 @@ class HotPathRenderer:
         if model.training:
             tr = cfg["train"]
             if tr["ori_weight"] > 0 and normals is not None and (not real_view):
-                t_dirs = safe_normalize(rays_d[ray_indices])
+                t_dirs = safe_normalize(rays_d[ri_long()])
                 lo = weights.detach() * (normals * t_dirs).sum(-1).clamp(min=0) ** 2
                 results["loss_orient"] = lo.sum(-1).mean()
             if tr["normal_smooth_3d"] > 0 and normals is not None:
@@ -217,8 +231,8 @@ class HotPathRenderer:
             if tr["normal_smoothness"] > 0:
                 results["normal_reg"] = self.get_normal_smoothness_loss(rays_o, rays_d, rays_t, depth)
             if rays_depth is not None:
-                t_gt = rays_depth[ray_indices]
-                t_mask = None if rays_mask is None else rays_mask[ray_indices]
+                t_gt = rays_depth[ri_long()]
+                t_mask = None if rays_mask is None else rays_mask[ri_long()]
                 fs_loss, sdf_loss = sdf_losses(t_positions, t_gt, sdf, tr["trunc"], mask=t_mask)
                 results["sdf_loss"], results["fs_loss"] = sdf_loss, fs_loss
         return results
