@@ -226,6 +226,8 @@ def main():
             roof_hash["bwd_kernel"] = bwd_name
             roof_hash["bwd_achieved"] = round(gbb, 1)
             roof_hash["bwd_frac"] = round(gbb / HBM_PEAK_GBS, 4)
+            roof_hash["bwd_note"] = ("algorithmic bytes of the reference's formulation (2188 B per point incl. the atomics' "
+                                     "read-modify-write); the brick kernel accumulates on-chip, so this rate can exceed the HBM peak")
     out = {
         "metric": "rays/sec (fwd+bwd, 128 samples/ray)", "value": round(total_rays / elapsed, 1), "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
