@@ -351,3 +351,76 @@ def test_weight_norm_all_matches_torch():
         (w2 * p).sum().backward()
         assert_close(v.grad, v2.grad, 2e-5, f"dv[{i}]", floor=1e-2)
         assert_close(gg.grad, g2.grad, 2e-5, f"dg[{i}]", floor=1e-2)
+
+
+SWEEP_SIZES = [1, 31, 32, 33, 127, 128, 129, 255, 257, 1025, 4099]
+
+
+def test_mlp_and_grid_size_sweep():
+    """Ragged sizes around every tile / workgroup boundary (32-point tiles, 128- and 256-point workgroups, persistent
+    loops).  Per-point results do not depend on how many points ride along, so a run on the first M points must
+    reproduce the first M rows of one big run BIT FOR BIT, and its parameter gradients must equal the big run's with
+    the upstream gradient zeroed beyond M (same terms, different summation order) -- any contribution of padding
+    lanes, clamped duplicate points or unwritten scratch tiles would show up here."""
+    from morpheus_amd import ops
+    MB = 4099
+    pg = _state("b", DEV, grad=False)
+    x = synth.hash_tensor((MB, 3), 700, 1.0).to(DEV)
+    slot = (torch.arange(MB) % 2).int().to(DEV)
+    tvals = torch.tensor([0.2, 0.7], device=DEV)
+    code = of.multicode_sample([pg[f"deform_code.volumes.{k}"] for k in range(3)], tvals[:, None])
+    wd_, wt_ = synth.hash_tensor((MB, 3), 701, 1.0).to(DEV), synth.hash_tensor((MB, 2), 702, 1.0).to(DEV)
+    fs, fc = synth.hash_tensor((MB, 32), 703, 0.1).to(DEV), synth.hash_tensor((MB, 32), 704, 0.1).to(DEV)
+    topo = synth.hash_tensor((MB, 2), 705, 0.3).to(DEV)
+    ws, wc = synth.hash_tensor((MB,), 706, 1.0).to(DEV), synth.hash_tensor((MB, 3), 707, 1.0).to(DEV)
+    offs, sc = synth.grid_offsets()
+    res = level_resolutions(16, sc, 16)
+    gw = synth.hash_tensor((MB, 32), 708, 1.0).to(DEV)
+
+    def run(M, zero_beyond=None):
+        """-> per-point outputs [M rows] and a dict of parameter gradients"""
+        leaves = {}
+
+        def leaf(name, t):
+            leaves[name] = t.detach().clone().requires_grad_(True)
+            return leaves[name]
+        plist, b0s = [], []
+        for pre in ("deform_net", "topo_net"):
+            W = [of.wn_weight(leaf(f"{pre}.g{l}", pg[f"{pre}.net.{l}.weight_g"]), leaf(f"{pre}.v{l}", pg[f"{pre}.net.{l}.weight_v"]))
+                 for l in range(6)]
+            b = [leaf(f"{pre}.b{l}", pg[f"{pre}.net.{l}.bias"]) for l in range(6)]
+            plist.append([W[0][:, :39]] + W[1:] + b)
+            b0s.append(torch.addmm(b[0], code, W[0][:, 39:].t()))
+        mask = torch.ones(M, 1, device=DEV)
+        if zero_beyond is not None:
+            mask[zero_beyond:] = 0
+        xs = x[:M].clone().requires_grad_(True)
+        d, t = ops.warp_mlp(xs, slot[:M].contiguous(), b0s[0], b0s[1], 6, plist[0], plist[1])
+        Ws = [leaf(f"sdf.w{l}", pg[f"sdf_net.net.{l}.weight"]) for l in range(3)]
+        Wc = [of.wn_weight(leaf(f"col.g{l}", pg[f"color_net.net.{l}.weight_g"]), leaf(f"col.v{l}", pg[f"color_net.net.{l}.weight_v"]))
+              for l in range(3)]
+        bs = [leaf(f"sdf.b{l}", pg[f"sdf_net.net.{l}.bias"]) for l in range(3)]
+        bc = [leaf(f"col.b{l}", pg[f"color_net.net.{l}.bias"]) for l in range(3)]
+        beta = pg["sdf2density.beta"].abs() + 1e-4
+        sdf, sig, alb = ops.field_mlp(x[:M].contiguous(), fs[:M].contiguous(), fc[:M].contiguous(), topo[:M].contiguous(), beta, 6,
+                                      True, Ws + Wc + bs + bc)
+        emb = leaf("emb", pg["encoder.embeddings"])
+        feat = ops.grid_encode(x[:M].contiguous().clone().requires_grad_(True), emb, offs, res, 1.01)
+        loss = ((d * wd_[:M] + 0).sum(-1, keepdim=True) * mask).sum() + ((t * wt_[:M]).sum(-1, keepdim=True) * mask).sum() + \
+            (sdf[:, None] * ws[:M, None] * mask).sum() + ((alb * wc[:M]).sum(-1, keepdim=True) * mask).sum() + \
+            ((feat * gw[:M]).sum(-1, keepdim=True) * mask).sum()
+        loss.backward()
+        return (d.detach(), t.detach(), sdf.detach(), sig.detach(), alb.detach(), feat.detach()), \
+            {k: v.grad.detach().clone() for k, v in leaves.items() if v.grad is not None}
+
+    outs_big, _ = run(MB)
+    for M in SWEEP_SIZES:
+        outs, grads = run(M)
+        for a, b, name in zip(outs, outs_big, ("deform", "topo", "sdf", "sigma", "albedo", "hash features")):
+            assert torch.equal(a, b[:M]), f"{name}: M={M} differs from the first {M} rows of the {MB}-point run"
+        _, grads_ref = run(MB, zero_beyond=M)
+        assert grads.keys() == grads_ref.keys()
+        for k in grads:
+            scale = float(grads_ref[k].abs().max()) + 1e-20
+            err = float((grads[k] - grads_ref[k]).abs().max()) / scale
+            assert err <= 2e-5, f"grad {k}: M={M} vs masked {MB}-point run: {err:.2e}"
