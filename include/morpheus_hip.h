@@ -49,10 +49,12 @@ const char *mh_status_string(int status);
  *           (res_l = (uint32)ceil(exp2f(l*S)*H) evaluated in float32 by the caller)
  * out:      [M, L*2] point-major, level-major/channel-minor inside a point (grid.py:64)
  * n_levels: levels >= n_levels are written as zero (grid.py:42,53)
- * Out-of-range points give zeros and zero gradients (gridencoder.cu:105-130, :279-284). */
+ * Out-of-range points give zeros and zero gradients (gridencoder.cu:105-130, :279-284).
+ * group:    performance hint, >= 1: every `group` consecutive points lie close together (6 = the finite-difference
+ *           taps of one sample, models/model.py:367-385) and may share gathered corners; results do not depend on it. */
 int mh_grid_encode_fwd(const float *x, const float *emb, const int32_t *offsets_host,
                        const int32_t *res_host, float *out, int64_t M, int32_t L, int32_t n_levels,
-                       float bound, void *stream);
+                       float bound, int32_t group, void *stream);
 /* grad: [M, L*2]; grad_emb: [rows,2] ACCUMULATED into (caller zeroes it, as grid.py:84 does);
  * grad_x: NULL or [M,3], receives d/dx (the 1/(2*bound) chain factor included).  The slope uses
  * the kernel's dy_dx definition, which ignores the border clamp (gridencoder.cu:205-247). */

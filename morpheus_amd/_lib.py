@@ -17,7 +17,7 @@ _I32, _I64, _F = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 _SIGS = {
     "mh_abi_version": (ctypes.c_int, []),
     "mh_status_string": (ctypes.c_char_p, [ctypes.c_int]),
-    "mh_grid_encode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
+    "mh_grid_encode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _I32, _P]),
     "mh_grid_encode_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_grid_bin_workspace_ints": (_I64, []),
     "mh_grid_bin_bricks": (_I32, []),

@@ -186,8 +186,8 @@ class GridEncoder(nn.Module):
         self.n_params = total * level_dim
         self.embeddings = nn.Parameter(torch.empty(total, level_dim).uniform_(-1e-4, 1e-4))
 
-    def forward(self, inputs, bound=1, max_level=None):
-        return ops.grid_encode(inputs, self.embeddings, self._offsets_np, self._res_np, float(bound), max_level)
+    def forward(self, inputs, bound=1, max_level=None, group=1):
+        return ops.grid_encode(inputs, self.embeddings, self._offsets_np, self._res_np, float(bound), max_level, group)
 
 
 class LaplaceDensity(nn.Module):
@@ -300,14 +300,14 @@ class scene_representation(nn.Module):
     def get_topo(self, x, t):
         return self.warp(x, t)[1]
 
-    def get_sigma_albedo(self, x, topo=None, app_code=None, return_color=True):
+    def get_sigma_albedo(self, x, topo=None, app_code=None, return_color=True, _group=1):
         if return_color:
             # both tables share the sample points: one autograd node, one brick binning in backward
             feat_s, feat_c = ops.grid_encode_multi(x, (self.encoder.embeddings, self.encoder_c.embeddings),
                                                    self.encoder._offsets_np, self.encoder._res_np, self.bound,
                                                    self.max_level)
         else:
-            feat_s, feat_c = self.encoder(x, bound=self.bound, max_level=self.max_level), None
+            feat_s, feat_c = self.encoder(x, bound=self.bound, max_level=self.max_level, group=_group), None
         params = self.sdf_net.weights() + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
             self.color_net.biases()
         sdf, sigma, albedo = ops.field_mlp(x, feat_s, feat_c, topo, self.sdf2density.get_beta(), self._n_bands(),
@@ -342,7 +342,7 @@ class scene_representation(nn.Module):
         # cache lines (the taps lie within 2 eps of each other) and they fall into the same backward brick
         taps = (x[:, None] + off).clamp(-self.bound, self.bound).reshape(6 * M, 3)
         topo6 = None if topo is None else topo[:, None].expand(M, 6, topo.shape[-1]).reshape(6 * M, -1)
-        sdf = self.get_sigma_albedo(taps, topo=topo6, return_color=False)[0].view(M, 6)
+        sdf = self.get_sigma_albedo(taps, topo=topo6, return_color=False, _group=6)[0].view(M, 6)
         return torch.stack([0.5 * (sdf[:, 0] - sdf[:, 1]) / epsilon, 0.5 * (sdf[:, 2] - sdf[:, 3]) / epsilon,
                             0.5 * (sdf[:, 4] - sdf[:, 5]) / epsilon], -1)
 

@@ -119,7 +119,7 @@ class _GridEncode(torch.autograd.Function):
     No dy_dx tensor is materialised; backward recomputes corner weights."""
 
     @staticmethod
-    def forward(ctx, x, offsets_np, res_np, n_levels, bound, *embs):
+    def forward(ctx, x, offsets_np, res_np, n_levels, bound, group, *embs):
         require_gpu(x, *embs)
         lib = _lib.load()
         x = x.detach().contiguous().float()
@@ -131,7 +131,8 @@ class _GridEncode(torch.autograd.Function):
             embc = emb.detach().contiguous()
             out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
             _e = TIMER.start()
-            check(lib.mh_grid_encode_fwd(ptr(x), ptr(embc), o_p, r_p, ptr(out), M, L, n_levels, float(bound), stream()),
+            check(lib.mh_grid_encode_fwd(ptr(x), ptr(embc), o_p, r_p, ptr(out), M, L, n_levels, float(bound), int(group),
+                                         stream()),
                   "mh_grid_encode_fwd")
             TIMER.stop("mh_grid_encode_fwd", _e)
             outs.append(out)
@@ -173,21 +174,22 @@ class _GridEncode(torch.autograd.Function):
             g_embs.append(g_emb)
             if need_dx:
                 g_x_total = g_x if g_x_total is None else g_x_total + g_x
-        return (g_x_total, None, None, None, None, *g_embs)
+        return (g_x_total, None, None, None, None, None, *g_embs)
 
 
-def grid_encode(x, emb, offsets_np, res_np, bound, max_level=None):
-    """x [..,3] in world units -> [.., L*2] (grid.py:152-169)."""
+def grid_encode(x, emb, offsets_np, res_np, bound, max_level=None, group: int = 1):
+    """x [..,3] in world units -> [.., L*2] (grid.py:152-169).  group: every `group` consecutive points are neighbours
+    (6 = finite-difference taps, point-major): a gather-sharing hint, results do not depend on it."""
     L = len(res_np)
     lead = list(x.shape[:-1])
-    (out,) = _GridEncode.apply(x.reshape(-1, 3), offsets_np, res_np, effective_levels(max_level, L), bound, emb)
+    (out,) = _GridEncode.apply(x.reshape(-1, 3), offsets_np, res_np, effective_levels(max_level, L), bound, group, emb)
     return out.view(lead + [L * 2])
 
 
 def grid_encode_multi(x, embs, offsets_np, res_np, bound, max_level=None):
     """Several tables with identical level geometry at the same points -> tuple of [M, L*2]."""
     L = len(res_np)
-    return _GridEncode.apply(x.reshape(-1, 3), offsets_np, res_np, effective_levels(max_level, L), bound, *embs)
+    return _GridEncode.apply(x.reshape(-1, 3), offsets_np, res_np, effective_levels(max_level, L), bound, 1, *embs)
 
 
 # ------------------------------------------------------------------------------------ compositor

@@ -424,3 +424,27 @@ def test_mlp_and_grid_size_sweep():
             scale = float(grads_ref[k].abs().max()) + 1e-20
             err = float((grads[k] - grads_ref[k]).abs().max()) / scale
             assert err <= 2e-5, f"grad {k}: M={M} vs masked {MB}-point run: {err:.2e}"
+
+
+def test_grid_encode_grouped_taps_bit_identical():
+    """The finite-difference tap layout (6 consecutive points within 2 eps of each other) through the corner-caching
+    grouped kernel equals the ungrouped kernel bit for bit, incl. taps clamped at / pushed across the box boundary,
+    taps straddling cell and brick boundaries, and progressive levels."""
+    from morpheus_amd import ops
+    emb, offs, res = _grid_setup()
+    M = 3001
+    g = torch.Generator().manual_seed(11)
+    c = (torch.rand(M, 3, generator=g) * 2 - 1) * 1.02            # some centres outside the box
+    c[:200] = torch.round(c[:200] * 64) / 64 * 1.01               # centres sitting exactly on cell faces
+    off = torch.zeros(1, 6, 3)
+    for k in range(3):
+        off[0, 2 * k, k], off[0, 2 * k + 1, k] = 2e-3, -2e-3
+    taps = (c[:, None] + off).clamp(-1.01, 1.01).reshape(-1, 3).to(DEV)
+    embg = emb.to(DEV)
+    for ml in (None, 0.5):
+        a = ops.grid_encode(taps, embg, offs, res, 1.01, ml, group=6)
+        b = ops.grid_encode(taps, embg, offs, res, 1.01, ml, group=1)
+        assert torch.equal(a, b)
+    # a hint that does not divide the point count is ignored, not an error
+    assert torch.equal(ops.grid_encode(taps[:-1], embg, offs, res, 1.01, None, group=6),
+                       ops.grid_encode(taps[:-1], embg, offs, res, 1.01, None))

@@ -42,8 +42,8 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_argument_validation_without_gpu(lib):
     """status codes, never exceptions or launches, for bad arguments"""
-    assert lib.mh_grid_encode_fwd(None, None, None, None, None, 10, 16, 16, 1.01, None) == 1
-    assert lib.mh_grid_encode_fwd(None, None, None, None, None, 0, 16, 16, 1.01, None) == 0      # empty input is fine
+    assert lib.mh_grid_encode_fwd(None, None, None, None, None, 10, 16, 16, 1.01, 1, None) == 1
+    assert lib.mh_grid_encode_fwd(None, None, None, None, None, 0, 16, 16, 1.01, 1, None) == 0      # empty input is fine
     assert lib.mh_composite_fwd(*([None] * 10), 0, None) == 0
     assert lib.mh_composite_fwd(*([None] * 10), 5, None) == 1
     assert lib.mh_warp_fwd(*([None] * 8), 6, None, None, None, 128, None) == 1

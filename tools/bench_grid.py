@@ -40,7 +40,7 @@ def run(x, tag):
     t = timeit(lambda: lib.mh_grid_encode_bwd(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), g_emb.data_ptr(), None, M, 16, 16, 1.01, st), 2)
     print(f"   naive  n_levels=16 dx=0: {t:.3f} ms")
     out = torch.empty(M, 32, device=dev)
-    t = timeit(lambda: lib.mh_grid_encode_fwd(x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), out.data_ptr(), M, 16, 16, 1.01, st))
+    t = timeit(lambda: lib.mh_grid_encode_fwd(x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), out.data_ptr(), M, 16, 16, 1.01, 1, st))
     print(f"   fwd: {t:.3f} ms")
 
 
