@@ -520,6 +520,18 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
     }
     wp += 1024;
     // sdf L2: 64 -> [geo(32) | sdf], no activation
+    if (!with_color) {
+        // sdf-only pass (finite-difference taps): the geo tile feeds nothing -- evaluate the tile holding the sdf row only
+        f32x16 a1[1];
+        acc_bias<1>(a1, bias + 128 + 32, h);
+        mfma_layer_at<32, 1>(wp + 8 * 64, bin, a1, lane);
+        if (h == 0 && live) {
+            const float s = a1[0][0];
+            sdf[p] = s;
+            if (sigma) sigma[p] = laplace_sigma(s, *beta_p);
+        }
+        continue;
+    }
     acc_bias<2>(acc, bias + 128, h);
     mfma_layer_at<32, 2>(wp, bin, acc, lane);
     wp += 1024;
@@ -528,7 +540,6 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
         sdf[p] = s;
         if (sigma) sigma[p] = laplace_sigma(s, *beta_p);
     }
-    if (!with_color) continue;
     // color L0: [hash_c(32) | geo(32)] -> 64
     float binc[32];
     {
@@ -684,9 +695,27 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
             d2[16 + r] = 0.f;
         }
         d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
-        store_acc_rows<2>(dtile + 128 * TILE, d2, pt, h);
+        if (with_color) {
+            store_acc_rows<2>(dtile + 128 * TILE, d2, pt, h);
             acc_zero<2>(acc);
-        mfma_layer_at<32, 2>(wt, d2, acc, lane);
+            mfma_layer_at<32, 2>(wt, d2, acc, lane);
+        } else {
+            // sdf-only pass (finite-difference taps): dP2 has ONE non-zero row, the sdf output -- tile 1, row 0, i.e.
+            // k-step 16 of the 32.  dH2 = W2[sdf,:]^T g_sdf is that single k-step (2 MFMAs instead of 64), and only
+            // tile 1 of dP2 is parked (mh_mlp_wgrad is pointed at it with a 32-row out tile by the caller)
+            float t1[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) t1[r] = d2[16 + r];
+            store_acc_rows<1>(dtile + (128 + 32) * TILE, t1, pt, h);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const f32x4 a = wt[(t * 8 + 4) * 64 + lane];
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = 0.f;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], gs, z, 0, 0, 0);
+            }
+        }
         wt += 1024;
     }
     // mask S2 -> dP1

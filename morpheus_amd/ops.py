@@ -471,12 +471,19 @@ class _FieldMLP(torch.autograd.Function):
                          [r * 32 for r in dpre_rows], pk.wg_in, pk.wg_out, n_tiles, dev, "field")
             (gw,), (gb,) = field_joint_packer().unpack_grads(raw)
         else:   # FD-normal taps: the sdf net only; the colour net's gradients are zero
+            # dP2 has one non-zero row (the sdf output, first row of its second 32-row tile): the kernel parked only that
+            # tile, so layer 2's weight gradient is a 32-row launch on it; the geo rows' gradients are zero
+            wg_out = [pk.wg_out[0], pk.wg_out[1], 32]
             raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows[:3]],
-                         [r * 32 for r in dpre_rows[:3]], pk.wg_in[:3], pk.wg_out[:3], n_tiles, dev, "field")
-            n_dw = sum(i * o for i, o in zip(pk.wg_in[:3], pk.wg_out[:3]))
-            dw_raw, db_raw = raw[:n_dw], raw[n_dw:]
-            dw_raw = torch.cat([dw_raw, dw_raw.new_zeros(pk.raw_dw - dw_raw.numel())])
-            db_raw = torch.cat([db_raw, db_raw.new_zeros(pk.raw_db - db_raw.numel())])
+                         [dpre_rows[0] * 32, dpre_rows[1] * 32, (dpre_rows[2] + 32) * 32], pk.wg_in[:3], wg_out, n_tiles, dev,
+                         "field")
+            n01 = pk.wg_in[0] * pk.wg_out[0] + pk.wg_in[1] * pk.wg_out[1]
+            n2 = pk.wg_in[2] * 32
+            dw01, dw2, db = raw[:n01], raw[n01:n01 + n2], raw[n01 + n2:]
+            nb01 = pk.wg_out[0] + pk.wg_out[1]
+            z = raw.new_zeros
+            dw_raw = torch.cat([dw01, z(n2), dw2, z(pk.raw_dw - n01 - 2 * n2)])          # [.. | L2 tile 0 = 0 | L2 tile 1 | colour = 0]
+            db_raw = torch.cat([db[:nb01], z(32), db[nb01:], z(pk.raw_db - nb01 - 64)])
             gw, gb = pk.unpack_grads(dw_raw, db_raw)
         g_beta = g_bp.sum().reshape(())
         return (g_xc, g_fs, g_fc, g_tp if has_topo else None, g_beta, None, None, *gw, *gb)
