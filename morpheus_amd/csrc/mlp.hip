@@ -738,23 +738,33 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
     // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
     f32x16 e[3];
     acc_zero<3>(e);
-    mfma_layer_at<32, 3>(wt, dbin, e, lane);
-    float encb[20], dsc[18];
-    enc_bin(xv, h, n_bands, encb, dsc);
     float gx[3] = {0.f, 0.f, 0.f};
+    if (g_xc) {
+        mfma_layer_at<32, 3>(wt, dbin, e, lane);
+        float encb[20], dsc[18];
+        enc_bin(xv, h, n_bands, encb, dsc);
 #pragma unroll
-    for (int k = 0; k < 18; k++) {
-        const float de = k < 16 ? e[0][k] : e[1][k - 16];
-        gx[k % 3] += de * dsc[k];
-    }
-    if (h == 0) {
-        gx[0] += e[1][2];
-        gx[2] += e[1][3];
+        for (int k = 0; k < 18; k++) {
+            const float de = k < 16 ? e[0][k] : e[1][k - 16];
+            gx[k % 3] += de * dsc[k];
+        }
+        if (h == 0) {
+            gx[0] += e[1][2];
+            gx[2] += e[1][3];
+        } else {
+            gx[1] += e[1][2];
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
     } else {
-        gx[1] += e[1][2];
+        // nobody asks for d/d(position) (canonical rendering, finite-difference taps): the encoding tile of W0^T and the
+        // 18 sincos derivatives are skipped; tiles 1 (topo) and 2 (hash features) are contiguous in the pack
+        f32x16 e12[2];
+        acc_zero<2>(e12);
+        mfma_layer_at<32, 2>(wt + 8 * 64, dbin, e12, lane);
+        e[1] = e12[0];
+        e[2] = e12[1];
     }
-#pragma unroll
-    for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
     if (live) {
         if (g_xc && h == 0) {
             g_xc[p * 3 + 0] = gx[0];

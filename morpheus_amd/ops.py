@@ -448,7 +448,7 @@ class _FieldMLP(torch.autograd.Function):
         dpre = torch.empty(lib.mh_field_dpre_floats(M), device=dev)
         if not with_color:
             g_albedo = None   # colour rows of the scratch are neither written nor read on this path
-        g_xc = torch.empty(M, 3, device=dev)
+        g_xc = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL: the kernel skips the d/dx stage
         g_fs = torch.empty(M, 32, device=dev)
         g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
         g_tp = torch.empty(M, 2, device=dev)
