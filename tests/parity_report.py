@@ -1,4 +1,4 @@
-"""GPU-box tool: HIP path vs the CPU oracle on identical inputs -- per-output and per-parameter-gradient
+"""GPU-box checker (test infrastructure, lives under tests/ because it uses the oracle): HIP path vs the CPU oracle on identical inputs -- per-output and per-parameter-gradient
 errors, printed as JSON (feeds DESIGN.md's parity table; not part of the product path)."""
 from __future__ import annotations
 

@@ -116,7 +116,7 @@ def test_model_entry_points_vs_reference_goldens(kind):
                     # d(hash)/dx is piecewise constant: a probe point whose warped position differs by 1e-7
                     # between two fp32 implementations can change cell at some level and flip its
                     # contribution, so with only 2048 points the deform-branch gradients agree to ~2e-3
-                    # (relative L2; tools/parity_report.py); the canonical branch and the 65k-point
+                    # (relative L2; tests/parity_report.py); the canonical branch and the 65k-point
                     # render cases agree to <1e-4.
                     gtol = 5e-4 if (shading == "albedo" and cano) else 5e-3
                     n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None},

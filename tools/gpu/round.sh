@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -q -m gpu 2>&1 | grep -E "^(E  |FAILED|PASSED|tests/|[0-9]+ (passed|failed))|Error|passed|failed" | head -120 > gpurun_out/gpu_tests.log
 timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
-timeout 600 python tools/parity_report.py > gpurun_out/parity.log 2>&1
+timeout 600 python tests/parity_report.py > gpurun_out/parity.log 2>&1
 timeout 600 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1
 timeout 600 python bench.py --steps 10 --warmup 3 --workload cfg2 --no-cpu-baseline > gpurun_out/bench_cfg2.log 2>&1
 REPO=$(pwd)
