@@ -4,10 +4,20 @@
 One "step" = one pass of the render_rays hot path over one batch of synthetic rays:
   sampler -> warp (deform/topo MLPs) -> hash grids -> sdf/colour MLPs + Laplace density ->
   transmittance compositor -> loss = MSE(image) + MSE(depth) -> backward to every parameter group
-  (both hash tables included) -> [N>1: one RCCL all-reduce of the flat gradient bucket] -> Adam step.
+  (both hash tables included) -> [N>1: RCCL all-reduce of the flat gradient bucket] -> Adam step.
 Workload at N=1: BASELINE configs[2] ("cfg3": snoopy.yaml, full deform field, 16384 rays x 128 samples);
---workload cfg2 selects configs[1] (canonical field only).  N>1 = configs[4]: one frame per rank
-(weak scaling), no data-path collective other than the gradient all-reduce.
+N>1 = configs[4] ("cfg5"): one frame per rank (frames 0,25,...,175; weak scaling), no data-path collective other than
+the gradient all-reduce (the hash tables' 6.4 of 7.45 MB go out on a side stream under the rest of backward).
+
+`python bench.py --gpus N` launches itself: without torchrun's RANK/WORLD_SIZE in the environment and N > 1 it re-execs
+through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per
+GPU over RCCL; if the box has fewer GPUs than ranks the ranks share devices over gloo and the line says so).  Under
+torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE as given.
+
+Other workloads (parity / tier cases, not the headline): cfg2 (canonical field only), cfg3b (deform + FD normals),
+train_real (the reference's real-view training step, morpheus.py:1147-1236: 2048 rays of one frame, occupancy-marched
+ragged samples, albedo_normal, shipped regularisers, point loss, pose optimisation, occupancy refresh every 16 steps),
+density128 (forward-only model.density on a 128^3 grid: export_mesh / update_occ_grid's query, morpheus.py:367-408).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel: algorithmic FLOPs per launch / HIP-event launch time vs the fp32 MFMA peak
@@ -19,10 +29,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,19 +41,77 @@ sys.path.insert(0, ROOT)
 MACS = dict(deform=77056, topo=76928, sdf=10880, color=8384)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+L2_PEAK_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 bandwidth
 GRID_FWD_BYTES, GRID_BWD_BYTES = 1164, 2188   # per point per encoder
+GRID_GATHERS_PER_POINT = 16 * 8   # 8 corners x 16 levels, one 8-byte row each -> one 64-byte L2 sector each (worst case)
+WORKLOADS = ["cfg3", "cfg2", "cfg3b", "train_real", "density128"]
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (32 for train_real: two occupancy refreshes)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=WORKLOADS,
+                    help="cfg3: deform field, albedo (headline); cfg2: canonical only; cfg3b: deform + albedo_normal "
+                         "shading (FD normals); train_real: the reference's real-view training step; density128: "
+                         "forward-only field query on a 128^3 grid")
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU per step (default 16384; 2048 for train_real)")
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1024)
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: one all-reduce after backward instead of the early "
+                                                              "side-stream exchange of the hash-table gradients")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one whole step (render fwd+bwd, all-reduce excluded, Adam) in a HIP graph and replay it; "
+                         "disables the per-kernel event timers")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 32 if args.workload == "train_real" else 20
+    if args.rays is None:
+        args.rays = 2048 if args.workload == "train_real" else 128 * 128
+    return args
+
+
+# ------------------------------------------------------------------------------------------------ self-launch
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: spawn N ranks of this script, one per GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("MORPHEUS_BENCH_STUB"):
+        env["MORPHEUS_DIST_BACKEND"] = "gloo"
+    elif "MORPHEUS_DIST_BACKEND" not in env:
+        import torch
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            # fewer GPUs than ranks (a 1-GPU box): the ranks share devices and exchange over gloo -- exercises the N>1
+            # path, is NOT a scaling data point (the JSON line carries devices_visible and the backend)
+            env["MORPHEUS_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(workload: str, n_rays: int, S: int, reps: int = 2):
     """Oracle (CPU restatement, kind 'port') fwd+bwd on a bounded sample of the same workload, in a
     subprocess per thread count (all-core runs of these small GEMMs are slower than 16-64 threads,
     so a few settings are tried and the best is reported with the thread count actually used)."""
-    import subprocess
     ncpu = os.cpu_count() or 1
     tried, best = [], None
+    wl = workload
     for th in sorted({min(ncpu, 16), min(ncpu, 32), min(ncpu, 64)}):
         try:
-            out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--workload", workload, "--rays", str(n_rays),
+            out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", "--workload", wl, "--rays", str(n_rays),
                                   "--samples", str(S), "--threads", str(th), "--reps", str(reps)], cwd=ROOT,
                                  capture_output=True, text=True, timeout=240)
             r = json.loads(out.stdout.strip().splitlines()[-1])
@@ -56,41 +124,45 @@ def cpu_baseline(workload: str, n_rays: int, S: int, reps: int = 2):
     if best is None:
         return dict(value=None, unit="rays/s", cores=0, kind="port", sample="failed", tried=tried)
     return dict(value=round(best["rays_per_s"], 1), unit="rays/s", cores=best["threads"], kind="port",
-                sample=f"{n_rays} rays x {S} samples of the same frame/weights, fwd+bwd, min of {reps} after 1 warm-up "
-                       f"(oracle/field.py + oracle/hashgrid.c, OpenMP + torch CPU); host has {ncpu} logical CPUs",
+                sample=f"{n_rays} rays x {S} samples of the same frame/weights ({wl} render fwd+bwd), min of {reps} after 1 "
+                       f"warm-up (oracle/field.py + oracle/hashgrid.c, OpenMP + torch CPU); host has {ncpu} logical CPUs",
                 tried=tried)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg3b"],
-                    help="cfg3: deform field, albedo (headline); cfg2: canonical only; cfg3b: deform + albedo_normal "
-                         "shading (FD normals: the reference's real-view training mode, SURVEY 8d optional case)")
-    ap.add_argument("--rays", type=int, default=128 * 128)
-    ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=1024)
-    ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture one whole step (render fwd+bwd, all-reduce excluded, Adam) in a HIP graph and replay it; "
-                         "disables the per-kernel event timers")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------------ workloads
+def build_stub(args, rank, world):
+    """MORPHEUS_BENCH_STUB=1 (CPU test of the launcher / timing / JSON plumbing, tests/test_bench_launcher.py): a toy
+    step on the CPU with the same bucket + all-reduce + barrier structure.  Never used for a reported number."""
+    import torch
     from morpheus_amd import dist as mdist
-    from morpheus_amd import harness, ops, synth
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.ReLU(), torch.nn.Linear(32, 3))
+    table = torch.nn.Parameter(torch.randn(256, 2))
+    params = [table] + list(net.parameters())
+    bucket = mdist.GradBucket(params)
+    if not args.no_overlap:
+        bucket.overlap_early([table])
+    opt = torch.optim.Adam(params, lr=1e-3)
+    x = torch.randn(args.rays, 6, generator=torch.Generator().manual_seed(rank))
+    idx = torch.arange(args.rays) % 256
+
+    def step():
+        bucket.zero()
+        loss = ((net(x) + table[idx].sum(-1, keepdim=True)) ** 2).mean()
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        return loss
+
+    return dict(step=step, rays_per_step=args.rays, bucket=bucket, desc="stub (CPU toy step, plumbing test only)",
+                samples=lambda: args.rays * args.samples)
+
+
+def build_render_workload(args, rank, world, dev):
+    import torch
+    from morpheus_amd import dist as mdist
+    from morpheus_amd import harness, synth
     from morpheus_amd.optim import FlatAdam
-    import torch.distributed as dist
-
-    rank, local, world = mdist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
     cano = args.workload == "cfg2"
     model = harness.build_model("b", dev).train()
     cfg = model.config
@@ -113,22 +185,123 @@ def main():
         # Adam of morpheus.py:154-155 over one flat bucket: one mh_adam_step launch per step, gradients in opt.bucket
         opt = FlatAdam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
         bucket = opt.bucket
+    if world > 1 and not args.no_overlap:
+        bucket.overlap_early([model.encoder.embeddings, model.encoder_c.embeddings])
+    shading = "albedo_normal" if args.workload == "cfg3b" else "albedo"
 
     def step():
         bucket.zero()
-        res = rend.render_rays(o, d, t, rid, hw, hw, ambient_ratio=1.0, light_d=light,
-                               shading="albedo_normal" if args.workload == "cfg3b" else "albedo", cano=cano)
+        res = rend.render_rays(o, d, t, rid, hw, hw, ambient_ratio=1.0, light_d=light, shading=shading, cano=cano)
         loss = harness.bench_loss(res, timg, tdep)
         loss.backward()
         bucket.allreduce_mean()
         opt.step()
         return loss
 
+    desc = ("snoopy.yaml full deform field" + (" + FD normals (albedo_normal)" if args.workload == "cfg3b" else "")
+            if not cano else "snoopy.yaml canonical field only") + \
+        f", {N} rays x {S} samples per GPU, fwd+bwd+Adam ({args.workload}" + (", one frame per rank = cfg5" if world > 1 else "") + ")"
+    return dict(step=step, rays_per_step=N, bucket=bucket, desc=desc, samples=lambda: N * S, frame=frame)
+
+
+def build_train_real(args, rank, world, dev):
+    """The reference's real-view training step (morpheus_amd/trainstep.py restates morpheus.py:1147-1236 around render_rays)."""
+    import torch
+    from morpheus_amd import harness, trainstep
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.optim import FlatAdam
+    from morpheus_amd.render import HotPathRenderer
+    model = harness.build_model("b", dev).train()
+    cfg = model.config                                   # shipped snoopy.yaml values: every regulariser on
+    grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(dev)
+    rend = HotPathRenderer(model, cfg, grid, 200)
+    frames = trainstep.make_frames([(25 * rank + 8 * k) % 200 for k in range(8)], 256, 256, dev)
+    ts = trainstep.RealViewTrainStep(rend, frames, ray_num=args.rays)
+    ts.epoch = 1000                                       # mid-training: progressive level 0.75
+    opt = FlatAdam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
+    bucket = opt.bucket
+    if world > 1 and not args.no_overlap:
+        bucket.overlap_early([model.encoder.embeddings, model.encoder_c.embeddings])
+    with torch.no_grad():
+        trainstep.warm_up_occupancy(ts)                   # trained-like occupancy from the field's own density
+    ts.global_step = 4096                                 # past the estimator's warm-up: partial refresh every 16 steps
+    occ = float(grid.binaries.float().mean())
+    sample_log = []
+
+    def step():
+        bucket.zero()
+        loss = ts()
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        sample_log.append(ts.last_samples)
+        return loss
+
+    desc = (f"snoopy.yaml real-view training step (morpheus.py:1147-1236): {args.rays} random rays of one frame per GPU, "
+            f"occupancy-marched ragged samples (step 0.01, {occ * 100:.1f}% of 128^3 cells occupied), albedo_normal, "
+            "normal_smooth_3d + normal_smoothness + code_reg, depth/mask/sdf/surface-point losses, pose optimisation, "
+            "occupancy refresh every 16 steps, Adam")
+    return dict(step=step, rays_per_step=args.rays, bucket=bucket, desc=desc,
+                samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ)
+
+
+def build_density128(args, rank, world, dev):
+    """Forward-only dense field query: export_mesh / update_occ_grid call model.density on grid points
+    (morpheus.py:367-408, 905-913).  A 'step' = all 128^3 points in chunks of 2^21, no_grad, colour included."""
+    import torch
+    from morpheus_amd import harness
+    model = harness.build_model("b", dev).eval()
+    R = 128
+    c = (torch.arange(R, device=dev).float() + 0.5) / R * 2 * model.bound - model.bound
+    pts = torch.stack(torch.meshgrid(c, c, c, indexing="ij"), -1).reshape(-1, 3).contiguous()
+    t = torch.full((1, 1), 25 / 200, device=dev)
+
+    def step():
+        with torch.no_grad():
+            tot = 0.0
+            for i in range(0, pts.shape[0], 1 << 21):
+                out = model.density(pts[i:i + (1 << 21)], t, allow_shape=True)
+                tot = tot + out["sdf"][0]
+        return tot
+
+    return dict(step=step, rays_per_step=pts.shape[0], bucket=None, samples=lambda: pts.shape[0],
+                desc=f"forward-only model.density (warp + both hash grids + sdf/colour nets) on {R}^3 grid points, no_grad")
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args, argv))
+
+    import torch
+    import torch.distributed as dist
+    from morpheus_amd import dist as mdist
+    from morpheus_amd import ops
+
+    stub = bool(os.environ.get("MORPHEUS_BENCH_STUB"))
+    rank, local, world = mdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if stub:
+        dev = torch.device("cpu")
+        wl = build_stub(args, rank, world)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        builder = {"train_real": build_train_real, "density128": build_density128}.get(args.workload, build_render_workload)
+        wl = builder(args, rank, world, dev)
+    step = wl["step"]
+    sync = (lambda: None) if stub else torch.cuda.synchronize
+
     for _ in range(args.warmup):
         step()
     graph = None
     if args.graph:
-        assert world == 1, "--graph captures the single-GPU step"
+        assert world == 1 and args.workload in ("cfg3", "cfg2", "cfg3b"), "--graph captures the single-GPU fixed-shape step"
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -136,28 +309,28 @@ def main():
             step()                                   # warm the allocator on the capture stream
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss_g = step()
         eager_step = step
+        with torch.cuda.graph(graph):
+            loss_g = eager_step()
 
         def step():                                  # noqa: F811 -- replay the captured step
             graph.replay()
             return loss_g
-    ops.TIMER.reset(enabled=(rank == 0 and not args.no_kernel_timers and graph is None))
+    ops.TIMER.reset(enabled=(rank == 0 and not stub and not args.no_kernel_timers and graph is None))
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+        elapsed = float(el.item())
     timers = ops.TIMER.summary() if rank == 0 else {}
     ops.TIMER.reset(False)
 
@@ -165,18 +338,22 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    M = N * S
+    N, S = wl["rays_per_step"], args.samples
+    M = float(wl["samples"]())                     # sample points per step per GPU (ragged workloads: mean over the timed steps)
     ms_step = elapsed / args.steps * 1e3
     total_rays = N * world * args.steps
+    render_wl = args.workload in ("cfg3", "cfg2", "cfg3b")
     # algorithmic FLOPs per launch of each timed C-ABI call (2 FLOPs per MAC; bwd-data = wgrad = fwd)
     warp_f = 2.0 * (MACS["deform"] + MACS["topo"]) * M
     field_f = 2.0 * (MACS["sdf"] + MACS["color"]) * M
     flops = {"mh_warp_fwd": warp_f, "mh_warp_bwd_data": warp_f, "mh_mlp_wgrad[warp]": warp_f,
-             "mh_field_fwd": field_f, "mh_field_bwd_data": field_f, "mh_mlp_wgrad[field]": field_f}
+             "mh_field_fwd": field_f, "mh_field_bwd_data": field_f, "mh_mlp_wgrad[field]": field_f} if render_wl and \
+        args.workload != "cfg3b" else ({"mh_warp_fwd": warp_f, "mh_warp_bwd_data": warp_f, "mh_mlp_wgrad[warp]": warp_f}
+                                       if args.workload == "cfg3b" else {})
     ktab, dominant = {}, None
     for name, (calls, total_ms) in sorted(timers.items(), key=lambda kv: -kv[1][1]):
         avg_ms = total_ms / max(calls, 1)
-        ktab[name] = dict(calls_per_step=calls / args.steps, avg_ms=round(avg_ms, 4),
+        ktab[name] = dict(calls_per_step=round(calls / args.steps, 3), avg_ms=round(avg_ms, 4),
                           ms_per_step=round(total_ms / args.steps, 4))
         if name in flops:
             ktab[name]["tflops"] = round(flops[name] / (avg_ms * 1e-3) / 1e12, 2)
@@ -184,42 +361,55 @@ def main():
             # launches plus a reduction (each <= 0.65 ms) and is listed in "kernels" with its own TFLOP/s
             if dominant is None and not name.startswith("mh_mlp_wgrad"):
                 dominant = name
+
     def pmc_traffic(kernel_symbol):
         """HBM bytes per launch measured by the committed rocprofv3 --pmc passes of this same command
-        (profiles/r01_pmc_summary.csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB units)."""
-        try:
-            import csv
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")) as f:
-                for row in csv.DictReader(f):
-                    if row["k"] == kernel_symbol:
-                        return round((float(row["hbm_read_MB_per_launch"]) + float(row["hbm_write_MB_per_launch"])) * 1024 * 1024)
-        except Exception:      # noqa: BLE001
-            pass
+        (profiles/r0N_pmc_summary.csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB units)."""
+        import csv
+        for rnd in ("r02", "r01"):
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.csv")) as f:
+                    for row in csv.DictReader(f):
+                        if row["k"] == kernel_symbol:
+                            return round((float(row["hbm_read_MB_per_launch"]) + float(row["hbm_write_MB_per_launch"])) * 1024 * 1024)
+            except Exception:      # noqa: BLE001
+                continue
         return None
 
     symbol = {"mh_warp_fwd": "warp_fwd_kernel", "mh_warp_bwd_data": "warp_bwd_kernel", "mh_field_fwd": "field_fwd_kernel",
               "mh_field_bwd_data": "field_bwd_kernel"}
+    full = render_wl and N * S == 128 * 128 * 128
     roofline = None
     if dominant is not None:
         ach = flops[dominant] / (ktab[dominant]["avg_ms"] * 1e-3) / 1e12
         roofline = dict(kernel=dominant, bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=pmc_traffic(symbol.get(dominant, "")) if (N * S == 128 * 128 * 128 and args.workload == "cfg3") else None,
+                        traffic=pmc_traffic(symbol.get(dominant, "")) if (full and args.workload == "cfg3") else None,
                         traffic_note="HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), not a live "
                                      "measurement; null when the workload differs from the profiled one",
                         flops_per_launch=flops[dominant], avg_launch_ms=ktab[dominant]["avg_ms"])
+        step_flops = 3.0 * (warp_f * (0 if args.workload == "cfg2" else 1) + field_f)
+        if args.workload != "cfg3b":
+            roofline["whole_step"] = dict(flops=step_flops, tflops=round(step_flops / (ms_step * 1e-3) / 1e12, 2),
+                                          frac=round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
     roof_hash = None
-    if "mh_grid_encode_fwd" in ktab:
+    if render_wl and "mh_grid_encode_fwd" in ktab:
         # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b), averaged over launches
         enc_points = (2 * M + (6 * M if args.workload == "cfg3b" else 0))
         pts_per_launch = enc_points / ktab["mh_grid_encode_fwd"]["calls_per_step"]
-        gb = GRID_FWD_BYTES * pts_per_launch / (ktab["mh_grid_encode_fwd"]["avg_ms"] * 1e-3) / 1e9
+        secs = ktab["mh_grid_encode_fwd"]["avg_ms"] * 1e-3
+        gb = GRID_FWD_BYTES * pts_per_launch / secs / 1e9
+        l2 = GRID_GATHERS_PER_POINT * 64 * pts_per_launch / secs / 1e9
+        traffic = pmc_traffic("grid_fwd_kernel") if (full and args.workload != "cfg3b") else None
         roof_hash = dict(kernel="grid_fwd_kernel", bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                         frac=round(gb / HBM_PEAK_GBS, 4),
-                         traffic=pmc_traffic("grid_fwd_kernel") if (N * S == 128 * 128 * 128 and args.workload != "cfg3b") else None,
+                         frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic,
                          bytes_per_launch=round(GRID_FWD_BYTES * pts_per_launch),
-                         note="algorithmic bytes; both 3.2 MB tables are L2/MALL resident, so gathers are "
-                              "cache-served (SURVEY 8d caveat)")
+                         hbm_measured_gbs=None if traffic is None else round(traffic / secs / 1e9, 1),
+                         l2_sector_gbs=round(l2, 1), l2_sector_frac=round(l2 / L2_PEAK_GBS, 4),
+                         note="achieved = ALGORITHMIC bytes (SURVEY 8d: 1164 B/point) / time; both 3.2 MB tables are L2/MALL "
+                              "resident, so the gathers are cache-served: hbm_measured_gbs is the PMC traffic / time, and "
+                              "l2_sector_gbs prices every 8-byte corner gather at one 64-byte L2 sector (upper bound of the "
+                              "sector traffic; neighbouring corners share sectors) against the 34.5 TB/s aggregate L2")
         bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
         if bwd_name in ktab:
             gbb = GRID_BWD_BYTES * (enc_points / ktab[bwd_name]["calls_per_step"]) / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9
@@ -227,25 +417,39 @@ def main():
             roof_hash["bwd_achieved"] = round(gbb, 1)
             roof_hash["bwd_frac"] = round(gbb / HBM_PEAK_GBS, 4)
             roof_hash["bwd_note"] = ("algorithmic bytes of the reference's formulation (2188 B per point incl. the atomics' "
-                                     "read-modify-write); the brick kernel accumulates on-chip, so this rate can exceed the HBM peak")
+                                     "read-modify-write); the brick kernel accumulates on-chip, so this rate can exceed the HBM "
+                                     "peak -- it is a throughput in the reference's units, not an HBM utilisation")
+    bucket = wl["bucket"]
+    backend = dist.get_backend() if world > 1 else None
+    n_dev = 0 if stub else torch.cuda.device_count()
+    headline = args.workload in ("cfg3", "cfg2", "cfg3b")
     out = {
-        "metric": "rays/sec (fwd+bwd, 128 samples/ray)", "value": round(total_rays / elapsed, 1), "unit": "rays/s",
+        "metric": "rays/sec (fwd+bwd, 128 samples/ray)" if headline else
+                  {"train_real": "rays/sec (real-view training step, ragged occupancy samples)",
+                   "density128": "points/sec (forward-only field query)"}[args.workload],
+        "value": round(total_rays / elapsed, 1), "unit": "rays/s" if args.workload != "density128" else "points/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("snoopy.yaml full deform field" + (" + FD normals (albedo_normal)" if args.workload == "cfg3b" else "")
-                                if not cano else "snoopy.yaml canonical field only")
-                   + f", {N} rays x {S} samples per GPU, fwd+bwd+Adam ({args.workload})",
-                   "rays_per_gpu": N, "samples_per_ray": S, "parallelism": f"dp{world} (rays/frames sharded, "
-                   f"one {bucket.nbytes / 1e6:.2f} MB gradient all-reduce per step)", "weights": "closed-form state b",
-                   "loss": float(loss.item())},
+        "config": {"workload": wl["desc"], "rays_per_gpu": N, "samples_per_ray": S if headline else round(M / max(N, 1), 1),
+                   "sample_points_per_step_per_gpu": round(M),
+                   "parallelism": f"dp{world}" + ("" if bucket is None else
+                                                  f" (rays/frames sharded, {bucket.nbytes / 1e6:.2f} MB of gradients all-reduced "
+                                                  f"per step" + (", hash-table range early on a side stream" if world > 1 and
+                                                                 not args.no_overlap else "") + ")"),
+                   "world_size": world, "backend": backend, "devices_visible": n_dev,
+                   "ranks_share_devices": bool(world > 1 and n_dev < world),
+                   "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
         "roofline": roofline, "roofline_hashgrid": roof_hash, "kernels": ktab,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if "occupied" in wl:
+        out["config"]["occupied_fraction"] = round(wl["occupied"], 4)
+    if world == 1 and not args.no_cpu_baseline and not stub and headline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_rays, S)
-        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if out["cpu_baseline"]["value"]:
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -118,6 +118,19 @@ int mh_march_fill(const float *rays_o, const float *rays_d, const float *jitter,
                   int32_t R, const uint8_t *binary, const int32_t *ray_start, int32_t *ray_idx, float *t_starts,
                   float *t_ends, void *stream);
 
+/* Single-pass form of the same marcher, one wavefront per ray (64 steps per iteration, ballot/popcount compaction):
+ * mh_march_slots writes ray_cnt [N] and the kept intervals of ray r to slot_ts/slot_te [r*cap .. r*cap+cnt), cap >=
+ * mh_march_cap(step, bound) (steps on the AABB diagonal for unit-or-longer directions); *overflow (device int, zeroed by
+ * the caller) is set if some ray needed more than cap slots -- the caller then falls back to count/fill.  After the
+ * exclusive scan of ray_cnt, mh_march_pack copies the slot rows to the packed ray_idx / t_starts / t_ends.  Results are
+ * bit-identical to mh_march_count + mh_march_fill. */
+int32_t mh_march_cap(float step, float bound);
+int mh_march_slots(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step, float bound,
+                   int32_t R, const uint8_t *binary, int32_t cap, int32_t *ray_cnt, float *slot_ts, float *slot_te,
+                   int32_t *overflow, void *stream);
+int mh_march_pack(const int32_t *ray_start, const int32_t *ray_cnt, const float *slot_ts, const float *slot_te, int32_t N,
+                  int32_t cap, int32_t *ray_idx, float *t_starts, float *t_ends, void *stream);
+
 /* ---- fused tiny-MLP evaluators on fp32 MFMA (v_mfma_f32_32x32x2_f32) -------------------------
  * Weight operands are PRE-PACKED by the host into the MFMA A-fragment order (see
  * morpheus_amd/packing.py): for layer l, tile mt, k-quad q: float4 per lane.  `wpack` is the

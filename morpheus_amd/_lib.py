@@ -30,6 +30,9 @@ _SIGS = {
     "mh_sample_uniform": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
     "mh_march_count": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _P, _P]),
     "mh_march_fill": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _P, _P, _P, _P, _P]),
+    "mh_march_cap": (_I32, [_F, _F]),
+    "mh_march_slots": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _I32, _P, _P, _P, _P, _P]),
+    "mh_march_pack": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
     "mh_mlp_tiles": (_I64, [_I64]),
     "mh_warp_acts_floats": (_I64, [_I64]),
     "mh_warp_dpre_floats": (_I64, [_I64]),

@@ -2,26 +2,33 @@
 
 `python -m morpheus_amd.build` or morpheus_amd.build.build().  hipcc cross-compiles without a
 GPU; the .so lands in morpheus_amd/_build/ (git-ignored, shipped to the GPU box by gpurun).
+Each source is compiled to its own object (in parallel, only when it or a header changed), then linked.
 """
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 SO = os.path.join(OUT_DIR, "libmorpheus_hip.so")
 SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "optim.hip", "wnorm.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "morpheus_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _newer(deps, target) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def _stale() -> bool:
-    if not os.path.exists(SO):
-        return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "morpheus_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _newer([os.path.join(CSRC, f) for f in os.listdir(CSRC)] + HEADERS, SO)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -29,8 +36,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", SO] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    extra = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc")]
+
+    def compile_one(src):
+        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        if force or _newer([os.path.join(CSRC, src)] + HEADERS + extra, obj):
+            cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -159,6 +159,63 @@ __global__ __launch_bounds__(64) void march_kernel(const float *__restrict__ ray
     if (!FILL) ray_cnt[r] = n;
 }
 
+// Wave-per-ray marcher: one wavefront walks one ray, 64 consecutive steps per iteration (a lane = one step: setup once,
+// one occupancy byte per lane in flight instead of a 350-iteration dependent-load loop per thread), ballot + prefix
+// popcount compacts the occupied steps into the ray's slot row [cap]; 2 048 rays fill 2 048 waves (8 per CU) where the
+// thread-per-ray form filled 32 workgroups.  A second launch copies the slot rows to their packed positions once the
+// exclusive scan of the counts is known -- the march itself runs ONCE (the count/fill pair above runs it twice).
+// Per-step arithmetic is the same expression as march_kernel's, so the samples are bit-identical.
+__global__ __launch_bounds__(256) void march_wave_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                         const float *__restrict__ jitter, int N, float step, float bound,
+                                                         int R, const uint8_t *__restrict__ binary, int cap,
+                                                         int32_t *__restrict__ ray_cnt, float *__restrict__ slot_ts,
+                                                         float *__restrict__ slot_te, int32_t *__restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const MarchRay m = march_setup(rays_o, rays_d, jitter, r, step, bound);
+    float *row_s = slot_ts + (int64_t)r * cap, *row_e = slot_te + (int64_t)r * cap;
+    int n = 0, k0 = 0;
+    for (; k0 < cap; k0 += 64) {
+        const int k = k0 + lane;
+        const float ts = m.t0 + (float)k * step;
+        const bool in = ts < m.tfar;
+        if (__ballot(in) == 0ull) break;
+        const float te = fminf(ts + step, m.tfar);
+        const bool occ = in && march_occupied(m, ts, te, bound, R, binary);
+        const unsigned long long mask = __ballot(occ);
+        const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
+        if (occ && pos < cap) {
+            row_s[pos] = ts;
+            row_e[pos] = te;
+        }
+        n += __popcll(mask);
+    }
+    if (lane == 0) {
+        ray_cnt[r] = n < cap ? n : cap;
+        // a ray with more steps than the slot row holds (directions much shorter than unit length): tell the host, which
+        // re-runs the batch through the un-capped count/fill pair
+        if (n > cap || (m.t0 + (float)k0 * step) < m.tfar) atomicOr(overflow, 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void march_pack_kernel(const int32_t *__restrict__ ray_start, const int32_t *__restrict__ ray_cnt,
+                                                         const float *__restrict__ slot_ts, const float *__restrict__ slot_te,
+                                                         int N, int cap, int32_t *__restrict__ ray_idx,
+                                                         float *__restrict__ t_starts, float *__restrict__ t_ends) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= N) return;
+    const int n = ray_cnt[r];
+    const int64_t base = ray_start[r];
+    const float *row_s = slot_ts + (int64_t)r * cap, *row_e = slot_te + (int64_t)r * cap;
+    for (int i = lane; i < n; i += 64) {
+        ray_idx[base + i] = r;
+        t_starts[base + i] = row_s[i];
+        t_ends[base + i] = row_e[i];
+    }
+}
+
 extern "C" int mh_generate_rays(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
                                 float *rays_o, float *rays_d, void *stream) {
     if (!c2w_host || !rays_o || !rays_d || H <= 0 || W <= 0) return MH_ERR_ARG;
@@ -208,6 +265,37 @@ extern "C" int mh_march_fill(const float *rays_o, const float *rays_d, const flo
         return MH_ERR_ARG;
     hipLaunchKernelGGL(march_kernel<true>, dim3((N + 63) / 64), dim3(64), 0, mh_stream(stream), rays_o, rays_d, jitter, (int)N,
                        step, bound, (int)R, binary, (int32_t *)nullptr, ray_start, ray_idx, t_starts, t_ends);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+// upper bound of the steps one ray can take inside the AABB: its longest chord is the diagonal 2*bound*sqrt(3)
+extern "C" int32_t mh_march_cap(float step, float bound) {
+    if (!(step > 0.f) || !(bound > 0.f)) return 0;
+    const double n = 2.0 * (double)bound * 1.7320508075688772 / (double)step;
+    return (int32_t)n + 4;
+}
+
+extern "C" int mh_march_slots(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step,
+                              float bound, int32_t R, const uint8_t *binary, int32_t cap, int32_t *ray_cnt,
+                              float *slot_ts, float *slot_te, int32_t *overflow, void *stream) {
+    if (N == 0) return MH_OK;
+    if (!rays_o || !rays_d || !binary || !ray_cnt || !slot_ts || !slot_te || !overflow || N < 0 || R <= 0 ||
+        !(step > 0.f) || !(bound > 0.f) || cap <= 0)
+        return MH_ERR_ARG;
+    hipLaunchKernelGGL(march_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, mh_stream(stream), rays_o, rays_d, jitter, (int)N,
+                       step, bound, (int)R, binary, (int)cap, ray_cnt, slot_ts, slot_te, overflow);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_march_pack(const int32_t *ray_start, const int32_t *ray_cnt, const float *slot_ts, const float *slot_te,
+                             int32_t N, int32_t cap, int32_t *ray_idx, float *t_starts, float *t_ends, void *stream) {
+    if (N == 0) return MH_OK;
+    if (!ray_start || !ray_cnt || !slot_ts || !slot_te || !ray_idx || !t_starts || !t_ends || N < 0 || cap <= 0)
+        return MH_ERR_ARG;
+    hipLaunchKernelGGL(march_pack_kernel, dim3((N + 3) / 4), dim3(256), 0, mh_stream(stream), ray_start, ray_cnt, slot_ts,
+                       slot_te, (int)N, (int)cap, ray_idx, t_starts, t_ends);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

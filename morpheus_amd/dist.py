@@ -59,13 +59,71 @@ class GradBucket:
         self._layout = layout
         self.params: List[torch.nn.Parameter] = [p for p, _, _ in layout]
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self._early = {}          # id(param) -> (param, offset, numel): gradients exchanged as soon as they land
+        self._early_hooks = []
+        self._early_seen = 0
+        self._early_work = []     # outstanding async collectives of this step
+        self._side = None         # side stream the early exchange is queued on (GPU only)
         self.rebind(force=True)
+
+    # ---- overlap of the exchange with the tail of backward -----------------------------------------------
+    def overlap_early(self, early_params: Iterable[torch.nn.Parameter]):
+        """Exchange the gradients of `early_params` while backward is still running.
+
+        On the render path the two hash tables (6.4 of the 7.45 MB) get their gradients from the brick kernels in the
+        MIDDLE of backward; everything after that (the warp nets' backward-data and weight gradients, about half of the
+        backward pass) does not touch them.  A post-accumulate hook on each early parameter copies its fresh gradient
+        into the bucket and, once all of them have landed, queues ONE all-reduce of their (contiguous) range on a side
+        stream, so it runs under the rest of backward; `allreduce_mean()` then only has the small remainder left on the
+        critical path.  Contract: one backward per `zero()` (the bench / the reference's real-view steps); call
+        `overlap_early([])` to switch it off for gradient-accumulating callers."""
+        for h in self._early_hooks:
+            h.remove()
+        self._early_hooks, self._early = [], {}
+        ids = {id(p) for p in early_params}
+        for p, o, k in self._layout:
+            if id(p) in ids:
+                self._early[id(p)] = (p, o, k)
+        if not self._early:
+            return
+        spans = sorted((o, o + k) for _, o, k in self._early.values())
+        self._early_span = (spans[0][0], spans[-1][1])
+        covered = sum(b - a for a, b in spans)
+        # pad elements between groups (optim.FlatAdam aligns groups to 4) may sit inside the span: they are zero everywhere
+        if self._early_span[1] - self._early_span[0] - covered > 4 * len(spans):
+            raise ValueError("early parameters must be adjacent in the bucket layout (put them first)")
+        for p, _, _ in self._early.values():
+            self._early_hooks.append(p.register_post_accumulate_grad_hook(self._on_early_grad))
+
+    def _on_early_grad(self, p):
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        _, o, k = self._early[id(p)]
+        view = self.flat[o:o + k].view(p.shape)
+        if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view
+        self._early_seen += 1
+        if self._early_seen != len(self._early):
+            return
+        a, b = self._early_span
+        seg = self.flat[a:b]
+        if seg.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=seg.device)
+            cur = torch.cuda.current_stream(seg.device)      # the autograd thread's stream: the copies above are on it
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
 
     def zero(self):
         """Start a step: clear the bucket and detach `p.grad`, so that autograd hands each parameter its fresh gradient
         tensor (a pointer move) instead of launching one accumulate-add per parameter into a bound view; `collect()`
         gathers them with one multi-tensor copy."""
         self.flat.zero_()
+        self._early_seen = 0
         for p in self.params:
             p.grad = None
 
@@ -92,9 +150,23 @@ class GradBucket:
 
     def allreduce_mean(self):
         self.collect()
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if self._early_work:
+            # the early range is already summed (or in flight on the side stream): exchange only what is left
+            a, b = self._early_span
+            n = self.flat.numel()
+            for lo, hi in ((0, a), (b, n)):
+                if hi > lo:
+                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+            for w in self._early_work:
+                w.wait()                       # nccl: the current stream waits for the collective; gloo: host wait
+            if self._side is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+            self._early_work = []
+        else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+        self.flat.div_(dist.get_world_size())
 
     @property
     def nbytes(self) -> int:

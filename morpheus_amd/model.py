@@ -252,18 +252,30 @@ class scene_representation(nn.Module):
             self.in_dim_bg, self.in_dim_bg_t = 39, 13
             self.bg_net = MLP(self.in_dim_bg + self.in_dim_bg_t, 3, hidden_dim_bg, num_layers_bg)
         self.sdf2density = LaplaceDensity(0.1)
-        self._frame_slots = None   # optional (t [M,1] object, t_unique [F], slot [M] int32) hint set by the renderer
 
     # -- helpers ----------------------------------------------------------------------------
     def _n_bands(self) -> int:
         return 6 if self.max_level is None else int(self.max_level * 6)
 
-    def _slots(self, t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """distinct frame times and per-sample slot ids.  The renderer supplies them without a host
-        sync (a batch row is one frame); otherwise fall back to torch.unique."""
-        if self._frame_slots is not None and self._frame_slots[0] is t:
-            return self._frame_slots[1], self._frame_slots[2]
-        tu, inv = torch.unique(t.reshape(-1), return_inverse=True)
+    PER_SAMPLE_SLOTS = 1 << 17   # up to this many samples a non-constant time tensor gets one code slot per sample
+
+    def _slots(self, t: torch.Tensor, frame_slots=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """-> (slot times [F], per-sample slot ids [M] int32 or None when F == 1), without a device->host sync on any
+        path the training step takes:
+          * `frame_slots = (t_rows [F], slot [M])` from the renderer (a batch row is one frame, SURVEY C.11);
+          * a time tensor that is an expanded scalar (stride 0: `rays_t[:1].expand(M, 1)`, how the renderer and
+            `density(allow_shape=True)` / `density(t=float)` hand over a single frame) is constant by construction;
+          * otherwise every sample gets its own slot (the per-frame code bias becomes a per-sample one; exact, costs
+            M x 128 floats per net) up to PER_SAMPLE_SLOTS samples -- `get_real_view_point_loss` sends N = 2048;
+          * beyond that, torch.unique (sort + sync) keeps the bias table small."""
+        if frame_slots is not None:
+            return frame_slots
+        tf = t.reshape(-1)
+        if tf.numel() == 1 or (t.dim() >= 1 and t.shape[0] > 1 and t.stride(0) == 0):
+            return tf[:1], None
+        if tf.numel() <= self.PER_SAMPLE_SLOTS:
+            return tf, torch.arange(tf.numel(), device=t.device, dtype=torch.int32)
+        tu, inv = torch.unique(tf, return_inverse=True)
         return tu, inv.to(torch.int32)
 
     def _warp_params(self, net: MLP, w):
@@ -285,9 +297,9 @@ class scene_representation(nn.Module):
         R, t = self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)
         return rays_o + t, (rays_d[..., None, :] * R).sum(-1)
 
-    def warp(self, x, t):
-        """-> deform [M,3], topo [M,2], app_code (None)   (model.py:412-437)."""
-        tu, slot = self._slots(t)
+    def warp(self, x, t, frame_slots=None):
+        """-> deform [M,3], topo [M,2], app_code (None)   (model.py:412-437).  `frame_slots`: see `_slots`."""
+        tu, slot = self._slots(t, frame_slots)
         code = self.deform_code.sample(tu[:, None])                       # [F,48], F = distinct frames
         w_all = wn_effective_batched(list(self.deform_net.net) + list(self.topo_net.net))
         pd, wcode_d, b0_d = self._warp_params(self.deform_net, w_all[:6])
@@ -297,8 +309,8 @@ class scene_representation(nn.Module):
         deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), pd, pt)
         return deform, topo, None
 
-    def get_topo(self, x, t):
-        return self.warp(x, t)[1]
+    def get_topo(self, x, t, frame_slots=None):
+        return self.warp(x, t, frame_slots)[1]
 
     def get_sigma_albedo(self, x, topo=None, app_code=None, return_color=True, _group=1):
         if return_color:
@@ -346,9 +358,9 @@ class scene_representation(nn.Module):
         return torch.stack([0.5 * (sdf[:, 0] - sdf[:, 1]) / epsilon, 0.5 * (sdf[:, 2] - sdf[:, 3]) / epsilon,
                             0.5 * (sdf[:, 4] - sdf[:, 5]) / epsilon], -1)
 
-    def normal(self, x, t=None, cano=False, topo=None):
+    def normal(self, x, t=None, cano=False, topo=None, frame_slots=None):
         if t is not None and not cano:
-            deform, topo, _ = self.warp(x, t)
+            deform, topo, _ = self.warp(x, t, frame_slots)
             x = x + deform
         raw = self.finite_difference_normal(x, topo=topo)
         return torch.nan_to_num(safe_normalize(raw)), raw
@@ -360,27 +372,33 @@ class scene_representation(nn.Module):
     def density(self, x, t=None, cano=False, allow_shape=False, return_color=True):
         topo = None
         if not (cano or t is None):
+            # a single time for all points travels as an expanded scalar: `_slots` sees one frame, no per-sample work
             if isinstance(t, float):
-                t = t * torch.ones(x.shape[0], 1, device=x.device)
+                t = torch.full((1, 1), t, device=x.device).expand(x.shape[0], 1)
             if x.shape[0] != t.shape[0]:
                 if not allow_shape:
                     raise Exception("Shape inconsistent!!!")
-                t = t[0, 0] * torch.ones(x.shape[0], 1, device=x.device)
+                t = t.reshape(-1)[:1].view(1, 1).expand(x.shape[0], 1)
             deform, topo, _ = self.warp(x, t)
             x = x + deform
         sdf, sigma, albedo = self.get_sigma_albedo(x, topo=topo, return_color=return_color)
         return {"sdf": sdf, "sigma": sigma, "albedo": albedo}
 
-    def forward(self, x, t, light_dir=None, ratio=1, shading="albedo", cano=False, return_color=True):
+    def forward(self, x, t, light_dir=None, ratio=1, shading="albedo", cano=False, return_color=True, *,
+                frame_slots=None):
         deform = topo = None
         xc = x
         if not cano:
-            deform, topo, _ = self.warp(x, t)
+            deform, topo, _ = self.warp(x, t, frame_slots)
             xc = x + deform
         sdf, sigma, albedo = self.get_sigma_albedo(xc, topo, None, return_color)
         if shading == "albedo":
             return sdf, sigma, albedo, None, deform, None
         normal, raw = self.normal(x, topo=topo)        # un-warped x, warped point's topo (model.py:515-521)
+        if ratio == 1 and shading not in ("textureless", "normal"):
+            # real-view steps shade with ambient_ratio = 1.0 (morpheus.py:869-871): lam = 1 + 0 * (n.l)+ is exactly 1 and
+            # carries an exactly-zero gradient to the normal, so the lambertian factor is dropped
+            return sdf, sigma, albedo, normal, deform, raw
         lam = ratio + (1 - ratio) * (normal * light_dir).sum(-1).clamp(min=0)
         if shading == "textureless":
             color = lam.unsqueeze(-1).repeat(1, 3)

@@ -271,16 +271,45 @@ def sample_uniform(rays_o, rays_d, jitter, S: int, bound: float, with_xyz: bool 
     return ri, ts, te, xyz, rs, rc
 
 
+MARCH_TWO_PASS = os.environ.get("MORPHEUS_MARCH", "") == "two_pass"   # A/B switch: thread-per-ray count + fill
+
+
 def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.Tensor):
     """Occupancy-grid marcher -> (ray_idx int32 [M], t_starts [M], t_ends [M], ray_start [N], ray_cnt [N]).
-    The only host sync on the path: M = total sample count is needed to size the packed arrays
-    (nerfacc synchronises at the same point)."""
+    One host sync on the path: M = total sample count sizes the packed arrays (nerfacc synchronises at the same point).
+    Single pass, one wavefront per ray (mh_march_slots + mh_march_pack); a batch with rays that overflow the per-ray slot
+    row (directions much shorter than unit length) is re-run through the un-capped thread-per-ray count/fill pair."""
     require_gpu(rays_o, rays_d, jitter, binary)
     lib = _lib.load()
     o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
     j = None if jitter is None else jitter.contiguous()
     assert binary.dtype == torch.uint8 and binary.is_contiguous() and binary.dim() == 3
     N, R, dev = o.shape[0], binary.shape[0], o.device
+    if N == 0:
+        e = torch.empty(0, device=dev)
+        z = torch.empty(0, dtype=torch.int32, device=dev)
+        return z, e, e.clone(), z.clone(), z.clone()
+    if not MARCH_TWO_PASS:
+        cap = int(lib.mh_march_cap(float(step), float(bound)))
+        cnt_ovf = torch.zeros(N + 1, dtype=torch.int32, device=dev)     # [ray_cnt | overflow flag]
+        cnt = cnt_ovf[:N]
+        slots = torch.empty(2, N, cap, device=dev)
+        _e = TIMER.start()
+        check(lib.mh_march_slots(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), cap, ptr(cnt),
+                                 ptr(slots[0]), ptr(slots[1]), cnt_ovf.data_ptr() + 4 * N, stream()), "mh_march_slots")
+        TIMER.stop("mh_march_slots", _e)
+        csum = torch.cumsum(cnt_ovf, 0, dtype=torch.int32)              # last element = M + overflow flag
+        start = (csum[:N] - cnt).contiguous()
+        M, tot = csum[N - 1:].tolist()                                  # the one device->host sync
+        if tot == M:                                                    # no overflow
+            ri = torch.empty(M, dtype=torch.int32, device=dev)
+            ts, te = torch.empty(M, device=dev), torch.empty(M, device=dev)
+            if M > 0:
+                _e = TIMER.start()
+                check(lib.mh_march_pack(ptr(start), ptr(cnt), ptr(slots[0]), ptr(slots[1]), N, cap, ptr(ri), ptr(ts), ptr(te),
+                                        stream()), "mh_march_pack")
+                TIMER.stop("mh_march_pack", _e)
+            return ri, ts, te, start, cnt.contiguous()
     cnt = torch.empty(N, dtype=torch.int32, device=dev)
     _e = TIMER.start()
     check(lib.mh_march_count(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), ptr(cnt), stream()),
@@ -288,7 +317,7 @@ def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.
     TIMER.stop("mh_march_count", _e)
     csum = torch.cumsum(cnt, 0, dtype=torch.int32)
     start = (csum - cnt).contiguous()
-    M = int(csum[-1].item()) if N > 0 else 0
+    M = int(csum[-1].item())
     ri = torch.empty(M, dtype=torch.int32, device=dev)
     ts, te = torch.empty(M, device=dev), torch.empty(M, device=dev)
     if M > 0:

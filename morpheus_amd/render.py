@@ -83,27 +83,41 @@ class HotPathRenderer:
         self.frame_batched = frame_batched
 
     # -- helpers of morpheus.py:518-556
-    def get_ortho_normal_dir(self, normals):
+    def get_ortho_normal_dir(self, normals, phi=None):
+        """morpheus.py:518-528; `phi` injects the random angle (parity tests)."""
         n = torch.nn.functional.normalize(normals, dim=-1)
         u = torch.nn.functional.normalize(n[..., [1, 0, 2]] * torch.tensor([1.0, -1.0, 0.0], device=n.device), dim=-1)
         v = torch.cross(n, u, dim=-1)
-        phi = torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
+        if phi is None:
+            phi = torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
         return torch.cos(phi) * u + torch.sin(phi) * v
 
-    def get_normal_smoothness_loss(self, rays_o, rays_d, rays_t, depth):
+    def get_normal_smoothness_loss(self, rays_o, rays_d, rays_t, depth, offsets=None, phi=None, ray_slots=None):
+        """morpheus.py:530-556: normals at npts = trunc*100+1 points around the rendered depth of every ray vs normals at
+        points displaced by smoothness_std along a random direction orthogonal to the normal.  The reference drops the
+        points outside the 1.1 sphere with a boolean index (a device->host sync and a data-dependent shape); here they
+        stay in the batch and leave the mean through a 0/1 weight -- the same value, no sync.
+        `offsets` [npts] / `phi` [npts*N, 1] inject the two random draws (parity tests); `ray_slots` = (t_rows, slot per
+        ray) for multi-frame batches."""
         trunc = self.config["train"]["trunc"]
         npts = int(trunc * 100 + 1)
-        off = torch.linspace(-0.5 * trunc, 0.5 * trunc, npts)
-        off = off + 0.01 * torch.rand_like(off)
+        if offsets is None:
+            off = torch.linspace(-0.5 * trunc, 0.5 * trunc, npts)
+            off = off + 0.01 * torch.rand_like(off)
+        else:
+            off = offsets
         pts = (depth + off[:, None].to(depth))[..., None] * rays_d[None] + rays_o[None]
         pts = pts.view(-1, 3)
-        tt = rays_t[None].repeat(npts, 1, 1).view(-1, 1)
-        keep = torch.linalg.norm(pts, ord=2, dim=-1) < 1.1
-        pts, tt = pts[keep], tt[keep]
-        n1, _ = self.model.normal(pts, t=tt)
-        w = self.get_ortho_normal_dir(n1)
-        n2, _ = self.model.normal(pts + w * self.config["train"]["smoothness_std"], t=tt)
-        return torch.mean(torch.square(n1 - n2))
+        n_rays = rays_t.shape[0]
+        if ray_slots is None:      # one frame: the time is an expanded scalar (model._slots sees a single slot)
+            tt, fs = rays_t[:1].expand(npts * n_rays, 1), None
+        else:
+            tt, fs = rays_t[None].repeat(npts, 1, 1).view(-1, 1), (ray_slots[0], ray_slots[1].repeat(npts))
+        keep = (torch.linalg.norm(pts, ord=2, dim=-1) < 1.1).float()[:, None]
+        n1, _ = self.model.normal(pts, t=tt, frame_slots=fs)
+        w = self.get_ortho_normal_dir(n1, phi)
+        n2, _ = self.model.normal(pts + w * self.config["train"]["smoothness_std"], t=tt, frame_slots=fs)
+        return (torch.square(n1 - n2) * keep).sum() / (3.0 * keep.sum()).clamp(min=1.0)
 
     # -- the hot path
     def render_rays(self, rays_o, rays_d, rays_t, rays_id, H, W, perturb=True, bg_color=None, ambient_ratio=1.0,
@@ -159,20 +173,20 @@ class HotPathRenderer:
                            weights_sum=None, normal=None, deform=None, normal_raw=None)
             return results
 
-        # per-frame deform-code slots without a device->host sync
-        if single_frame:
-            model._frame_slots = (time_step, rays_t[:1, 0].contiguous(), None)     # one slot: the kernel needs no index
-        elif not cano and self.frame_batched and len(prefix) == 2:
+        # per-frame deform-code slots without a device->host sync.  One frame: `time_step` is an expanded scalar, which
+        # the model recognises as a single slot by itself.  Several frames (a batch row is one frame): slot per ray row.
+        frame_slots = ray_slots = None
+        if not single_frame and not cano and self.frame_batched and len(prefix) == 2:
             B, n_per = prefix
             slot_ray = torch.arange(B, device=rays_o.device, dtype=torch.int32).repeat_interleave(n_per)
-            model._frame_slots = (time_step, rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray[ri_long()].contiguous())
-        try:
-            # per-sample light directions are only read by the shaded modes (model.py:515-531)
-            t_light = light_d[ri_long()] if shading != "albedo" else None
-            sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, t_light, ratio=ambient_ratio,
-                                                                   shading=shading, cano=cano)
-        finally:
-            model._frame_slots = None
+            ray_slots = (rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray)
+            frame_slots = (ray_slots[0], slot_ray[ri_long()].contiguous())
+        # per-sample light directions are only read by the shaded modes (model.py:515-531), and not at ambient_ratio = 1
+        # (real-view steps), where the lambertian factor is exactly 1
+        lit = shading != "albedo" and (ambient_ratio != 1 or shading in ("textureless", "normal"))
+        t_light = light_d[ri_long()] if lit else None
+        sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, t_light, ratio=ambient_ratio,
+                                                               shading=shading, cano=cano, frame_slots=frame_slots)
 
         packed = getattr(self.occupancy_grid, "packed", None)
         ray_start, ray_cnt = packed if packed is not None else ops.packed_info(ri_long(), N)
@@ -203,19 +217,20 @@ class HotPathRenderer:
                 if tr["topo_none"]:
                     normals_p, _ = model.normal(xyzs_p, topo=None, cano=cano)
                 else:
-                    normals_p, _ = model.normal(xyzs_p, topo=model.get_topo(xyzs_p, t=time_step), cano=cano)
+                    normals_p, _ = model.normal(xyzs_p, topo=model.get_topo(xyzs_p, t=time_step, frame_slots=frame_slots),
+                                                cano=cano)
                 results["loss_normal_perturb"] = (normals - normals_p).abs().mean()
                 if tr["normal_smooth_3d_t"] > 0:
                     tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
                     normals_pt, _ = model.normal(xyzs, topo=model.get_topo(xyzs, t=tt), cano=cano)
                     results["loss_normal_perturb_t"] = (normals - normals_pt).abs().mean()
                 if tr["deform_smooth"] > 0 and not cano:
-                    deform_p, _, _ = model.warp(xyzs_p, t=time_step)
+                    deform_p, _, _ = model.warp(xyzs_p, t=time_step, frame_slots=frame_slots)
                     results["loss_deform_perturb"] = (deform - deform_p).abs().mean()
             if (tr["deform_smooth_t"] > 0 or tr["topo_smooth_t"] > 0) and not cano:
                 tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
                 deform_pt, topo_pt, _ = model.warp(xyzs, t=tt)
-                topo_now = model.get_topo(xyzs, t=time_step)      # the reference reads an undefined `topo` here
+                topo_now = model.get_topo(xyzs, t=time_step, frame_slots=frame_slots)   # the reference reads an undefined `topo` here
                 results["loss_deform_perturb_t"] = (deform - deform_pt).abs().mean()
                 results["loss_topo_perturb_t"] = (topo_now - topo_pt).abs().mean()
             if tr["code_reg"] > 0 and not cano:
@@ -225,11 +240,14 @@ class HotPathRenderer:
                 cn = model.get_deform_code(t0 + 1 / self.num_frames)
                 results["loss_code"] = torch.square(2 * code - cp - cn).mean()
             if tr["normal_smooth_2d"] > 0 and normals is not None and (not real_view):
-                _, _, _, nimg = ops.composite(sigmas.detach(), t_starts_.contiguous(), t_ends_.contiguous(),
-                                              (normals + 1) / 2, ray_start, ray_cnt)
+                # accumulate_along_rays(weights, (normals+1)/2) with the LIVE weights (morpheus.py:775): the density
+                # gradient of the normal image is part of the normal_smooth_2d loss
+                _, _, _, nimg = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), (normals + 1) / 2,
+                                              ray_start, ray_cnt)
                 results["normal_image"] = nimg
             if tr["normal_smoothness"] > 0:
-                results["normal_reg"] = self.get_normal_smoothness_loss(rays_o, rays_d, rays_t, depth)
+                results["normal_reg"] = self.get_normal_smoothness_loss(rays_o, rays_d, rays_t, depth.reshape(1, -1),
+                                                                        ray_slots=ray_slots)
             if rays_depth is not None:
                 t_gt = rays_depth[ri_long()]
                 t_mask = None if rays_mask is None else rays_mask[ri_long()]

@@ -1,0 +1,42 @@
+"""bench.py's own launcher and N>1 plumbing on the CPU: `python bench.py --gpus 2` (no torchrun environment) must spawn
+two ranks through torch.distributed.run, rendezvous on 127.0.0.1, run warm-up + timed steps bracketed by barriers,
+take the MAX over ranks and print ONE JSON line from rank 0 that says what world it saw.  The step itself is the
+MORPHEUS_BENCH_STUB toy (the real step needs an MI355X; tests/test_gpu_dist.py covers it on the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MORPHEUS_BENCH_STUB"] = "1"
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "64"])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["config"]["world_size"] == 2 and r["config"]["backend"] == "gloo"
+    assert r["value"] > 0 and abs(r["value"] - 2 * 64 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-3   # whole-job rays/s
+    assert r["scaling"] == "weak" and r["higher_is_better"] is True and r["cpu_baseline"] is None
+
+
+def test_single_rank_needs_no_launcher_and_overlap_switch():
+    r = _run(["--steps", "2", "--warmup", "1", "--rays", "32", "--no-overlap"])
+    assert r["n_gpus"] == 1 and r["config"]["world_size"] == 1 and r["config"]["backend"] is None
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, MORPHEUS_BENCH_STUB="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

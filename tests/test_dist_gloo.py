@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from morpheus_amd import dist as mdist
@@ -28,6 +28,8 @@ def _worker(rank, world, port, out):
     table = torch.nn.Parameter(torch.randn(64, 2))         # stands in for a hash table (sparse-ish gradient)
     params = list(net.parameters()) + [table]
     bucket = mdist.GradBucket(params)
+    if overlap:
+        bucket.overlap_early([table])                      # its gradient is exchanged from the autograd hook
     opt = torch.optim.Adam(params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
     g = torch.Generator().manual_seed(123)
     rays = torch.randn(64, 6, generator=g)                 # the full batch; each rank renders its shard
@@ -53,6 +55,59 @@ def test_gradient_bucket_allreduce_two_ranks():
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert torch.allclose(out[0], out[1], atol=0, rtol=0), "ranks diverged after all-reduce + Adam"
     assert out["nbytes"] == (6 * 16 + 16 + 16 * 3 + 3 + 128) * 4
+
+
+def test_early_overlapped_exchange_matches_the_single_allreduce():
+    """overlap_early(): the early range leaves from the post-accumulate hook while backward is still running and the
+    remainder follows in allreduce_mean(); parameters after 3 Adam steps are bit-identical to the one-call exchange."""
+    mgr = mp.Manager()
+    ref, ovl = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ref, False), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), ovl, True), nprocs=2, join=True)
+    assert torch.equal(ovl[0], ovl[1]) and torch.equal(ovl[0], ref[0])
+
+
+def _real_layout_worker(rank, world, port, out):
+    """The REAL model's parameter set in optim.FlatAdam's layout (groups of get_params_all, hash tables first) with
+    rank-dependent closed-form gradients: the flat bucket after the (early + remainder) exchange must be the mean of the
+    two ranks' gradients, element for element, and every p.grad must be a view of the bucket."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from morpheus_amd import dist as mdist
+    from morpheus_amd import harness, synth
+    from morpheus_amd.optim import FlatAdam
+    mdist.init_from_env(backend="gloo")
+    model = harness.build_model("b", "cpu")
+    opt = FlatAdam(model.get_params_all(5e-4), betas=(0.9, 0.99), eps=1e-15)      # construction works on the CPU; step() does not
+    bucket = opt.bucket
+    bucket.overlap_early([model.encoder.embeddings, model.encoder_c.embeddings])
+    named = dict(model.named_parameters())
+    grads = lambda r: {k: synth.hash_tensor(tuple(p.shape), 9000 + 17 * i + 1000 * r, 1.0) for i, (k, p) in enumerate(named.items())}
+    mine, other = grads(rank), grads(1 - rank)
+    bucket.zero()
+    # hand the gradients over the way autograd does: through backward, so that the post-accumulate hooks fire
+    loss = sum((p * mine[k]).sum() for k, p in named.items())
+    loss.backward()
+    bucket.allreduce_mean()
+    worst = 0.0
+    for k, p in named.items():
+        want = 0.5 * (mine[k] + other[k])
+        worst = max(worst, float((p.grad - want).abs().max()))
+        assert p.grad.data_ptr() >= bucket.flat.data_ptr() and p.grad.data_ptr() < bucket.flat.data_ptr() + bucket.nbytes, k
+    out[rank] = (worst, bucket.nbytes, bucket._early_span)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_model_bucket_two_ranks():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_real_layout_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        worst, nbytes, span = out[r]
+        assert worst <= 1e-7, worst
+        assert 7.3e6 < nbytes < 7.6e6                      # the 7.45 MB bucket of SURVEY 8e
+        assert span == (0, 2 * 839280)                     # both hash tables: the first 6.4 MB, exchanged early
 
 
 def test_single_process_equivalence():

@@ -1,0 +1,83 @@
+"""GPU, world_size 2 on ONE device (gloo for the exchange): the real render step under the data-parallel path of
+bench.py -- each rank renders its own frame (cfg5's partitioning), the hash-table gradients leave early on the side
+stream, the remainder follows, every rank ends with the MEAN gradient -- against the same two frames rendered one after
+the other in a single process."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HW, S = 16, 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _frame_grads(frame, bucket_factory=None):
+    from morpheus_amd import harness, synth
+    dev = torch.device("cuda", 0)
+    model = harness.build_model("b", dev).train()
+    for k in ("normal_smoothness", "normal_smooth_3d", "code_reg", "ori_weight"):
+        model.config["train"][k] = 0.0
+    o, d, t, rid = [v.to(dev) for v in synth.frame_rays(frame, HW, HW)]
+    N = o.shape[1]
+    rend = harness.make_renderer(model, S, jitter=synth.ray_jitter(N).to(dev))
+    timg, tdep = [v.to(dev) for v in synth.targets(N)]
+    bucket = bucket_factory(model) if bucket_factory else None
+    if bucket is not None:
+        bucket.zero()
+    res = rend.render_rays(o, d, t, rid, HW, HW, ambient_ratio=1.0, shading="albedo",
+                           light_d=torch.nn.functional.normalize(o[0] + 0.3, dim=-1))
+    harness.bench_loss(res, timg, tdep).backward()
+    return model, bucket
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from morpheus_amd import dist as mdist
+    from morpheus_amd.optim import FlatAdam
+    mdist.init_from_env(backend="gloo")
+
+    def factory(model):
+        opt = FlatAdam(model.get_params_all(5e-4), betas=(0.9, 0.99), eps=1e-15)
+        opt.bucket.overlap_early([model.encoder.embeddings, model.encoder_c.embeddings])
+        return opt.bucket
+
+    model, bucket = _frame_grads(25 * rank, factory)
+    assert len(bucket._early_work) == 1, "the hash-table range should have left from the autograd hook"
+    bucket.allreduce_mean()
+    torch.cuda.synchronize()
+    out[rank] = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_render_and_average_gradients():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ref = []
+    for frame in (0, 25):
+        model, _ = _frame_grads(frame)
+        ref.append({k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
+    checked = 0
+    for k in ref[0]:
+        want = 0.5 * (ref[0][k].double() + ref[1][k].double())
+        if float(want.norm()) == 0:
+            continue
+        for r in (0, 1):
+            err = float((out[r][k].double() - want).norm() / want.norm())
+            assert err < 1e-5, (k, r, err)
+        assert torch.equal(out[0][k], out[1][k]), k       # both ranks hold the same bucket after the exchange
+        checked += 1
+    assert checked >= 40, checked
