@@ -45,7 +45,9 @@ class OccupancyGrid(torch.nn.Module):
             raise NotImplementedError("density-based pruning / cone marching are not used by the reference's call "
                                       "(morpheus.py:629-638) and are not implemented")
         n = rays_o.shape[0]
-        if self.fixed_jitter is not None:
+        if isinstance(self.fixed_jitter, float):
+            u = torch.full((n,), self.fixed_jitter, device=rays_o.device)     # one value for every ray (chunk-invariant)
+        elif self.fixed_jitter is not None:
             u = self.fixed_jitter
         elif stratified:
             u = torch.rand(n, device=rays_o.device)

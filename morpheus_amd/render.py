@@ -119,6 +119,27 @@ class HotPathRenderer:
         n2, _ = self.model.normal(pts + w * self.config["train"]["smoothness_std"], t=tt, frame_slots=fs)
         return (torch.square(n1 - n2) * keep).sum() / (3.0 * keep.sum()).clamp(min=1.0)
 
+    # -- forward-only consumer (f-4)
+    def eval_step(self, data, cano=False, optimize_pose=False, max_chunk=300 * 300):
+        """MorpheuS.eval_step (morpheus.py:1238-1269; the same loop is in visualizer.py:69-91): a whole view rendered in
+        chunks of <= max_chunk rays, forward only (callers wrap it in no_grad), RGB and depth images re-assembled."""
+        rays_o, rays_d, rays_t, rays_id = data["rays_o"], data["rays_d"], data["rays_t"], data["rays_id"]
+        B, N = rays_o.shape[:2]
+        H, W = data["H"], data["W"]
+        shading = data["shading"] if "shading" in data else "albedo"
+        ambient_ratio = data["ambient_ratio"] if "ambient_ratio" in data else 1.0
+        scale_factor = int(N // max_chunk + 1)
+        if N > max_chunk:
+            max_chunk = N // scale_factor + 1
+        pred_rgb, pred_depth = [], []
+        for i in range(0, N, max_chunk):
+            out = self.render_rays(rays_o[:, i:i + max_chunk], rays_d[:, i:i + max_chunk], rays_t[:, i:i + max_chunk],
+                                   rays_id[:, i:i + max_chunk], H, W, perturb=True, ambient_ratio=ambient_ratio,
+                                   shading=shading, cano=cano, optimize_pose=optimize_pose)
+            pred_rgb.append(out["image"])
+            pred_depth.append(out["depth"])
+        return torch.cat(pred_rgb, dim=1).reshape(B, H, W, 3), torch.cat(pred_depth, dim=1).reshape(B, H, W)
+
     # -- the hot path
     def render_rays(self, rays_o, rays_d, rays_t, rays_id, H, W, perturb=True, bg_color=None, ambient_ratio=1.0,
                     light_d=None, shading="albedo", real_view=True, cano=False, rays_depth=None, rays_mask=None,
@@ -142,8 +163,11 @@ class HotPathRenderer:
             ray_indices, t_starts_, t_ends_ = self.occupancy_grid.sampling(
                 rays_o, rays_d, sigma_fn=None, render_step_size=cfg["render"]["step_size"], alpha_thre=0,
                 stratified=True, cone_angle=0.0, early_stop_eps=0)
-        if light_d is None:
-            light_d = safe_normalize(rays_o + torch.randn(3, device=rays_o.device))
+        # per-sample light directions are only read by the shaded modes (model.py:515-531), and not at ambient_ratio = 1
+        # (real-view steps), where the lambertian factor is exactly 1
+        lit = shading != "albedo" and (ambient_ratio != 1 or shading in ("textureless", "normal"))
+        if light_d is None and lit:
+            light_d = safe_normalize(rays_o + torch.randn(3, device=rays_o.device))      # morpheus.py:641
         M_samples = ray_indices.shape[0]
         single_frame = (not cano) and self.frame_batched and len(prefix) == 2 and prefix[0] == 1
         ray_idx32 = ray_indices
@@ -181,9 +205,6 @@ class HotPathRenderer:
             slot_ray = torch.arange(B, device=rays_o.device, dtype=torch.int32).repeat_interleave(n_per)
             ray_slots = (rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray)
             frame_slots = (ray_slots[0], slot_ray[ri_long()].contiguous())
-        # per-sample light directions are only read by the shaded modes (model.py:515-531), and not at ambient_ratio = 1
-        # (real-view steps), where the lambertian factor is exactly 1
-        lit = shading != "albedo" and (ambient_ratio != 1 or shading in ("textureless", "normal"))
         t_light = light_d[ri_long()] if lit else None
         sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, t_light, ratio=ambient_ratio,
                                                                shading=shading, cano=cano, frame_slots=frame_slots)

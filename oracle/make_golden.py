@@ -309,14 +309,148 @@ def gen_render():
     print("render.npz", len(g), "arrays")
 
 
+# ----------------------------------------------------------------------------- round-2 fixtures (extras.npz)
+class DrawInjector:
+    """Closed-form stand-ins for torch.rand / rand_like / randn_like while a reference (or HIP) function runs: the k-th
+    draw of shape `shape` is synth.hash_tensor(shape, 8000 + k) (uniform: +0.5; normal: x 3.4 ~ unit variance), so the
+    reference here and the HIP path on the GPU box see IDENTICAL random perturbations as long as they draw in the same
+    order with the same shapes (tests/util.py carries the same class)."""
+
+    def __init__(self, base=8000):
+        self.k, self.base = 0, base
+
+    def _next(self, shape, normal, device=None, dtype=None):
+        self.k += 1
+        v = synth.hash_tensor(tuple(shape), self.base + self.k, 0.5)          # [-0.5, 0.5)
+        v = v * 3.4 if normal else v + 0.5
+        return v.to(device) if device is not None else v
+
+    def __enter__(self):
+        self._saved = (torch.rand, torch.rand_like, torch.randn_like)
+        inj = self
+
+        def rand(*size, device=None, dtype=None, **kw):
+            size = size[0] if len(size) == 1 and isinstance(size[0], (list, tuple, torch.Size)) else size
+            return inj._next(size, False, device)
+
+        torch.rand = rand
+        torch.rand_like = lambda t, **kw: inj._next(t.shape, False, t.device)
+        torch.randn_like = lambda t, **kw: inj._next(t.shape, True, t.device)
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.rand_like, torch.randn_like = self._saved
+
+
+def real_view_case(kind="b", hw=32, S=64, n_keep=96):
+    """A real-view training call whose surface-band points all lie inside the 1.1 sphere (so that the reference's
+    boolean drop `surf_pts[norm < 1.1]` keeps everything and the shapes of its random draws are data-independent):
+    the first n_keep rays of frame 25 whose oracle-rendered opacity exceeds 0.99."""
+    o, d, t, rid = synth.frame_rays(25, hw, hw)
+    N = o.shape[1]
+    st = synth.make_state(kind)
+    f = ofield.OracleField({k: v for k, v in st.items()}, 1.01, 0.75)
+    smp = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
+    with torch.no_grad():
+        r = ofield.render_rays(f, o, d, t, rid, smp, ambient_ratio=1.0, shading="albedo",
+                               light_d=ofield.safe_normalize(o[0] + 0.3))
+    ok = torch.ones(N, dtype=torch.bool)
+    for off in (-0.06, 0.0, 0.07):        # the band is depth + [-trunc/2, trunc/2 + 0.01): keep a margin
+        ok &= torch.linalg.norm(o[0] + d[0] * (r["depth"][0][:, None] + off), dim=-1) < 1.08
+    sel = torch.nonzero(ok)[:n_keep, 0]
+    assert sel.numel() == n_keep, sel.numel()
+    return sel
+
+
+def gen_extras():
+    import morpheus as ref_morpheus
+    from datasets.utils import get_camera_rays
+    from morpheus_amd import trainstep
+    g = {}
+    # ---- a1: ray generation = get_camera_rays (datasets/utils.py:28-65) + the c2w application of dataset.py:355-366
+    for tag, (H, W) in (("sq", (24, 24)), ("rect", (20, 28))):
+        fx = fy = torch.tensor(1.2 * W)
+        cx, cy = 0.5 * W, 0.5 * H
+        rays_d_cam = get_camera_rays(H, W, fx, fy, cx, cy)
+        pose = torch.from_numpy(np.stack([synth.look_at_pose(60.0, -40.0), synth.look_at_pose(75.0, 130.0, 1.3)]))
+        rays_o = pose[..., None, None, :3, -1].repeat(1, H, W, 1)
+        rays_d = torch.sum(rays_d_cam[None, ...].repeat(2, 1, 1, 1)[..., None, :] * pose[:, None, None, :3, :3], -1)
+        g[f"raygen_{tag}|rays_o"], g[f"raygen_{tag}|rays_d"] = npf(rays_o), npf(rays_d)
+    # ---- a13: background net (models/model.py:400-410)
+    dirs = ofield.safe_normalize(synth.hash_tensor((256, 3), 340, 1.0))
+    tt = synth.hash_tensor((256, 1), 341, 0.5, 0.5)
+    for kind in ("a", "b"):
+        for ml_tag, ml in (("full", None), ("half", 0.5)):
+            m, _ = build_ref_model(synth.make_state(kind), ml)
+            m.zero_grad()
+            c = m.background(dirs, tt)
+            (c ** 2).sum().backward()
+            g[f"bg_{kind}_{ml_tag}|color"] = npf(c)
+            g[f"bg_{kind}_{ml_tag}|grad_w0"] = npf(m.bg_net.net[0].weight_v.grad)
+            g[f"bg_{kind}_{ml_tag}|grad_b1"] = npf(m.bg_net.net[1].bias.grad)
+    # ---- f-2: the in-render regularisers with the random draws INJECTED, and the three caller-side loss groups of the
+    #      real-view step (morpheus.py:946-1029, 1090-1145) evaluated by the reference's own methods
+    kind, hw, S = "b", 32, 64
+    sel = real_view_case(kind, hw, S)
+    g["realview|sel"] = sel.numpy().astype(np.int32)
+    o, d, t, rid = [v[:, sel] for v in synth.frame_rays(25, hw, hw)]
+    N = o.shape[1]
+    samples = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(hw * hw)[sel], S, 1.01)
+    m, cfg = build_ref_model(synth.make_state(kind), 0.75)
+    m.train()
+    sampler = _PresetSampler()
+    sampler.samples = samples
+    fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg, dataset=types.SimpleNamespace(num_frames=200),
+                                 global_step=1000)
+    fake.get_ortho_normal_dir = types.MethodType(ref_morpheus.MorpheuS.get_ortho_normal_dir, fake)
+    fake.get_normal_smoothness_loss = types.MethodType(ref_morpheus.MorpheuS.get_normal_smoothness_loss, fake)
+    frame = trainstep.make_frames([25], hw, hw, "cpu")[0]
+    data = trainstep.sample_real_view_rays(frame, N, sel)
+    bg = synth.hash_tensor((N, 3), 350, 0.5, 0.5)
+    with DrawInjector() as inj:
+        res = ref_morpheus.MorpheuS.render_rays(fake, o, d, t, rid, N, 1, bg_color=bg, ambient_ratio=1.0,
+                                                light_d=ofield.safe_normalize(o[0] + 0.3), shading="albedo_normal", real_view=True, cano=False,
+                                                rays_depth=data["depth"].view(1, -1, 1), rays_mask=data["mask"].view(1, -1, 1),
+                                                optimize_pose=True)
+        g["realview|n_draws"] = np.int32(inj.k)
+    for lk in ("loss_normal_perturb", "normal_reg", "loss_code", "sdf_loss", "fs_loss"):
+        g["realview|" + lk] = npf(res[lk])
+    g["realview|image"], g["realview|depth"] = npf(res["image"]), npf(res["depth"])
+    g["realview|weights_sum"], g["realview|sdf_s8"] = npf(res["weights_sum"]), npf(res["sdf"][::8])
+    g["realview|beta"] = npf(m.sdf2density.get_beta())
+    g["realview|normal_s8"] = npf(res["normal"][::8])
+    B, H, W = 1, N, 1
+    pred_rgb, pred_depth, pred_mask, pred_normal, pred_sdf = ref_morpheus.MorpheuS.get_pred_from_outputs(fake, res, B, H, W)
+    fake.device = "cpu"
+    gt_rgb, gt_depth, gt_mask = ref_morpheus.MorpheuS.get_gt_from_data(fake, {k: (v.clone() if torch.is_tensor(v) else v)
+                                                                          for k, v in data.items()}, bg, B, H, W)
+    l_render = ref_morpheus.MorpheuS.get_real_view_render_loss(fake, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth,
+                                                                gt_mask, data["rays_o"], data["rays_d"])
+    l_point = ref_morpheus.MorpheuS.get_real_view_point_loss(fake, gt_rgb, gt_depth, gt_mask, data["rays_o"], data["rays_d"],
+                                                              data["rays_t"], res)
+    l_reg = ref_morpheus.MorpheuS.get_regularization_loss(fake, res, pred_normal, cano=False)
+    g["realview|loss_render"], g["realview|loss_point"], g["realview|loss_reg"] = npf(l_render), npf(l_point), npf(l_reg)
+    g["realview|gt_rgb"] = npf(gt_rgb)
+    total = l_render + l_point + l_reg
+    m.zero_grad()
+    total.backward()
+    g["realview|loss"] = npf(total)
+    for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
+        g["realview|grad|" + kk] = v
+    np.savez_compressed(os.path.join(OUT, "extras.npz"), **g)
+    print("extras.npz", len(g), "arrays")
+
+
 def main():
     assert os.path.isdir(REF), "make_golden.py needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     torch.set_num_threads(8)
-    gen_operators()
-    gen_model()
-    gen_render()
+    if "--extras-only" not in sys.argv:
+        gen_operators()
+        gen_model()
+        gen_render()
+    gen_extras()
 
 
 if __name__ == "__main__":

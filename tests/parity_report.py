@@ -20,6 +20,21 @@ def rel(a, b, floor):
     return float(((a - b).abs() / b.abs().clamp(min=floor)).max())
 
 
+SURVEY_FLOOR = 1e-3      # rel = |a-b| / max(|b|, 1e-3)
+
+
+def detail(a, b, relaxed_floor):
+    """One output at both floors: the contract's and the relaxed one the tests use, with the worst
+    element at the contract floor (its reference value and absolute error) and how many elements exceed 1e-4 there."""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    err = (a - b).abs()
+    r3 = err / b.abs().clamp(min=SURVEY_FLOOR)
+    i = int(r3.argmax())
+    return dict(rel_floor_1e3=float(r3.max()), rel_floor_relaxed=float((err / b.abs().clamp(min=relaxed_floor)).max()),
+                relaxed_floor=relaxed_floor, max_abs=float(err.max()), worst_ref=float(b[i]), worst_abs=float(err[i]),
+                n_over_1e4_at_1e3=int((r3 > 1e-4).sum()), n=int(b.numel()))
+
+
 def nrm(a, b):
     a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
@@ -72,7 +87,9 @@ def render_case(kind, hw, S, cano, nray=None):
     (((rg["image"][0] - timg.to(DEV)) ** 2).mean() + ((rg["depth"][0] - tdep.to(DEV)) ** 2).mean()).backward()
     out = dict(case=f"render {kind} {N}x{S} {'cano' if cano else 'deform'}", image=rel(rg["image"], ro["image"], 1e-2),
                depth=rel(rg["depth"], ro["depth"], 5e-2), sdf=rel(rg["sdf"], ro["sdf"], 1e-2),
-               opacity=rel(rg["weights_sum"], ro["weights_sum"], 1e-2))
+               opacity=rel(rg["weights_sum"], ro["weights_sum"], 1e-2),
+               detail=dict(image=detail(rg["image"], ro["image"], 1e-2), depth=detail(rg["depth"], ro["depth"], 5e-2),
+                           sdf=detail(rg["sdf"], ro["sdf"], 1e-2), opacity=detail(rg["weights_sum"], ro["weights_sum"], 1e-2)))
     grads = {}
     for k, prm in m.named_parameters():
         if prm.grad is not None and p[k].grad is not None:

@@ -340,3 +340,157 @@ def test_training_steps_track_the_oracle():
     for a, b in zip(losses_hip, losses_ref):
         assert abs(a - b) <= 1e-3 * abs(b), (losses_hip, losses_ref)
     assert losses_hip[2] < losses_hip[0]
+
+
+def test_real_view_step_vs_reference_golden():
+    """The reference's real-view training call (morpheus.py:1191 with shading='albedo_normal', depth/mask supervision, pose
+    optimisation, normal_smooth_3d / normal_smoothness / code_reg ON) and its three caller-side loss groups, against
+    fixtures produced by the reference's OWN render_rays + loss methods with the random draws injected (the same
+    closed-form draws are injected here): numeric values of loss_normal_perturb and normal_reg, not finiteness.
+    FD normals amplify round-off x250, so quantities that pass through them are compared at 2e-2."""
+    import numpy as np
+    from morpheus_amd import harness, trainstep
+    from tests.util import DrawInjector
+    g = load_golden("extras.npz")
+    sel = torch.from_numpy(g["realview|sel"].astype(np.int64))
+    hw, S = 32, 64
+    o, d, t, rid = [v[:, sel] for v in synth.frame_rays(25, hw, hw)]
+    N = o.shape[1]
+    smp = of.uniform_samples(o[0], d[0], synth.ray_jitter(hw * hw)[sel], S, 1.01)
+    model = harness.build_model("b", DEV, 0.75).train()
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    frame = trainstep.make_frames([25], hw, hw, DEV)[0]
+    data = trainstep.sample_real_view_rays(frame, N, sel.to(DEV))
+    bg = synth.hash_tensor((N, 3), 350, 0.5, 0.5).to(DEV)
+    light = of.safe_normalize(o[0] + 0.3).to(DEV)
+    with DrawInjector() as inj:
+        res = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), N, 1, bg_color=bg, ambient_ratio=1.0,
+                               light_d=light, shading="albedo_normal", real_view=True, cano=False,
+                               rays_depth=data["depth"].view(1, -1, 1), rays_mask=data["mask"].view(1, -1, 1),
+                               optimize_pose=True)
+        assert inj.k == int(g["realview|n_draws"]), "the HIP path must draw what the reference draws, in its order"
+    assert_close(res["image"], g["realview|image"], TOL, "image", floor=FLOOR)
+    assert_close(res["depth"], g["realview|depth"], TOL, "depth", floor=DEPTH_FLOOR)
+    assert_close(res["weights_sum"], g["realview|weights_sum"], TOL, "opacity", floor=FLOOR)
+    assert_close(res["sdf"][::8], g["realview|sdf_s8"], TOL, "sdf", floor=FLOOR)
+    assert_close(res["normal"][::8], g["realview|normal_s8"], 2e-2, "normal (FD)", floor=5e-2)
+    assert_close(res["loss_code"], g["realview|loss_code"], TOL, "loss_code")
+    assert_close(res["sdf_loss"], g["realview|sdf_loss"], TOL, "sdf_loss")
+    assert_close(res["fs_loss"], g["realview|fs_loss"], 1e-3, "fs_loss", floor=1e-4)
+    assert_close(res["loss_normal_perturb"], g["realview|loss_normal_perturb"], 2e-2, "loss_normal_perturb")
+    assert_close(res["normal_reg"], g["realview|normal_reg"], 2e-2, "normal_reg")
+    B, H, W = 1, N, 1
+    tr = model.config["train"]
+    pred_depth, pred_mask = res["depth"].reshape(B, 1, H, W), res["weights_sum"].reshape(B, 1, H, W)
+    pred_rgb = res["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+    gt_rgb, gt_depth, gt_mask = trainstep.get_gt_from_data(data, bg, B, H, W)
+    l_render = trainstep.get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask,
+                                                   data["rays_o"], data["rays_d"])
+    # N surface points through model.density(x, t) with colour, x and t of equal length (morpheus.py:1013-1026)
+    l_point = trainstep.get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, data["rays_o"], data["rays_d"],
+                                                 data["rays_t"], res)
+    l_reg = trainstep.get_regularization_loss(tr, model, res, None, 1000, 220000)
+    assert_close(l_render, g["realview|loss_render"], TOL, "render loss")
+    assert_close(l_point, g["realview|loss_point"], 2e-4, "point loss")
+    assert_close(l_reg, g["realview|loss_reg"], 1e-2, "regularisation loss")
+    model.zero_grad()
+    (l_render + l_point + l_reg).backward()
+    n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, "realview", 3e-2)
+    assert n_ok >= 40, n_ok
+    for k in ("encoder.embeddings", "encoder_c.embeddings", "deform_code.volumes.2", "pose_array.data"):
+        assert dict(model.named_parameters())[k].grad.abs().sum() > 0, k
+
+
+def test_generate_rays_kernel_vs_reference_golden():
+    """mh_generate_rays against the reference's get_camera_rays + c2w application (fixture), bit for bit."""
+    import numpy as np
+    from morpheus_amd import ops
+    g = load_golden("extras.npz")
+    for tag, (H, W) in (("sq", (24, 24)), ("rect", (20, 28))):
+        for b, pose in enumerate((synth.look_at_pose(60.0, -40.0), synth.look_at_pose(75.0, 130.0, 1.3))):
+            o, d = ops.generate_rays(np.float32(1.2 * W), np.float32(1.2 * W), 0.5 * W, 0.5 * H, pose, H, W, torch.device(DEV))
+            assert np.array_equal(o.cpu().numpy().reshape(H, W, 3), g[f"raygen_{tag}|rays_o"][b]), (tag, b)
+            assert np.array_equal(d.cpu().numpy().reshape(H, W, 3), g[f"raygen_{tag}|rays_d"][b]), (tag, b)
+
+
+def test_full_size_canonical_properties():
+    """BASELINE configs[1] at full size (16384 rays x 128 samples, cano=True: hash grids + sdf/colour nets + compositor):
+    deterministic forward, opacity = sum of weights in [0,1], first 256 rays equal to the reference-generated golden,
+    no deformation outputs, gradients reach both tables / both field nets and nothing on the warp side."""
+    from morpheus_amd import harness
+    g = load_golden("render.npz")
+    model = harness.build_model("b", DEV).eval()
+    o, d, t, rid = [v.to(DEV) for v in synth.frame_rays(25, 128, 128)]
+    N, S = o.shape[1], 128
+    rend = harness.make_renderer(model, S, jitter=synth.ray_jitter(N).to(DEV))
+    light = of.safe_normalize(o[0].cpu() + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
+    with torch.no_grad():
+        r2 = rend.render_rays(o, d, t, rid, 128, 128, ambient_ratio=0.3, light_d=light, shading="albedo", cano=True)
+    res = rend.render_rays(o, d, t, rid, 128, 128, ambient_ratio=0.3, light_d=light, shading="albedo", cano=True)
+    assert torch.equal(res["image"], r2["image"]) and torch.equal(res["sdf"], r2["sdf"])
+    assert res["deform"] is None and res["normal"] is None
+    op = res["weights_sum"][:, 0]
+    assert float(op.min()) >= 0.0 and float(op.max()) <= 1.0 + 1e-5
+    assert_close(res["weights"].view(N, S).sum(-1), op, 1e-5, "sum of weights", floor=1e-3)
+    key = "b_cfg3head_eval_albedo_cano"
+    assert_close(res["image"][0, :256], g[key + "|image"][0], TOL, "first 256 rays image", floor=FLOOR)
+    assert_close(res["depth"][0, :256], g[key + "|depth"][0], TOL, "first 256 rays depth", floor=DEPTH_FLOOR)
+    assert_close(res["weights_sum"][:256], g[key + "|weights_sum"], TOL, "first 256 rays opacity", floor=FLOOR)
+    timg, tdep = [v.to(DEV) for v in synth.targets(N)]
+    model.zero_grad()
+    harness.bench_loss(res, timg, tdep).backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    for k in ("encoder.embeddings", "encoder_c.embeddings", "sdf_net.net.0.weight", "color_net.net.2.weight_v", "sdf2density.beta"):
+        assert grads[k] is not None and torch.isfinite(grads[k]).all() and float(grads[k].abs().sum()) > 0, k
+    for k in ("deform_net.net.0.weight_v", "topo_net.net.3.bias", "deform_code.volumes.0"):
+        assert grads[k] is None or float(grads[k].abs().sum()) == 0.0, k
+
+
+def test_normal_image_carries_the_density_gradient():
+    """morpheus.py:775 accumulates the normal image with the LIVE weights: d(normal_image)/d(beta) is non-zero
+    (beta only acts through the density)."""
+    from morpheus_amd import harness
+    hw, S = 12, 32
+    o, d, t, rid = [v.to(DEV) for v in synth.frame_rays(25, hw, hw)]
+    N = o.shape[1]
+    model = harness.build_model("b", DEV).train()
+    tr = model.config["train"]
+    tr["normal_smooth_2d"], tr["normal_smoothness"], tr["normal_smooth_3d"] = 0.1, 0.0, 0.0
+    rend = harness.make_renderer(model, S, jitter=synth.ray_jitter(N).to(DEV))
+    light = of.safe_normalize(o[0].cpu() + 0.3).to(DEV)
+    res = rend.render_rays(o, d, t, rid, hw, hw, ambient_ratio=0.3, light_d=light, shading="lambertian", real_view=False)
+    assert res["normal_image"].shape == (N, 3)
+    (gb,) = torch.autograd.grad(res["normal_image"].sum(), model.sdf2density.beta, retain_graph=True)
+    assert float(gb.abs()) > 0
+
+
+def test_eval_step_chunked_ragged_forward():
+    """f-4: MorpheuS.eval_step's call shape (morpheus.py:1238-1269) -- a whole view in chunks, no_grad, ragged
+    occupancy-marched samples -- equals the un-chunked render bit for bit (rays are independent), and the un-chunked
+    render equals the CPU oracle on the oracle-marched samples."""
+    from morpheus_amd import harness
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.render import HotPathRenderer
+    hw = 40
+    o, d, t, rid = synth.frame_rays(25, hw, hw)
+    N = o.shape[1]
+    c = (torch.arange(128).float() + 0.5) / 128 * 2.02 - 1.01
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    ball = ((X ** 2 + Y ** 2 + Z ** 2).sqrt() < 0.7).to(torch.uint8).contiguous()
+    model = harness.build_model("b", DEV).eval()
+    grid = OccupancyGrid([-1.01] * 3 + [1.01] * 3, 128).to(DEV)
+    grid.set_binary(ball.to(DEV))
+    grid.fixed_jitter = 0.25
+    rend = HotPathRenderer(model, model.config, grid, 200)
+    data = dict(rays_o=o.to(DEV), rays_d=d.to(DEV), rays_t=t.to(DEV), rays_id=rid.to(DEV), H=hw, W=hw)
+    with torch.no_grad():
+        rgb_c, dep_c = rend.eval_step(data, max_chunk=500)           # 1600 rays -> 4 chunks of 401/401/401/397
+        full = rend.render_rays(data["rays_o"], data["rays_d"], data["rays_t"], data["rays_id"], hw, hw, shading="albedo")
+    assert rgb_c.shape == (1, hw, hw, 3) and dep_c.shape == (1, hw, hw)
+    assert torch.equal(rgb_c.reshape(1, N, 3), full["image"]) and torch.equal(dep_c.reshape(1, N), full["depth"])
+    smp = of.march_samples(o[0], d[0], torch.full((N,), 0.25), 0.01, 1.01, ball)
+    f = of.OracleField({k: v for k, v in synth.make_state("b").items()}, 1.01, None)
+    with torch.no_grad():
+        ro = of.render_rays(f, o, d, t, rid, smp, ambient_ratio=1.0, light_d=of.safe_normalize(o[0] + 0.3), shading="albedo")
+    assert_close(full["image"], ro["image"], TOL, "image", floor=FLOOR)
+    assert_close(full["depth"], ro["depth"], TOL, "depth", floor=DEPTH_FLOOR)

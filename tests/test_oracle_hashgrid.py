@@ -112,3 +112,40 @@ def test_border_band_slope_follows_kernel():
         flat = oracle_grid_encode(x + torch.tensor([[1e-4, 0, 0]]), emb, offs, res, 1.0)
     assert torch.allclose(flat[:, 0], out[:, 0].detach(), atol=1e-7)
     assert x.grad[0, 0].abs() > 0
+
+
+def test_second_derivation_agrees_on_1e5_points():
+    """oracle/hashgrid.c against oracle/hashgrid_np.py -- a second restatement written independently from the .cu
+    (vectorised numpy over [points, corners]) -- on 10^5 points: interior, the border band, exact cell boundaries and
+    out-of-range inputs, all 16 levels (dense rows for levels 0-5, hashed from level 6: 37^3 > 32768): features to 2
+    ulp, d/du to 1e-5 of the level's slope scale, embedding gradients to 1e-6 relative."""
+    from oracle import hashgrid_np as hnp
+    from oracle.hashgrid import _OracleGridEncode
+    emb, offs, res, _ = make()
+    M = 100_000
+    u = (synth.hash_tensor((M, 3), 9100, 0.55) + 0.5).clamp_(-0.05, 1.05)             # ~9% outside [0,1] before the clamp
+    u[:2000] = (torch.round(u[:2000] * 37) + 0.5) / 37                                   # level-6 cell boundaries (res 37)
+    u[2000:4000] = torch.round(u[2000:4000] * 32) / 32                                   # level-5 cell centres / borders
+    u[4000:4200, 0] = 0.0
+    u[4200:4400, 1] = 1.0
+    u[4400:4500] = 1.0 + 1e-7                                                            # just outside
+    offs_np, res_np, emb_np = offs.numpy(), res.numpy(), emb.numpy()
+    for n_levels in (16, 8):
+        ut = u.clone().requires_grad_(True)
+        embt = emb.clone().requires_grad_(True)
+        out_c = _OracleGridEncode.apply(ut, embt, offs, res, n_levels, True)
+        out_np = hnp.forward(u.numpy(), emb_np, offs_np, res_np, n_levels)
+        ulp = np.spacing(np.abs(out_np).astype(np.float32)).astype(np.float64)
+        assert np.all(np.abs(out_c.detach().numpy().astype(np.float64) - out_np) <= 2 * ulp + 1e-12)
+        # the dense -> hash switch really happens between levels 5 and 6
+        T = offs_np[1:] - offs_np[:-1]
+        assert res_np[5] ** 3 <= T[5] and res_np[6] ** 3 > T[6]
+        go = synth.hash_tensor((M, 32), 9101, 1.0)
+        (out_c * go).sum().backward()
+        g_np = hnp.backward_embeddings(u.numpy(), go.numpy(), offs_np, res_np, n_levels, emb.shape[0], 2)
+        ge = embt.grad.numpy().astype(np.float64)
+        assert np.abs(ge - g_np).max() <= 1e-6 * np.abs(g_np).max() + 1e-9
+        d_np = hnp.dy_du(u.numpy()[:20000], emb_np, offs_np, res_np, n_levels)          # [m, L, 3, C]
+        gu_np = np.einsum("mldc,mlc->md", d_np.astype(np.float64), go.numpy()[:20000].reshape(-1, 16, 2).astype(np.float64))
+        gu_c = ut.grad.numpy()[:20000].astype(np.float64)
+        assert np.abs(gu_c - gu_np).max() <= 1e-5 * np.abs(gu_np).max()

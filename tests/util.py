@@ -51,3 +51,34 @@ def grad_digest_check(named_grads, golden, prefix, tol, skip=()):
         assert err <= tol * max(float(smp.abs().max()), rms) * 4 + 1e-12, f"{k} samples err {err}"
         checked += 1
     return checked
+
+
+class DrawInjector:
+    """Closed-form stand-ins for torch.rand / rand_like / randn_like (same class as oracle/make_golden.py): the k-th draw
+    of shape `shape` is synth.hash_tensor(shape, 8000 + k), so the HIP path sees exactly the random perturbations the
+    reference saw when the fixture was generated -- provided it draws in the same order with the same shapes."""
+
+    def __init__(self, base=8000):
+        self.k, self.base = 0, base
+
+    def _next(self, shape, normal, device=None):
+        self.k += 1
+        v = synth.hash_tensor(tuple(shape), self.base + self.k, 0.5)
+        v = v * 3.4 if normal else v + 0.5
+        return v.to(device) if device is not None else v
+
+    def __enter__(self):
+        self._saved = (torch.rand, torch.rand_like, torch.randn_like)
+        inj = self
+
+        def rand(*size, device=None, dtype=None, **kw):
+            size = size[0] if len(size) == 1 and isinstance(size[0], (list, tuple, torch.Size)) else size
+            return inj._next(size, False, device)
+
+        torch.rand = rand
+        torch.rand_like = lambda t, **kw: inj._next(t.shape, False, t.device)
+        torch.randn_like = lambda t, **kw: inj._next(t.shape, True, t.device)
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.rand_like, torch.randn_like = self._saved
