@@ -36,7 +36,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 1
+#define MH_ABI_VERSION 2
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -131,6 +131,26 @@ int mh_march_slots(const float *rays_o, const float *rays_d, const float *jitter
 int mh_march_pack(const int32_t *ray_start, const int32_t *ray_cnt, const float *slot_ts, const float *slot_te, int32_t N,
                   int32_t cap, int32_t *ray_idx, float *t_starts, float *t_ends, void *stream);
 
+/* ---- glue of the field queries as single launches (csrc/normal.hip) ----------------------------------------------------
+ * Finite-difference normals (models/model.py:367-398): mh_fd_taps writes the 6 clamped taps of every sample, point-major
+ * (+x,-x,+y,-y,+z,-z; taps [6M,3]) and replicates topo [M,topo_dim] to topo6 [6M,topo_dim] (topo NULL: skipped);
+ * mh_fd_taps_bwd sums the taps' gradients back (clamp passes inside [-bound, bound]); g_x / g_topo NULL: not computed.
+ * mh_fd_normal_fwd: sdf6 [M,6] -> raw [M,3] = 0.5 (s+ - s-) / eps and normal = nan_to_num(raw / sqrt(max(|raw|^2, 1e-20)));
+ * mh_fd_normal_bwd: (g_normal, g_raw; either may be NULL) -> g_sdf6 [M,6].
+ * Sample assembly (morpheus.py:644-647): xyz[m] = rays_o[r] + rays_d[r] * (t_starts[m] + t_ends[m]) / 2, r = ray_idx[m];
+ * backward = per-ray segment sums over the packed samples (ray_start / ray_cnt), one wavefront per ray. */
+int mh_fd_taps(const float *x, const float *topo, int32_t topo_dim, float eps, float bound, int64_t M, float *taps,
+               float *topo6, void *stream);
+int mh_fd_taps_bwd(const float *x, const float *g_taps, const float *g_topo6, int32_t topo_dim, float eps, float bound,
+                   int64_t M, float *g_x, float *g_topo, void *stream);
+int mh_fd_normal_fwd(const float *sdf6, float eps, int64_t M, float *normal, float *raw, void *stream);
+int mh_fd_normal_bwd(const float *sdf6, const float *g_normal, const float *g_raw, float eps, int64_t M, float *g_sdf6,
+                     void *stream);
+int mh_sample_positions(const float *rays_o, const float *rays_d, const int32_t *ray_idx, const float *t_starts,
+                        const float *t_ends, int64_t M, float *xyz, void *stream);
+int mh_sample_positions_bwd(const float *g_xyz, const float *t_starts, const float *t_ends, const int32_t *ray_start,
+                            const int32_t *ray_cnt, int32_t N, float *g_o, float *g_d, void *stream);
+
 /* ---- fused tiny-MLP evaluators on fp32 MFMA (v_mfma_f32_32x32x2_f32) -------------------------
  * Weight operands are PRE-PACKED by the host into the MFMA A-fragment order (see
  * morpheus_amd/packing.py): for layer l, tile mt, k-quad q: float4 per lane.  `wpack` is the
@@ -212,12 +232,14 @@ int mh_weight_norm_bwd(int32_t n_layers, const float *const *v_host, const float
 
 /* ---- optimiser step over the flat parameter bucket (the step after the path) ---- */
 /* Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9,0.99), eps=1e-15).step() of morpheus.py:154-155,
- * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned;
- * param groups are contiguous segments: seg_end_host[s] = exclusive end offset of group s (last == n), seg_lr_host[s]
- * its learning rate (HOST arrays, n_segs <= 16).  step = 1-based step count (bias correction). */
+ * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned.
+ * The bucket is cut into contiguous segments, normally ONE PER PARAMETER TENSOR (plus alignment pads): seg_end_host[s] =
+ * exclusive end offset (last == n), seg_lr_host[s] = its group's learning rate, seg_step_host[s] = the 1-based step count
+ * of that parameter for its bias corrections, or 0 = the parameter has no gradient this time and is left untouched
+ * (moments, value and count), which is what torch.optim.Adam does for grad None (HOST arrays, n_segs <= 160). */
 int mh_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
-                 const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps, int64_t step,
-                 void *stream);
+                 const int64_t *seg_end_host, const float *seg_lr_host, const int64_t *seg_step_host, float beta1,
+                 float beta2, float eps, void *stream);
 
 #ifdef __cplusplus
 }

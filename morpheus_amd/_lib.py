@@ -33,6 +33,12 @@ _SIGS = {
     "mh_march_cap": (_I32, [_F, _F]),
     "mh_march_slots": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "mh_march_pack": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
+    "mh_fd_taps": (ctypes.c_int, [_P, _P, _I32, _F, _F, _I64, _P, _P, _P]),
+    "mh_fd_taps_bwd": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I64, _P, _P, _P]),
+    "mh_fd_normal_fwd": (ctypes.c_int, [_P, _F, _I64, _P, _P, _P]),
+    "mh_fd_normal_bwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
+    "mh_sample_positions": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "mh_sample_positions_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "mh_mlp_tiles": (_I64, [_I64]),
     "mh_warp_acts_floats": (_I64, [_I64]),
     "mh_warp_dpre_floats": (_I64, [_I64]),
@@ -50,7 +56,7 @@ _SIGS = {
     "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mh_weight_norm_fwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
     "mh_weight_norm_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "mh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _F, _F, _F, _I64, _P]),
+    "mh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _P]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -73,7 +79,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mh_abi_version() != 1:
+        if lib.mh_abi_version() != 2:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1023,10 +1023,39 @@ extern "C" int mh_warp_bwd_data(const float *x, const float *g_deform, const flo
     return MH_OK;
 }
 
+// compute units of the current device, queried once per device (256 on MI355X; partitioned modes expose fewer)
+static int mh_cu_count() {
+    static int cached_dev = -1, cached_cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached_cus = n;
+        cached_dev = dev;
+    }
+    return cached_cus;
+}
+
 // persistent field kernels: one 8-wave block per CU (the resident weights take 94-98 KB of its LDS)
 static inline unsigned field_blocks(int64_t n_tiles) {
     const int64_t need = (n_tiles + FIELD_THREADS / 64 - 1) / (FIELD_THREADS / 64);
-    return (unsigned)(need < 256 ? need : 256);
+    const int64_t cus = mh_cu_count();
+    return (unsigned)(need < cus ? need : cus);
+}
+
+// the resident-weight kernels need more than the default 64 KB of dynamic LDS: opt in once per kernel, not per launch
+static int field_lds_opt_in() {
+    static int done = 0;
+    if (!done) {
+        if (hipFuncSetAttribute((const void *)field_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FIELD_WPACK * sizeof(float))) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FIELD_WPACKT * sizeof(float))) != hipSuccess)
+            return MH_ERR_LAUNCH;
+        done = 1;
+    }
+    return MH_OK;
 }
 
 extern "C" int mh_field_fwd(const float *xc, const float *feat_s, const float *feat_c, const float *topo,
@@ -1037,8 +1066,7 @@ extern "C" int mh_field_fwd(const float *xc, const float *feat_s, const float *f
     if (with_color && (!feat_c || !albedo)) return MH_ERR_ARG;
     const int64_t n_tiles = n_tiles_for(M);  // dead tail tiles are processed too: wgrad reads every scratch tile
     const size_t lds = (size_t)FIELD_WPACK * sizeof(float);
-    if (hipFuncSetAttribute((const void *)field_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MH_ERR_LAUNCH;
+    if (field_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
     hipLaunchKernelGGL(field_fwd_kernel, dim3(field_blocks(n_tiles)), dim3(FIELD_THREADS), lds, mh_stream(stream), xc, feat_s,
                        feat_c, topo, wpack, bias, beta, (int)n_bands, (int)with_color, sdf, sigma, albedo, acts, M, n_tiles);
     MH_CHECK_LAUNCH();
@@ -1055,8 +1083,7 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
     if (with_color && !albedo) return MH_ERR_ARG;
     const int64_t n_tiles = n_tiles_for(M);  // dead tail tiles are processed too: wgrad reads every scratch tile
     const size_t lds = (size_t)FIELD_WPACKT * sizeof(float);
-    if (hipFuncSetAttribute((const void *)field_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return MH_ERR_LAUNCH;
+    if (field_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
     hipLaunchKernelGGL(field_bwd_kernel, dim3(field_blocks(n_tiles)), dim3(FIELD_THREADS), lds, mh_stream(stream), xc, sdf,
                        albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, (int)n_bands, (int)with_color, acts, dpre, g_xc, g_feat_s,
                        g_feat_c, g_topo, g_beta_partial, gmax_bits, M, n_tiles);
@@ -1065,8 +1092,8 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
 }
 
 static inline int wg_chunks(int out_pad, int64_t n_tiles) {
-    // 1024 waves per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
-    int64_t c = 1024 / (out_pad / 32);
+    // 4 waves per CU per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
+    int64_t c = (int64_t)(4 * mh_cu_count()) / (out_pad / 32);
     if (c > n_tiles) c = n_tiles;
     return (int)(c < 1 ? 1 : c);
 }
@@ -1106,6 +1133,7 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
     }
     int64_t dw_total = 0;
     for (int l = 0; l < n_layers; l++) dw_total += (int64_t)in_feats_host[l] * out_feats_host[l];
+    if (db_raw != dw_raw + dw_total) return MH_ERR_ARG;  // dw_raw and db_raw must be one contiguous buffer (checked BEFORE any launch)
     rd.first[0] = 0;
     for (int l = 0; l < n_layers; l++) {
         const int in = in_feats_host[l], out = out_feats_host[l];
@@ -1137,7 +1165,6 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
         db_out += out;
     }
     for (int s = 0; s < rd.n; s++) rd.first[s + 1] = rd.first[s] + rd.len[s];
-    if (db_raw != dw_raw + dw_total) return MH_ERR_ARG;  // dw_raw and db_raw must be one contiguous buffer
     const int64_t total = rd.first[rd.n];
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, mh_stream(stream), workspace,
                        dw_raw, rd);

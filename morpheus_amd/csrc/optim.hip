@@ -9,19 +9,33 @@
 // -- the operation order of torch's fused Adam kernel, so the two agree to fp32 round-off.
 #include "common.h"
 
-#define ADAM_MAX_SEGS 16
+#define ADAM_MAX_SEGS 160
 struct AdamSegs {
     int n;
     int64_t end[ADAM_MAX_SEGS];
-    float step_size[ADAM_MAX_SEGS];  // lr / (1 - b1^t)
+    float step_size[ADAM_MAX_SEGS];  // lr / (1 - b1^t_s);  < 0: the segment is skipped (its parameter had no gradient)
+    float bc2_sqrt[ADAM_MAX_SEGS];   // sqrt(1 - b2^t_s)
 };
 
+// A segment is ONE parameter tensor (or a group's 4-element alignment pad): torch.optim.Adam keeps a step count per
+// parameter and leaves a parameter whose gradient is None untouched -- no moment decay, no move, no step increment
+// (the reference steps the pose group only on real-view iterations, morpheus.py:1399-1424 with freeze_lr) -- so the
+// bias corrections and the skip flag travel per segment.
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps,
-                                                   float bc2_sqrt, int64_t n) {
+                                                   int64_t n) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= n) return;
     const int cnt = (n - i0) < 4 ? (int)(n - i0) : 4;
+    // first segment whose end is beyond i0 (binary search over <= 160 ends)
+    int lo = 0, hi = segs.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (i0 >= segs.end[mid]) lo = mid + 1; else hi = mid;
+    }
+    int seg = lo;
+    const bool one_seg = (i0 + cnt) <= segs.end[seg];
+    if (one_seg && segs.step_size[seg] < 0.f) return;       // skipped parameter: nothing is read or written
     float pv[4], gv[4], mv[4], vv[4];
     if (cnt == 4) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(p + i0), b = *reinterpret_cast<const f32x4 *>(g + i0);
@@ -31,16 +45,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     } else {
         for (int k = 0; k < cnt; k++) pv[k] = p[i0 + k], gv[k] = g[i0 + k], mv[k] = m[i0 + k], vv[k] = v[i0 + k];
     }
-    int seg = 0;
-    while (seg < segs.n - 1 && i0 >= segs.end[seg]) seg++;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (k < cnt) {
             while (seg < segs.n - 1 && i0 + k >= segs.end[seg]) seg++;
-            mv[k] = mv[k] + (gv[k] - mv[k]) * (1.0f - beta1);
-            vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
-            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
-            pv[k] -= segs.step_size[seg] * mv[k] / denom;
+            if (segs.step_size[seg] >= 0.f) {
+                mv[k] = mv[k] + (gv[k] - mv[k]) * (1.0f - beta1);
+                vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
+                const float denom = sqrtf(vv[k]) / segs.bc2_sqrt[seg] + eps;
+                pv[k] -= segs.step_size[seg] * mv[k] / denom;
+            }
         }
     }
     if (cnt == 4) {
@@ -56,27 +70,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 }
 
 extern "C" int mh_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
-                            const int64_t *seg_end_host, const float *seg_lr_host, float beta1, float beta2, float eps,
-                            int64_t step, void *stream) {
+                            const int64_t *seg_end_host, const float *seg_lr_host, const int64_t *seg_step_host, float beta1,
+                            float beta2, float eps, void *stream) {
     if (n == 0) return MH_OK;
     if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || n_segs <= 0 || n_segs > ADAM_MAX_SEGS || !seg_end_host ||
-        !seg_lr_host || step <= 0 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
+        !seg_lr_host || !seg_step_host || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f))
         return MH_ERR_ARG;
     if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return MH_ERR_ARG;
     AdamSegs segs;
     segs.n = n_segs;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
     int64_t prev = 0;
     for (int s = 0; s < n_segs; s++) {
-        if (seg_end_host[s] < prev || seg_end_host[s] > n) return MH_ERR_ARG;
+        if (seg_end_host[s] < prev || seg_end_host[s] > n || seg_step_host[s] < 0) return MH_ERR_ARG;
         prev = segs.end[s] = seg_end_host[s];
-        segs.step_size[s] = (float)((double)seg_lr_host[s] / bc1);
+        if (seg_step_host[s] == 0) {            // step 0: no gradient for this parameter this time -> untouched
+            segs.step_size[s] = -1.0f;
+            segs.bc2_sqrt[s] = 1.0f;
+        } else {
+            const double bc1 = 1.0 - pow((double)beta1, (double)seg_step_host[s]);
+            const double bc2 = 1.0 - pow((double)beta2, (double)seg_step_host[s]);
+            segs.step_size[s] = (float)((double)seg_lr_host[s] / bc1);
+            segs.bc2_sqrt[s] = (float)sqrt(bc2);
+        }
     }
     if (prev != n) return MH_ERR_ARG;
     const int64_t threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, mh_stream(stream), params, grads,
-                       exp_avg, exp_avg_sq, segs, beta1, beta2, eps, (float)sqrt(bc2), n);
+                       exp_avg, exp_avg_sq, segs, beta1, beta2, eps, n);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

@@ -64,6 +64,7 @@ class GradBucket:
         self._early_seen = 0
         self._early_work = []     # outstanding async collectives of this step
         self._side = None         # side stream the early exchange is queued on (GPU only)
+        self.missing = set()      # layout indices whose p.grad was None at the last collect() (optim.FlatAdam skips them)
         self.rebind(force=True)
 
     # ---- overlap of the exchange with the tail of backward -----------------------------------------------
@@ -123,6 +124,7 @@ class GradBucket:
         tensor (a pointer move) instead of launching one accumulate-add per parameter into a bound view; `collect()`
         gathers them with one multi-tensor copy."""
         self.flat.zero_()
+        self.missing = set()
         self._early_seen = 0
         for p in self.params:
             p.grad = None
@@ -130,9 +132,10 @@ class GradBucket:
     def collect(self):
         """Gather the gradients autograd produced into the flat bucket and re-bind `p.grad` to its views."""
         dst, src = [], []
-        for p, o, k in self._layout:
+        for i, (p, o, k) in enumerate(self._layout):
             g = p.grad
             if g is None:
+                self.missing.add(i)
                 p.grad = self.flat[o:o + k].view(p.shape)       # no gradient this step: the zeros of zero()
             elif g.data_ptr() != self.flat[o:o + k].data_ptr():
                 view = self.flat[o:o + k].view(p.shape)

@@ -12,6 +12,7 @@ raise NotImplementedError instead of silently taking a slow path.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import List, Optional, Tuple
 
@@ -252,6 +253,7 @@ class scene_representation(nn.Module):
             self.in_dim_bg, self.in_dim_bg_t = 39, 13
             self.bg_net = MLP(self.in_dim_bg + self.in_dim_bg_t, 3, hidden_dim_bg, num_layers_bg)
         self.sdf2density = LaplaceDensity(0.1)
+        self._opcache = None        # operand cache of the current operand_scope() (None outside a scope)
 
     # -- helpers ----------------------------------------------------------------------------
     def _n_bands(self) -> int:
@@ -282,6 +284,59 @@ class scene_representation(nn.Module):
         b = net.biases()
         return [w[0][:, :39]] + w[1:] + b, w[0][:, 39:], b[0]
 
+    # -- operands that depend only on the parameters: prepared once per scope ------------------------------------------
+    @contextlib.contextmanager
+    def operand_scope(self):
+        """Within a scope (render_rays opens one; a training step may open one around render + point loss) everything that
+        depends only on the parameters -- effective (weight-normed) weights, the MFMA operand packs, the per-frame code
+        bias, beta -- is prepared ONCE and shared by all warp / field calls: a real-view step evaluates the warp nets 4x and
+        the field nets 6x, and the weight gradients of all those calls meet in one raw-gradient token per net group
+        (ops._PackOperands) instead of one accumulation per parameter per call.  Parameters must not change inside a scope."""
+        outer = self._opcache
+        if outer is None:
+            self._opcache = {}
+        try:
+            yield self
+        finally:
+            if outer is None:
+                self._opcache = None
+
+    def _cached(self, key, build):
+        c = self._opcache
+        if c is None:
+            return build()
+        key = (key, torch.is_grad_enabled())
+        if key not in c:
+            c[key] = build()
+        return c[key]
+
+    def _warp_operands(self):
+        def build():
+            w_all = wn_effective_batched(list(self.deform_net.net) + list(self.topo_net.net))
+            pd, wcode_d, b0_d = self._warp_params(self.deform_net, w_all[:6])
+            pt, wcode_t, b0_t = self._warp_params(self.topo_net, w_all[6:])
+            return ops.prepare_warp_operands(pd, pt), (wcode_d, b0_d, wcode_t, b0_t)
+        return self._cached("warp", build)
+
+    def _warp_bias0(self, tu, code_w):
+        """per-slot first-layer bias W0[:,39:] code(t) + b0 of both nets; cached per scope for a single-frame time (the
+        cache entry keeps `tu` alive, so its address cannot be recycled while the entry exists)."""
+        wcode_d, b0_d, wcode_t, b0_t = code_w
+
+        def build():
+            code = self.deform_code.sample(tu[:, None])                       # [F,48], F = distinct frames / slots
+            return torch.addmm(b0_d, code, wcode_d.t()), torch.addmm(b0_t, code, wcode_t.t()), tu
+        if tu.numel() != 1:
+            return build()[:2]
+        return self._cached(("bias0", tu.data_ptr(), tu._version), build)[:2]
+
+    def _field_operands(self):
+        def build():
+            params = self.sdf_net.weights() + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
+                self.color_net.biases()
+            return ops.prepare_field_operands(params), self.sdf2density.get_beta()
+        return self._cached("field", build)
+
     # -- public API (names/signatures of the reference) ----------------------------------------
     def get_deform_code(self, t, app=False):
         if app:
@@ -292,7 +347,18 @@ class scene_representation(nn.Module):
         ids = frame_ids.squeeze()
         return self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)
 
-    def pose_optimisation(self, rays_o, rays_d, frame_ids):
+    def pose_optimisation(self, rays_o, rays_d, frame_ids, rows=None):
+        """models/model.py:335-346.  rows = (B, n): the N = B*n rays are B batch rows of n rays, ONE frame per row (how the
+        reference's dataset builds every batch): R and t are evaluated for the B frames and broadcast over
+        their rays -- same arithmetic per ray, but the gradient reaches pose_array through a B-row gather instead of an
+        N-row one (torch's index backward serialises on 2048 identical indices: 0.57 ms per gather)."""
+        if rows is not None:
+            B, n = rows
+            ids = frame_ids.reshape(B, n)[:, 0]
+            R, t = self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)   # [B,3,3], [B,3]
+            o = (rays_o.view(B, n, 3) + t[:, None]).view(-1, 3)
+            d = (rays_d.view(B, n, 1, 3) * R[:, None]).sum(-1).view(-1, 3)
+            return o, d
         ids = frame_ids.squeeze()
         R, t = self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)
         return rays_o + t, (rays_d[..., None, :] * R).sum(-1)
@@ -300,30 +366,21 @@ class scene_representation(nn.Module):
     def warp(self, x, t, frame_slots=None):
         """-> deform [M,3], topo [M,2], app_code (None)   (model.py:412-437).  `frame_slots`: see `_slots`."""
         tu, slot = self._slots(t, frame_slots)
-        code = self.deform_code.sample(tu[:, None])                       # [F,48], F = distinct frames
-        w_all = wn_effective_batched(list(self.deform_net.net) + list(self.topo_net.net))
-        pd, wcode_d, b0_d = self._warp_params(self.deform_net, w_all[:6])
-        pt, wcode_t, b0_t = self._warp_params(self.topo_net, w_all[6:])
-        bias0_d = torch.addmm(b0_d, code, wcode_d.t())                    # per-frame first-layer bias
-        bias0_t = torch.addmm(b0_t, code, wcode_t.t())
-        deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), pd, pt)
+        opnd, code_w = self._warp_operands()
+        bias0_d, bias0_t = self._warp_bias0(tu, code_w)                   # per-frame first-layer bias
+        deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), opnd)
         return deform, topo, None
 
     def get_topo(self, x, t, frame_slots=None):
         return self.warp(x, t, frame_slots)[1]
 
     def get_sigma_albedo(self, x, topo=None, app_code=None, return_color=True, _group=1):
-        if return_color:
-            # both tables share the sample points: one autograd node, one brick binning in backward
-            feat_s, feat_c = ops.grid_encode_multi(x, (self.encoder.embeddings, self.encoder_c.embeddings),
-                                                   self.encoder._offsets_np, self.encoder._res_np, self.bound,
-                                                   self.max_level)
-        else:
-            feat_s, feat_c = self.encoder(x, bound=self.bound, max_level=self.max_level, group=_group), None
-        params = self.sdf_net.weights() + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
-            self.color_net.biases()
-        sdf, sigma, albedo = ops.field_mlp(x, feat_s, feat_c, topo, self.sdf2density.get_beta(), self._n_bands(),
-                                           return_color, params)
+        """hash grid(s) -> sdf_net -> Laplace density (-> color_net)   (model.py:273-307), one autograd node
+        (ops._FieldQuery).  _group: every `_group` consecutive points are neighbours (6 = finite-difference taps)."""
+        opnd, beta = self._field_operands()
+        sdf, sigma, albedo = ops.field_query(x, topo, beta, self.encoder.embeddings,
+                                             self.encoder_c.embeddings if return_color else None, self.encoder._offsets_np,
+                                             self.encoder._res_np, self.bound, self.max_level, _group, self._n_bands(), opnd)
         return sdf, sigma, (albedo if return_color else None)
 
     def get_params_all(self, lr):
@@ -342,28 +399,24 @@ class scene_representation(nn.Module):
             groups.append({"name": "decoder_bg", "params": self.bg_net.parameters(), "lr": lr})
         return groups
 
-    def finite_difference_normal(self, x, epsilon=2e-3, topo=None):
-        """6 clamped taps of the SDF (model.py:367-385), evaluated as ONE batch of 6M points: one hash-grid pass,
-        one sdf-net pass and one brick binning instead of six of each (same arithmetic per tap)."""
+    def _fd_normals(self, x, epsilon=2e-3, topo=None):
+        """-> (normal, raw).  6 clamped taps of the SDF (model.py:367-385), evaluated as ONE batch of 6M points, point-major
+        (a sample's six taps adjacent: shared hash-corner cache lines, same backward brick): one launch builds the taps
+        (and replicates topo), one hash-grid pass, one sdf-net pass, one launch turns the six values into the raw and the
+        normalised normal (model.py:387-398); the same four launches run backward."""
         M = x.shape[0]
-        off = x.new_zeros(1, 6, 3)
-        for k in range(3):
-            off[0, 2 * k, k] = epsilon
-            off[0, 2 * k + 1, k] = -epsilon
-        # point-major tap order: a point's six taps sit next to each other, so their hash-corner gathers hit the same
-        # cache lines (the taps lie within 2 eps of each other) and they fall into the same backward brick
-        taps = (x[:, None] + off).clamp(-self.bound, self.bound).reshape(6 * M, 3)
-        topo6 = None if topo is None else topo[:, None].expand(M, 6, topo.shape[-1]).reshape(6 * M, -1)
+        taps, topo6 = ops.fd_taps(x, topo, epsilon, self.bound)
         sdf = self.get_sigma_albedo(taps, topo=topo6, return_color=False, _group=6)[0].view(M, 6)
-        return torch.stack([0.5 * (sdf[:, 0] - sdf[:, 1]) / epsilon, 0.5 * (sdf[:, 2] - sdf[:, 3]) / epsilon,
-                            0.5 * (sdf[:, 4] - sdf[:, 5]) / epsilon], -1)
+        return ops.fd_normal(sdf, epsilon)
+
+    def finite_difference_normal(self, x, epsilon=2e-3, topo=None):
+        return self._fd_normals(x, epsilon, topo)[1]
 
     def normal(self, x, t=None, cano=False, topo=None, frame_slots=None):
         if t is not None and not cano:
             deform, topo, _ = self.warp(x, t, frame_slots)
             x = x + deform
-        raw = self.finite_difference_normal(x, topo=topo)
-        return torch.nan_to_num(safe_normalize(raw)), raw
+        return self._fd_normals(x, topo=topo)
 
     def background(self, d, t):
         h = torch.cat([_freq_encode_torch(d, 6, None), _freq_encode_torch(t, 6, self.max_level)], -1)

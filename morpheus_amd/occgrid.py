@@ -30,10 +30,16 @@ class OccupancyGrid(torch.nn.Module):
         b = float(aabb[3])
         assert torch.allclose(aabb[:3], -aabb[3:]) and torch.allclose(aabb[3:], aabb[3:4].expand(3)), \
             "the marcher assumes the reference's cubic AABB [-bound, bound]^3 (morpheus.py:113-127)"
-        self.bound, self.resolution = b, int(resolution)
+        self.bound = b
+        R = int(resolution)
+        # buffer names / shapes / dtypes of nerfacc 0.5.x's OccGridEstimator with levels = 1 (as recalled from its public
+        # source; the package is not in the reference tree): resolution int32 [3], aabbs [1,6], occs [R^3],
+        # binaries bool [1,R,R,R] -- so that the reference's checkpoint entry 'estimator' (morpheus.py:341,355) loads
+        self.register_buffer("resolution", torch.tensor([R, R, R], dtype=torch.int32))
         self.register_buffer("aabbs", aabb[None].clone())
-        self.register_buffer("occs", torch.zeros(self.resolution ** 3))
-        self.register_buffer("binaries", torch.zeros(self.resolution, self.resolution, self.resolution, dtype=torch.uint8))
+        self.register_buffer("occs", torch.zeros(R ** 3))
+        self.register_buffer("binaries", torch.zeros(1, R, R, R, dtype=torch.bool))
+        self._R = R
         self.packed = None       # (ray_start, ray_cnt) of the last sampling() call, consumed by the compositor
         self.fixed_jitter: Optional[torch.Tensor] = None   # parity runs pin the per-ray jitter
 
@@ -53,13 +59,15 @@ class OccupancyGrid(torch.nn.Module):
             u = torch.rand(n, device=rays_o.device)
         else:
             u = None
-        ri, ts, te, rs, rc = ops.march_rays(rays_o, rays_d, u, float(render_step_size), self.bound, self.binaries)
+        # a bool tensor is one byte per cell holding 0/1: the marcher reads it as uint8 without a copy
+        ri, ts, te, rs, rc = ops.march_rays(rays_o, rays_d, u, float(render_step_size), self.bound,
+                                            self.binaries[0].view(torch.uint8))
         self.packed = (rs, rc)
         return ri, ts, te
 
     # -- occupancy update -------------------------------------------------------------------------
     def _cell_points(self, idx: torch.Tensor) -> torch.Tensor:
-        R = self.resolution
+        R = self._R
         ijk = torch.stack([idx // (R * R), (idx // R) % R, idx % R], -1).float()
         x = (ijk + torch.rand_like(ijk)) / R                       # [0,1]^3, one jittered point per cell
         return x * (2 * self.bound) - self.bound
@@ -69,7 +77,7 @@ class OccupancyGrid(torch.nn.Module):
                              warmup_steps: int = 256, n: int = 16):
         if step % n != 0:
             return
-        R3, dev = self.resolution ** 3, self.occs.device
+        R3, dev = self._R ** 3, self.occs.device
         if step < warmup_steps:
             idx = torch.arange(R3, device=dev)
         else:
@@ -82,8 +90,8 @@ class OccupancyGrid(torch.nn.Module):
         occ = occ_eval_fn(self._cell_points(idx)).reshape(-1).float()
         self.occs[idx] = torch.maximum(self.occs[idx] * ema_decay, occ)
         thre = torch.clamp(self.occs.mean(), max=occ_thre)
-        self.binaries.copy_((self.occs > thre).view_as(self.binaries).to(torch.uint8))
+        self.binaries.copy_((self.occs > thre).view_as(self.binaries))
 
     def set_binary(self, binary: torch.Tensor):
         """Install a binary grid directly (tests / loading an external estimator)."""
-        self.binaries.copy_(binary.to(torch.uint8).view_as(self.binaries))
+        self.binaries.copy_(binary.to(torch.bool).view_as(self.binaries))

@@ -85,32 +85,54 @@ def _bin_points(lib, x, bound):
     return perm, bstart
 
 
-class _GradMaxHint:
-    """max |grad| of a feature-gradient tensor, computed on the fly by the kernel that produced it (mh_field_bwd_data)
-    and handed to the hash-grid backward, which needs it for its fixed-point accumulation -- autograd only carries the
-    tensor, so the device word travels beside it keyed by the tensor's address; a miss just means the grid backward
-    reduces max |grad| itself (one more pass over the gradient)."""
-
-    def __init__(self):
-        self._by_ptr = {}
-
-    def put(self, tensor, words, index):
-        if tensor is not None:
-            self._by_ptr = {k: v for k, v in self._by_ptr.items() if v[0] is words}   # keep only the current producer's
-            self._by_ptr[tensor.data_ptr()] = (words, index, tensor.numel(), torch._C._current_graph_task_id())
-
-    def take(self, grad):
-        """device address of the word, or None; valid only inside the backward pass that produced the hint"""
-        hit = self._by_ptr.pop(grad.data_ptr(), None)
-        if hit is None or hit[2] != grad.numel() or hit[3] != torch._C._current_graph_task_id() or hit[3] < 0:
-            return None
-        return hit[0].data_ptr() + 4 * hit[1]
-
-
-_GMAX = _GradMaxHint()
-
-
 GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B switch: per-point global atomics
+
+
+def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
+    """One forward launch per table at the same points -> list of [M, L*2]."""
+    M = x.shape[0]
+    outs = []
+    for emb in embs:
+        out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
+        _e = TIMER.start()
+        check(lib.mh_grid_encode_fwd(ptr(x), ptr(emb), o_p, r_p, ptr(out), M, L, n_levels, float(bound), int(group), stream()),
+              "mh_grid_encode_fwd")
+        TIMER.stop("mh_grid_encode_fwd", _e)
+        outs.append(out)
+    return outs
+
+
+def _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gmax_ptrs=None):
+    """Embedding (and position) gradients of several tables evaluated at the same points: ONE brick binning shared by all
+    tables.  gmax_ptrs[k]: device address of max|grads[k]| as float bits when its producer reduced it on the fly
+    (mh_field_bwd_data), else None -> the kernel reduces it itself.  -> (g_x or None, [g_emb or None])."""
+    M = x.shape[0]
+    g_x_total, g_embs, binned = None, [], None
+    for k, (emb, grad) in enumerate(zip(embs, grads)):
+        if grad is None:
+            g_embs.append(None)
+            continue
+        grad = grad.contiguous()
+        g_emb = torch.zeros_like(emb)
+        g_x = torch.empty_like(x) if need_dx else None
+        if M > 0 and not GRID_BWD_NAIVE and L == 16:
+            if binned is None:
+                binned = _bin_points(lib, x, bound)
+            _e = TIMER.start()
+            check(lib.mh_grid_encode_bwd_binned(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(binned[0]), ptr(binned[1]),
+                                                ptr(g_emb), ptr(g_x), M, L, n_levels, bound,
+                                                None if gmax_ptrs is None else gmax_ptrs[k], stream()),
+                  "mh_grid_encode_bwd_binned")
+            TIMER.stop("mh_grid_encode_bwd_binned", _e)
+        else:
+            _e = TIMER.start()
+            check(lib.mh_grid_encode_bwd(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(g_emb), ptr(g_x), M, L, n_levels,
+                                         bound, stream()), "mh_grid_encode_bwd")
+            TIMER.stop("mh_grid_encode_bwd", _e)
+        g_embs.append(g_emb)
+        if need_dx:
+            g_x_total = g_x if g_x_total is None else g_x_total + g_x
+    return g_x_total, g_embs
 
 
 class _GridEncode(torch.autograd.Function):
@@ -123,20 +145,11 @@ class _GridEncode(torch.autograd.Function):
         require_gpu(x, *embs)
         lib = _lib.load()
         x = x.detach().contiguous().float()
-        M, L = x.shape[0], len(res_np)
+        L = len(res_np)
         o_np, o_p = _i32arr(offsets_np)
         r_np, r_p = _i32arr(res_np)
-        outs, saved = [], []
-        for emb in embs:
-            embc = emb.detach().contiguous()
-            out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
-            _e = TIMER.start()
-            check(lib.mh_grid_encode_fwd(ptr(x), ptr(embc), o_p, r_p, ptr(out), M, L, n_levels, float(bound), int(group),
-                                         stream()),
-                  "mh_grid_encode_fwd")
-            TIMER.stop("mh_grid_encode_fwd", _e)
-            outs.append(out)
-            saved.append(embc)
+        saved = [emb.detach().contiguous() for emb in embs]
+        outs = _grid_fwd(lib, x, saved, o_p, r_p, L, n_levels, bound, group)
         ctx.save_for_backward(x, *saved)
         ctx.meta = (o_np, r_np, n_levels, float(bound), L)
         return tuple(outs)
@@ -147,34 +160,8 @@ class _GridEncode(torch.autograd.Function):
         x, *embs = ctx.saved_tensors
         o_np, r_np, n_levels, bound, L = ctx.meta
         o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
-        M = x.shape[0]
-        need_dx = ctx.needs_input_grad[0]
-        g_x_total, g_embs = None, []
-        binned = None
-        for emb, grad in zip(embs, grads):
-            if grad is None:
-                g_embs.append(None)
-                continue
-            grad = grad.contiguous()
-            g_emb = torch.zeros_like(emb)
-            g_x = torch.empty_like(x) if need_dx else None
-            if M > 0 and not GRID_BWD_NAIVE and L == 16:
-                if binned is None:
-                    binned = _bin_points(lib, x, bound)
-                _e = TIMER.start()
-                check(lib.mh_grid_encode_bwd_binned(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(binned[0]), ptr(binned[1]),
-                                                    ptr(g_emb), ptr(g_x), M, L, n_levels, bound, _GMAX.take(grad), stream()),
-                      "mh_grid_encode_bwd_binned")
-                TIMER.stop("mh_grid_encode_bwd_binned", _e)
-            else:
-                _e = TIMER.start()
-                check(lib.mh_grid_encode_bwd(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(g_emb), ptr(g_x), M, L, n_levels,
-                                             bound, stream()), "mh_grid_encode_bwd")
-                TIMER.stop("mh_grid_encode_bwd", _e)
-            g_embs.append(g_emb)
-            if need_dx:
-                g_x_total = g_x if g_x_total is None else g_x_total + g_x
-        return (g_x_total, None, None, None, None, None, *g_embs)
+        g_x, g_embs = _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, ctx.needs_input_grad[0])
+        return (g_x, None, None, None, None, None, *g_embs)
 
 
 def grid_encode(x, emb, offsets_np, res_np, bound, max_level=None, group: int = 1):
@@ -328,6 +315,109 @@ def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.
     return ri, ts, te, start, cnt
 
 
+# ------------------------------------------------------------------------------------ field-query glue (csrc/normal.hip)
+class _FdTaps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, topo, eps, bound):
+        require_gpu(x, topo)
+        lib = _lib.load()
+        xc = x.detach().contiguous().float()
+        M, dev = xc.shape[0], xc.device
+        tc = None if topo is None else topo.detach().contiguous().float()
+        C = 0 if tc is None else tc.shape[1]
+        taps = torch.empty(6 * M, 3, device=dev)
+        topo6 = torch.empty(6 * M, C, device=dev) if tc is not None else torch.empty(0, device=dev)
+        check(lib.mh_fd_taps(ptr(xc), ptr(tc), C, float(eps), float(bound), M, ptr(taps), ptr(topo6 if tc is not None else None),
+                             stream()), "mh_fd_taps")
+        ctx.save_for_backward(xc)
+        ctx.meta = (float(eps), float(bound), C, topo is not None)
+        if not ctx.needs_input_grad[0]:
+            ctx.mark_non_differentiable(taps)       # taps of positions without gradient: the field skips its d/dx stage
+        if topo is None or not ctx.needs_input_grad[1]:
+            ctx.mark_non_differentiable(topo6)
+        return taps, topo6
+
+    @staticmethod
+    def backward(ctx, g_taps, g_topo6):
+        lib = _lib.load()
+        (xc,) = ctx.saved_tensors
+        eps, bound, C, has_topo = ctx.meta
+        M, dev = xc.shape[0], xc.device
+        want_x = ctx.needs_input_grad[0] and g_taps is not None
+        want_t = has_topo and ctx.needs_input_grad[1] and g_topo6 is not None
+        g_x = torch.empty(M, 3, device=dev) if want_x else None
+        g_t = torch.empty(M, C, device=dev) if want_t else None
+        if want_x or want_t:
+            check(lib.mh_fd_taps_bwd(ptr(xc), ptr(g_taps.contiguous() if want_x else None),
+                                     ptr(g_topo6.contiguous() if want_t else None), C, eps, bound, M, ptr(g_x), ptr(g_t), stream()),
+                  "mh_fd_taps_bwd")
+        return g_x, g_t, None, None
+
+
+def fd_taps(x, topo, eps: float, bound: float):
+    """-> taps [6M,3] (point-major: +x,-x,+y,-y,+z,-z, clamped to the box), topo6 [6M,C] or None  (model.py:367-376)."""
+    taps, topo6 = _FdTaps.apply(x, topo, eps, bound)
+    return taps, (None if topo is None else topo6)
+
+
+class _FdNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf6, eps):
+        require_gpu(sdf6)
+        lib = _lib.load()
+        s = sdf6.detach().contiguous().float()
+        M, dev = s.shape[0], s.device
+        normal, raw = torch.empty(M, 3, device=dev), torch.empty(M, 3, device=dev)
+        check(lib.mh_fd_normal_fwd(ptr(s), float(eps), M, ptr(normal), ptr(raw), stream()), "mh_fd_normal_fwd")
+        ctx.save_for_backward(s)
+        ctx.eps = float(eps)
+        return normal, raw
+
+    @staticmethod
+    def backward(ctx, g_n, g_r):
+        lib = _lib.load()
+        (s,) = ctx.saved_tensors
+        g = torch.empty_like(s)
+        c = lambda t: None if t is None else t.contiguous()
+        check(lib.mh_fd_normal_bwd(ptr(s), ptr(c(g_n)), ptr(c(g_r)), ctx.eps, s.shape[0], ptr(g), stream()), "mh_fd_normal_bwd")
+        return g, None
+
+
+def fd_normal(sdf6, eps: float):
+    """sdf6 [M,6] -> (normal [M,3] = nan_to_num(safe_normalize(raw)), raw [M,3])   (model.py:377-398)."""
+    return _FdNormal.apply(sdf6, eps)
+
+
+class _SamplePositions(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, ray_idx, ts, te, ray_start, ray_cnt):
+        require_gpu(rays_o, rays_d, ray_idx, ts, te)
+        lib = _lib.load()
+        o, d = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+        M = ts.shape[0]
+        xyz = torch.empty(M, 3, device=o.device)
+        check(lib.mh_sample_positions(ptr(o), ptr(d), ptr(ray_idx), ptr(ts), ptr(te), M, ptr(xyz), stream()), "mh_sample_positions")
+        ctx.save_for_backward(ts, te, ray_start, ray_cnt)
+        ctx.n = o.shape[0]
+        return xyz
+
+    @staticmethod
+    def backward(ctx, g_xyz):
+        lib = _lib.load()
+        ts, te, ray_start, ray_cnt = ctx.saved_tensors
+        g_o, g_d = torch.empty(ctx.n, 3, device=ts.device), torch.empty(ctx.n, 3, device=ts.device)
+        check(lib.mh_sample_positions_bwd(ptr(g_xyz.contiguous()), ptr(ts), ptr(te), ptr(ray_start), ptr(ray_cnt), ctx.n, ptr(g_o),
+                                          ptr(g_d), stream()), "mh_sample_positions_bwd")
+        return g_o, g_d, None, None, None, None, None
+
+
+def sample_positions(rays_o, rays_d, ray_idx, t_starts, t_ends, ray_start, ray_cnt):
+    """xyz [M,3] = rays_o[ri] + rays_d[ri] * (t_starts + t_ends) / 2 (morpheus.py:644-647) for packed, ray-major samples;
+    backward is a per-ray segment sum (no sort, no atomics).  ray_idx int32 [M]; ray_start / ray_cnt int32 [N]."""
+    return _SamplePositions.apply(rays_o, rays_d, ray_idx.contiguous(), t_starts.contiguous(), t_ends.contiguous(),
+                                  ray_start.contiguous(), ray_cnt.contiguous())
+
+
 # ------------------------------------------------------------------------------------ fused MLPs
 def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag):
     n_layers = len(act_off)
@@ -351,26 +441,80 @@ WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640 + 40, 2 * 672     # csrc/mlp.hip: a
 FIELD_ACT_ROWS, FIELD_DPRE_ROWS = 96 + 64 * 5 + 8, 64 * 5 + 32   # activations + 8 rows of ReLU masks
 
 
+class _PackOperands(torch.autograd.Function):
+    """Natural (effective) weights + biases of the nets of one JointPacker -> the kernels' operands, ONCE per step:
+
+        fwd pack  [A fragments | bias packs]         (non-differentiable: the kernels read them)
+        bwd pack  [transposed A fragments]           (non-differentiable)
+        token     [raw_len] uninitialised carrier    (differentiable)
+
+    Every MLP call of the step takes the token as an input and returns `mh_mlp_wgrad`'s raw tile-order gradient
+    (dW tiles | db tiles) as the token's gradient; autograd sums the calls' contributions (ONE add of one flat tensor per
+    extra call instead of one per parameter per call) and this Function's backward maps the sum to the natural layout
+    with one gather.  `zero_bias0`: the first-layer bias of the warp nets reaches its parameter through the per-frame
+    bias0 (model.warp), so its slot in the raw gradient is dropped here."""
+
+    @staticmethod
+    def forward(ctx, jp, zero_bias0, n_w, *params):
+        require_gpu(*params)
+        weights, biases, o = [], [], 0
+        for pk in jp.packers:
+            weights.append([p.detach() for p in params[o:o + len(pk.specs)]])
+            o += len(pk.specs)
+        for pk in jp.packers:
+            biases.append([p.detach() for p in params[o:o + len(pk.specs)]])
+            o += len(pk.specs)
+        assert o == len(params) == n_w
+        fpack, bpack = jp.pack(weights, biases)
+        token = fpack.new_empty(jp.raw_len)
+        ctx.jp, ctx.zero_bias0 = jp, zero_bias0
+        ctx.mark_non_differentiable(fpack, bpack)
+        return fpack, bpack, token
+
+    @staticmethod
+    def backward(ctx, _gf, _gb, g_token):
+        if g_token is None:
+            return (None,) * (3 + sum(2 * len(pk.specs) for pk in ctx.jp.packers))
+        nat_w, nat_b = ctx.jp.unpack_grads(g_token, zero_bias0=ctx.zero_bias0)
+        flat = [g for net in nat_w for g in net] + [g for net in nat_b for g in net]
+        return (None, None, None, *flat)
+
+
+class MLPOperands:
+    """Prepared operands of the warp nets (deform_net + topo_net) or of the field nets (sdf_net + color_net)."""
+
+    def __init__(self, jp, fpack, bpack, token):
+        self.jp, self.fpack, self.bpack, self.token = jp, fpack, bpack, token
+        self.w = [jp.take(fpack, sl) for sl in jp.w]
+        self.b = [jp.take(fpack, sl) for sl in jp.b]
+        self.wT = [jp.take(bpack, sl) for sl in jp.wT]
+
+
+def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[torch.Tensor]) -> MLPOperands:
+    """params_{d,t}: W0x [128,39], W1..W4 [128,128], W5 [n_out,128], b0 (its gradient travels through bias0), b1..b5."""
+    jp = warp_joint_packer()
+    flat = list(params_d[:6]) + list(params_t[:6]) + list(params_d[6:]) + list(params_t[6:])
+    return MLPOperands(jp, *_PackOperands.apply(jp, True, len(flat), *flat))
+
+
+def prepare_field_operands(params: Sequence[torch.Tensor]) -> MLPOperands:
+    """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
+    jp = field_joint_packer()
+    return MLPOperands(jp, *_PackOperands.apply(jp, False, len(params), *params))
+
+
 class _WarpMLP(torch.autograd.Function):
     """deform_net + topo_net on [freq(x), per-slot code bias]  (model.py:412-437).
 
-    params = 12 tensors per net, deform first:  W0x [128,39], W1..W4 [128,128], W5 [n_out,128],
-    b0 (unused here: it lives in bias0), b1..b4 [128], b5 [n_out]  -- natural, effective weights.
-    bias0_{d,t} [n_slots,128] = code_slot @ W0[:,39:].T + b0, built by the caller in torch so that
-    autograd carries the gradient on to the deform code, W0's code columns and b0.
+    bias0_{d,t} [n_slots,128] = code_slot @ W0[:,39:].T + b0, built by the caller in torch so that autograd carries the
+    gradient on to the deform code, W0's code columns and b0.  `token` / `opnd`: see _PackOperands / MLPOperands.
     """
 
     @staticmethod
-    def forward(ctx, x, slot, bias0_d, bias0_t, n_bands, *params):
-        require_gpu(x, bias0_d, bias0_t, *params)
+    def forward(ctx, x, slot, bias0_d, bias0_t, token, n_bands, opnd):
+        require_gpu(x, bias0_d, bias0_t)
         lib = _lib.load()
-        assert len(params) == 24
-        pd, pt_ = params[:12], params[12:]
-        jp = warp_joint_packer()       # both nets' fragments, transposed fragments and bias packs: 2 gathers in all
-        det = lambda ts: [p.detach() for p in ts]
-        fpack, bpack = jp.pack([det(pd[:6]), det(pt_[:6])], [det(pd[6:]), det(pt_[6:])])
-        wd, wt, bd, bt = jp.take(fpack, jp.w[0]), jp.take(fpack, jp.w[1]), jp.take(fpack, jp.b[0]), jp.take(fpack, jp.b[1])
-        wdT, wtT = jp.take(bpack, jp.wT[0]), jp.take(bpack, jp.wT[1])
+        (wd, wt), (bd, bt), (wdT, wtT) = opnd.w, opnd.b, opnd.wT
         x = x.detach().contiguous().float()
         M, dev = x.shape[0], x.device
         need_grad = any(ctx.needs_input_grad)
@@ -383,7 +527,7 @@ class _WarpMLP(torch.autograd.Function):
                               ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
         TIMER.stop("mh_warp_fwd", _e)
         ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
-        ctx.n_bands, ctx.n_slots = n_bands, bias0_d.shape[0]
+        ctx.n_bands, ctx.n_slots, ctx.jp = n_bands, bias0_d.shape[0], opnd.jp
         return deform, topo
 
     @staticmethod
@@ -399,71 +543,129 @@ class _WarpMLP(torch.autograd.Function):
         check(lib.mh_warp_bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts),
                                    ptr(dpre), ptr(g_x), M, stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)
-        act_off, dpre_off, in_pad, out_pad = [], [], [], []
-        for net in range(2):
-            for l in range(6):
-                act_off.append(0 if l == 0 else (64 + net * 640 + (l - 1) * 128) * 32)
-                dpre_off.append((net * 672 + l * 128) * 32)
-                in_pad.append(64 if l == 0 else 128)
-                out_pad.append(32 if l == 5 else 128)
-        raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, act_off, dpre_off, in_pad, out_pad, n_tiles,
-                     dev, "warp")
-        (gw_d, gw_t), (gb_d, gb_t) = warp_joint_packer().unpack_grads(raw)
+        raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
+                     _WARP_WG[3], n_tiles, dev, "warp")
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
-            g_b0d, g_b0t = gb_d[0][None], gb_t[0][None]
+            (od, ot) = ctx.jp.bias0_raw
+            g_b0d, g_b0t = raw[od:od + 128][None], raw[ot:ot + 128][None]
         else:
             dp = dpre.view(n_tiles, WARP_DPRE_ROWS, 32)
             per_pt_d = dp[:, 0:128, :].permute(0, 2, 1).reshape(-1, 128)[:M]
             per_pt_t = dp[:, 672:800, :].permute(0, 2, 1).reshape(-1, 128)[:M]
-            idx = slot.long()
-            g_b0d = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_d)
-            g_b0t = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_t)
-        zero_b0 = lambda g: torch.zeros_like(g)   # b0 itself gets its gradient through bias0
-        grads_d = gw_d + [zero_b0(gb_d[0])] + gb_d[1:]
-        grads_t = gw_t + [zero_b0(gb_t[0])] + gb_t[1:]
-        return (g_x, None, g_b0d, g_b0t, None, *grads_d, *grads_t)
+            if ctx.n_slots == M:          # one slot per sample (model._slots): the per-point rows ARE the answer
+                g_b0d, g_b0t = per_pt_d, per_pt_t
+            else:
+                idx = slot.long()
+                g_b0d = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_d)
+                g_b0t = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_t)
+        return (g_x, None, g_b0d, g_b0t, raw, None, None)
 
 
-def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, params_d: Sequence[torch.Tensor], params_t: Sequence[torch.Tensor]):
-    return _WarpMLP.apply(x, slot, bias0_d, bias0_t, n_bands, *params_d, *params_t)
+def _warp_wg_geometry():
+    act_off, dpre_off, in_pad, out_pad = [], [], [], []
+    for net in range(2):
+        for l in range(6):
+            act_off.append(0 if l == 0 else (64 + net * 640 + (l - 1) * 128) * 32)
+            dpre_off.append((net * 672 + l * 128) * 32)
+            in_pad.append(64 if l == 0 else 128)
+            out_pad.append(32 if l == 5 else 128)
+    return act_off, dpre_off, in_pad, out_pad
+
+
+_WARP_WG = _warp_wg_geometry()
+
+
+def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, opnd: MLPOperands):
+    return _WarpMLP.apply(x, slot, bias0_d, bias0_t, opnd.token, n_bands, opnd)
+
+
+def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad):
+    """-> sdf, sigma, albedo|None, acts|None (parked activations for backward)."""
+    w, b = opnd.w[0], opnd.b[0]
+    M, dev = xc.shape[0], xc.device
+    acts = torch.empty(lib.mh_field_acts_floats(M), device=dev) if need_grad else None
+    sdf, sigma = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    albedo = torch.empty(M, 3, device=dev) if with_color else None
+    _e = TIMER.start()
+    check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands, int(bool(with_color)),
+                           ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd")
+    TIMER.stop("mh_field_fwd", _e)
+    return sdf, sigma, albedo, acts
+
+
+def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
+               need_dx, jp):
+    """Backward-data + weight gradients of the field nets.
+    -> g_xc|None, g_fs, g_fc|None, g_tp|None, g_beta, raw (tile-order weight gradient), gmax (int32[2]: max|g_fs|, max|g_fc|
+    as float bits, reduced on the fly by the kernel for the hash-grid backward's fixed point)."""
+    M, dev = xc.shape[0], xc.device
+    n_tiles = lib.mh_mlp_tiles(M)
+    dpre = torch.empty(lib.mh_field_dpre_floats(M), device=dev)
+    if not with_color:
+        g_albedo = None   # colour rows of the scratch are neither written nor read on this path
+    g_xc = torch.empty(M, 3, device=dev) if need_dx else None   # NULL: the kernel skips the d/dx stage
+    g_fs = torch.empty(M, 32, device=dev)
+    g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
+    g_tp = torch.empty(M, 2, device=dev) if has_topo else None
+    g_bp = torch.empty(n_tiles, device=dev)
+    gmax = torch.zeros(2, dtype=torch.int32, device=dev)
+    c = lambda t: None if t is None else t.contiguous()
+    _e = TIMER.start()
+    check(lib.mh_field_bwd_data(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)),
+                                ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dpre),
+                                ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()),
+          "mh_field_bwd_data")
+    TIMER.stop("mh_field_bwd_data", _e)
+    pk = field_packer()
+    act_rows = [0, 96, 160, 224, 288, 352]
+    dpre_rows = [0, 64, 128, 192, 256, 320]
+    if with_color:
+        raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows],
+                     [r * 32 for r in dpre_rows], pk.wg_in, pk.wg_out, n_tiles, dev, "field")
+    else:   # FD-normal taps: the sdf net only; the colour net's gradients are zero
+        # dP2 has one non-zero row (the sdf output, first row of its second 32-row tile): the kernel parked only that
+        # tile, so layer 2's weight gradient is a 32-row launch on it; the geo rows' gradients are zero
+        wg_out = [pk.wg_out[0], pk.wg_out[1], 32]
+        part = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows[:3]],
+                      [dpre_rows[0] * 32, dpre_rows[1] * 32, (dpre_rows[2] + 32) * 32], pk.wg_in[:3], wg_out, n_tiles, dev,
+                      "field")
+        n01 = pk.wg_in[0] * pk.wg_out[0] + pk.wg_in[1] * pk.wg_out[1]
+        n2 = pk.wg_in[2] * 32
+        nb01 = pk.wg_out[0] + pk.wg_out[1]
+        # full-length raw gradient: [dW s0 s1 | L2 tile 0 = 0 | L2 tile 1 | colour = 0 || db s0 s1 | 0 | sdf tile | 0]
+        raw = part.new_zeros(jp.raw_len)
+        raw[:n01] = part[:n01]
+        raw[n01 + n2:n01 + 2 * n2] = part[n01:n01 + n2]
+        db = part[n01 + n2:]
+        raw[pk.raw_dw:pk.raw_dw + nb01] = db[:nb01]
+        raw[pk.raw_dw + nb01 + 32:pk.raw_dw + nb01 + 64] = db[nb01:]
+    return g_xc, g_fs, g_fc, g_tp, g_bp.sum().reshape(()), raw, gmax
 
 
 class _FieldMLP(torch.autograd.Function):
-    """sdf_net (+Laplace density) and color_net on [freq(xc), hash, topo] / [hash_c, geo]
-    (model.py:273-307, density.py:22-31).
+    """sdf_net (+Laplace density) and color_net on [freq(xc), hash, topo] / [hash_c, geo] with the hash features GIVEN
+    (model.py:273-307, density.py:22-31).  The model itself goes through _FieldQuery (hash grids + nets in one node).
 
-    params: Ws0 [64,73], Ws1 [64,64], Ws2 [33,64], Wc0 [64,64], Wc1 [64,64], Wc2 [3,64],
-            bs0, bs1, bs2, bc0, bc1, bc2   (natural, effective weights)
-    beta: 0-dim device tensor = |beta_param| + 1e-4 (stays on the device: no host sync).
+    beta: 0-dim device tensor = |beta_param| + 1e-4 (stays on the device: no host sync).  `token` / `opnd`: the
+    prepared operands of prepare_field_operands.
     """
 
     @staticmethod
-    def forward(ctx, xc, feat_s, feat_c, topo, beta, n_bands, with_color, *params):
-        require_gpu(xc, feat_s, feat_c, topo, beta, *params)
+    def forward(ctx, xc, feat_s, feat_c, topo, beta, token, n_bands, with_color, opnd):
+        require_gpu(xc, feat_s, feat_c, topo, beta)
         lib = _lib.load()
-        assert len(params) == 12
-        jp = field_joint_packer()
-        fpack, bpack = jp.pack([[p.detach() for p in params[:6]]], [[p.detach() for p in params[6:]]])
-        w, b, wT = jp.take(fpack, jp.w[0]), jp.take(fpack, jp.b[0]), jp.take(bpack, jp.wT[0])
         xc = xc.detach().contiguous().float()
-        M, dev = xc.shape[0], xc.device
         fs = feat_s.detach().contiguous()
         fc = None if feat_c is None else feat_c.detach().contiguous()
         tp = None if topo is None else topo.detach().contiguous()
         beta_c = beta.detach().reshape(1).contiguous().float()
-        need_grad = any(ctx.needs_input_grad)
-        acts = torch.empty(lib.mh_field_acts_floats(M), device=dev) if need_grad else None
-        sdf, sigma = torch.empty(M, device=dev), torch.empty(M, device=dev)
-        albedo = torch.empty(M, 3, device=dev) if with_color else None
-        _e = TIMER.start()
-        check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands,
-                               int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd")
-        TIMER.stop("mh_field_fwd", _e)
-        ctx.save_for_backward(xc, wT, beta_c, acts, sdf, albedo)
+        sdf, sigma, albedo, acts = _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, any(ctx.needs_input_grad))
+        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo)
         ctx.cfg = (n_bands, bool(with_color), topo is not None, feat_c is not None)
+        ctx.jp = opnd.jp
         if albedo is None:
-            albedo = torch.zeros(0, device=dev)
+            albedo = torch.zeros(0, device=xc.device)
             ctx.mark_non_differentiable(albedo)
         return sdf, sigma, albedo
 
@@ -472,55 +674,67 @@ class _FieldMLP(torch.autograd.Function):
         lib = _lib.load()
         xc, wT, beta_c, acts, sdf, albedo = ctx.saved_tensors
         n_bands, with_color, has_topo, has_fc = ctx.cfg
-        M, dev = xc.shape[0], xc.device
-        n_tiles = lib.mh_mlp_tiles(M)
-        dpre = torch.empty(lib.mh_field_dpre_floats(M), device=dev)
-        if not with_color:
-            g_albedo = None   # colour rows of the scratch are neither written nor read on this path
-        g_xc = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL: the kernel skips the d/dx stage
-        g_fs = torch.empty(M, 32, device=dev)
-        g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
-        g_tp = torch.empty(M, 2, device=dev)
-        g_bp = torch.empty(n_tiles, device=dev)
-        gmax = torch.zeros(2, dtype=torch.int32, device=dev)     # max |g_fs|, max |g_fc| as float bits
-        c = lambda t: None if t is None else t.contiguous()
-        _e = TIMER.start()
-        check(lib.mh_field_bwd_data(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)),
-                                    ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color),
-                                    ptr(acts), ptr(dpre), ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax),
-                                    M, stream()), "mh_field_bwd_data")
-        TIMER.stop("mh_field_bwd_data", _e)
-        _GMAX.put(g_fs, gmax, 0)
-        _GMAX.put(g_fc, gmax, 1)
-        pk = field_packer()
-        act_rows = [0, 96, 160, 224, 288, 352]
-        dpre_rows = [0, 64, 128, 192, 256, 320]
-        if with_color:
-            raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows],
-                         [r * 32 for r in dpre_rows], pk.wg_in, pk.wg_out, n_tiles, dev, "field")
-            (gw,), (gb,) = field_joint_packer().unpack_grads(raw)
-        else:   # FD-normal taps: the sdf net only; the colour net's gradients are zero
-            # dP2 has one non-zero row (the sdf output, first row of its second 32-row tile): the kernel parked only that
-            # tile, so layer 2's weight gradient is a 32-row launch on it; the geo rows' gradients are zero
-            wg_out = [pk.wg_out[0], pk.wg_out[1], 32]
-            raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows[:3]],
-                         [dpre_rows[0] * 32, dpre_rows[1] * 32, (dpre_rows[2] + 32) * 32], pk.wg_in[:3], wg_out, n_tiles, dev,
-                         "field")
-            n01 = pk.wg_in[0] * pk.wg_out[0] + pk.wg_in[1] * pk.wg_out[1]
-            n2 = pk.wg_in[2] * 32
-            dw01, dw2, db = raw[:n01], raw[n01:n01 + n2], raw[n01 + n2:]
-            nb01 = pk.wg_out[0] + pk.wg_out[1]
-            z = raw.new_zeros
-            dw_raw = torch.cat([dw01, z(n2), dw2, z(pk.raw_dw - n01 - 2 * n2)])          # [.. | L2 tile 0 = 0 | L2 tile 1 | colour = 0]
-            db_raw = torch.cat([db[:nb01], z(32), db[nb01:], z(pk.raw_db - nb01 - 64)])
-            gw, gb = pk.unpack_grads(dw_raw, db_raw)
-        g_beta = g_bp.sum().reshape(())
-        return (g_xc, g_fs, g_fc, g_tp if has_topo else None, g_beta, None, None, *gw, *gb)
+        g_xc, g_fs, g_fc, g_tp, g_beta, raw, _ = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
+                                                            n_bands, with_color, has_topo, has_fc, ctx.needs_input_grad[0],
+                                                            ctx.jp)
+        return (g_xc, g_fs, g_fc, g_tp, g_beta, raw, None, None, None)
 
 
-def field_mlp(xc, feat_s, feat_c, topo, beta, n_bands, with_color, params: Sequence[torch.Tensor]):
+def field_mlp(xc, feat_s, feat_c, topo, beta, n_bands, with_color, opnd: MLPOperands):
     """-> sdf [M], sigma [M], albedo [M,3] (empty when with_color is False)."""
-    return _FieldMLP.apply(xc, feat_s, feat_c, topo, beta, n_bands, with_color, *params)
+    return _FieldMLP.apply(xc, feat_s, feat_c, topo, beta, opnd.token, n_bands, with_color, opnd)
+
+
+class _FieldQuery(torch.autograd.Function):
+    """get_sigma_albedo (model.py:273-307) as ONE autograd node: hash-grid encode of the sdf (and colour) table at xc ->
+    sdf_net + Laplace density (+ color_net).  Backward runs the field backward, then the brick backward of the tables with
+    max|feature gradient| handed over directly (the field backward-data kernel reduces it on the fly; the brick kernel's
+    fixed-point accumulation needs it) -- the features and their gradients never surface as autograd tensors."""
+
+    @staticmethod
+    def forward(ctx, xc, topo, beta, token, emb_s, emb_c, offsets_np, res_np, n_levels, bound, group, n_bands, opnd):
+        with_color = emb_c is not None
+        require_gpu(xc, topo, beta, emb_s, emb_c)
+        lib = _lib.load()
+        xc = xc.detach().contiguous().float()
+        L = len(res_np)
+        o_np, o_p = _i32arr(offsets_np)
+        r_np, r_p = _i32arr(res_np)
+        embs = [emb_s.detach().contiguous()] + ([emb_c.detach().contiguous()] if with_color else [])
+        feats = _grid_fwd(lib, xc, embs, o_p, r_p, L, n_levels, bound, group)
+        tp = None if topo is None else topo.detach().contiguous()
+        beta_c = beta.detach().reshape(1).contiguous().float()
+        sdf, sigma, albedo, acts = _field_fwd(lib, xc, feats[0], feats[1] if with_color else None, tp, beta_c, n_bands,
+                                              with_color, opnd, any(ctx.needs_input_grad))
+        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo, *embs)
+        ctx.cfg = (n_bands, with_color, topo is not None, o_np, r_np, n_levels, float(bound), L)
+        ctx.jp = opnd.jp
+        if albedo is None:
+            albedo = torch.zeros(0, device=xc.device)
+            ctx.mark_non_differentiable(albedo)
+        return sdf, sigma, albedo
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_sigma, g_albedo):
+        lib = _lib.load()
+        xc, wT, beta_c, acts, sdf, albedo, *embs = ctx.saved_tensors
+        n_bands, with_color, has_topo, o_np, r_np, n_levels, bound, L = ctx.cfg
+        need_dx = ctx.needs_input_grad[0]
+        g_xc, g_fs, g_fc, g_tp, g_beta, raw, gmax = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
+                                                               n_bands, with_color, has_topo, with_color, need_dx, ctx.jp)
+        o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
+        grads = [g_fs] + ([g_fc] if with_color else [])
+        gptrs = [gmax.data_ptr(), gmax.data_ptr() + 4][:len(grads)]
+        g_x_grid, g_embs = _grid_bwd(lib, xc, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gptrs)
+        g_x = (g_xc + g_x_grid) if need_dx else None
+        return (g_x, g_tp, g_beta, raw, g_embs[0], g_embs[1] if with_color else None, None, None, None, None, None, None, None)
+
+
+def field_query(xc, topo, beta, emb_s, emb_c, offsets_np, res_np, bound, max_level, group, n_bands, opnd: MLPOperands):
+    """-> sdf [M], sigma [M], albedo [M,3] (empty when emb_c is None: the sdf-only pass of the finite-difference taps)."""
+    n_levels = effective_levels(max_level, len(res_np))
+    return _FieldQuery.apply(xc, topo, beta, opnd.token, emb_s, emb_c, offsets_np, res_np, n_levels, float(bound), int(group),
+                             n_bands, opnd)
 
 
 class _WeightNormAll(torch.autograd.Function):

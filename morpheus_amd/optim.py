@@ -36,8 +36,6 @@ class FlatAdam(torch.optim.Optimizer):
         plist: List[torch.nn.Parameter] = [p for g in self.param_groups for p in g["params"]]
         if not plist:
             raise ValueError("FlatAdam got an empty parameter list")
-        if len(self.param_groups) > 16:
-            raise NotImplementedError("mh_adam_step takes at most 16 parameter groups")
         dev = plist[0].device
         for p in plist:
             if p.dtype != torch.float32 or p.device != dev or not p.requires_grad:
@@ -47,15 +45,28 @@ class FlatAdam(torch.optim.Optimizer):
                 raise NotImplementedError("FlatAdam: betas/eps are shared by all groups (as in the reference)")
         # every group starts on a 4-element boundary so that the kernel's float4 lanes never straddle two groups' tensors
         # needlessly; the pad elements have zero gradient and never move
+        # segments of the kernel: one per parameter tensor (its own step count and skip flag, as torch.optim.Adam keeps
+        # them) plus one per alignment pad (permanently skipped)
         self._views = []
         off = 0
-        self._seg_end = []
-        for g in self.param_groups:
+        self._seg_end = []          # group boundaries (kept for callers / tests)
+        self._kseg_end, self._kseg_group, self._kseg_param = [], [], []     # kernel segments: end, group index, param index|-1
+        for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
+                self._kseg_param.append(len(self._views))
                 self._views.append((p, off, p.numel()))
                 off += p.numel()
-            off = (off + 3) // 4 * 4
+                self._kseg_end.append(off)
+                self._kseg_group.append(gi)
+            pad = (off + 3) // 4 * 4
+            if pad != off:
+                off = pad
+                self._kseg_end.append(off)
+                self._kseg_group.append(gi)
+                self._kseg_param.append(-1)
             self._seg_end.append(off)
+        if len(self._kseg_end) > 160:
+            raise NotImplementedError("mh_adam_step takes at most 160 segments (parameter tensors + pads)")
         self.n = off
         self.flat_p = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros_like(self.flat_p)
@@ -65,38 +76,35 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat_p[o:o + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[o:o + k].view(p.shape)
         self.bucket = GradBucket.from_layout(self._views, self.n, dev)
-        self._step = 0
-        self._seg_end_c = (ctypes.c_int64 * len(self._seg_end))(*self._seg_end)
+        self._steps = [0] * len(self._views)      # per-parameter step counts (torch.optim.Adam's state['step'])
+        self._kseg_end_c = (ctypes.c_int64 * len(self._kseg_end))(*self._kseg_end)
         self._bind_state()
 
     # ---- torch.optim.Adam-format state -----------------------------------------------------------------------------
     def _bind_state(self):
-        for p, o, k in self._views:
-            self.state[p] = {"step": torch.tensor(float(self._step)),
+        for i, (p, o, k) in enumerate(self._views):
+            self.state[p] = {"step": torch.tensor(float(self._steps[i])),
                              "exp_avg": self.exp_avg[o:o + k].view(p.shape),
                              "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape)}
 
     def state_dict(self):
-        for p, _, _ in self._views:
-            self.state[p]["step"] = torch.tensor(float(self._step))
+        for i, (p, _, _) in enumerate(self._views):
+            self.state[p]["step"] = torch.tensor(float(self._steps[i]))
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        steps = set()
         with torch.no_grad():
-            for p, o, k in self._views:
+            for i, (p, o, k) in enumerate(self._views):
                 st = self.state.get(p, {})
                 if "exp_avg" in st:
                     self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
                     self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-                    steps.add(int(float(st["step"])))
+                    self._steps[i] = int(float(st["step"]))     # per parameter: a freeze_lr run steps the pose group less often
                 else:   # torch's Adam creates state lazily: a parameter that never had a gradient has none
                     self.exp_avg[o:o + k].zero_()
                     self.exp_avg_sq[o:o + k].zero_()
-        if len(steps) > 1:
-            raise NotImplementedError(f"FlatAdam keeps one step count; checkpoint has {sorted(steps)}")
-        self._step = steps.pop() if steps else 0
+                    self._steps[i] = 0
         self._bind_state()
 
     # ---- stepping ---------------------------------------------------------------------------------------------------
@@ -111,21 +119,43 @@ class FlatAdam(torch.optim.Optimizer):
             raise MorpheusHipError("FlatAdam steps on an MI355X only; there is no CPU path")
         lib = _lib.load()
         self.bucket.collect()       # no-op when allreduce_mean() already gathered the gradients
-        self._step += 1
+        # torch.optim.Adam skips a parameter whose gradient is None: no moment decay, no move, no step increment
+        no_grad = self.bucket.missing
+        steps = []
+        for pi in self._kseg_param:
+            if pi < 0 or pi in no_grad:
+                steps.append(0)
+            else:
+                self._steps[pi] += 1
+                steps.append(self._steps[pi])
+        self.bucket.missing = set()
         g0 = self.param_groups[0]
-        lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
-        check(lib.mh_adam_step(ptr(self.flat_p), ptr(self.bucket.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
-                               len(self.param_groups), self._seg_end_c, lrs, float(g0["betas"][0]), float(g0["betas"][1]),
-                               float(g0["eps"]), self._step, stream()), "mh_adam_step")
+        ns = len(self._kseg_end)
+        lrs = (ctypes.c_float * ns)(*[float(self.param_groups[gi]["lr"]) for gi in self._kseg_group])
+        check(lib.mh_adam_step(ptr(self.flat_p), ptr(self.bucket.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n, ns,
+                               self._kseg_end_c, lrs, (ctypes.c_int64 * ns)(*steps), float(g0["betas"][0]),
+                               float(g0["betas"][1]), float(g0["eps"]), stream()), "mh_adam_step")
 
 
 class FlatEMA:
     """Exponential moving average of a FlatAdam bucket (one fused op per update); torch_ema's interface."""
 
-    def __init__(self, optimizer: FlatAdam, decay: float, use_num_updates: bool = True):
+    def __init__(self, optimizer: FlatAdam, decay: float, use_num_updates: bool = True, parameters=None):
+        """parameters: the iterable torch_ema would be given -- the reference passes `self.model.parameters()`
+        (morpheus.py:160-162), whose REGISTRATION order (pose_array, deform_code, deform_net, ...) is the order of
+        `shadow_params` in its checkpoints; without it the optimiser's group order is used (not interchangeable)."""
         if not 0.0 <= decay <= 1.0:
             raise ValueError("Decay must be between 0 and 1")
         self.opt = optimizer
+        by_id = {id(p): (p, o, k) for p, o, k in optimizer._views}
+        if parameters is None:
+            self._order = list(optimizer._views)
+        else:
+            plist = [p for p in parameters if p.requires_grad]
+            missing = [tuple(p.shape) for p in plist if id(p) not in by_id]
+            if missing or len(plist) != len(by_id):
+                raise ValueError(f"FlatEMA: parameters and optimizer disagree ({len(plist)} vs {len(by_id)}; unknown {missing[:3]})")
+            self._order = [by_id[id(p)] for p in plist]
         self.decay = decay
         self.num_updates = 0 if use_num_updates else None
         self.shadow = optimizer.flat_p.detach().clone()
@@ -155,16 +185,26 @@ class FlatEMA:
         self.collected = None
 
     def state_dict(self):
-        per = lambda flat: None if flat is None else [flat[o:o + k].view(p.shape).clone() for p, o, k in self.opt._views]
+        per = lambda flat: None if flat is None else [flat[o:o + k].view(p.shape).clone() for p, o, k in self._order]
         return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": per(self.shadow),
                 "collected_params": per(self.collected)}
 
     @torch.no_grad()
     def load_state_dict(self, sd):
+        for name in ("shadow_params", "collected_params"):
+            lst = sd.get(name)
+            if lst is None:
+                continue
+            if len(lst) != len(self._order):
+                raise ValueError(f"FlatEMA.load_state_dict: {name} has {len(lst)} tensors, expected {len(self._order)}")
+            for (p, o, k), t in zip(self._order, lst):
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError(f"FlatEMA.load_state_dict: {name} shape {tuple(t.shape)} vs parameter {tuple(p.shape)} "
+                                     "(was the EMA built with the same parameter order?)")
         self.decay, self.num_updates = sd["decay"], sd["num_updates"]
-        for (p, o, k), s in zip(self.opt._views, sd["shadow_params"]):
-            self.shadow[o:o + k].copy_(s.reshape(-1))
+        for (p, o, k), t in zip(self._order, sd["shadow_params"]):
+            self.shadow[o:o + k].copy_(t.reshape(-1))
         if sd.get("collected_params") is not None:
             self.collected = torch.zeros_like(self.shadow)
-            for (p, o, k), s in zip(self.opt._views, sd["collected_params"]):
-                self.collected[o:o + k].copy_(s.reshape(-1))
+            for (p, o, k), t in zip(self._order, sd["collected_params"]):
+                self.collected[o:o + k].copy_(t.reshape(-1))

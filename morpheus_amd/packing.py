@@ -311,13 +311,27 @@ class JointPacker:
             dbo += p.raw_db
         self.grad_index = np.concatenate(g)
         self.raw_len = dbo
+        # raw offsets of the FIRST layer's bias gradient of every net (tile-row order == natural order for these layers),
+        # and a copy of the gradient map in which those entries read a zero sentinel appended to the raw vector: the warp
+        # nets' first-layer bias reaches its parameter through the per-frame bias0, not through the raw gradient
+        self.bias0_raw, off = [], raw_dw
+        for p in self.packers:
+            self.bias0_raw.append(off)
+            off += p.raw_db
+        gz = self.grad_index.copy()
+        pos = sum(p.n_weights for p in self.packers)
+        for p in self.packers:
+            gz[pos:pos + p.specs[0].out_dim] = self.raw_len
+            pos += p.n_biases
+        self.grad_index_nob0 = gz
         self._dev: Dict[Tuple[str, int], Dict[str, torch.Tensor]] = {}
 
     def on(self, device: torch.device) -> Dict[str, torch.Tensor]:
         key = (device.type, device.index or 0)
         if key not in self._dev:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-            self._dev[key] = dict(fwd=t(self.fwd_index), bwd=t(self.bwd_index), grad=t(self.grad_index))
+            self._dev[key] = dict(fwd=t(self.fwd_index), bwd=t(self.bwd_index), grad=t(self.grad_index),
+                                  grad_nob0=t(self.grad_index_nob0))
         return self._dev[key]
 
     def pack(self, weights: Sequence[Sequence[torch.Tensor]], biases: Sequence[Sequence[torch.Tensor]]):
@@ -332,11 +346,14 @@ class JointPacker:
     def take(buf: torch.Tensor, sl: Tuple[int, int]) -> torch.Tensor:
         return buf[sl[0]:sl[0] + sl[1]]
 
-    def unpack_grads(self, raw: torch.Tensor):
+    def unpack_grads(self, raw: torch.Tensor, zero_bias0: bool = False):
         """raw [raw_len] = mh_mlp_wgrad's dw_raw | db_raw -> per net (list of natural dW, list of natural db), views of
-        one gathered buffer."""
+        one gathered buffer.  zero_bias0: the first layer's bias gradient of every net comes out as zeros."""
         assert raw.numel() == self.raw_len
-        nat = raw[self.on(raw.device)["grad"]]
+        if zero_bias0:
+            nat = torch.cat([raw, raw.new_zeros(1)])[self.on(raw.device)["grad_nob0"]]
+        else:
+            nat = raw[self.on(raw.device)["grad"]]
         out_w, out_b, o = [], [], 0
         for p in self.packers:
             ws = []

@@ -144,6 +144,12 @@ class HotPathRenderer:
     def render_rays(self, rays_o, rays_d, rays_t, rays_id, H, W, perturb=True, bg_color=None, ambient_ratio=1.0,
                     light_d=None, shading="albedo", real_view=True, cano=False, rays_depth=None, rays_mask=None,
                     optimize_pose=False):
+        with self.model.operand_scope():      # weight operands prepared once for every field query of this call
+            return self._render_rays(rays_o, rays_d, rays_t, rays_id, H, W, perturb, bg_color, ambient_ratio, light_d,
+                                     shading, real_view, cano, rays_depth, rays_mask, optimize_pose)
+
+    def _render_rays(self, rays_o, rays_d, rays_t, rays_id, H, W, perturb, bg_color, ambient_ratio, light_d, shading,
+                     real_view, cano, rays_depth, rays_mask, optimize_pose):
         model, cfg = self.model, self.config
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
@@ -151,7 +157,8 @@ class HotPathRenderer:
         rays_t = rays_t.contiguous().view(-1, 1)
         rays_id = rays_id.contiguous().view(-1, 1)
         if not cano and optimize_pose:
-            rays_o, rays_d = model.pose_optimisation(rays_o, rays_d, rays_id)
+            rows = tuple(prefix) if (self.frame_batched and len(prefix) == 2) else None
+            rays_o, rays_d = model.pose_optimisation(rays_o, rays_d, rays_id, rows=rows)
         if rays_depth is not None:
             rays_depth = rays_depth.contiguous().view(-1, 1)
         if rays_mask is not None:
@@ -182,11 +189,13 @@ class HotPathRenderer:
         xyzs = getattr(self.occupancy_grid, "xyz", None)
         if xyzs is not None:
             self.occupancy_grid.xyz = None             # one use: it belongs to the sampling call above
-        t_positions = None
-        if xyzs is None or rays_o.requires_grad or rays_d.requires_grad or rays_depth is not None:
-            t_positions = (t_starts + t_ends) / 2.0
+        packed = getattr(self.occupancy_grid, "packed", None)    # (ray_start, ray_cnt) of the sampling call above
+        ray_start, ray_cnt = packed if packed is not None else ops.packed_info(ri_long(), N)
+        t_positions = (t_starts + t_ends) / 2.0 if rays_depth is not None else None
         if xyzs is None or rays_o.requires_grad or rays_d.requires_grad:   # pose optimisation: positions carry gradients
-            xyzs = rays_o[ri_long()] + rays_d[ri_long()] * t_positions
+            # xyz = o[ri] + d[ri] * (ts + te) / 2 (morpheus.py:644-647) as one launch; its backward is a per-ray segment sum
+            ri32 = ray_idx32 if ray_idx32.dtype == torch.int32 else ray_idx32.to(torch.int32)
+            xyzs = ops.sample_positions(rays_o, rays_d, ri32, t_starts_, t_ends_, ray_start, ray_cnt)
         # a batch row is one frame: with a single row every sample shares rays_t[0] -- no gather needed
         time_step = rays_t[:1].expand(M_samples, 1) if single_frame else rays_t[ri_long()]
 
@@ -209,8 +218,6 @@ class HotPathRenderer:
         sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, t_light, ratio=ambient_ratio,
                                                                shading=shading, cano=cano, frame_slots=frame_slots)
 
-        packed = getattr(self.occupancy_grid, "packed", None)
-        ray_start, ray_cnt = packed if packed is not None else ops.packed_info(ri_long(), N)
         weights, opacity, depth, rgb_acc = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), rgbs,
                                                          ray_start, ray_cnt)
         opacity, depth = opacity[:, None], depth[:, None]

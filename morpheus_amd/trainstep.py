@@ -173,6 +173,10 @@ class RealViewTrainStep:
         self.r.occupancy_grid.update_every_n_steps(step=self.global_step - 1, occ_eval_fn=occ_eval_fn)
 
     def __call__(self, frame_index: Optional[int] = None, pixel_index: Optional[torch.Tensor] = None):
+        with self.model.operand_scope():      # render_rays and the point loss share one set of prepared weight operands
+            return self._step(frame_index, pixel_index)
+
+    def _step(self, frame_index, pixel_index):
         tr = self.cfg["train"]
         self.global_step += 1
         if tr["progressive_level"]:                                   # morpheus.py:808-813

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/morpheus_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.mh_abi_version() == 1
+    assert lib.mh_abi_version() == 2
     assert lib.mh_status_string(1).decode().startswith("invalid argument")
     # size queries are pure host functions
     assert lib.mh_mlp_tiles(1) == 4 and lib.mh_mlp_tiles(129) == 8
@@ -240,3 +240,21 @@ def test_multicode_sample_matches_per_level_formula():
     assert torch.equal(got, torch.cat(want, -1))
     got.square().sum().backward()
     assert all(float(v.grad.abs().sum()) > 0 for v in mc.volumes)
+
+
+def test_raw_gradient_map_with_bias0_dropped():
+    """JointPacker.unpack_grads(zero_bias0=True): identical to the plain map except that every net's first-layer bias
+    gradient is zero (it reaches its parameter through the per-frame bias0), and bias0_raw points at those entries."""
+    import torch
+    from morpheus_amd.packing import warp_joint_packer
+    jp = warp_joint_packer()
+    raw = torch.randn(jp.raw_len, generator=torch.Generator().manual_seed(3))
+    (wa, ba), (wb, bb) = jp.unpack_grads(raw), jp.unpack_grads(raw, zero_bias0=True)
+    for net in range(2):
+        for l in range(6):
+            assert torch.equal(wa[net][l], wb[net][l])
+            if l == 0:
+                assert float(bb[net][0].abs().sum()) == 0.0 and float(ba[net][0].abs().sum()) > 0
+                assert torch.equal(ba[net][0], raw[jp.bias0_raw[net]:jp.bias0_raw[net] + 128])
+            else:
+                assert torch.equal(ba[net][l], bb[net][l])

@@ -50,7 +50,7 @@ def test_state_dict_interchanges_with_torch_adam():
         ref.step()
     opt = FlatAdam(_groups(a, b, c), betas=(0.9, 0.99), eps=1e-15)
     opt.load_state_dict(ref.state_dict())
-    assert opt._step == 3
+    assert opt._steps == [3, 3, 3]
     assert torch.equal(opt.exp_avg[:15].view(3, 5), ref.state[ra]["exp_avg"])
     assert torch.equal(opt.exp_avg_sq[24:28].view(2, 2), ref.state[rc]["exp_avg_sq"])
     sd = opt.state_dict()
@@ -100,3 +100,41 @@ def test_grad_bucket_custom_layout():
     a, b, c = _params()
     bk = GradBucket.from_layout([(a, 4, 15), (c, 20, 4)], 24, a.device)
     assert a.grad.data_ptr() == bk.flat[4:].data_ptr() and bk.nbytes == 96 and b.grad is None
+
+
+def test_per_parameter_steps_survive_a_freeze_lr_checkpoint():
+    """A reference run with freeze_lr steps the pose group only on real-view iterations (morpheus.py:1399-1424): its
+    torch.optim.Adam checkpoint holds DIFFERENT step counts per parameter.  FlatAdam keeps them per parameter."""
+    a, b, c = _params()
+    ra, rb, rc = (torch.nn.Parameter(t.detach().clone()) for t in (a, b, c))
+    ref = torch.optim.Adam(_groups(ra, rb, rc), betas=(0.9, 0.99), eps=1e-15)
+    for it in range(4):
+        ra.grad, rb.grad = torch.randn_like(ra), torch.randn_like(rb)
+        rc.grad = torch.randn_like(rc) if it % 2 == 0 else None          # the 'pose' group has no gradient every other step
+        ref.step()
+    assert float(ref.state[ra]["step"]) == 4 and float(ref.state[rc]["step"]) == 2
+    opt = FlatAdam(_groups(a, b, c), betas=(0.9, 0.99), eps=1e-15)
+    opt.load_state_dict(ref.state_dict())
+    assert opt._steps == [4, 4, 2]
+    sd = opt.state_dict()
+    assert [float(sd["state"][i]["step"]) for i in range(3)] == [4.0, 4.0, 2.0]
+    assert opt._kseg_end == [15, 22, 24, 28] and opt._kseg_param == [0, 1, -1, 2]   # parameter segments + the alignment pad
+
+
+def test_ema_follows_model_parameter_order_and_validates():
+    """torch_ema's shadow_params follow the order of the iterable it was built from (the reference: model.parameters(),
+    registration order), not the optimiser's group order."""
+    a, b, c = _params()
+    opt = FlatAdam(_groups(a, b, c))
+    ema = FlatEMA(opt, decay=0.9, parameters=[c, a, b])                    # a different order than the groups' (a, b, c)
+    sd = ema.state_dict()
+    assert [tuple(t.shape) for t in sd["shadow_params"]] == [(2, 2), (3, 5), (7,)]
+    assert torch.equal(sd["shadow_params"][0], c.detach()) and torch.equal(sd["shadow_params"][1], a.detach())
+    ema_wrong = FlatEMA(opt, decay=0.9)                                     # optimiser order: shapes do not line up
+    with pytest.raises(ValueError):
+        ema_wrong.load_state_dict(sd)
+    ema_ok = FlatEMA(opt, decay=0.5, parameters=[c, a, b])
+    ema_ok.load_state_dict(sd)
+    assert torch.equal(ema_ok.shadow, ema.shadow)
+    with pytest.raises(ValueError):
+        FlatEMA(opt, decay=0.9, parameters=[a, b])
