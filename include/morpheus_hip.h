@@ -230,6 +230,19 @@ int mh_weight_norm_bwd(int32_t n_layers, const float *const *v_host, const float
                        const float *const *dw_host, float *const *dv_host, float *const *dg_host,
                        const int32_t *rows_host, const int32_t *cols_host, void *stream);
 
+/* Fused form of mh_field_bwd_data + mh_mlp_wgrad for the field nets: one pass per net keeps the weight-gradient
+ * accumulators in registers, so the pre-activation gradients never reach HBM (no `dpre` buffer).  Same inputs / outputs as
+ * mh_field_bwd_data, plus: dgeo_scratch [mh_field_dgeo_floats(M)] (d(geo) handed from the colour launch to the sdf launch;
+ * may be NULL when with_color == 0), workspace [mh_field_bwd_fused_workspace_floats(M)] (per-wave partial sums), and
+ * raw [24 928] = the weight gradient in mh_mlp_wgrad's tile-row format for the layer list s0, s1, s2, c0, c1, c2
+ * (dW tiles | db tiles; the colour part is zero-filled when with_color == 0). */
+int64_t mh_field_bwd_fused_workspace_floats(int64_t M);
+int64_t mh_field_dgeo_floats(int64_t M);
+int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf, const float *g_sigma,
+                       const float *g_albedo, const float *wpackT, const float *beta, int32_t n_bands, int32_t with_color,
+                       const float *acts, float *dgeo_scratch, float *workspace, float *raw, float *g_xc, float *g_feat_s,
+                       float *g_feat_c, float *g_topo, float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream);
+
 /* ---- optimiser step over the flat parameter bucket (the step after the path) ---- */
 /* Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9,0.99), eps=1e-15).step() of morpheus.py:154-155,
  * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned.

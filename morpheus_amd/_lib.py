@@ -52,6 +52,9 @@ _SIGS = {
     "mh_warp_bwd_data": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_field_fwd": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_field_bwd_data": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 8 + [_I64, _P]),
+    "mh_field_bwd_fused_workspace_floats": (_I64, [_I64]),
+    "mh_field_dgeo_floats": (_I64, [_I64]),
+    "mh_field_bwd_fused": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 10 + [_I64, _P]),
     "mh_mlp_wgrad_workspace_floats": (_I64, [_I32, _P, _P, _I64]),
     "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mh_weight_norm_fwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P]),

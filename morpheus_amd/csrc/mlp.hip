@@ -105,11 +105,19 @@ __device__ long long mh_trace[256 * 64];
         if ((threadIdx.x == 0) && (blockIdx.x % 64 == 0) && (blockIdx.x / 64 < 256))       \
             mh_trace[(blockIdx.x / 64) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+// constant-rate (100 MHz) timestamp next to a shader-clock one: slot 62 at the first stamp, 63 at the last -- the ratio of
+// the two spans is the EFFECTIVE SHADER CLOCK the kernel ran at (the chip clocks to its power budget)
+#define MH_STAMP_REAL(slot)                                                                \
+    do {                                                                                   \
+        if ((threadIdx.x == 0) && (blockIdx.x % 64 == 0) && (blockIdx.x / 64 < 256))       \
+            mh_trace[(blockIdx.x / 64) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 extern "C" int mh_trace_read(long long *dst_host) {
     return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(mh_trace), sizeof(long long) * 256 * 64) == hipSuccess ? 0 : 2;
 }
 #else
 #define MH_STAMP(slot) do { } while (0)
+#define MH_STAMP_REAL(slot) do { } while (0)
 #endif
 
 template <int MT>
@@ -146,6 +154,25 @@ __device__ __forceinline__ void mfma_layer(const float (&bin)[KS], f32x16 (&acc)
 #pragma unroll
             for (int t = 0; t < MT; t++)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], bin[4 * q + j], acc[t], 0, 0, 0);
+    }
+}
+
+// acc[mt] = W_tile[mt] . bin, accumulators NOT pre-initialised: the first k-step's MFMA takes the inline constant 0 as its
+// C operand instead of 16 * MT v_mov instructions zeroing the accumulators beforehand (backward-data layers have no bias)
+template <int KS, int MT>
+__device__ __forceinline__ void mfma_layer_z(const f32x4 *__restrict__ w, const float (&bin)[KS], f32x16 (&acc)[MT], int lane) {
+    static_assert(KS % 4 == 0, "k-steps come in quads");
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KS / 4; q++) {
+        f32x4 a[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) a[t] = w[(t * (KS / 4) + q) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], bin[4 * q + j], (q == 0 && j == 0) ? zero : acc[t], 0, 0, 0);
     }
 }
 
@@ -188,12 +215,27 @@ __device__ __forceinline__ void stage_resident(const float *__restrict__ g, int 
     }
 }
 
+// max(x, 0) as ONE v_max_f32: fmaxf() costs two (hipcc first canonicalises its operand with v_max x, x, x), and on gfx950
+// every VALU instruction of the layer epilogue is serial with the fp32 MFMAs (they share the vector ALU's issue)
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
 template <int MT, bool RELU>
 __device__ __forceinline__ void acc_to_bin(const f32x16 (&acc)[MT], float (&bin)[16 * MT]) {
 #pragma unroll
     for (int t = 0; t < MT; t++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) bin[16 * t + r] = RELU ? fmaxf(acc[t][r], 0.f) : acc[t][r];
+        for (int r = 0; r < 16; r++) bin[16 * t + r] = RELU ? relu1(acc[t][r]) : acc[t][r];
+}
+
+// m = (m << 1) | (x > 0) in two VALU instructions: compare into VCC, then add-with-carry m + m + VCC (the C++ form
+// compiles to compare + select + shift + or: 188 instructions per 64 values, this is 128; exact, -0.0 and NaN -> 0)
+__device__ __forceinline__ uint32_t push_gt0(uint32_t m, float x) {
+    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
+    return m;
 }
 
 // ReLU mask of a lane's 64 post-activation values, bit 16t+r <-> bin[16t+r] > 0
@@ -201,8 +243,8 @@ __device__ __forceinline__ uint2 relu_mask64(const float (&bin)[64]) {
     uint32_t m0 = 0, m1 = 0;
 #pragma unroll
     for (int j = 31; j >= 0; j--) {
-        m0 = (m0 << 1) | (bin[j] > 0.f ? 1u : 0u);
-        m1 = (m1 << 1) | (bin[32 + j] > 0.f ? 1u : 0u);
+        m0 = push_gt0(m0, bin[j]);
+        m1 = push_gt0(m1, bin[32 + j]);
     }
     return make_uint2(m0, m1);
 }
@@ -210,8 +252,15 @@ __device__ __forceinline__ uint2 relu_mask64(const float (&bin)[64]) {
 __device__ __forceinline__ uint32_t relu_mask32(const float (&bin)[32]) {
     uint32_t m = 0;
 #pragma unroll
-    for (int j = 31; j >= 0; j--) m = (m << 1) | (bin[j] > 0.f ? 1u : 0u);
+    for (int j = 31; j >= 0; j--) m = push_gt0(m, bin[j]);
     return m;
+}
+
+// apply bit `r` of a ReLU mask word to a value in two VALU instructions: sign-extend the bit to 0 / ~0 (v_bfe_i32) and
+// AND it with the value's bits (the C++ ternary compiles to and + compare + select)
+__device__ __forceinline__ float mask_bit(uint32_t mw, int r, float v) {
+    const int m = __builtin_amdgcn_sbfe(mw, r, 1);
+    return __uint_as_float(__float_as_uint(v) & (uint32_t)m);
 }
 
 // feature-major tile store: row = 32t + acc_row(r,h)
@@ -254,6 +303,24 @@ __device__ __forceinline__ void enc_bin(const float (&x)[3], int h, int n_bands,
     bin[19] = h ? 0.f : x[2];
 }
 
+// d(encoding feature)/dx of enc_bin's 18 sin/cos k-steps from the PARKED encoding instead of 18 more sincosf calls
+// (~2 200 VALU instructions per tile, serial with the fp32 MFMAs): the forward kernels park the encoding k-step-major
+// (row 2k + h = half h's feature of k-step k: sin for h = 0, cos for h = 1; zero for switched-off bands), and
+// d sin(f x)/dx = f cos(f x), d cos(f x)/dx = -f sin(f x) are the OTHER half's parked value times +-f.
+__device__ __forceinline__ void enc_deriv_parked(const float *__restrict__ enc_tile, int pt, int h, float *__restrict__ dsc /*[18]*/) {
+    // keep the 18 loads HERE: hoisted to the top of the kernel (the scheduler's default for loads) they would occupy 18
+    // registers across the whole layer chain, which has none to spare
+    __builtin_amdgcn_sched_barrier(0);
+    const float *base = enc_tile + (1 - h) * TILE + pt;
+    asm volatile("" : "+v"(base)::"memory");
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+        const float f = (float)(1 << (k / 3));
+        const float other = base[2 * k * TILE];
+        dsc[k] = h ? -f * other : f * other;
+    }
+}
+
 // =====================================================================================
 // warp: deform_net + topo_net
 // =====================================================================================
@@ -281,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
     }
     uint2 *mk = tile ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
     MH_STAMP(0);
+    MH_STAMP_REAL(62);
     __syncthreads();
     stage_issue<1280>(wpack_d);
     for (int net = 0; net < 2; net++) {
@@ -350,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
             }
         }
         MH_STAMP(1 + (net * 6 + 5) * 5 + 4);
+        if (net == 1) MH_STAMP_REAL(63);
     }
 }
 
@@ -393,8 +462,7 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
         f32x16 acc[4];
         float dbin[64];
         stage_weights<1024>(wt);
-        acc_zero<4>(acc);
-        mfma_layer<16, 4>(d5, acc, lane);
+        mfma_layer_z<16, 4>(lds_w, d5, acc, lane);
         wt += 4096;
         for (int l = 4; l >= 0; l--) {
             // output of layer l is H_{l+1}; mask by its ReLU (sign bits parked by the forward kernel) and park dPre_l
@@ -404,15 +472,14 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
                 const uint32_t mw = (t < 2 ? m.x : m.y) >> (16 * (t & 1));
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float v = ((mw >> r) & 1u) ? acc[t][r] : 0.f;
+                    const float v = mask_bit(mw, r, acc[t][r]);
                     dbin[16 * t + r] = v;
                     dt[(l * 128 + 32 * t + acc_row(r, h)) * TILE + pt] = v;
                 }
             }
             if (l > 0) {
                 stage_weights<4096>(wt);
-                acc_zero<4>(acc);
-                mfma_layer<64, 4>(dbin, acc, lane);
+                mfma_layer_z<64, 4>(lds_w, dbin, acc, lane);
                 wt += 16384;
             } else if (g_x) {
                 // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5).  Skipped when nobody asks
@@ -420,12 +487,11 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
                 // 128 of the net's 1216 MFMAs
                 stage_weights<2048>(wt);
                 f32x16 e[2];
-                acc_zero<2>(e);
-                mfma_layer<64, 2>(dbin, e, lane);
-                // the encoding derivatives are (re)computed here, once per net, instead of living in 38 registers
-                // across the whole layer chain (the kernel sits at the 256-VGPR limit)
-                float encb[20], dsc[18];
-                enc_bin(xv, h, n_bands, encb, dsc);
+                mfma_layer_z<64, 2>(lds_w, dbin, e, lane);
+                // the encoding derivatives come from the parked encoding (rows 0..35 of the tile), fetched here, once per
+                // net, instead of living in registers across the whole layer chain (the kernel sits at the 256-VGPR limit)
+                float dsc[18];
+                enc_deriv_parked(atile, pt, h, dsc);
 #pragma unroll
                 for (int k = 0; k < 18; k++) {
                     const float de = k < 16 ? e[0][k] : e[1][k - 16];
@@ -625,28 +691,25 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
             }
         }
         store_acc_rows<1>(dtile + 320 * TILE, d2, pt, h);
-            acc_zero<2>(acc);
-        mfma_layer_at<16, 2>(wt, d2, acc, lane);
+        mfma_layer_z<16, 2>(wt, d2, acc, lane);
         wt += 512;
         // mask C2 -> dQ1
         {
             const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[3 * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
+            for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw, j, acc[j >> 4][j & 15]);
         }
         store_acc_rows<2>(dtile + 256 * TILE, dbin, pt, h);
-            acc_zero<2>(acc);
-        mfma_layer_at<32, 2>(wt, dbin, acc, lane);
+        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
         wt += 1024;
         // mask C1 -> dQ0
         {
             const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[2 * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
+            for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw, j, acc[j >> 4][j & 15]);
         }
         store_acc_rows<2>(dtile + 192 * TILE, dbin, pt, h);
-            acc_zero<2>(acc);
-        mfma_layer_at<32, 2>(wt, dbin, acc, lane);
+        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
         wt += 1024;
         if (g_feat_c && live) {
             f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_c + p * 32 + 16 * h);
@@ -697,8 +760,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
         d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
         if (with_color) {
             store_acc_rows<2>(dtile + 128 * TILE, d2, pt, h);
-            acc_zero<2>(acc);
-            mfma_layer_at<32, 2>(wt, d2, acc, lane);
+            mfma_layer_z<32, 2>(wt, d2, acc, lane);
         } else {
             // sdf-only pass (finite-difference taps): dP2 has ONE non-zero row, the sdf output -- tile 1, row 0, i.e.
             // k-step 16 of the 32.  dH2 = W2[sdf,:]^T g_sdf is that single k-step (2 MFMAs instead of 64), and only
@@ -725,8 +787,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
         for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
     }
     store_acc_rows<2>(dtile + 64 * TILE, dbin, pt, h);
-    acc_zero<2>(acc);
-    mfma_layer_at<32, 2>(wt, dbin, acc, lane);
+    mfma_layer_z<32, 2>(wt, dbin, acc, lane);
     wt += 1024;
     // mask S1 -> dP0
     {
@@ -737,12 +798,11 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
     store_acc_rows<2>(dtile, dbin, pt, h);
     // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
     f32x16 e[3];
-    acc_zero<3>(e);
     float gx[3] = {0.f, 0.f, 0.f};
     if (g_xc) {
-        mfma_layer_at<32, 3>(wt, dbin, e, lane);
-        float encb[20], dsc[18];
-        enc_bin(xv, h, n_bands, encb, dsc);
+        mfma_layer_z<32, 3>(wt, dbin, e, lane);
+        float dsc[18];
+        enc_deriv_parked(atile, pt, h, dsc);
 #pragma unroll
         for (int k = 0; k < 18; k++) {
             const float de = k < 16 ? e[0][k] : e[1][k - 16];
@@ -760,8 +820,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
         // nobody asks for d/d(position) (canonical rendering, finite-difference taps): the encoding tile of W0^T and the
         // 18 sincos derivatives are skipped; tiles 1 (topo) and 2 (hash features) are contiguous in the pack
         f32x16 e12[2];
-        acc_zero<2>(e12);
-        mfma_layer_at<32, 2>(wt + 8 * 64, dbin, e12, lane);
+        mfma_layer_z<32, 2>(wt + 8 * 64, dbin, e12, lane);
         e[1] = e12[0];
         e[2] = e12[1];
     }
@@ -797,6 +856,455 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
             if (max_s) atomicMax(gmax + 0, max_s);
             if (max_c) atomicMax(gmax + 1, max_c);
         }
+    }
+}
+
+// =====================================================================================
+// canonical field, FUSED backward: backward-data AND weight gradients in one pass, dPre never leaves the chip.
+//
+// The split form above writes every layer's pre-activation gradient (1.4 KB per point) and mh_mlp_wgrad reads it back
+// together with the parked activations (3.1 KB per point): 9.7 GB of HBM traffic per step at the benchmark size, which
+// bounds both kernels (field nets: 3.9 ms per step against a 1.5 ms MFMA floor).  Here a wave keeps the weight-gradient
+// accumulators of its net IN REGISTERS across all its tiles -- the field nets are small enough: sdf_net 14 336 floats =
+// 224 registers per lane, color_net 10 240 = 160 (the warp nets' 77 824 per net are not) -- so per
+// tile and layer it (1) starts the loads of the layer's parked input activations H_l (feature-major rows = the B operand
+// of the K = points MFMA, straight from HBM), (2) drops dPre_l (column form, in registers) into a private 9 KB LDS
+// scratch and runs the backward-data MFMAs of the layer under the loads' latency, (3) reads dPre_l back ROW-wise (the A
+// operand; row stride 36 floats keeps ds_read_b128 conflict-free and 16-byte aligned) and accumulates dW_l.
+// One wave per SIMD (up to 512 registers), persistent 4-wave blocks, transposed weight packs resident in LDS; the two
+// nets are two launches (color first: it hands d(geo) to the sdf launch through a 4 KB-per-tile scratch) so that either
+// accumulator set fits.  Per-wave partial sums go to the workspace in wgrad_kernel's [chunk][out x in] format and
+// wgrad_reduce_kernel finishes as before.
+// =====================================================================================
+#define FUSED_THREADS 256
+#define SCR_STRIDE 36                         // floats per scratch row (32 points + 4 pad)
+#define SCR_FLOATS (64 * SCR_STRIDE)          // per wave: 64 rows
+extern __shared__ f32x4 lds_fused[];
+
+template <int N_F4>
+__device__ __forceinline__ void stage_fused(const float *__restrict__ g, int dst_f4) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(g);
+    for (int i = threadIdx.x; i < N_F4; i += FUSED_THREADS) lds_fused[dst_f4 + i] = src[i];
+}
+
+// column form (lane = point, registers = rows in accumulator order) -> scratch rows [row][point]
+template <int MT>
+__device__ __forceinline__ void scr_put(float *__restrict__ scr, const float (&v)[16 * MT], int pt, int h) {
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) scr[(32 * t + acc_row(r, h)) * SCR_STRIDE + pt] = v[16 * t + r];
+}
+
+struct RowFrag {
+    f32x4 v[4];   // one feature row, 16 points of this lane half
+};
+
+__device__ __forceinline__ void scr_get(RowFrag &f, const float *__restrict__ scr, int row, int h) {
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(scr + row * SCR_STRIDE + 16 * h);
+#pragma unroll
+    for (int j = 0; j < 4; j++) f.v[j] = p[j];
+}
+
+// parked activation row (feature-major tile [F][32]) -> registers, asynchronously (the caller waits with fused_wait())
+__device__ __forceinline__ void row_load_async(RowFrag &f, const float *__restrict__ tile, int row, int h) {
+    const float *a = tile + (int64_t)row * TILE + 16 * h;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.v[0]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.v[1]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.v[2]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.v[3]) : "v"(a) : "memory");
+}
+
+__device__ __forceinline__ void fused_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// dW[out tile][in tile n] += dPre rows (A, from the scratch) x H rows (B, from HBM) over the tile's 32 points;
+// bsum += row sums of dPre (the bias gradient)
+template <int NI>
+__device__ __forceinline__ void dw_mma(const RowFrag &a, const RowFrag (&b)[NI], f32x16 (&acc)[NI], float &bsum) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bsum += a.v[j][q];
+#pragma unroll
+            for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j][q], b[n].v[j][q], acc[n], 0, 0, 0);
+        }
+}
+
+// partial of this wave in wgrad_kernel's layout: [chunk][out_pad x in_pad], D[row = out (acc_row)][col = in (lane & 31)]
+template <int NI>
+__device__ __forceinline__ void dw_store(float *__restrict__ dw, const f32x16 (&acc)[NI], int mt, int in_pad, int i, int h) {
+#pragma unroll
+    for (int n = 0; n < NI; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, h)) * in_pad + 32 * n + i] = acc[n][r];
+}
+
+struct FusedPart {            // where this launch's per-wave partial sums go (float offsets into the workspace)
+    int64_t dw[3];            // layer-major: [n_chunks][out_pad * in_pad]
+    int64_t db[3];            // [n_chunks][out_pad]
+};
+
+// ---- color_net: Q2 (3 rows) <- g_albedo, Q1, Q0; hands d(geo) to the sdf launch ------------------------------------
+__global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
+    const float *__restrict__ albedo, const float *__restrict__ g_albedo, const float *__restrict__ wpackT,
+    const float *__restrict__ acts, float *__restrict__ dgeo_scr, float *__restrict__ g_feat_c, float *__restrict__ ws,
+    FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5, i = lane & 31;
+    stage_fused<(2048 + 4096 + 4096) / 4>(wpackT, 0);     // TC2 | TC1 | TC0
+    float *scr = reinterpret_cast<float *>(lds_fused + (2048 + 4096 + 4096) / 4) + wave * SCR_FLOATS;
+    __syncthreads();
+    f32x16 w2[2], w1[2][2], w0[2][2];                      // dW of c2 [1 out tile][2 in], c1, c0 [2][2]: 160 registers
+    acc_zero<2>(w2);
+    acc_zero<2>(w1[0]);
+    acc_zero<2>(w1[1]);
+    acc_zero<2>(w0[0]);
+    acc_zero<2>(w0[1]);
+    float b2 = 0.f, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
+    uint32_t max_c = 0;
+    const int chunk = blockIdx.x * (FUSED_THREADS / 64) + wave, n_chunks = gridDim.x * (FUSED_THREADS / 64);
+    for (int64_t tile_id = chunk; tile_id < n_tiles; tile_id += n_chunks) {
+        const int64_t p = tile_id * TILE + pt;
+        const bool live = p < M;
+        const float *atile = acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE);
+        const uint32_t *masks = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE);
+        const f32x4 *wt = lds_fused;
+        RowFrag B[2], A;
+        f32x16 acc[2];
+        float dbin[32];
+        // dQ2 = g_albedo * a * (1 - a)
+        float d2[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) d2[r] = 0.f;
+        if (g_albedo && live && h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float a = albedo[p * 3 + c];
+                d2[c] = g_albedo[p * 3 + c] * a * (1.0f - a);
+            }
+        }
+        const uint32_t mw3 = masks[3 * 64 + lane], mw2 = masks[2 * 64 + lane];
+        // ---- layer c2: input C2 = rows 352..415
+        row_load_async(B[0], atile, 352 + i, h);
+        row_load_async(B[1], atile, 384 + i, h);
+        scr_put<1>(scr, d2, pt, h);
+        mfma_layer_z<16, 2>(wt, d2, acc, lane);
+        wt += 512;
+#pragma unroll
+        for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw3, j, acc[j >> 4][j & 15]);   // mask C2 -> dQ1
+        scr_get(A, scr, i, h);
+        fused_wait();
+        dw_mma<2>(A, B, w2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- layer c1: input C1 = rows 288..351
+        row_load_async(B[0], atile, 288 + i, h);
+        row_load_async(B[1], atile, 320 + i, h);
+        scr_put<2>(scr, dbin, pt, h);
+        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
+        wt += 1024;
+        {
+            float q1[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) q1[j] = mask_bit(mw2, j, acc[j >> 4][j & 15]);   // mask C1 -> dQ0
+            fused_wait();
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                scr_get(A, scr, 32 * mt + i, h);
+                dw_mma<2>(A, B, w1[mt], b1[mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 32; j++) dbin[j] = q1[j];
+        }
+        // ---- layer c0: input [hash_c | geo] = rows 224..287
+        row_load_async(B[0], atile, 224 + i, h);
+        row_load_async(B[1], atile, 256 + i, h);
+        scr_put<2>(scr, dbin, pt, h);
+        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
+        if (live) {
+            if (g_feat_c) {
+                f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_c + p * 32 + 16 * h);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) v[c] = acc[0][4 * q + c];
+                    o[q] = v;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) max_c = max(max_c, __float_as_uint(fabsf(acc[0][r])));
+            }
+        }
+        {   // d(geo), accumulator order, for the sdf launch: [tile][lane][16]
+            f32x4 *o = reinterpret_cast<f32x4 *>(dgeo_scr + (tile_id * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = acc[1][4 * q + c];
+                o[q] = v;
+            }
+        }
+        fused_wait();
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            scr_get(A, scr, 32 * mt + i, h);
+            dw_mma<2>(A, B, w0[mt], b0[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // partial sums of this wave: layers in the launch's order c0, c1, c2 = part.dw[0..2]
+    dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 32 * 64, w2, 0, 64, i, h);
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        dw_store<2>(ws + part.dw[1] + (int64_t)chunk * 64 * 64, w1[mt], mt, 64, i, h);
+        dw_store<2>(ws + part.dw[0] + (int64_t)chunk * 64 * 64, w0[mt], mt, 64, i, h);
+    }
+    b2 += __shfl_xor(b2, 32);
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        b1[mt] += __shfl_xor(b1[mt], 32);
+        b0[mt] += __shfl_xor(b0[mt], 32);
+    }
+    if (h == 0) {
+        ws[part.db[2] + (int64_t)chunk * 32 + i] = b2;
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            ws[part.db[1] + (int64_t)chunk * 64 + 32 * mt + i] = b1[mt];
+            ws[part.db[0] + (int64_t)chunk * 64 + 32 * mt + i] = b0[mt];
+        }
+    }
+    if (gmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) max_c = max(max_c, (uint32_t)__shfl_xor((int)max_c, o));
+        if (lane == 0 && max_c) atomicMax(gmax + 1, max_c);
+    }
+}
+
+// ---- sdf_net (+ Laplace density): P2 <- [d(geo) | g_sdf, g_sigma], P1, P0, d(inputs) ---------------------------------
+template <bool WITH_COLOR>
+__global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
+    const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ g_sdf,
+    const float *__restrict__ g_sigma, const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands,
+    const float *__restrict__ acts, const float *__restrict__ dgeo_scr, float *__restrict__ g_xc,
+    float *__restrict__ g_feat_s, float *__restrict__ g_topo, float *__restrict__ g_beta_partial, float *__restrict__ ws,
+    FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5, i = lane & 31;
+    stage_fused<(4096 + 4096 + 6144) / 4>(wpackT + 2048 + 4096 + 4096, 0);     // TS2 | TS1 | TS0
+    float *scr = reinterpret_cast<float *>(lds_fused + (4096 + 4096 + 6144) / 4) + wave * SCR_FLOATS;
+    __syncthreads();
+    constexpr int MT2 = WITH_COLOR ? 2 : 1;                // sdf-only pass: dP2 has ONE non-zero row (tile 1, row 0)
+    f32x16 w2[MT2][2], w1[2][2], w0[2][3];                 // 64 (32) + 64 + 96 = 224 (192) registers
+#pragma unroll
+    for (int mt = 0; mt < MT2; mt++) acc_zero<2>(w2[mt]);
+    acc_zero<2>(w1[0]);
+    acc_zero<2>(w1[1]);
+    acc_zero<3>(w0[0]);
+    acc_zero<3>(w0[1]);
+    float b2[2] = {0.f, 0.f}, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
+    uint32_t max_s = 0;
+    const float beta = *beta_p;
+    const int chunk = blockIdx.x * (FUSED_THREADS / 64) + wave, n_chunks = gridDim.x * (FUSED_THREADS / 64);
+    for (int64_t tile_id = chunk; tile_id < n_tiles; tile_id += n_chunks) {
+        const int64_t p = tile_id * TILE + pt;
+        const bool live = p < M;
+        const int64_t pc = live ? p : M - 1;
+        const float *atile = acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE);
+        const uint32_t *masks = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE);
+        const f32x4 *wt = lds_fused;
+        RowFrag A;
+        f32x16 acc[2];
+        float dbin[32];
+        // dP2 = [d geo | d sdf]
+        float gs = 0.f, gbeta = 0.f;
+        if (live && h == 0) {
+            const float s = sdf[p];
+            if (g_sdf) gs = g_sdf[p];
+            if (g_sigma) {
+                const float gsg = g_sigma[p];
+                const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+                const float a = fabsf(s) / beta;
+                const float ex = expf(-a);
+                gs += gsg * (-(0.5f / (beta * beta)) * sg * sg * ex);
+                gbeta = gsg * (-(1.0f / (beta * beta)) * (0.5f + 0.5f * sg * expm1f(-a)) +
+                               (1.0f / beta) * (0.5f * sg * ex * (fabsf(s) / (beta * beta))));
+            }
+        }
+        if (g_beta_partial) {
+            float tot = gbeta;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+            if (lane == 0) g_beta_partial[tile_id] = tot;
+        }
+        const uint32_t mw1 = masks[1 * 64 + lane], mw0 = masks[0 * 64 + lane];
+        float d2[32];
+        if (WITH_COLOR) {
+            const f32x4 *gsrc = reinterpret_cast<const f32x4 *>(dgeo_scr + (tile_id * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 v = gsrc[q];
+#pragma unroll
+                for (int c = 0; c < 4; c++) d2[4 * q + c] = v[c];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) d2[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) d2[16 + r] = 0.f;
+        d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
+        // ---- layer s2: input S2 = rows 160..223
+        {
+            RowFrag B[2];
+            row_load_async(B[0], atile, 160 + i, h);
+            row_load_async(B[1], atile, 192 + i, h);
+            scr_put<2>(scr, d2, pt, h);
+            if (WITH_COLOR) {
+                mfma_layer_z<32, 2>(wt, d2, acc, lane);
+            } else {
+                // dH2 = W2[sdf,:]^T g_sdf is the single k-step 16 of the 32 (2 MFMAs instead of 64)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const f32x4 a = wt[(t * 8 + 4) * 64 + lane];
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], gs, z, 0, 0, 0);
+                }
+            }
+            wt += 1024;
+#pragma unroll
+            for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw1, j, acc[j >> 4][j & 15]);   // mask S2 -> dP1
+            fused_wait();
+#pragma unroll
+            for (int mt = 0; mt < MT2; mt++) {
+                scr_get(A, scr, 32 * (WITH_COLOR ? mt : 1) + i, h);
+                dw_mma<2>(A, B, w2[mt], b2[WITH_COLOR ? mt : 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- layer s1: input S1 = rows 96..159
+        {
+            RowFrag B[2];
+            row_load_async(B[0], atile, 96 + i, h);
+            row_load_async(B[1], atile, 128 + i, h);
+            scr_put<2>(scr, dbin, pt, h);
+            mfma_layer_z<32, 2>(wt, dbin, acc, lane);
+            wt += 1024;
+            float q0[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) q0[j] = mask_bit(mw0, j, acc[j >> 4][j & 15]);     // mask S1 -> dP0
+            fused_wait();
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                scr_get(A, scr, 32 * mt + i, h);
+                dw_mma<2>(A, B, w1[mt], b1[mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 32; j++) dbin[j] = q0[j];
+        }
+        // ---- layer s0: input [enc | hash | topo] = rows 0..95 (k-step order)
+        {
+            RowFrag B[3];
+            row_load_async(B[0], atile, 0 + i, h);
+            row_load_async(B[1], atile, 32 + i, h);
+            row_load_async(B[2], atile, 64 + i, h);
+            scr_put<2>(scr, dbin, pt, h);
+            // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
+            f32x16 e[3];
+            if (g_xc) {
+                mfma_layer_z<32, 3>(wt, dbin, e, lane);
+            } else {
+                f32x16 e12[2];
+                mfma_layer_z<32, 2>(wt + 8 * 64, dbin, e12, lane);
+                e[1] = e12[0];
+                e[2] = e12[1];
+            }
+            // the weight gradient first (it frees the 48 registers of the activation rows), the sincos stage after it
+            fused_wait();
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                scr_get(A, scr, 32 * mt + i, h);
+                dw_mma<3>(A, B, w0[mt], b0[mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float gx[3] = {0.f, 0.f, 0.f};
+            if (g_xc) {
+                float dsc[18];
+                enc_deriv_parked(atile, pt, h, dsc);       // S0 rows 0..35 hold the encoding of xc
+#pragma unroll
+                for (int k = 0; k < 18; k++) {
+                    const float de = k < 16 ? e[0][k] : e[1][k - 16];
+                    gx[k % 3] += de * dsc[k];
+                }
+                if (h == 0) {
+                    gx[0] += e[1][2];
+                    gx[2] += e[1][3];
+                } else {
+                    gx[1] += e[1][2];
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
+            }
+            if (live) {
+                if (g_xc && h == 0) {
+                    g_xc[p * 3 + 0] = gx[0];
+                    g_xc[p * 3 + 1] = gx[1];
+                    g_xc[p * 3 + 2] = gx[2];
+                }
+                if (g_topo) g_topo[p * 2 + h] = e[1][4];
+                if (g_feat_s) {
+                    f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_s + p * 32 + 16 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        f32x4 v;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) v[c] = e[2][4 * q + c];
+                        o[q] = v;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) max_s = max(max_s, __float_as_uint(fabsf(e[2][r])));
+                }
+            }
+        }
+    }
+    // partial sums: layers s0, s1, s2 = part.dw[0..2]; the sdf-only pass fills tile 1 of s2 only (tile 0 = zeros)
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        dw_store<3>(ws + part.dw[0] + (int64_t)chunk * 64 * 96, w0[mt], mt, 96, i, h);
+        dw_store<2>(ws + part.dw[1] + (int64_t)chunk * 64 * 64, w1[mt], mt, 64, i, h);
+    }
+    if (WITH_COLOR) {
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++) dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 64 * 64, w2[mt], mt, 64, i, h);
+    } else {
+        f32x16 z[2];
+        acc_zero<2>(z);
+        dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 64 * 64, z, 0, 64, i, h);
+        dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 64 * 64, w2[0], 1, 64, i, h);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        b2[mt] += __shfl_xor(b2[mt], 32);
+        b1[mt] += __shfl_xor(b1[mt], 32);
+        b0[mt] += __shfl_xor(b0[mt], 32);
+    }
+    if (h == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            ws[part.db[2] + (int64_t)chunk * 64 + 32 * mt + i] = b2[mt];
+            ws[part.db[1] + (int64_t)chunk * 64 + 32 * mt + i] = b1[mt];
+            ws[part.db[0] + (int64_t)chunk * 64 + 32 * mt + i] = b0[mt];
+        }
+    }
+    if (gmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
+        if (lane == 0 && max_s) atomicMax(gmax + 0, max_s);
     }
 }
 
@@ -1168,6 +1676,115 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
     const int64_t total = rd.first[rd.n];
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, mh_stream(stream), workspace,
                        dw_raw, rd);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+// ---- fused field backward (backward-data + weight gradients, see field_fused_*_kernel) ---------------------------------
+static const int FUSED_IN[6] = {96, 64, 64, 64, 64, 64};    // raw-gradient layer order: s0, s1, s2, c0, c1, c2
+static const int FUSED_OUT[6] = {64, 64, 64, 64, 64, 32};
+
+static inline int fused_blocks(int64_t n_tiles) {
+    const int64_t need = (n_tiles + FUSED_THREADS / 64 - 1) / (FUSED_THREADS / 64);
+    const int64_t cus = mh_cu_count();
+    return (int)(need < cus ? need : cus);
+}
+
+extern "C" int64_t mh_field_bwd_fused_workspace_floats(int64_t M) {
+    const int64_t chunks = (int64_t)fused_blocks(n_tiles_for(M)) * (FUSED_THREADS / 64);
+    int64_t per = 0;
+    for (int l = 0; l < 6; l++) per += (int64_t)FUSED_IN[l] * FUSED_OUT[l] + FUSED_OUT[l];
+    return chunks * per;
+}
+extern "C" int64_t mh_field_dgeo_floats(int64_t M) { return n_tiles_for(M) * 64 * 16; }
+
+extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
+                                  const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
+                                  int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
+                                  float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
+                                  float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !xc || !sdf || !wpackT || !acts || !workspace || !raw || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
+    if (with_color && (!albedo || !dgeo_scratch)) return MH_ERR_ARG;
+    static int opted = 0;
+    const size_t lds_c = (size_t)(2048 + 4096 + 4096 + 4 * SCR_FLOATS) * sizeof(float);
+    const size_t lds_s = (size_t)(4096 + 4096 + 6144 + 4 * SCR_FLOATS) * sizeof(float);
+    if (!opted) {
+        if (hipFuncSetAttribute((const void *)field_fused_color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess)
+            return MH_ERR_LAUNCH;
+        opted = 1;
+    }
+    const int64_t n_tiles = n_tiles_for(M);
+    const int blocks = fused_blocks(n_tiles);
+    const int64_t chunks = (int64_t)blocks * (FUSED_THREADS / 64);
+    // workspace: [dW partials s0 | s1 | s2 | c0 | c1 | c2][db partials s0 | ... | c2], each [chunks][...]
+    int64_t dw_off[6], db_off[6], off = 0, dw_total = 0, db_total = 0;
+    for (int l = 0; l < 6; l++) {
+        dw_off[l] = off;
+        off += chunks * FUSED_IN[l] * FUSED_OUT[l];
+        dw_total += (int64_t)FUSED_IN[l] * FUSED_OUT[l];
+    }
+    for (int l = 0; l < 6; l++) {
+        db_off[l] = off;
+        off += chunks * FUSED_OUT[l];
+        db_total += FUSED_OUT[l];
+    }
+    FusedPart pc, ps;
+    for (int k = 0; k < 3; k++) {
+        ps.dw[k] = dw_off[k];
+        ps.db[k] = db_off[k];
+        pc.dw[k] = dw_off[3 + k];
+        pc.db[k] = db_off[3 + k];
+    }
+    hipStream_t st = mh_stream(stream);
+    if (with_color) {
+        hipLaunchKernelGGL(field_fused_color_kernel, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT,
+                           acts, dgeo_scratch, g_feat_c, workspace, pc, gmax_bits, M, n_tiles);
+        MH_CHECK_LAUNCH();
+        hipLaunchKernelGGL(field_fused_sdf_kernel<true>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf, g_sigma,
+                           wpackT, beta, (int)n_bands, acts, (const float *)dgeo_scratch, g_xc, g_feat_s, g_topo, g_beta_partial,
+                           workspace, ps, gmax_bits, M, n_tiles);
+    } else {
+        hipLaunchKernelGGL(field_fused_sdf_kernel<false>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf, g_sigma,
+                           wpackT, beta, (int)n_bands, acts, (const float *)nullptr, g_xc, g_feat_s, g_topo, g_beta_partial, workspace,
+                           ps, gmax_bits, M, n_tiles);
+    }
+    MH_CHECK_LAUNCH();
+    // reduce the per-wave partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format)
+    const int n_l = with_color ? 6 : 3;
+    WgReduce rd;
+    rd.n = 2 * n_l;
+    int64_t dw_out = 0, db_out = 0;
+    rd.first[0] = 0;
+    for (int l = 0; l < 6; l++) {
+        if (l < n_l) {
+            rd.chunks[l] = (int32_t)chunks;
+            rd.len[l] = FUSED_IN[l] * FUSED_OUT[l];
+            rd.part_off[l] = dw_off[l];
+            rd.out_off[l] = dw_out;
+            rd.chunks[n_l + l] = (int32_t)chunks;
+            rd.len[n_l + l] = FUSED_OUT[l];
+            rd.part_off[n_l + l] = db_off[l];
+            rd.out_off[n_l + l] = dw_total + db_out;
+        }
+        dw_out += (int64_t)FUSED_IN[l] * FUSED_OUT[l];
+        db_out += FUSED_OUT[l];
+    }
+    for (int sgm = 0; sgm < rd.n; sgm++) rd.first[sgm + 1] = rd.first[sgm] + rd.len[sgm];
+    if (!with_color) {   // the colour net's gradients are zero on the sdf-only pass
+        int64_t dw3 = 0, db3 = 0;
+        for (int l = 0; l < 3; l++) {
+            dw3 += (int64_t)FUSED_IN[l] * FUSED_OUT[l];
+            db3 += FUSED_OUT[l];
+        }
+        if (hipMemsetAsync(raw + dw3, 0, sizeof(float) * (size_t)(dw_total - dw3), st) != hipSuccess ||
+            hipMemsetAsync(raw + dw_total + db3, 0, sizeof(float) * (size_t)(db_total - db3), st) != hipSuccess)
+            return MH_ERR_LAUNCH;
+    }
+    const int64_t total = rd.first[rd.n];
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace, raw, rd);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

@@ -594,8 +594,47 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     return sdf, sigma, albedo, acts
 
 
+FIELD_BWD_SPLIT = os.environ.get("MORPHEUS_FIELD_BWD", "") == "split"   # A/B switch: backward-data + mh_mlp_wgrad
+
+
+def _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
+                     need_dx, jp):
+    """mh_field_bwd_fused: backward-data and weight gradients of the field nets in one pass per net (the pre-activation
+    gradients stay on the chip).  Same returns as _field_bwd."""
+    M, dev = xc.shape[0], xc.device
+    n_tiles = lib.mh_mlp_tiles(M)
+    if not with_color:
+        g_albedo = None
+    g_xc = torch.empty(M, 3, device=dev) if need_dx else None
+    g_fs = torch.empty(M, 32, device=dev)
+    g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
+    g_tp = torch.empty(M, 2, device=dev) if has_topo else None
+    g_bp = torch.empty(n_tiles, device=dev)
+    gmax = torch.zeros(2, dtype=torch.int32, device=dev)
+    dgeo = torch.empty(lib.mh_field_dgeo_floats(M), device=dev) if with_color else None
+    ws = torch.empty(lib.mh_field_bwd_fused_workspace_floats(M), device=dev)
+    raw = torch.empty(jp.raw_len, device=dev)
+    c = lambda t: None if t is None else t.contiguous()
+    _e = TIMER.start()
+    check(lib.mh_field_bwd_fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)),
+                                 ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws),
+                                 ptr(raw), ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()),
+          "mh_field_bwd_fused")
+    TIMER.stop("mh_field_bwd_fused", _e)
+    return g_xc, g_fs, g_fc, g_tp, g_bp.sum().reshape(()), raw, gmax
+
+
 def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
                need_dx, jp):
+    if not FIELD_BWD_SPLIT:
+        return _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo,
+                                has_fc, need_dx, jp)
+    return _field_bwd_split(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
+                            need_dx, jp)
+
+
+def _field_bwd_split(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
+                     need_dx, jp):
     """Backward-data + weight gradients of the field nets.
     -> g_xc|None, g_fs, g_fc|None, g_tp|None, g_beta, raw (tile-order weight gradient), gmax (int32[2]: max|g_fs|, max|g_fc|
     as float bits, reduced on the fly by the kernel for the hash-grid backward's fixed point)."""

@@ -42,6 +42,12 @@ def run(x, tag):
     out = torch.empty(M, 32, device=dev)
     t = timeit(lambda: lib.mh_grid_encode_fwd(x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), out.data_ptr(), M, 16, 16, 1.01, 1, st))
     print(f"   fwd: {t:.3f} ms")
+    # share of the LDS-sized levels: levels 0..3 are dense tables of 32 / 55 / 85 / 125 KB (level 4 = 176 KB exceeds the
+    # 160 KB of LDS); levels >= n_levels are written as zeros by idle lanes, so the launch / store cost is the same in
+    # every row and the differences are the gather cost of the added levels
+    for nl in (1, 4, 5, 6, 10, 16):
+        t = timeit(lambda: lib.mh_grid_encode_fwd(x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), out.data_ptr(), M, 16, nl, 1.01, 1, st), 10)
+        print(f"   fwd, levels 0..{nl - 1:2d} active: {t:.3f} ms")
 
 
 o, d, t, rid = [v.to(dev) for v in synth.frame_rays(0, 128, 128)]

@@ -73,14 +73,15 @@ def pmc_summary(tag):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     os.makedirs(PROF, exist_ok=True)
-    for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b")):
+    for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b"),
+                    ("bench_train_real.log", "train_real"), ("bench_density128.log", "density128"), ("bench_n2.log", "n2_one_gpu_gloo")):
         line = json_line(os.path.join(OUT, log))
         if line:
             open(os.path.join(PROF, f"{tag}_bench_{wl}.json"), "w").write(line)
             print("bench", wl)
-    for d, wl in (("prof", "cfg3"), ("prof_cfg3b", "cfg3b")):
+    for d, wl in (("prof", "cfg3"), ("prof_cfg3b", "cfg3b"), ("prof_train_real", "train_real")):
         f = latest(f"{d}/runc/*_kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(PROF, f"{tag}_bench_{wl}_kernel_stats.csv"))
@@ -91,6 +92,12 @@ def main():
         if lines:
             open(os.path.join(PROF, f"{tag}_parity_report.jsonl"), "w").writelines(lines)
             print("parity", len(lines), "records")
+    for log, name in (("phase_trace.log", "phase_trace_warp_fwd.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
+                      ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt")):
+        src = os.path.join(OUT, log)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(PROF, f"{tag}_{name}"))
+            print("copied", name)
     print("pmc summary", pmc_summary(tag))
 
 

@@ -27,7 +27,7 @@ deform, topo = torch.empty(M, 3, device=dev), torch.empty(M, 2, device=dev)
 acts = None if os.environ.get("MH_TRACE_NOPARK") else torch.empty(lib.mh_warp_acts_floats(M), device=dev)
 st = torch.cuda.current_stream().cuda_stream
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for it in range(3):
+for it in range(int(os.environ.get('MH_TRACE_ITERS', '3'))):
     e0.record()
     rc = lib.mh_warp_fwd(x.data_ptr(), None, b0d.data_ptr(), b0t.data_ptr(), wd.data_ptr(), wt.data_ptr(), bd.data_ptr(),
                          bt.data_ptr(), 6, deform.data_ptr(), topo.data_ptr(), None if acts is None else acts.data_ptr(), M, st)
@@ -40,6 +40,10 @@ assert lib.mh_trace_read(buf) == 0
 t = np.frombuffer(buf, dtype=np.int64).reshape(256, 64).astype(np.float64)
 span = t[:, 60] - t[:, 0]
 print("ticks per traced workgroup: mean %.0f  (min %.0f max %.0f)" % (span.mean(), span.min(), span.max()))
+real = t[:, 63] - t[:, 62]          # the same span on the constant 100 MHz counter
+ok = real > 0
+print("effective shader clock while the traced workgroups ran: %.0f MHz (s_memtime ticks per s_memrealtime tick x 100 MHz)"
+      % (100.0 * (span[ok] / real[ok]).mean()))
 # calibrate: 16384 workgroups / 512 resident => 32 rounds per kernel
 tick_us = None
 names = ["wait+barrier -> burst start", "MFMA burst", "barrier after burst", "DMA issue", "epilogue (ReLU + stores)"]
