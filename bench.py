@@ -405,11 +405,14 @@ def main(argv=None):
                          frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic,
                          bytes_per_launch=round(GRID_FWD_BYTES * pts_per_launch),
                          hbm_measured_gbs=None if traffic is None else round(traffic / secs / 1e9, 1),
-                         l2_sector_gbs=round(l2, 1), l2_sector_frac=round(l2 / L2_PEAK_GBS, 4),
-                         note="achieved = ALGORITHMIC bytes (SURVEY 8d: 1164 B/point) / time; both 3.2 MB tables are L2/MALL "
-                              "resident, so the gathers are cache-served: hbm_measured_gbs is the PMC traffic / time, and "
-                              "l2_sector_gbs prices every 8-byte corner gather at one 64-byte L2 sector (upper bound of the "
-                              "sector traffic; neighbouring corners share sectors) against the 34.5 TB/s aggregate L2")
+                         gathers_per_s=round(GRID_GATHERS_PER_POINT * pts_per_launch / secs / 1e9, 1),
+                         l2_sector_gbs_if_every_gather_missed_l1=round(l2, 1), l2_peak_gbs=L2_PEAK_GBS,
+                         note="achieved = ALGORITHMIC bytes (SURVEY 8d: 1164 B/point) / time -- the yardstick north_star asks "
+                              "for, NOT an HBM utilisation: both 3.2 MB tables are L2/MALL resident, so the gathers are "
+                              "cache-served (hbm_measured_gbs = PMC traffic / time).  What bounds the kernel is the gather rate "
+                              "(gathers_per_s, in G 8-byte gathers/s): at one 64-byte L2 sector per gather it would need more "
+                              "than the 34.5 TB/s aggregate L2 bandwidth, i.e. part of the gathers is served by the per-CU L1 "
+                              "(ray-ordered points share cells); see DESIGN.md section 3")
         bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
         if bwd_name in ktab:
             gbb = GRID_BWD_BYTES * (enc_points / ktab[bwd_name]["calls_per_step"]) / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9
