@@ -393,17 +393,25 @@ def main(argv=None):
             roofline["whole_step"] = dict(flops=step_flops, tflops=round(step_flops / (ms_step * 1e-3) / 1e12, 2),
                                           frac=round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
     roof_hash = None
-    if render_wl and "mh_grid_encode_fwd" in ktab:
-        # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b), averaged over launches
+    if render_wl and ("mh_grid_encode_fwd" in ktab or "mh_grid_encode_fwd2" in ktab):
+        # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b).  The two-table launch
+        # (mh_grid_encode_fwd2: sdf + colour encoder at the same points) does two table-passes per point, reading x once.
         enc_points = (2 * M + (6 * M if args.workload == "cfg3b" else 0))
-        pts_per_launch = enc_points / ktab["mh_grid_encode_fwd"]["calls_per_step"]
-        secs = ktab["mh_grid_encode_fwd"]["avg_ms"] * 1e-3
-        gb = GRID_FWD_BYTES * pts_per_launch / secs / 1e9
+        if "mh_grid_encode_fwd2" in ktab:
+            fwd_key = "mh_grid_encode_fwd2"
+            pts_per_launch = 2 * M                      # table-passes in that launch
+            fwd_bytes = (2 * GRID_FWD_BYTES - 12) / 2.0  # algorithmic bytes per table-pass (x is read once for both)
+        else:
+            fwd_key = "mh_grid_encode_fwd"
+            pts_per_launch = enc_points / ktab[fwd_key]["calls_per_step"]
+            fwd_bytes = GRID_FWD_BYTES
+        secs = ktab[fwd_key]["avg_ms"] * 1e-3
+        gb = fwd_bytes * pts_per_launch / secs / 1e9
         l2 = GRID_GATHERS_PER_POINT * 64 * pts_per_launch / secs / 1e9
-        traffic = pmc_traffic("grid_fwd_kernel") if (full and args.workload != "cfg3b") else None
+        traffic = pmc_traffic("grid_fwd_kernel<true>" if fwd_key.endswith("2") else "grid_fwd_kernel") if (full and args.workload != "cfg3b") else None
         roof_hash = dict(kernel="grid_fwd_kernel", bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic,
-                         bytes_per_launch=round(GRID_FWD_BYTES * pts_per_launch),
+                         bytes_per_launch=round(fwd_bytes * pts_per_launch), launch=fwd_key,
                          hbm_measured_gbs=None if traffic is None else round(traffic / secs / 1e9, 1),
                          gathers_per_s=round(GRID_GATHERS_PER_POINT * pts_per_launch / secs / 1e9, 1),
                          l2_sector_gbs_if_every_gather_missed_l1=round(l2, 1), l2_peak_gbs=L2_PEAK_GBS,

@@ -55,6 +55,11 @@ const char *mh_status_string(int status);
 int mh_grid_encode_fwd(const float *x, const float *emb, const int32_t *offsets_host,
                        const int32_t *res_host, float *out, int64_t M, int32_t L, int32_t n_levels,
                        float bound, int32_t group, void *stream);
+/* Two tables of identical level geometry at the same points in one launch (the sdf and colour encoders, model.py:144-157):
+ * cell location, row indices and corner weights are computed once; results are bit-identical to two mh_grid_encode_fwd calls. */
+int mh_grid_encode_fwd2(const float *x, const float *emb_a, const float *emb_b, const int32_t *offsets_host,
+                        const int32_t *res_host, float *out_a, float *out_b, int64_t M, int32_t L, int32_t n_levels,
+                        float bound, void *stream);
 /* grad: [M, L*2]; grad_emb: [rows,2] ACCUMULATED into (caller zeroes it, as grid.py:84 does);
  * grad_x: NULL or [M,3], receives d/dx (the 1/(2*bound) chain factor included).  The slope uses
  * the kernel's dy_dx definition, which ignores the border clamp (gridencoder.cu:205-247). */

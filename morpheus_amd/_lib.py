@@ -18,6 +18,7 @@ _SIGS = {
     "mh_abi_version": (ctypes.c_int, []),
     "mh_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mh_grid_encode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _I32, _P]),
+    "mh_grid_encode_fwd2": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_grid_encode_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_grid_bin_workspace_ints": (_I64, []),
     "mh_grid_bin_bricks": (_I32, []),

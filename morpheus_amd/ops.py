@@ -86,11 +86,23 @@ def _bin_points(lib, x, bound):
 
 
 GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B switch: per-point global atomics
+# A/B switch: "two" = both tables of a query in ONE forward launch (mh_grid_encode_fwd2: shared indices and weights).
+# Measured on MI355X (cfg3, same box): 1.05 ms against 2 x 0.43 = 0.86 ms for two launches -- twice the gathers in flight per
+# lane cost more occupancy than the shared index arithmetic saves -- so one launch per table stays the default.
+GRID_FWD_TWO = os.environ.get("MORPHEUS_GRID_FWD", "") == "two"
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
     """One forward launch per table at the same points -> list of [M, L*2]."""
     M = x.shape[0]
+    if len(embs) == 2 and int(group) == 1 and GRID_FWD_TWO:
+        out_a = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
+        out_b = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
+        _e = TIMER.start()
+        check(lib.mh_grid_encode_fwd2(ptr(x), ptr(embs[0]), ptr(embs[1]), o_p, r_p, ptr(out_a), ptr(out_b), M, L, n_levels,
+                                      float(bound), stream()), "mh_grid_encode_fwd2")
+        TIMER.stop("mh_grid_encode_fwd2", _e)
+        return [out_a, out_b]
     outs = []
     for emb in embs:
         out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)

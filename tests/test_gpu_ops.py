@@ -527,3 +527,23 @@ def test_field_query_glue_vs_torch():
     assert_close(ob.grad, oa.grad, 1e-5, "d xyz / d o", floor=1e-2)
     assert_close(db.grad, da.grad, 1e-5, "d xyz / d d", floor=1e-2)
     assert float(ob.grad[5].abs().sum()) == 0.0 and float(db.grad[40].abs().sum()) == 0.0
+
+
+def test_two_table_forward_is_bit_identical_to_two_launches():
+    """mh_grid_encode_fwd2 (sdf + colour table at the same points, one launch, shared indices / weights) against two
+    mh_grid_encode_fwd launches, incl. out-of-range points and a reduced level count; gradients unchanged."""
+    from morpheus_amd import ops
+    emb, offs, res = _grid_setup()
+    emb_b = synth.hash_tensor(tuple(emb.shape), 9011, 0.1)
+    x = synth.hash_tensor((5003, 3), 9012, 1.1).to(DEV)
+    old = ops.GRID_FWD_TWO
+    try:
+        for ml in (None, 0.5):
+            ops.GRID_FWD_TWO = True
+            a2, b2 = ops.grid_encode_multi(x, (emb.to(DEV), emb_b.to(DEV)), offs, res, 1.01, ml)
+            ops.GRID_FWD_TWO = False
+            a1, b1 = ops.grid_encode_multi(x, (emb.to(DEV), emb_b.to(DEV)), offs, res, 1.01, ml)
+            assert torch.equal(a2, a1) and torch.equal(b2, b1)
+            assert torch.equal(a1, ops.grid_encode(x, emb.to(DEV), offs, res, 1.01, ml))
+    finally:
+        ops.GRID_FWD_TWO = old
