@@ -1376,13 +1376,12 @@ __device__ __forceinline__ void wg_mma(const WgFrag<IT> &f, f32x16 (&acc)[IT], f
 }
 
 template <int IT>
-__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
-                                                       int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
-                                                       int dpre_off, int out_pad, float *__restrict__ dw_part,
-                                                       float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
+__device__ __forceinline__ void wgrad_body(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                           int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off, int dpre_off,
+                                           int out_pad, float *__restrict__ dw_part, float *__restrict__ db_part,
+                                           int64_t n_tiles, int n_chunks, int chunk) {
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int chunk = blockIdx.x;
     // tiles are dealt round-robin: at any instant the resident workgroups read NEIGHBOURING tiles (172 KB apart,
     // spread over all HBM channels) rather than addresses a fixed 2^20-multiple apart (channel camping)
     const int64_t st = n_chunks;
@@ -1436,8 +1435,44 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__
     if (h == 0) db_part[(int64_t)chunk * out_pad + 32 * mt + i] = bsum;
 }
 
-// sum the per-chunk partials of every layer in one launch
+template <int IT>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                       int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                                       int dpre_off, int out_pad, float *__restrict__ dw_part,
+                                                       float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
+    wgrad_body<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, out_pad, dw_part, db_part, n_tiles,
+                   n_chunks, (int)blockIdx.x);
+}
+
+// All layers of a net group in ONE launch: block b belongs to the layer whose block range holds it.  Used for small
+// batches, where one launch per layer (12 for the warp nets) is mostly ramp-up, drain and launch gaps; big batches keep
+// the per-layer launches (see mh_mlp_wgrad).
 #define WG_MAX_LAYERS 16
+struct WgAll {
+    int32_t n;
+    int32_t first_block[WG_MAX_LAYERS + 1];
+    int32_t act_off[WG_MAX_LAYERS], dpre_off[WG_MAX_LAYERS], out_pad[WG_MAX_LAYERS], in_tiles[WG_MAX_LAYERS];
+    int32_t chunks[WG_MAX_LAYERS];
+    int64_t dw_off[WG_MAX_LAYERS], db_off[WG_MAX_LAYERS];
+};
+
+__global__ __launch_bounds__(256, 1) void wgrad_all_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                           int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                                                           float *__restrict__ ws, WgAll d, int64_t n_tiles) {
+    int l = 0;
+    while (l < d.n - 1 && (int)blockIdx.x >= d.first_block[l + 1]) l++;
+    const int chunk = (int)blockIdx.x - d.first_block[l];
+    if ((int)(threadIdx.x >> 6) >= d.out_pad[l] / 32) return;      // layers with fewer than four 32-row output tiles
+    float *dw = ws + d.dw_off[l], *db = ws + d.db_off[l];
+    switch (d.in_tiles[l]) {
+        case 1: wgrad_body<1>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
+        case 2: wgrad_body<2>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
+        case 3: wgrad_body<3>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
+        default: wgrad_body<4>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
+    }
+}
+
+// sum the per-chunk partials of every layer in one launch
 struct WgReduce {
     int32_t n;
     int32_t chunks[2 * WG_MAX_LAYERS];
@@ -1643,22 +1678,41 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
     for (int l = 0; l < n_layers; l++) dw_total += (int64_t)in_feats_host[l] * out_feats_host[l];
     if (db_raw != dw_raw + dw_total) return MH_ERR_ARG;  // dw_raw and db_raw must be one contiguous buffer (checked BEFORE any launch)
     rd.first[0] = 0;
+    // One launch per layer for big batches, ONE launch for all layers for small ones (measured on MI355X, same box):
+    // at 2 M points the merged launch is slower (warp nets 6.6 vs 6.0 ms: workgroups of different layers stream
+    // different 2 GB regions at once), at the 2 k-140 k-point calls of a training step it is faster (1.11 vs 1.28 ms
+    // per step: the twelve launches are mostly ramp-up and drain).  MORPHEUS_WGRAD=per_layer / merged forces either.
+    static const char *wg_mode = getenv("MORPHEUS_WGRAD");
+    const bool per_layer = wg_mode ? (wg_mode[0] == 'p') : (n_tiles >= 16384);
+    WgAll all;
+    all.n = n_layers;
+    all.first_block[0] = 0;
     for (int l = 0; l < n_layers; l++) {
         const int in = in_feats_host[l], out = out_feats_host[l];
         const int chunks = wg_chunks(out, n_tiles);
-        const dim3 grid((unsigned)chunks), block((unsigned)(out / 32) * 64);
+        all.act_off[l] = act_off_host[l];
+        all.dpre_off[l] = dpre_off_host[l];
+        all.out_pad[l] = out;
+        all.in_tiles[l] = in / 32;
+        all.chunks[l] = chunks;
+        all.dw_off[l] = dw_poff[l];
+        all.db_off[l] = db_poff[l];
+        all.first_block[l + 1] = all.first_block[l] + chunks;
+        if (per_layer) {
+            const dim3 grid((unsigned)chunks), block((unsigned)(out / 32) * 64);
 #define WG_LAUNCH(IT)                                                                                         \
     hipLaunchKernelGGL(wgrad_kernel<IT>, grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats,     \
                        dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, workspace + dw_poff[l], \
                        workspace + db_poff[l], n_tiles, chunks)
-        switch (in / 32) {
-            case 1: WG_LAUNCH(1); break;
-            case 2: WG_LAUNCH(2); break;
-            case 3: WG_LAUNCH(3); break;
-            default: WG_LAUNCH(4); break;
-        }
+            switch (in / 32) {
+                case 1: WG_LAUNCH(1); break;
+                case 2: WG_LAUNCH(2); break;
+                case 3: WG_LAUNCH(3); break;
+                default: WG_LAUNCH(4); break;
+            }
 #undef WG_LAUNCH
-        MH_CHECK_LAUNCH();
+            MH_CHECK_LAUNCH();
+        }
         // reduction segments: dW of layer l, then (second half) db of layer l; both outputs live in ONE buffer:
         // out = dw_raw for e < dw_total, db_raw is addressed relative to dw_raw via out_off (caller passes them contiguous)
         rd.chunks[l] = chunks;
@@ -1671,6 +1725,11 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
         rd.part_off[n_layers + l] = db_poff[l];
         rd.out_off[n_layers + l] = dw_total + db_out;
         db_out += out;
+    }
+    if (!per_layer) {
+        hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)all.first_block[n_layers]), dim3(256), 0, mh_stream(stream), acts,
+                           dpre, acts_tile_floats, dpre_tile_floats, workspace, all, n_tiles);
+        MH_CHECK_LAUNCH();
     }
     for (int s = 0; s < rd.n; s++) rd.first[s + 1] = rd.first[s] + rd.len[s];
     const int64_t total = rd.first[rd.n];
