@@ -39,6 +39,32 @@ __device__ __forceinline__ void burst(const f32x4 *w, const float (&bin)[64], f3
     }
 }
 
+// same bytes as 16 dwordx4 stores per lane (what a [row/4][point][4] parked layout would allow)
+__device__ __forceinline__ void epilogue4(const f32x16 (&acc)[4], float (&bin)[64], float *park, int lane) {
+#pragma unroll
+    for (int i = 0; i < 64; i += 4) {
+        f32x4 y;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float t;
+            asm("v_max_f32 %0, 0, %1" : "=v"(t) : "v"(acc[(i + c) >> 4][(i + c) & 15] * 0.37f + 0.011f));
+            bin[i + c] = t;
+            y[c] = t;
+        }
+        *reinterpret_cast<f32x4 *>(park + (i / 4) * 256 + lane * 4) = y;     // 16 stores of 1 KB per wave
+    }
+}
+
+// ReLU only: no parking (inference form)
+__device__ __forceinline__ void epilogue0(const f32x16 (&acc)[4], float (&bin)[64], float *park, int lane) {
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        float y;
+        asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(acc[i >> 4][i & 15] * 0.37f + 0.011f));
+        bin[i] = y;
+    }
+}
+
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[4], float (&bin)[64], float *park, int lane) {
 #pragma unroll
     for (int i = 0; i < 64; i++) {
@@ -49,7 +75,8 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[4], float (&bin)[64
     }
 }
 
-// P: product-like
+// P: product-like; EPI selects the epilogue: 0 = 64 dword stores, 1 = 16 dwordx4 stores, 2 = no stores
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void kP(float *out, const float *in, const float *wts, float *park, int layers) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 *lw = lds_dyn;
@@ -66,7 +93,10 @@ __global__ __launch_bounds__(256, 2) void kP(float *out, const float *in, const 
         burst(lw, bin, acc, lane);
         __syncthreads();
         dma_layer(src + (size_t)((l + 1) & 7) * 4096, lw, threadIdx.x, 256);
-        epilogue(acc, bin, mypark + (size_t)(l & 15) * (size_t)gridDim.x * 4 * 4096, lane);
+        float *pk = mypark + (size_t)(l & 15) * (size_t)gridDim.x * 4 * 4096;
+        if (EPI == 0) epilogue(acc, bin, pk, lane);
+        else if (EPI == 1) epilogue4(acc, bin, pk, lane);
+        else epilogue0(acc, bin, pk, lane);
     }
     float s = 0;
     for (int i = 0; i < 64; i++) s += bin[i];
@@ -134,9 +164,12 @@ void run(const char *name, K kern, int blocks, int threads, size_t lds) {
     hipFree(out); hipFree(in); hipFree(wts); hipFree(park);
 }
 int main() {
-    run("P: 2 x 4-wave workgroups per CU (product structure)", kP, 512, 256, 65536);
+    run("P: 2 x 4-wave workgroups per CU (product structure)", kP<0>, 512, 256, 65536);
     run("Q: 1 x 8-wave workgroup per CU, ping-pong phases", kQ, 256, 512, 131072);
-    run("P again", kP, 512, 256, 65536);
+    run("P again", kP<0>, 512, 256, 65536);
     run("Q again", kQ, 256, 512, 131072);
+    run("P with 16 dwordx4 parking stores instead of 64 dword", kP<1>, 512, 256, 65536);
+    run("P without parking stores", kP<2>, 512, 256, 65536);
+    run("P with 16 dwordx4 parking stores (again)", kP<1>, 512, 256, 65536);
     return 0;
 }
