@@ -50,8 +50,9 @@ WORKLOADS = ["cfg3", "cfg2", "cfg3b", "train_real", "density128"]
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default 20 (32 for train_real: two occupancy refreshes)")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (32 for train_real: two occupancy refreshes; 60 for "
+                                                            "cfg2, whose 5 ms steps need a longer timed region)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 5 (15 for cfg2)")
     ap.add_argument("--workload", default="cfg3", choices=WORKLOADS,
                     help="cfg3: deform field, albedo (headline); cfg2: canonical only; cfg3b: deform + albedo_normal "
                          "shading (FD normals); train_real: the reference's real-view training step; density128: "
@@ -68,7 +69,9 @@ def parse_args(argv=None):
                          "disables the per-kernel event timers")
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 32 if args.workload == "train_real" else 20
+        args.steps = {"train_real": 32, "cfg2": 60}.get(args.workload, 20)
+    if args.warmup is None:
+        args.warmup = 15 if args.workload == "cfg2" else 5
     if args.rays is None:
         args.rays = 2048 if args.workload == "train_real" else 128 * 128
     return args
@@ -297,6 +300,8 @@ def main(argv=None):
     step = wl["step"]
     sync = (lambda: None) if stub else torch.cuda.synchronize
 
+    timers_on = rank == 0 and not stub and not args.no_kernel_timers and not args.graph
+    ops.TIMER.reset(enabled=timers_on)          # warm-up steps also fill the timer's event pool
     for _ in range(args.warmup):
         step()
     graph = None
@@ -316,7 +321,7 @@ def main(argv=None):
         def step():                                  # noqa: F811 -- replay the captured step
             graph.replay()
             return loss_g
-    ops.TIMER.reset(enabled=(rank == 0 and not stub and not args.no_kernel_timers and graph is None))
+    ops.TIMER.reset(enabled=timers_on)
     if world > 1:
         dist.barrier()
     sync()

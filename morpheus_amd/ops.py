@@ -23,26 +23,36 @@ from .packing import field_joint_packer, field_packer, warp_joint_packer, warp_p
 
 class KernelTimer:
     """Optional per-C-ABI-call timing with events recorded on the launch stream (torch's current
-    stream, which is the one handed to the library).  Used by bench.py for the roofline numbers."""
+    stream, which is the one handed to the library).  Used by bench.py for the roofline numbers.
+    Events come from a pool that is recycled at reset(): creating two fresh events per call costs the host 20-50 us,
+    which a short step (cfg2: 5 ms of GPU work, ~12 timed calls) would feel."""
 
     def __init__(self):
         self.enabled = False
         self.records = {}
+        self._pool, self._used = [], 0
 
     def reset(self, enabled: bool):
-        self.enabled, self.records = enabled, {}
+        self.enabled, self.records, self._used = enabled, {}, 0
+
+    def _event(self):
+        if self._used == len(self._pool):
+            self._pool.append(torch.cuda.Event(enable_timing=True))
+        e = self._pool[self._used]
+        self._used += 1
+        return e
 
     def start(self):
         if not self.enabled:
             return None
-        e = torch.cuda.Event(enable_timing=True)
+        e = self._event()
         e.record()
         return e
 
     def stop(self, name: str, e0):
         if e0 is None:
             return
-        e1 = torch.cuda.Event(enable_timing=True)
+        e1 = self._event()
         e1.record()
         self.records.setdefault(name, []).append((e0, e1))
 
