@@ -109,15 +109,23 @@ class GradBucket:
             return
         a, b = self._early_span
         seg = self.flat[a:b]
-        if seg.is_cuda:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=seg.device)
-            cur = torch.cuda.current_stream(seg.device)      # the autograd thread's stream: the copies above are on it
-            self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
+        try:
+            if seg.is_cuda:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=seg.device)
+                cur = torch.cuda.current_stream(seg.device)      # the autograd thread's stream: the copies above are on it
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+            else:
                 self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
-        else:
-            self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+        except Exception as e:      # noqa: BLE001 -- never lose a step to the overlap: fall back to the single exchange
+            import warnings
+            warnings.warn(f"early gradient exchange disabled ({type(e).__name__}: {e}); using one all-reduce after backward")
+            self._early_work = []
+            for h in self._early_hooks:
+                h.remove()
+            self._early_hooks, self._early = [], {}
 
     def zero(self):
         """Start a step: clear the bucket and detach `p.grad`, so that autograd hands each parameter its fresh gradient
