@@ -437,6 +437,49 @@ def gen_extras():
     g["realview|loss"] = npf(total)
     for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
         g["realview|grad|" + kk] = v
+    # ---- virtual-view training call: lambertian shading, orientation loss and the 2-D normal image (accumulated with the
+    #      LIVE weights, morpheus.py:775) -- no random draws on this path
+    hw2, S2 = 16, 32
+    o, d, t, rid = synth.frame_rays(25, hw2, hw2)
+    N2 = o.shape[1]
+    smp2 = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(N2), S2, 1.01)
+    light2 = ofield.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    m, cfg = build_ref_model(synth.make_state("b"), None)
+    m.train()
+    cfg["train"].update(normal_smooth_2d=0.1, normal_smooth_3d=0.0, normal_smoothness=0.0)
+    sampler = _PresetSampler()
+    sampler.samples = smp2
+    fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg, dataset=types.SimpleNamespace(num_frames=200))
+    res = ref_morpheus.MorpheuS.render_rays(fake, o, d, t, rid, hw2, hw2, bg_color=torch.tensor([0.2, 0.5, 0.7]), ambient_ratio=0.3,
+                                            light_d=light2, shading="lambertian", real_view=False, cano=False)
+    g["virt|image"], g["virt|normal_image"] = npf(res["image"]), npf(res["normal_image"])
+    g["virt|loss_orient"], g["virt|loss_code"] = npf(res["loss_orient"]), npf(res["loss_code"])
+    wimg = synth.hash_tensor((N2, 3), 360, 1.0)
+    total = (res["normal_image"] * wimg).sum() + res["loss_orient"] + res["loss_code"] + (res["image"] ** 2).mean()
+    m.zero_grad()
+    total.backward()
+    g["virt|loss"] = npf(total)
+    for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
+        g["virt|grad|" + kk] = v
+    # ---- two frames in one batch (B = 2 rows, one frame per row: how cfg5 / multi-frame batches reach render_rays)
+    fr = [synth.frame_rays(fid, hw2, hw2) for fid in (0, 25)]
+    o, d, t, rid = [torch.cat([f[k] for f in fr], 0) for k in range(4)]
+    smpb = ofield.uniform_samples(o.reshape(-1, 3), d.reshape(-1, 3), synth.ray_jitter(2 * N2), 48, 1.01)
+    lightb = ofield.safe_normalize(o.reshape(-1, 3) + torch.tensor([0.3, -0.2, 0.5]))
+    m, cfg = build_ref_model(synth.make_state("b"), None)
+    m.eval()
+    sampler = _PresetSampler()
+    sampler.samples = smpb
+    fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg, dataset=types.SimpleNamespace(num_frames=200))
+    res = ref_morpheus.MorpheuS.render_rays(fake, o, d, t, rid, hw2, hw2, ambient_ratio=1.0, light_d=lightb, shading="albedo")
+    g["two|image"], g["two|depth"], g["two|deform_s16"] = npf(res["image"]), npf(res["depth"]), npf(res["deform"][::16])
+    timg, tdep = synth.targets(2 * N2)
+    lossb = ((res["image"].reshape(-1, 3) - timg) ** 2).mean() + ((res["depth"].reshape(-1) - tdep) ** 2).mean()
+    m.zero_grad()
+    lossb.backward()
+    g["two|loss"] = npf(lossb)
+    for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
+        g["two|grad|" + kk] = v
     np.savez_compressed(os.path.join(OUT, "extras.npz"), **g)
     print("extras.npz", len(g), "arrays")
 

@@ -494,3 +494,58 @@ def test_eval_step_chunked_ragged_forward():
         ro = of.render_rays(f, o, d, t, rid, smp, ambient_ratio=1.0, light_d=of.safe_normalize(o[0] + 0.3), shading="albedo")
     assert_close(full["image"], ro["image"], TOL, "image", floor=FLOOR)
     assert_close(full["depth"], ro["depth"], TOL, "depth", floor=DEPTH_FLOOR)
+
+
+def test_virtual_view_training_outputs_vs_reference_golden():
+    """A virtual-view training call (lambertian shading, orientation loss, 2-D normal image accumulated with the live weights,
+    morpheus.py:708-776) against the reference's own render_rays (fixture extras.npz:virt|*): outputs and the gradient of a
+    loss that reaches the parameters THROUGH the normal image's weights."""
+    from morpheus_amd import harness
+    g = load_golden("extras.npz")
+    hw, S = 16, 32
+    o, d, t, rid = synth.frame_rays(25, hw, hw)
+    N = o.shape[1]
+    smp = of.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
+    light = of.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    model = harness.build_model("b", DEV).train()
+    model.config["train"].update(normal_smooth_2d=0.1, normal_smooth_3d=0.0, normal_smoothness=0.0)
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    res = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, bg_color=torch.tensor([0.2, 0.5, 0.7], device=DEV),
+                           ambient_ratio=0.3, light_d=light.to(DEV), shading="lambertian", real_view=False, cano=False)
+    assert_close(res["image"], g["virt|image"], 3e-3, "image (lambertian: FD normals)", floor=FLOOR)
+    assert_close(res["normal_image"], g["virt|normal_image"], 3e-3, "normal image", floor=FLOOR)
+    assert_close(res["loss_orient"], g["virt|loss_orient"], 1e-2, "loss_orient")
+    assert_close(res["loss_code"], g["virt|loss_code"], TOL, "loss_code")
+    wimg = synth.hash_tensor((N, 3), 360, 1.0).to(DEV)
+    total = (res["normal_image"] * wimg).sum() + res["loss_orient"] + res["loss_code"] + (res["image"] ** 2).mean()
+    assert_close(total, g["virt|loss"], 1e-2, "loss")
+    model.zero_grad()
+    total.backward()
+    n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, "virt", 3e-2)
+    assert n_ok >= 40, n_ok
+
+
+def test_two_frames_vs_reference_golden():
+    """B = 2 frames in one batch against the reference's own render_rays (fixture extras.npz:two|*)."""
+    from morpheus_amd import harness
+    g = load_golden("extras.npz")
+    hw, S = 16, 48
+    fr = [synth.frame_rays(fid, hw, hw) for fid in (0, 25)]
+    o, d, t, rid = [torch.cat([f[k] for f in fr], 0) for k in range(4)]
+    N = o.shape[1]
+    smp = of.uniform_samples(o.reshape(-1, 3), d.reshape(-1, 3), synth.ray_jitter(2 * N), S, 1.01)
+    light = of.safe_normalize(o.reshape(-1, 3) + torch.tensor([0.3, -0.2, 0.5]))
+    model = harness.build_model("b", DEV).eval()
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    res = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, ambient_ratio=1.0, light_d=light.to(DEV),
+                           shading="albedo")
+    assert_close(res["image"], g["two|image"], TOL, "image", floor=FLOOR)
+    assert_close(res["depth"], g["two|depth"], TOL, "depth", floor=DEPTH_FLOOR)
+    assert_close(res["deform"][::16], g["two|deform_s16"], TOL, "deform", floor=1e-3)
+    timg, tdep = [v.to(DEV) for v in synth.targets(2 * N)]
+    loss = ((res["image"].reshape(-1, 3) - timg) ** 2).mean() + ((res["depth"].reshape(-1) - tdep) ** 2).mean()
+    assert_close(loss, g["two|loss"], TOL, "loss")
+    model.zero_grad()
+    loss.backward()
+    n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, "two", 5e-4)
+    assert n_ok >= 40, n_ok
