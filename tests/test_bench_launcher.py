@@ -30,6 +30,11 @@ def test_self_launch_two_ranks():
     assert r["scaling"] == "weak" and r["higher_is_better"] is True and r["cpu_baseline"] is None
 
 
+def test_self_launch_eight_ranks():
+    r = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--rays", "32"])
+    assert r["n_gpus"] == 8 and r["config"]["world_size"] == 8 and r["value"] > 0
+
+
 def test_single_rank_needs_no_launcher_and_overlap_switch():
     r = _run(["--steps", "2", "--warmup", "1", "--rays", "32", "--no-overlap"])
     assert r["n_gpus"] == 1 and r["config"]["world_size"] == 1 and r["config"]["backend"] is None

@@ -4,6 +4,7 @@ parameters after the optimiser step."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -83,7 +84,8 @@ def _real_layout_worker(rank, world, port, out):
     bucket.overlap_early([model.encoder.embeddings, model.encoder_c.embeddings])
     named = dict(model.named_parameters())
     grads = lambda r: {k: synth.hash_tensor(tuple(p.shape), 9000 + 17 * i + 1000 * r, 1.0) for i, (k, p) in enumerate(named.items())}
-    mine, other = grads(rank), grads(1 - rank)
+    mine = grads(rank)
+    mean = {k: sum(grads(r)[k] for r in range(world)) / world for k in named}
     bucket.zero()
     # hand the gradients over the way autograd does: through backward, so that the post-accumulate hooks fire
     loss = sum((p * mine[k]).sum() for k, p in named.items())
@@ -91,21 +93,23 @@ def _real_layout_worker(rank, world, port, out):
     bucket.allreduce_mean()
     worst = 0.0
     for k, p in named.items():
-        want = 0.5 * (mine[k] + other[k])
-        worst = max(worst, float((p.grad - want).abs().max()))
+        worst = max(worst, float((p.grad - mean[k]).abs().max()))
         assert p.grad.data_ptr() >= bucket.flat.data_ptr() and p.grad.data_ptr() < bucket.flat.data_ptr() + bucket.nbytes, k
     out[rank] = (worst, bucket.nbytes, bucket._early_span)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_real_model_bucket_two_ranks():
+@pytest.mark.parametrize("world", [2, 8])
+def test_real_model_bucket_all_ranks_get_the_mean(world):
+    """world 8 = the node the path is meant for (cfg5: one frame per GPU); gloo on the CPU exercises the same bucket,
+    early range and remainder exchange."""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_real_layout_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    for r in (0, 1):
+    mp.spawn(_real_layout_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
         worst, nbytes, span = out[r]
-        assert worst <= 1e-7, worst
+        assert worst <= 5e-7, worst
         assert 7.3e6 < nbytes < 7.6e6                      # the 7.45 MB bucket of SURVEY 8e
         assert span == (0, 2 * 839280)                     # both hash tables: the first 6.4 MB, exchanged early
 
