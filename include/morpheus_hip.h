@@ -153,6 +153,13 @@ int mh_fd_normal_bwd(const float *sdf6, const float *g_normal, const float *g_ra
                      void *stream);
 int mh_sample_positions(const float *rays_o, const float *rays_d, const int32_t *ray_idx, const float *t_starts,
                         const float *t_ends, int64_t M, float *xyz, void *stream);
+/* MultiCode.sample (models/deform_code.py:20-38): three [C, size_l] tables (the reference's volumes [1,C,size,1]) sampled
+ * linearly in time, grid_sample(align_corners=True) coordinate rule, t clamped to [0,1]; out [F, 3*C] level-major.
+ * Backward accumulates into g0/g1/g2 (same shapes as the tables, ZEROED by the caller) with atomics. */
+int mh_multicode_fwd(const float *t, const float *v0, const float *v1, const float *v2, int32_t s0, int32_t s1, int32_t s2,
+                     int32_t C, int32_t F, float *out, void *stream);
+int mh_multicode_bwd(const float *t, const float *g_out, float *g0, float *g1, float *g2, int32_t s0, int32_t s1, int32_t s2,
+                     int32_t C, int32_t F, void *stream);
 int mh_sample_positions_bwd(const float *g_xyz, const float *t_starts, const float *t_ends, const int32_t *ray_start,
                             const int32_t *ray_cnt, int32_t N, float *g_o, float *g_d, void *stream);
 

@@ -171,6 +171,51 @@ __global__ __launch_bounds__(256) void sample_positions_bwd_kernel(const float *
     }
 }
 
+// ---- MultiCode.sample (models/deform_code.py:20-38) --------------------------------------------------------------------------
+// Per level: a [C, size] table sampled linearly in time with F.grid_sample(align_corners=True, border padding): the
+// normalised coordinate 2t-1 is mapped back by ((x+1)/2)*(size-1).  One thread per (time, level, channel); the reference
+// (and the torch form this replaces) spends a dozen launches per call and as many again in backward.
+struct CodeLevels {
+    const float *v[3];
+    float *g[3];
+    int size[3];
+};
+
+__device__ __forceinline__ void code_taps(float t, int size, int &i0, int &i1, float &fr) {
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float r = (((t * 2.0f - 1.0f) + 1.0f) / 2.0f) * (float)(size - 1);
+    const float r0 = floorf(r);
+    fr = r - r0;
+    i0 = min(max((int)r0, 0), size - 1);
+    i1 = min(i0 + 1, size - 1);
+}
+
+__global__ __launch_bounds__(256) void multicode_fwd_kernel(const float *__restrict__ t, CodeLevels lv, int C, int F,
+                                                            float *__restrict__ out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= F * 3 * C) return;
+    const int f = gid / (3 * C), l = (gid / C) % 3, c = gid % C;
+    int i0, i1;
+    float fr;
+    code_taps(t[f], lv.size[l], i0, i1, fr);
+    const float *v = lv.v[l] + (int64_t)c * lv.size[l];
+    out[gid] = v[i0] * (1.0f - fr) + v[i1] * fr;
+}
+
+__global__ __launch_bounds__(256) void multicode_bwd_kernel(const float *__restrict__ t, const float *__restrict__ g_out,
+                                                            CodeLevels lv, int C, int F) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= F * 3 * C) return;
+    const int f = gid / (3 * C), l = (gid / C) % 3, c = gid % C;
+    int i0, i1;
+    float fr;
+    code_taps(t[f], lv.size[l], i0, i1, fr);
+    float *g = lv.g[l] + (int64_t)c * lv.size[l];
+    const float go = g_out[gid];
+    atomicAdd(g + i0, go * (1.0f - fr));
+    atomicAdd(g + i1, go * fr);
+}
+
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
@@ -230,6 +275,28 @@ extern "C" int mh_sample_positions_bwd(const float *g_xyz, const float *t_starts
     if (N < 0 || !g_xyz || !t_starts || !t_ends || !ray_start || !ray_cnt || !g_o || !g_d) return MH_ERR_ARG;
     hipLaunchKernelGGL(sample_positions_bwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, mh_stream(stream), g_xyz,
                        t_starts, t_ends, ray_start, ray_cnt, (int)N, g_o, g_d);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_multicode_fwd(const float *t, const float *v0, const float *v1, const float *v2, int32_t s0, int32_t s1,
+                                int32_t s2, int32_t C, int32_t F, float *out, void *stream) {
+    if (F == 0) return MH_OK;
+    if (!t || !v0 || !v1 || !v2 || !out || F < 0 || C <= 0 || s0 <= 0 || s1 <= 0 || s2 <= 0) return MH_ERR_ARG;
+    CodeLevels lv = {{v0, v1, v2}, {nullptr, nullptr, nullptr}, {(int)s0, (int)s1, (int)s2}};
+    hipLaunchKernelGGL(multicode_fwd_kernel, dim3(blocks_for((int64_t)F * 3 * C)), dim3(256), 0, mh_stream(stream), t, lv, (int)C,
+                       (int)F, out);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_multicode_bwd(const float *t, const float *g_out, float *g0, float *g1, float *g2, int32_t s0, int32_t s1,
+                                int32_t s2, int32_t C, int32_t F, void *stream) {
+    if (F == 0) return MH_OK;
+    if (!t || !g_out || !g0 || !g1 || !g2 || F < 0 || C <= 0 || s0 <= 0 || s1 <= 0 || s2 <= 0) return MH_ERR_ARG;
+    CodeLevels lv = {{nullptr, nullptr, nullptr}, {g0, g1, g2}, {(int)s0, (int)s1, (int)s2}};
+    hipLaunchKernelGGL(multicode_bwd_kernel, dim3(blocks_for((int64_t)F * 3 * C)), dim3(256), 0, mh_stream(stream), t, g_out, lv,
+                       (int)C, (int)F);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

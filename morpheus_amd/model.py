@@ -61,27 +61,11 @@ class MultiCode(nn.Module):
         self.volumes = nn.ParameterList([nn.Parameter(torch.randn(1, c, s, 1)) for s in sizes])
 
     def sample(self, t: torch.Tensor) -> torch.Tensor:
-        """All levels at once (same arithmetic per element as deform_code.py:20-38, a dozen launches instead of three
-        dozen): the volumes are concatenated along the time axis and both taps of every level come from one
-        index_select (whose backward is an index_add, not a sort)."""
-        t = t.reshape(-1).clamp(0, 1)
-        sizes = [v.shape[2] for v in self.volumes]
-        key = (t.device, tuple(sizes))
-        if getattr(self, "_lvl", (None,))[0] != key:
-            sz = torch.tensor(sizes, device=t.device, dtype=torch.float32)
-            off = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], device=t.device)
-            self._lvl = (key, sz, sz.long(), off)
-        _, sz, szi, off = self._lvl
-        vcat = torch.cat([v[0, :, :, 0] for v in self.volumes], 1)            # [c, sum(sizes)]
-        r = ((t[:, None] * 2 - 1) + 1) / 2 * (sz - 1)                         # [F, L]
-        r0 = torch.floor(r)
-        fr = r - r0
-        i0 = torch.minimum(r0.long().clamp(min=0), szi - 1)
-        i1 = torch.minimum(i0 + 1, szi - 1)
-        F, L = r.shape
-        taps = vcat.index_select(1, torch.cat([(i0 + off).reshape(-1), (i1 + off).reshape(-1)])).view(-1, 2, F, L)
-        code = taps[:, 0] * (1 - fr) + taps[:, 1] * fr                        # [c, F, L]
-        return code.permute(1, 2, 0).reshape(F, -1)                           # [F, L*c], level-major as the reference
+        """[F] or [F,1] times -> [F, L*c], level-major as the reference (deform_code.py:20-38): all levels from ONE HIP launch
+        each way (ops.multicode_sample; GPU only, like every op on the path)."""
+        if len(self.volumes) != 3:
+            raise NotImplementedError("the code kernel is specialised to the reference's three levels (model.py:88-92)")
+        return ops.multicode_sample(t, list(self.volumes))
 
     def get_code(self, level=-1):
         return self.volumes[level].squeeze().permute(1, 0)

@@ -410,6 +410,42 @@ def fd_normal(sdf6, eps: float):
     return _FdNormal.apply(sdf6, eps)
 
 
+class _MultiCode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, v0, v1, v2):
+        require_gpu(t, v0, v1, v2)
+        lib = _lib.load()
+        tc = t.detach().reshape(-1).contiguous().float()
+        vs = [v.detach().contiguous() for v in (v0, v1, v2)]           # [1, C, size, 1]: contiguous == [C, size]
+        C, sizes, F = vs[0].shape[1], [v.shape[2] for v in vs], tc.shape[0]
+        out = torch.empty(F, 3 * C, device=tc.device)
+        check(lib.mh_multicode_fwd(ptr(tc), ptr(vs[0]), ptr(vs[1]), ptr(vs[2]), sizes[0], sizes[1], sizes[2], C, F, ptr(out),
+                                   stream()), "mh_multicode_fwd")
+        ctx.save_for_backward(tc)
+        ctx.meta = (C, sizes, [tuple(v.shape) for v in vs])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        (tc,) = ctx.saved_tensors
+        C, sizes, shapes = ctx.meta
+        flat = torch.zeros(C * sum(sizes), device=tc.device)
+        gs, o = [], 0
+        for sz in sizes:
+            gs.append(flat[o:o + C * sz])
+            o += C * sz
+        check(lib.mh_multicode_bwd(ptr(tc), ptr(g_out.contiguous()), ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), sizes[0], sizes[1],
+                                   sizes[2], C, tc.shape[0], stream()), "mh_multicode_bwd")
+        return (None, *[g.view(sh) for g, sh in zip(gs, shapes)])
+
+
+def multicode_sample(t, volumes):
+    """t [F] or [F,1] in [0,1] (clamped) -> [F, 3*C]: deform_code.py:20-38 for the three-level code grid, one launch."""
+    assert len(volumes) == 3
+    return _MultiCode.apply(t, *volumes)
+
+
 class _SamplePositions(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, ray_idx, ts, te, ray_start, ray_cnt):

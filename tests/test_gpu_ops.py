@@ -547,3 +547,39 @@ def test_two_table_forward_is_bit_identical_to_two_launches():
             assert torch.equal(a1, ops.grid_encode(x, emb.to(DEV), offs, res, 1.01, ml))
     finally:
         ops.GRID_FWD_TWO = old
+
+
+def test_multicode_sample_kernel():
+    """mh_multicode_fwd/bwd: bit for bit the per-level lerp of deform_code.py:20-38 written in torch on the same device,
+    the reference's own output (fixture operators.npz:multicode, generated by the reference's MultiCode.sample), and the
+    gradient of torch autograd through that formula (atomics: round-off)."""
+    from morpheus_amd.model import MultiCode
+    from tests.util import load_golden
+    st = synth.make_state("b")
+    mc = MultiCode([25, 50, 200], 16).to(DEV)
+    mc.load_state_dict({f"volumes.{k}": st[f"deform_code.volumes.{k}"] for k in range(3)})
+    t = torch.tensor([[0.0], [7 / 200], [0.5], [199 / 200], [1.3], [-0.2], [0.123456]], device=DEV)
+    got = mc.sample(t)
+    assert_close(got, load_golden("operators.npz")["multicode"], 1e-5, "vs the reference's MultiCode.sample", floor=1e-3)
+    tl = torch.rand(4099, device=DEV) * 1.2 - 0.1                     # per-sample times (the point-loss call shape)
+    gw = synth.hash_tensor((4099, 48), 811, 1.0).to(DEV)
+    vols = [v.detach().clone().requires_grad_(True) for v in mc.volumes]
+    tt = tl.clamp(0, 1)
+    want = []
+    for vol in vols:
+        v = vol[0, :, :, 0]
+        size = v.shape[1]
+        r = ((tt * 2 - 1) + 1) / 2 * (size - 1)
+        r0 = torch.floor(r)
+        fr = (r - r0)[None]
+        i0 = r0.long().clamp(0, size - 1)
+        i1 = (i0 + 1).clamp(0, size - 1)
+        want.append((v[:, i0] * (1 - fr) + v[:, i1] * fr).t())
+    want = torch.cat(want, -1)
+    (want * gw).sum().backward()
+    got = mc.sample(tl)
+    assert torch.equal(got, want)
+    mc.zero_grad()
+    (got * gw).sum().backward()
+    for k in range(3):
+        assert_close(mc.volumes[k].grad, vols[k].grad, 1e-5, f"d volumes.{k}", floor=1e-2 * float(vols[k].grad.abs().max()))

@@ -219,29 +219,6 @@ def test_joint_packer_equals_per_net_packers():
     assert torch.equal(fj.take(f, fj.b[0]), fp.pack_biases(Bs, skip_first=False))
 
 
-def test_multicode_sample_matches_per_level_formula():
-    """The all-levels-at-once MultiCode.sample equals the per-level lerp of deform_code.py:20-38 bit for bit."""
-    from morpheus_amd.model import MultiCode
-    torch.manual_seed(1)
-    mc = MultiCode([25, 50, 200], 16)
-    t = torch.tensor([0.0, 7 / 200, 0.5, 199 / 200, 1.3, -0.2, 0.12345])[:, None]
-    got = mc.sample(t)
-    tt = t.reshape(-1).clamp(0, 1)
-    want = []
-    for vol in mc.volumes:
-        v = vol[0, :, :, 0]
-        size = v.shape[1]
-        r = ((tt * 2 - 1) + 1) / 2 * (size - 1)
-        r0 = torch.floor(r)
-        fr = (r - r0)[None]
-        i0 = r0.long().clamp(0, size - 1)
-        i1 = (i0 + 1).clamp(0, size - 1)
-        want.append((v[:, i0] * (1 - fr) + v[:, i1] * fr).t())
-    assert torch.equal(got, torch.cat(want, -1))
-    got.square().sum().backward()
-    assert all(float(v.grad.abs().sum()) > 0 for v in mc.volumes)
-
-
 def test_raw_gradient_map_with_bias0_dropped():
     """JointPacker.unpack_grads(zero_bias0=True): identical to the plain map except that every net's first-layer bias
     gradient is zero (it reaches its parameter through the per-frame bias0), and bias0_raw points at those entries."""
