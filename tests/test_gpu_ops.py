@@ -582,4 +582,4 @@ def test_multicode_sample_kernel():
     mc.zero_grad()
     (got * gw).sum().backward()
     for k in range(3):
-        assert_close(mc.volumes[k].grad, vols[k].grad, 1e-5, f"d volumes.{k}", floor=1e-2 * float(vols[k].grad.abs().max()))
+        assert_close(mc.volumes[k].grad, vols[k].grad, 1e-4, f"d volumes.{k}", floor=1e-2 * float(vols[k].grad.abs().max()))
