@@ -160,6 +160,14 @@ int mh_multicode_fwd(const float *t, const float *v0, const float *v1, const flo
                      int32_t C, int32_t F, float *out, void *stream);
 int mh_multicode_bwd(const float *t, const float *g_out, float *g0, float *g1, float *g2, int32_t s0, int32_t s1, int32_t s2,
                      int32_t C, int32_t F, void *stream);
+/* get_sdf_loss (utils.py:91-113) on packed samples: per-ray depth [N] / mask [N] (NULL: none) are read through ray_idx, the
+ * sample depth is (t_starts + t_ends)/2.  sums [3] (device) = free-space sum, near-surface sum, count of samples whose target
+ * depth is non-zero; the caller divides the two sums by the count.  Backward: g_fs / g_sl are device scalars (NULL = 0). */
+int mh_sdf_losses_fwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
+                      const float *rays_depth, const float *rays_mask, float trunc, int64_t M, float *sums, void *stream);
+int mh_sdf_losses_bwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
+                      const float *rays_depth, const float *rays_mask, float trunc, int64_t M, const float *sums,
+                      const float *g_fs, const float *g_sl, float *g_pred, void *stream);
 int mh_sample_positions_bwd(const float *g_xyz, const float *t_starts, const float *t_ends, const int32_t *ray_start,
                             const int32_t *ray_cnt, int32_t N, float *g_o, float *g_d, void *stream);
 

@@ -40,6 +40,8 @@ _SIGS = {
     "mh_fd_normal_bwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
     "mh_multicode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "mh_multicode_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "mh_sdf_losses_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _P, _P]),
+    "mh_sdf_losses_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P, _P]),
     "mh_sample_positions": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "mh_sample_positions_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "mh_mlp_tiles": (_I64, [_I64]),

@@ -216,6 +216,76 @@ __global__ __launch_bounds__(256) void multicode_bwd_kernel(const float *__restr
     atomicAdd(g + i1, go * fr);
 }
 
+// ---- free-space / near-surface SDF losses on packed samples (utils.py:91-113, called at morpheus.py:789) ---------------------
+// Per sample m of ray r: z = (ts + te)/2, target = rays_depth[r];  front = z < target - trunc  or  (target < 0 and z < 3.5);
+// bnd = target - z (10 if target < 0);  smask = |bnd| <= trunc and target > 0 (and rays_mask[r] > 0.5);  n = front + smask + 1e-8;
+//   fs += max(max(exp(-5 p) - 1, p - bnd), 0) * front / n        sl += |p - bnd| * smask / n        nd += (target != 0)
+// and the caller divides both sums by nd.  The torch form is ~25 launches forward, ~20 backward and two [M] gathers.
+struct SdfLossTerm {
+    float fs, sl, dfs, dsl;   // the sample's two loss terms and their derivatives w.r.t. the predicted sdf
+    bool nz;
+};
+
+__device__ __forceinline__ SdfLossTerm sdf_loss_term(float z, float target, float p, float trunc, bool masked_in) {
+    SdfLossTerm o;
+    const bool front = (z < (target - trunc)) || ((target < 0.0f) && (z < 3.5f));
+    const float bnd = (target < 0.0f) ? 10.0f : (target - z);
+    const bool smask = (fabsf(bnd) <= trunc) && (target > 0.0f) && masked_in;
+    const float n = (front ? 1.0f : 0.0f) + (smask ? 1.0f : 0.0f) + 1e-8f;
+    const float a = expf(-5.0f * p) - 1.0f, b = p - bnd;
+    const float mx = fmaxf(a, b);
+    const float dmx = (a > b) ? (-5.0f * expf(-5.0f * p)) : ((a < b) ? 1.0f : 0.5f * (1.0f - 5.0f * expf(-5.0f * p)));
+    const bool pos = mx > 0.0f;
+    o.fs = front ? (pos ? mx : 0.0f) / n : 0.0f;
+    o.dfs = (front && pos) ? dmx / n : 0.0f;
+    const float d = p - bnd;
+    o.sl = smask ? fabsf(d) / n : 0.0f;
+    o.dsl = smask ? ((d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f)) / n : 0.0f;
+    o.nz = target != 0.0f;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void sdf_losses_kernel(const float *__restrict__ pred, const float *__restrict__ ts,
+                                                         const float *__restrict__ te, const int32_t *__restrict__ ray_idx,
+                                                         const float *__restrict__ rays_depth, const float *__restrict__ rays_mask,
+                                                         float trunc, int64_t M, float *__restrict__ sums /*[3]: fs, sl, nd*/) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float fs = 0.f, sl = 0.f, nd = 0.f;
+    if (m < M) {
+        const int r = ray_idx[m];
+        const SdfLossTerm o = sdf_loss_term((ts[m] + te[m]) / 2.0f, rays_depth[r], pred[m], trunc, rays_mask ? rays_mask[r] > 0.5f : true);
+        fs = o.fs;
+        sl = o.sl;
+        nd = o.nz ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        fs += __shfl_xor(fs, o);
+        sl += __shfl_xor(sl, o);
+        nd += __shfl_xor(nd, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(sums + 0, fs);
+        atomicAdd(sums + 1, sl);
+        atomicAdd(sums + 2, nd);
+    }
+}
+
+// g_pred[m] = (g_fs * dfs_m + g_sl * dsl_m) / nd;  g = [g_fs, g_sl] on the device, nd = sums[2] of the forward launch
+__global__ __launch_bounds__(256) void sdf_losses_bwd_kernel(const float *__restrict__ pred, const float *__restrict__ ts,
+                                                             const float *__restrict__ te, const int32_t *__restrict__ ray_idx,
+                                                             const float *__restrict__ rays_depth,
+                                                             const float *__restrict__ rays_mask, float trunc, int64_t M,
+                                                             const float *__restrict__ sums, const float *__restrict__ g_fs,
+                                                             const float *__restrict__ g_sl, float *__restrict__ g_pred) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int r = ray_idx[m];
+    const SdfLossTerm o = sdf_loss_term((ts[m] + te[m]) / 2.0f, rays_depth[r], pred[m], trunc, rays_mask ? rays_mask[r] > 0.5f : true);
+    const float nd = sums[2];
+    g_pred[m] = ((g_fs ? *g_fs : 0.0f) * o.dfs + (g_sl ? *g_sl : 0.0f) * o.dsl) / nd;
+}
+
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
@@ -297,6 +367,30 @@ extern "C" int mh_multicode_bwd(const float *t, const float *g_out, float *g0, f
     CodeLevels lv = {{nullptr, nullptr, nullptr}, {g0, g1, g2}, {(int)s0, (int)s1, (int)s2}};
     hipLaunchKernelGGL(multicode_bwd_kernel, dim3(blocks_for((int64_t)F * 3 * C)), dim3(256), 0, mh_stream(stream), t, g_out, lv,
                        (int)C, (int)F);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_sdf_losses_fwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
+                                 const float *rays_depth, const float *rays_mask, float trunc, int64_t M, float *sums,
+                                 void *stream) {
+    if (!sums) return MH_ERR_ARG;
+    if (hipMemsetAsync(sums, 0, 3 * sizeof(float), mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
+    if (M == 0) return MH_OK;
+    if (M < 0 || !pred_sdf || !t_starts || !t_ends || !ray_idx || !rays_depth) return MH_ERR_ARG;
+    hipLaunchKernelGGL(sdf_losses_kernel, dim3(blocks_for(M)), dim3(256), 0, mh_stream(stream), pred_sdf, t_starts, t_ends, ray_idx,
+                       rays_depth, rays_mask, trunc, M, sums);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_sdf_losses_bwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
+                                 const float *rays_depth, const float *rays_mask, float trunc, int64_t M, const float *sums,
+                                 const float *g_fs, const float *g_sl, float *g_pred, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !pred_sdf || !t_starts || !t_ends || !ray_idx || !rays_depth || !sums || !g_pred) return MH_ERR_ARG;
+    hipLaunchKernelGGL(sdf_losses_bwd_kernel, dim3(blocks_for(M)), dim3(256), 0, mh_stream(stream), pred_sdf, t_starts, t_ends,
+                       ray_idx, rays_depth, rays_mask, trunc, M, sums, g_fs, g_sl, g_pred);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

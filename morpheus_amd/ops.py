@@ -446,6 +446,39 @@ def multicode_sample(t, volumes):
     return _MultiCode.apply(t, *volumes)
 
 
+class _SdfLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_sdf, ts, te, ray_idx, rays_depth, rays_mask, trunc):
+        require_gpu(pred_sdf, ts, te, ray_idx, rays_depth, rays_mask)
+        lib = _lib.load()
+        p = pred_sdf.detach().contiguous().float()
+        dep = rays_depth.detach().reshape(-1).contiguous().float()
+        msk = None if rays_mask is None else rays_mask.detach().reshape(-1).contiguous().float()
+        sums = torch.empty(3, device=p.device)
+        check(lib.mh_sdf_losses_fwd(ptr(p), ptr(ts), ptr(te), ptr(ray_idx), ptr(dep), ptr(msk), float(trunc), p.shape[0], ptr(sums),
+                                    stream()), "mh_sdf_losses_fwd")
+        ctx.save_for_backward(p, ts, te, ray_idx, dep, msk, sums)
+        ctx.trunc = float(trunc)
+        return sums[0] / sums[2], sums[1] / sums[2]
+
+    @staticmethod
+    def backward(ctx, g_fs, g_sl):
+        lib = _lib.load()
+        p, ts, te, ray_idx, dep, msk, sums = ctx.saved_tensors
+        g = torch.empty_like(p)
+        c = lambda t: None if t is None else t.reshape(1).contiguous().float()
+        check(lib.mh_sdf_losses_bwd(ptr(p), ptr(ts), ptr(te), ptr(ray_idx), ptr(dep), ptr(msk), ctx.trunc, p.shape[0], ptr(sums),
+                                    ptr(c(g_fs)), ptr(c(g_sl)), ptr(g), stream()), "mh_sdf_losses_bwd")
+        return g, None, None, None, None, None, None
+
+
+def sdf_losses(pred_sdf, t_starts, t_ends, ray_idx, rays_depth, rays_mask, trunc: float):
+    """-> (fs_loss, sdf_loss) of utils.py:91-113 on packed samples; rays_depth / rays_mask are PER RAY ([N] or [N,1], mask may
+    be None) and read through ray_idx (int32 [M]); the sample depth is (t_starts + t_ends) / 2."""
+    return _SdfLosses.apply(pred_sdf, t_starts.contiguous(), t_ends.contiguous(), ray_idx.contiguous(), rays_depth, rays_mask,
+                            trunc)
+
+
 class _SamplePositions(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, ray_idx, ts, te, ray_start, ray_cnt):

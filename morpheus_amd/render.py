@@ -56,24 +56,6 @@ class PresetSampler:
         return self.samples
 
 
-def sdf_losses(z_vals, target_d, pred_sdf, trunc, mask=None):
-    """Free-space and near-surface SDF losses on packed samples (utils.py:91-113)."""
-    pred = pred_sdf[..., None]
-    depth_mask = target_d > 0.0
-    front = (z_vals < (target_d - trunc)) | ((target_d < 0.0) & (z_vals < 3.5))
-    bnd = target_d - z_vals
-    bnd = torch.where((target_d[:, 0] < 0.0)[:, None], torch.full_like(bnd, 10.0), bnd)
-    smask = (bnd.abs() <= trunc) & depth_mask
-    if mask is not None:
-        smask = smask & (mask > 0.5)
-    n = front.sum(-1) + smask.sum(-1) + 1e-8
-    nd = torch.count_nonzero(target_d)
-    fs = torch.max(torch.exp(-5.0 * pred) - 1.0, pred - bnd).clamp(min=0.0) * front
-    fs = (fs.sum(-1) / n).sum() / nd
-    sl = ((torch.abs(pred - bnd) * smask).sum(-1) / n).sum() / nd
-    return fs, sl
-
-
 class HotPathRenderer:
     def __init__(self, model: scene_representation, config: dict, occupancy_grid, num_frames: int,
                  frame_batched: bool = True):
@@ -185,17 +167,21 @@ class HotPathRenderer:
                 _long.append(ray_idx32.long())
             return _long[0]
 
-        t_starts, t_ends = t_starts_[..., None], t_ends_[..., None]
+        _i32 = []
+
+        def ri32():             # int32 indices for the HIP kernels (the marcher / uniform sampler already produce int32)
+            if not _i32:
+                _i32.append(ray_idx32 if ray_idx32.dtype == torch.int32 else ray_idx32.to(torch.int32))
+            return _i32[0]
+
         xyzs = getattr(self.occupancy_grid, "xyz", None)
         if xyzs is not None:
             self.occupancy_grid.xyz = None             # one use: it belongs to the sampling call above
         packed = getattr(self.occupancy_grid, "packed", None)    # (ray_start, ray_cnt) of the sampling call above
         ray_start, ray_cnt = packed if packed is not None else ops.packed_info(ri_long(), N)
-        t_positions = (t_starts + t_ends) / 2.0 if rays_depth is not None else None
         if xyzs is None or rays_o.requires_grad or rays_d.requires_grad:   # pose optimisation: positions carry gradients
             # xyz = o[ri] + d[ri] * (ts + te) / 2 (morpheus.py:644-647) as one launch; its backward is a per-ray segment sum
-            ri32 = ray_idx32 if ray_idx32.dtype == torch.int32 else ray_idx32.to(torch.int32)
-            xyzs = ops.sample_positions(rays_o, rays_d, ri32, t_starts_, t_ends_, ray_start, ray_cnt)
+            xyzs = ops.sample_positions(rays_o, rays_d, ri32(), t_starts_, t_ends_, ray_start, ray_cnt)
         # a batch row is one frame: with a single row every sample shares rays_t[0] -- no gather needed
         time_step = rays_t[:1].expand(M_samples, 1) if single_frame else rays_t[ri_long()]
 
@@ -277,8 +263,7 @@ class HotPathRenderer:
                 results["normal_reg"] = self.get_normal_smoothness_loss(rays_o, rays_d, rays_t, depth.reshape(1, -1),
                                                                         ray_slots=ray_slots)
             if rays_depth is not None:
-                t_gt = rays_depth[ri_long()]
-                t_mask = None if rays_mask is None else rays_mask[ri_long()]
-                fs_loss, sdf_loss = sdf_losses(t_positions, t_gt, sdf, tr["trunc"], mask=t_mask)
+                # get_sdf_loss (utils.py:91-113, morpheus.py:789) on the packed samples: one launch each way
+                fs_loss, sdf_loss = ops.sdf_losses(sdf, t_starts_, t_ends_, ri32(), rays_depth, rays_mask, tr["trunc"])
                 results["sdf_loss"], results["fs_loss"] = sdf_loss, fs_loss
         return results

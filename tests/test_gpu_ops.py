@@ -583,3 +583,31 @@ def test_multicode_sample_kernel():
     (got * gw).sum().backward()
     for k in range(3):
         assert_close(mc.volumes[k].grad, vols[k].grad, 1e-4, f"d volumes.{k}", floor=1e-2 * float(vols[k].grad.abs().max()))
+
+
+def test_sdf_losses_kernel_vs_reference_formula():
+    """mh_sdf_losses_fwd/bwd against utils.py:91-113 written in torch on the same device (the oracle's sdf_losses is that
+    function restated; the reference's own values are pinned by the render goldens), values and d/d(pred_sdf): free space,
+    truncation band, negative and zero target depths, masked rays."""
+    from morpheus_amd import ops
+    N, trunc = 64, 0.1
+    cnt = (torch.arange(N) * 31 % 17 + 3).int()
+    ri = torch.repeat_interleave(torch.arange(N), cnt.long())
+    M = ri.numel()
+    depth = synth.hash_tensor((N, 1), 820, 0.6, 1.2)
+    depth[::7] = -1.0                                   # "no depth": everything in front counts as free space
+    depth[3::11] = 0.0                                  # zero depth: excluded from the normalisation count
+    mask = (synth.hash_tensor((N, 1), 821, 0.5, 0.5) > 0.3).float()
+    ts = synth.hash_tensor((M,), 822, 0.8, 1.2)
+    te = ts + 0.01
+    pred = synth.hash_tensor((M,), 823, 0.3)
+    for use_mask in (True, False):
+        po = pred.clone().requires_grad_(True)
+        fs_o, sl_o = of.sdf_losses(((ts + te) / 2)[:, None], depth[ri], po, trunc, mask[ri] if use_mask else None)
+        (2.0 * fs_o + 3.0 * sl_o).backward()
+        pg = pred.to(DEV).requires_grad_(True)
+        fs_g, sl_g = ops.sdf_losses(pg, ts.to(DEV), te.to(DEV), ri.int().to(DEV), depth.to(DEV), mask.to(DEV) if use_mask else None, trunc)
+        (2.0 * fs_g + 3.0 * sl_g).backward()
+        assert_close(fs_g, fs_o, 1e-5, "fs_loss", floor=1e-6)
+        assert_close(sl_g, sl_o, 1e-5, "sdf_loss", floor=1e-6)
+        assert_close(pg.grad, po.grad, 1e-5, "d/d pred", floor=1e-2 * float(po.grad.abs().max()))
