@@ -193,6 +193,23 @@ int64_t mh_warp_wpackT_floats(void);  /* per net, transposed pack */
 int mh_warp_fwd(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t,
                 const float *wpack_d, const float *wpack_t, const float *bias_d, const float *bias_t,
                 int32_t n_bands, float *out_deform, float *out_topo, float *acts, int64_t M, void *stream);
+/* ---- the same networks with exact fp32 products on the bf16 matrix pipe (csrc/mlp_b3.hip) ------
+ * Every fp32 operand is cut into three bf16 slices (hi + mid + lo == x exactly) and a product is the six significant
+ * cross terms through v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade results (what is dropped is <= 3 * 2^-24
+ * of a product), 6/16 of the fp32-MFMA cycles.  Values, parked tiles and the C-ABI stay fp32; only the weight operand has
+ * its own pack.
+ *
+ * mh_b3_slice: fp32 fragments in the 32x32x16 order (packing.py: fwd3_index; per layer [out tile][k16 step][lane][8]) ->
+ *   per layer three bf16 planes [hi | mid | lo][out tile][k16 step][lane][8 bf16].  src_off / n in floats (n % 8 == 0),
+ *   dst_off in 16-byte units; host arrays of n_layers entries (<= 16).
+ * mh_warp_fwd_b3: mh_warp_fwd with w3_{d,t} = one net's sliced pack (mh_warp_w3_bytes() bytes: layer 0 padded to whole
+ *   512 x 16-byte DMA rounds).  Same outputs, same parked tiles (mh_warp_bwd_data / mh_mlp_wgrad consume them). */
+int mh_b3_slice(const float *src, void *dst, int32_t n_layers, const int32_t *src_off_host, const int32_t *n_host,
+                const int32_t *dst_off_f4_host, void *stream);
+int64_t mh_warp_w3_bytes(void);
+int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w3_d,
+                   const void *w3_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
+                   float *out_topo, float *acts, int64_t M, void *stream);
 /* backward-data: consumes g_deform [M,3], g_topo [M,2] (either may be NULL = zero), acts from the
  * forward and the TRANSPOSED packs; writes g_x [M,3] (d/dx through the frequency encoding; pass NULL when the
  * sample positions carry no gradient and the first-layer transposed GEMM is skipped) and

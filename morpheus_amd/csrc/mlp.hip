@@ -29,33 +29,9 @@
 //  * The kernels are ISSUE-bound: on gfx950 one wave's VALU / store / DMA instructions do not issue under
 //    the co-resident wave's fp32 MFMAs (tools/phase_trace.py), so every non-MFMA instruction of the layer
 //    loop is paid in full and the design effort goes into having few of them.
-#include "common.h"
+#include "mlp_dev.h"
 #include <stdlib.h>
 
-#define TILE 32
-#define BLOCK_PTS 128
-
-// ---- per-tile scratch geometry (floats) -------------------------------------------------------
-// warp acts : H0 [64 rows: 2kk+h, 40 used] | deform H1..H5 [5 x 128] | topo H1..H5 [5 x 128] | ReLU sign masks
-//             [net][layer][lane][2] uint32 (bit 16t+r of the lane's 64 outputs): backward-data reads 8 bytes per lane and
-//             layer instead of re-loading the 256-byte activation column (the activations stay parked for the wgrad GEMM)
-// warp dpre : deform dPre0..4 [5 x 128], dPre5 [32] | topo same
-#define WARP_HID_ROWS (64 + 2 * 640)        // activations proper
-#define WARP_ACT_ROWS (WARP_HID_ROWS + 40)  // + ReLU masks: 10 layers x 64 lanes x 2 dwords = 40 rows of 32
-#define WARP_DPRE_ROWS (2 * 672)
-#define WARP_NET_WPACK (5120 + 4 * 16384 + 4096)       // fwd pack floats per net
-#define WARP_NET_WPACKT (4096 /*T5*/ + 4 * 16384 + 8192 /*T0: MT=2,KS=64*/)
-#define WARP_NET_BIAS (4 * 128 + 32)
-// field acts: S0 [96: 2kk+h, 80 used] | S1 [64] | S2 [64] | C0 [64: 2kk+h] | C1 [64] | C2 [64] | ReLU masks [4][64 lanes]
-// field dpre: P0 [64] | P1 [64] | P2 [64] | Q0 [64] | Q1 [64] | Q2 [32]
-#define FIELD_HID_ROWS (96 + 64 * 5)
-#define FIELD_ACT_ROWS (FIELD_HID_ROWS + 8)  // + ReLU masks of S1, S2, C1, C2: 4 x 64 lanes x 1 dword = 8 rows of 32
-#define FIELD_DPRE_ROWS (64 * 5 + 32)
-#define FIELD_WPACK (5120 + 4096 * 4 + 2048)
-#define FIELD_WPACKT (2048 /*TC2*/ + 4096 /*TC1*/ + 4096 /*TC0*/ + 4096 /*TS2*/ + 4096 /*TS1*/ + 6144 /*TS0 MT=3*/)
-#define FIELD_BIAS (64 * 5 + 32)
-
-__device__ __forceinline__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __shared__ f32x4 lds_w[4096];  // 64 KB: one layer's A fragments  [mt][q][lane] float4
 
@@ -120,25 +96,6 @@ extern "C" int mh_trace_read(long long *dst_host) {
 #define MH_STAMP_REAL(slot) do { } while (0)
 #endif
 
-template <int MT>
-__device__ __forceinline__ void acc_bias(f32x16 (&acc)[MT], const float *__restrict__ bias, int h) {
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(bias + 32 * t + 8 * r4 + 4 * h);
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = v[c];
-        }
-}
-
-template <int MT>
-__device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT]) {
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-}
 
 // acc[mt] += W_tile[mt] . bin   (KS k-steps of 2)
 template <int KS, int MT>
@@ -215,111 +172,6 @@ __device__ __forceinline__ void stage_resident(const float *__restrict__ g, int 
     }
 }
 
-// max(x, 0) as ONE v_max_f32: fmaxf() costs two (hipcc first canonicalises its operand with v_max x, x, x), and on gfx950
-// every VALU instruction of the layer epilogue is serial with the fp32 MFMAs (they share the vector ALU's issue)
-__device__ __forceinline__ float relu1(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
-
-template <int MT, bool RELU>
-__device__ __forceinline__ void acc_to_bin(const f32x16 (&acc)[MT], float (&bin)[16 * MT]) {
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) bin[16 * t + r] = RELU ? relu1(acc[t][r]) : acc[t][r];
-}
-
-// m = (m << 1) | (x > 0) in two VALU instructions: compare into VCC, then add-with-carry m + m + VCC (the C++ form
-// compiles to compare + select + shift + or: 188 instructions per 64 values, this is 128; exact, -0.0 and NaN -> 0)
-__device__ __forceinline__ uint32_t push_gt0(uint32_t m, float x) {
-    asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x) : "vcc");
-    return m;
-}
-
-// ReLU mask of a lane's 64 post-activation values, bit 16t+r <-> bin[16t+r] > 0
-__device__ __forceinline__ uint2 relu_mask64(const float (&bin)[64]) {
-    uint32_t m0 = 0, m1 = 0;
-#pragma unroll
-    for (int j = 31; j >= 0; j--) {
-        m0 = push_gt0(m0, bin[j]);
-        m1 = push_gt0(m1, bin[32 + j]);
-    }
-    return make_uint2(m0, m1);
-}
-
-__device__ __forceinline__ uint32_t relu_mask32(const float (&bin)[32]) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int j = 31; j >= 0; j--) m = push_gt0(m, bin[j]);
-    return m;
-}
-
-// apply bit `r` of a ReLU mask word to a value in two VALU instructions: sign-extend the bit to 0 / ~0 (v_bfe_i32) and
-// AND it with the value's bits (the C++ ternary compiles to and + compare + select)
-__device__ __forceinline__ float mask_bit(uint32_t mw, int r, float v) {
-    const int m = __builtin_amdgcn_sbfe(mw, r, 1);
-    return __uint_as_float(__float_as_uint(v) & (uint32_t)m);
-}
-
-// feature-major tile store: row = 32t + acc_row(r,h)
-template <int MT>
-__device__ __forceinline__ void store_acc_rows(float *__restrict__ tile, const float (&v)[16 * MT], int pt, int h) {
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) tile[(32 * t + acc_row(r, h)) * TILE + pt] = v[16 * t + r];
-}
-template <int MT>
-__device__ __forceinline__ void load_acc_rows(const float *__restrict__ tile, float (&v)[16 * MT], int pt, int h) {
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[16 * t + r] = tile[(32 * t + acc_row(r, h)) * TILE + pt];
-}
-// k-step ordered store: row = 2kk + h
-template <int KS>
-__device__ __forceinline__ void store_kk_rows(float *__restrict__ tile, const float (&v)[KS], int pt, int h) {
-#pragma unroll
-    for (int k = 0; k < KS; k++) tile[(2 * k + h) * TILE + pt] = v[k];
-}
-
-// frequency encoding of one point as B operands: k-step kk<18 = (band kk/3, dim kk%3): sin on
-// lanes 0-31, cos on lanes 32-63; kk 18 = (x0 | x1); kk 19 = (x2 | 0).   encodings.py:35-57
-__device__ __forceinline__ void enc_bin(const float (&x)[3], int h, int n_bands, float *__restrict__ bin /*[20]*/,
-                                        float *__restrict__ dsc /*[18] d(feature)/dx or null*/) {
-#pragma unroll
-    for (int k = 0; k < 18; k++) {
-        const int band = k / 3, dim = k % 3;
-        const float f = (float)(1 << band);
-        float s, c;
-        sincosf(x[dim] * f, &s, &c);
-        const bool on = band < n_bands;
-        bin[k] = on ? (h ? c : s) : 0.f;
-        if (dsc) dsc[k] = on ? (h ? -f * s : f * c) : 0.f;
-    }
-    bin[18] = h ? x[1] : x[0];
-    bin[19] = h ? 0.f : x[2];
-}
-
-// d(encoding feature)/dx of enc_bin's 18 sin/cos k-steps from the PARKED encoding instead of 18 more sincosf calls
-// (~2 200 VALU instructions per tile, serial with the fp32 MFMAs): the forward kernels park the encoding k-step-major
-// (row 2k + h = half h's feature of k-step k: sin for h = 0, cos for h = 1; zero for switched-off bands), and
-// d sin(f x)/dx = f cos(f x), d cos(f x)/dx = -f sin(f x) are the OTHER half's parked value times +-f.
-__device__ __forceinline__ void enc_deriv_parked(const float *__restrict__ enc_tile, int pt, int h, float *__restrict__ dsc /*[18]*/) {
-    // keep the 18 loads HERE: hoisted to the top of the kernel (the scheduler's default for loads) they would occupy 18
-    // registers across the whole layer chain, which has none to spare
-    __builtin_amdgcn_sched_barrier(0);
-    const float *base = enc_tile + (1 - h) * TILE + pt;
-    asm volatile("" : "+v"(base)::"memory");
-#pragma unroll
-    for (int k = 0; k < 18; k++) {
-        const float f = (float)(1 << (k / 3));
-        const float other = base[2 * k * TILE];
-        dsc[k] = h ? -f * other : f * other;
-    }
-}
 
 // =====================================================================================
 // warp: deform_net + topo_net

@@ -1,0 +1,302 @@
+// The warp networks (deform_net + topo_net, models/model.py:412-437) with EXACT fp32 products issued on the bf16 matrix pipe.
+//
+// gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector-ALU rate, 1/16 of the bf16 matrix rate, and blocks the
+// SIMD's VALU issue while it runs.  Here every fp32 operand is cut into three bf16 slices by truncation,
+//      x = hi + mid + lo   exactly   (8 + 8 + 8 significand bits),
+// and a product W.x is the six cross terms whose weight is >= 2^-16 of the leading one,
+//      Wh.xh + Wh.xm + Wm.xh + Wh.xl + Wm.xm + Wl.xh,
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  What is dropped (Wm.xl, Wl.xm, Wl.xl)
+// is <= 3 * 2^-24 of the product, the size of one fp32 rounding: the result is fp32-grade (tools/micro/mfma_b3.hip: max error
+// of a 128-term layer 1.37e-6 against float64, a fp32 fmaf chain 1.65e-6), for 6/16 of the matrix cycles.
+//
+// Layout facts the kernels rely on (32x32x16 bf16): lane (i = lane & 31, g = lane >> 5) supplies A[m = i][k = 8g..8g+7] and
+// B[k = 8g..8g+7][n = i] as 8 packed bf16 (4 VGPRs); D is the same 32x32 fp32 accumulator layout as the fp32 MFMA,
+// D[row = (r&3) + 8(r>>2) + 4g][col = i].  So accumulator registers 8s'..8s'+7 of output tile t, sliced and packed pairwise,
+// ARE the B operand of k16-step s = 2t + s' of the next layer: the register-resident chain of mlp.hip carries over, with the
+// k-permutation baked into the weight slices on the host (packing.py: frag_index_b3).  The parked tiles (activations
+// feature-major [F][32] + ReLU masks) are bit-for-bit in the layout of mlp.hip's kernels, which keep serving backward.
+//
+// Weight slices of a layer: [plane hi|mid|lo][out tile][k16 step][lane][8 bf16], 96 KB for a 128 x 128 layer, staged by
+// LDS-DMA once per 256-point workgroup (8 waves: two per SIMD share one copy, 160 KB of LDS do not hold two).
+#include "mlp_dev.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+union Frag {
+    f32x4 f;
+    bf16x8 h;
+    uint32_t u[4];
+};
+
+#define B3_THREADS 512
+#define B3_BLOCK_PTS 256
+#define B3_L0_F4 2560                                  // 3 planes x 4 tiles x 3 k16 steps x 64 lanes = 2304, padded to whole DMA rounds
+#define B3_LH_F4 6144                                  // 128 x 128
+#define B3_L5_F4 1536                                  // one padded output tile
+#define B3_NET_F4 (B3_L0_F4 + 4 * B3_LH_F4 + B3_L5_F4)  // 28 672 float4 = 448 KB per net
+
+extern __shared__ f32x4 lds_b3[];
+
+// two fp32 values -> the packed bf16 pairs of their three slices (truncation split, exact)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302);
+    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
+    const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(c1, c0, 0x07060302);
+    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+}
+
+template <int N_F4, int NTHR = B3_THREADS>
+__device__ __forceinline__ void b3_stage_issue(const f32x4 *__restrict__ src) {
+    static_assert(N_F4 % NTHR == 0, "whole rounds of the block");
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N_F4 / NTHR; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * NTHR + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_b3 + k * NTHR + wave * 64), 16, 0, 0);
+}
+__device__ __forceinline__ void b3_stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// acc[t] += W[t] . b : six slice products per k16 step, two output tiles in rotation (consecutive MFMAs never chain on one
+// accumulator), small terms first
+template <int KS, int MT>
+__device__ __forceinline__ void b3_layer(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
+                                         f32x16 (&acc)[MT], int lane) {
+    constexpr int PL = MT * KS * 64;
+    constexpr int NT = MT >= 2 ? 2 : 1;
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+#pragma unroll
+        for (int mp = 0; mp < MT; mp += NT) {
+            Frag ah[NT], am[NT], al[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                ah[t].f = w[0 * PL + ((mp + t) * KS + s) * 64 + lane];
+                am[t].f = w[1 * PL + ((mp + t) * KS + s) * 64 + lane];
+                al[t].f = w[2 * PL + ((mp + t) * KS + s) * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+        }
+    }
+}
+
+// mlp_dev.h's relu1 / push_gt0 are inline asm, and hipcc's hazard recognizer does not see an inline-asm READ of a register
+// an in-flight bf16 MFMA is still writing: the first v_max after the layer's last MFMA would return the stale accumulator
+// (found the hard way: the compiler sinks the layer's last MFMAs past the barrier and the DMA issue, right up to the first
+// asm statement; the fp32 MFMA of mlp.hip runs in the vector ALU's own order and is immune).  So the epilogue opens with the
+// wait states an 8-pass MFMA result needs (11; 16 given), fenced so that no MFMA moves below and no asm above them.
+__device__ __forceinline__ void mfma_results_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// layer epilogue: ReLU, park the tile feature-major (+ its sign mask), slice into the next layer's B operands
+__device__ __forceinline__ void b3_epilogue(const f32x16 (&acc)[4], float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
+                                            Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
+    uint32_t mt[4];
+    mfma_results_settle();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[r] = relu1(acc[t][r]);
+        if (ht) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) ht[(32 * t + acc_row(r, h)) * TILE + pt] = y[r];
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 15; r >= 0; r--) m = push_gt0(m, y[r]);
+        mt[t] = m;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split2(y[8 * s2 + 2 * e2], y[8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    }
+    if (mk) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void warp_fwd_b3_kernel(
+    const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
+    const float *__restrict__ bias0_t, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
+    const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
+    float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * NW + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const int64_t pc = p < M ? p : M - 1;
+    float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
+    const int sl = slot ? slot[pc] : 0;
+    // the scratch holds whole 128-point blocks (mh_mlp_tiles); a 256-point workgroup's tail tiles beyond it park nothing
+    float *tile = (acts && tile_id < n_tiles) ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
+
+    b3_stage_issue<B3_L0_F4, NW * 64>(w3_d);
+    float bin0[24];
+    enc_bin(xv, h, n_bands, bin0, nullptr);
+#pragma unroll
+    for (int k = 20; k < 24; k++) bin0[k] = 0.f;
+    if (tile) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) tile[(2 * k + h) * TILE + pt] = k < 20 ? bin0[k] : 0.f;  // k-step ordered, rows 40..63 pad
+    }
+    uint2 *mk = tile ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
+
+    for (int net = 0; net < 2; net++) {
+        const f32x4 *wp = net ? w3_t : w3_d;
+        const float *bs = net ? bias_t : bias_d;
+        const float *b0 = (net ? bias0_t : bias0_d) + (int64_t)sl * 128;
+        float *ht = tile ? tile + (64 + net * 640) * TILE : nullptr;
+        f32x16 acc[4];
+        Frag bh[8], bm[8], bl[8];
+        // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++) split2(bin0[8 * s + 2 * e2], bin0[8 * s + 2 * e2 + 1], bh[s].u[e2], bm[s].u[e2], bl[s].u[e2]);
+        acc_bias<4>(acc, b0, h);
+        b3_stage_wait();
+        b3_layer<3, 4>(lds_b3, bh, bm, bl, acc, lane);
+        __syncthreads();
+        wp += B3_L0_F4;
+        b3_stage_issue<B3_LH_F4, NW * 64>(wp);
+        b3_epilogue(acc, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bm, bl);
+        // layers 1..4: 128 -> 128
+        for (int l = 1; l <= 4; l++) {
+            acc_bias<4>(acc, bs + (l - 1) * 128, h);
+            b3_stage_wait();
+            b3_layer<8, 4>(lds_b3, bh, bm, bl, acc, lane);
+            __syncthreads();
+            wp += B3_LH_F4;
+            if (l < 4)
+                b3_stage_issue<B3_LH_F4, NW * 64>(wp);
+            else
+                b3_stage_issue<B3_L5_F4, NW * 64>(wp);
+            b3_epilogue(acc, ht ? ht + l * 128 * TILE : nullptr, mk ? mk + (net * 5 + l) * 64 + lane : nullptr, pt, h, bh, bm, bl);
+        }
+        // layer 5: 128 -> 3 | 2 (one padded tile)
+        f32x16 o[1];
+        acc_bias<1>(o, bs + 4 * 128, h);
+        b3_stage_wait();
+        b3_layer<8, 1>(lds_b3, bh, bm, bl, o, lane);
+        __syncthreads();
+        if (net == 0) b3_stage_issue<B3_L0_F4, NW * 64>(w3_t);
+        if (h == 0 && p < M) {
+            if (net == 0) {
+                out_deform[p * 3 + 0] = o[0][0];
+                out_deform[p * 3 + 1] = o[0][1];
+                out_deform[p * 3 + 2] = o[0][2];
+            } else {
+                out_topo[p * 2 + 0] = o[0][0];
+                out_topo[p * 2 + 1] = o[0][1];
+            }
+        }
+    }
+}
+
+// ---- fp32 fragments (b3 order, one gather of the natural weights on the host side) -> three bf16 planes per layer
+#define B3_MAX_LAYERS 16
+struct B3Layers {
+    int n_layers;
+    int src_off[B3_MAX_LAYERS];   // floats
+    int n8[B3_MAX_LAYERS];        // groups of 8 floats (= float4 of bf16 per plane)
+    int dst_off[B3_MAX_LAYERS];   // float4 units
+    int g_end[B3_MAX_LAYERS];     // running end of the layers' group ranges
+};
+
+__global__ void b3_slice_kernel(const float *__restrict__ src, f32x4 *__restrict__ dst, B3Layers L) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= L.g_end[L.n_layers - 1]) return;
+    int l = 0;
+    while (g >= L.g_end[l]) l++;
+    const int i = g - (l ? L.g_end[l - 1] : 0);
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(src + L.src_off[l] + 8 * i);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(src + L.src_off[l] + 8 * i + 4);
+    Frag fh, fm, fl;
+    split2(a[0], a[1], fh.u[0], fm.u[0], fl.u[0]);
+    split2(a[2], a[3], fh.u[1], fm.u[1], fl.u[1]);
+    split2(b[0], b[1], fh.u[2], fm.u[2], fl.u[2]);
+    split2(b[2], b[3], fh.u[3], fm.u[3], fl.u[3]);
+    f32x4 *d = dst + L.dst_off[l] + i;
+    d[0] = fh.f;
+    d[L.n8[l]] = fm.f;
+    d[2 * L.n8[l]] = fl.f;
+}
+
+extern "C" int mh_b3_slice(const float *src, void *dst, int32_t n_layers, const int32_t *src_off_host, const int32_t *n_host,
+                           const int32_t *dst_off_f4_host, void *stream) {
+    if (n_layers == 0) return MH_OK;
+    if (!src || !dst || n_layers < 0 || n_layers > B3_MAX_LAYERS || !src_off_host || !n_host || !dst_off_f4_host) return MH_ERR_ARG;
+    B3Layers L;
+    L.n_layers = n_layers;
+    int end = 0;
+    for (int l = 0; l < n_layers; l++) {
+        if (n_host[l] <= 0 || n_host[l] % 8 || src_off_host[l] % 4 || src_off_host[l] < 0 || dst_off_f4_host[l] < 0) return MH_ERR_ARG;
+        L.src_off[l] = src_off_host[l];
+        L.n8[l] = n_host[l] / 8;
+        L.dst_off[l] = dst_off_f4_host[l];
+        end += n_host[l] / 8;
+        L.g_end[l] = end;
+    }
+    hipLaunchKernelGGL(b3_slice_kernel, dim3((end + 255) / 256), dim3(256), 0, mh_stream(stream), src,
+                       reinterpret_cast<f32x4 *>(dst), L);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int64_t mh_warp_w3_bytes(void) { return (int64_t)B3_NET_F4 * 16; }
+
+static int b3_lds_opt_in() {
+    static int done = 0;
+    if (!done) {
+        if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
+                hipSuccess)
+            return MH_ERR_LAUNCH;
+        done = 1;
+    }
+    return MH_OK;
+}
+
+extern "C" int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w3_d,
+                              const void *w3_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
+                              float *out_topo, float *acts, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !x || !bias0_d || !bias0_t || !w3_d || !w3_t || !bias_d || !bias_t || !out_deform || !out_topo || n_bands < 0 ||
+        n_bands > 6)
+        return MH_ERR_ARG;
+    static const int nw = getenv("MH_B3_WAVES") ? atoi(getenv("MH_B3_WAVES")) : 8;   // debug: 4 = one wave per SIMD
+    const int64_t blocks = (M + nw * 32 - 1) / (nw * 32);
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
+    if (nw == 4)
+        hipLaunchKernelGGL(warp_fwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LH_F4 * 16, mh_stream(stream), x, slot,
+                           bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
+                           bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    else
+        hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LH_F4 * 16, mh_stream(stream), x,
+                           slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
+                           bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}

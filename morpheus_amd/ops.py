@@ -100,6 +100,8 @@ GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B swit
 # Measured on MI355X (cfg3, same box): 1.05 ms against 2 x 0.43 = 0.86 ms for two launches -- twice the gathers in flight per
 # lane cost more occupancy than the shared index arithmetic saves -- so one launch per table stays the default.
 GRID_FWD_TWO = os.environ.get("MORPHEUS_GRID_FWD", "") == "two"
+# warp nets: "b3" = exact fp32 products from three bf16 slices on the bf16 matrix pipe (csrc/mlp_b3.hip), "f32" = fp32 MFMA
+MLP_B3 = os.environ.get("MORPHEUS_MLP", "f32") == "b3"
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
@@ -546,7 +548,7 @@ class _PackOperands(torch.autograd.Function):
     bias0 (model.warp), so its slot in the raw gradient is dropped here."""
 
     @staticmethod
-    def forward(ctx, jp, zero_bias0, n_w, *params):
+    def forward(ctx, jp, zero_bias0, b3, n_w, *params):
         require_gpu(*params)
         weights, biases, o = [], [], 0
         for pk in jp.packers:
@@ -556,26 +558,42 @@ class _PackOperands(torch.autograd.Function):
             biases.append([p.detach() for p in params[o:o + len(pk.specs)]])
             o += len(pk.specs)
         assert o == len(params) == n_w
-        fpack, bpack = jp.pack(weights, biases)
+        flat = jp.flat(weights, biases)
+        m = jp.on(flat.device)
+        fpack, bpack = flat[m["fwd"]], flat[m["bwd"]]
+        if b3:
+            # bf16x3 forward fragments (csrc/mlp_b3.hip): the same weights gathered in the 32x32x16 fragment order, then cut
+            # into [hi | mid | lo] bf16 planes per layer by one launch
+            lib = _lib.load()
+            src = flat[m["fwd3"]]
+            w3 = torch.zeros(jp.fwd3_total_f4 * 4, device=flat.device)
+            so, sp = _i32arr([l[0] for l in jp.b3_layers])
+            no, np_ = _i32arr([l[1] for l in jp.b3_layers])
+            do, dp = _i32arr([l[2] for l in jp.b3_layers])
+            check(lib.mh_b3_slice(ptr(src), ptr(w3), len(jp.b3_layers), sp, np_, dp, stream()), "mh_b3_slice")
+        else:
+            w3 = fpack.new_empty(0)
         token = fpack.new_empty(jp.raw_len)
         ctx.jp, ctx.zero_bias0 = jp, zero_bias0
-        ctx.mark_non_differentiable(fpack, bpack)
-        return fpack, bpack, token
+        ctx.mark_non_differentiable(fpack, bpack, w3)
+        return fpack, bpack, w3, token
 
     @staticmethod
-    def backward(ctx, _gf, _gb, g_token):
+    def backward(ctx, _gf, _gb, _g3, g_token):
         if g_token is None:
-            return (None,) * (3 + sum(2 * len(pk.specs) for pk in ctx.jp.packers))
+            return (None,) * (4 + sum(2 * len(pk.specs) for pk in ctx.jp.packers))
         nat_w, nat_b = ctx.jp.unpack_grads(g_token, zero_bias0=ctx.zero_bias0)
         flat = [g for net in nat_w for g in net] + [g for net in nat_b for g in net]
-        return (None, None, None, *flat)
+        return (None, None, None, None, *flat)
 
 
 class MLPOperands:
     """Prepared operands of the warp nets (deform_net + topo_net) or of the field nets (sdf_net + color_net)."""
 
-    def __init__(self, jp, fpack, bpack, token):
+    def __init__(self, jp, fpack, bpack, w3, token):
         self.jp, self.fpack, self.bpack, self.token = jp, fpack, bpack, token
+        # bf16x3 slices per net (float32 storage, 4 floats per float4 unit), or None when the fp32-MFMA kernels serve
+        self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w3] if w3.numel() else None
         self.w = [jp.take(fpack, sl) for sl in jp.w]
         self.b = [jp.take(fpack, sl) for sl in jp.b]
         self.wT = [jp.take(bpack, sl) for sl in jp.wT]
@@ -585,13 +603,13 @@ def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[t
     """params_{d,t}: W0x [128,39], W1..W4 [128,128], W5 [n_out,128], b0 (its gradient travels through bias0), b1..b5."""
     jp = warp_joint_packer()
     flat = list(params_d[:6]) + list(params_t[:6]) + list(params_d[6:]) + list(params_t[6:])
-    return MLPOperands(jp, *_PackOperands.apply(jp, True, len(flat), *flat))
+    return MLPOperands(jp, *_PackOperands.apply(jp, True, MLP_B3, len(flat), *flat))
 
 
 def prepare_field_operands(params: Sequence[torch.Tensor]) -> MLPOperands:
     """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
     jp = field_joint_packer()
-    return MLPOperands(jp, *_PackOperands.apply(jp, False, len(params), *params))
+    return MLPOperands(jp, *_PackOperands.apply(jp, False, False, len(params), *params))
 
 
 class _WarpMLP(torch.autograd.Function):
@@ -614,8 +632,12 @@ class _WarpMLP(torch.autograd.Function):
         b0d, b0t = bias0_d.detach().contiguous(), bias0_t.detach().contiguous()
         slot_c = None if slot is None else slot.contiguous()
         _e = TIMER.start()
-        check(lib.mh_warp_fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(wd), ptr(wt), ptr(bd), ptr(bt), n_bands,
-                              ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
+        if opnd.w3 is not None:
+            check(lib.mh_warp_fwd_b3(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
+                                     n_bands, ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd_b3")
+        else:
+            check(lib.mh_warp_fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(wd), ptr(wt), ptr(bd), ptr(bt), n_bands,
+                                  ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
         TIMER.stop("mh_warp_fwd", _e)
         ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
         ctx.n_bands, ctx.n_slots, ctx.jp = n_bands, bias0_d.shape[0], opnd.jp

@@ -80,6 +80,27 @@ def _frag_index(row_of_lane: np.ndarray, col_of_k: np.ndarray, n_cols: int, tran
     return idx.reshape(-1)
 
 
+def _frag_index_b3(row_of_lane: np.ndarray, col_of_k: np.ndarray, n_cols: int, transpose: bool, sentinel: int,
+                   base: int) -> np.ndarray:
+    """Gather index [MT][KS16][64][8] for the bf16x3 kernels (csrc/mlp_b3.hip): with v_mfma_f32_32x32x16_bf16 lane
+    (i = lane & 31, g = lane >> 5) supplies A[m = i][k = 8g + e] of k16-step s, and the B operand of (s, g, e) is what the
+    fp32 chain carries in k-step 8s + e, lane half g -- so the same kmap serves both fragment shapes."""
+    MT, KS = row_of_lane.shape[0] // 32, col_of_k.shape[0]
+    KS16 = (KS + 7) // 8
+    km = np.full((KS16 * 8, 2), -1, dtype=np.int64)
+    km[:KS] = col_of_k
+    lane = np.arange(64)
+    a = row_of_lane.reshape(MT, 32)[:, lane & 31]                        # [MT, 64]
+    b = km.reshape(KS16, 8, 2)[:, :, lane >> 5].transpose(0, 2, 1)       # [KS16, 64, 8]
+    a4, b4 = a[:, None, :, None], b[None, :, :, :]
+    flat = (b4 * n_cols + a4) if transpose else (a4 * n_cols + b4)
+    idx = np.where((a4 >= 0) & (b4 >= 0), base + flat, sentinel)
+    return idx.reshape(-1)
+
+
+B3_DMA_F4 = 512      # a layer's slices are staged by whole rounds of the 512-thread block (16 bytes per thread and round)
+
+
 @dataclass
 class LayerSpec:
     """One linear layer as the kernels see it."""
@@ -188,6 +209,16 @@ class NetPacker:
                for i in bwd_order]
         self.fwd_index = np.concatenate(fwd)
         self.bwd_index = np.concatenate(bwd)
+        # bf16x3 fragments: fp32 gather in b3 order (sliced into three bf16 planes by mh_b3_slice); per layer the float count
+        # and the float4 offset of its [hi|mid|lo] planes in the sliced pack (padded to whole DMA rounds)
+        fwd3 = [_frag_index_b3(s.rowmap, s.kmap, s.in_dim, False, sentinel, o) for s, o in zip(self.specs, offs)]
+        self.fwd3_index = np.concatenate(fwd3)
+        self.fwd3_n = [len(f) for f in fwd3]
+        self.fwd3_f4, f4 = [], 0
+        for n in self.fwd3_n:
+            self.fwd3_f4.append(f4)
+            f4 += -(-(3 * n // 8) // B3_DMA_F4) * B3_DMA_F4
+        self.fwd3_total_f4 = f4
         # bias vector (accumulator-row order, padded to 32*MT) : gather from [b_0 | b_1 | ... | 0]
         b_offs, nb = [], 0
         for s in self.specs:
@@ -300,6 +331,18 @@ class JointPacker:
         self.fwd_index = np.concatenate(fwd + bias)
         self.bwd_index = np.concatenate(bwd)
         self.n_flat = zero + 1
+        # bf16x3 forward fragments of all nets: one fp32 gather + one slicing launch (mh_b3_slice)
+        f3, self.w3, self.b3_layers, wo, src, f4 = [], [], [], 0, 0, 0
+        for p in self.packers:
+            f3.append(np.where(p.fwd3_index == p.n_weights, zero, p.fwd3_index + wo))
+            self.w3.append((f4, p.fwd3_total_f4))                       # float4 units
+            for n, o4 in zip(p.fwd3_n, p.fwd3_f4):
+                self.b3_layers.append((src, n, f4 + o4))
+                src += n
+            f4 += p.fwd3_total_f4
+            wo += p.n_weights
+        self.fwd3_index = np.concatenate(f3)
+        self.fwd3_total_f4 = f4
         # gradients
         raw_dw = sum(p.raw_dw for p in self.packers)
         g, dwo, dbo = [], 0, raw_dw
@@ -331,7 +374,7 @@ class JointPacker:
         if key not in self._dev:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
             self._dev[key] = dict(fwd=t(self.fwd_index), bwd=t(self.bwd_index), grad=t(self.grad_index),
-                                  grad_nob0=t(self.grad_index_nob0))
+                                  grad_nob0=t(self.grad_index_nob0), fwd3=t(self.fwd3_index))
         return self._dev[key]
 
     def pack(self, weights: Sequence[Sequence[torch.Tensor]], biases: Sequence[Sequence[torch.Tensor]]):
@@ -341,6 +384,12 @@ class JointPacker:
         assert flat.numel() == self.n_flat
         m = self.on(flat.device)
         return flat[m["fwd"]], flat[m["bwd"]]
+
+    def flat(self, weights, biases) -> torch.Tensor:
+        parts = [w.reshape(-1) for net in weights for w in net] + [b.reshape(-1) for net in biases for b in net]
+        flat = torch.cat(parts + [parts[0].new_zeros(1)])
+        assert flat.numel() == self.n_flat
+        return flat
 
     @staticmethod
     def take(buf: torch.Tensor, sl: Tuple[int, int]) -> torch.Tensor:
