@@ -203,10 +203,15 @@ int mh_warp_fwd(const float *x, const int32_t *slot, const float *bias0_d, const
  *   per layer three bf16 planes [hi | mid | lo][out tile][k16 step][lane][8 bf16].  src_off / n in floats (n % 8 == 0),
  *   dst_off in 16-byte units; host arrays of n_layers entries (<= 16).
  * mh_warp_fwd_b3: mh_warp_fwd with w3_{d,t} = one net's sliced pack (mh_warp_w3_bytes() bytes: layer 0 padded to whole
- *   512 x 16-byte DMA rounds).  Same outputs, same parked tiles (mh_warp_bwd_data / mh_mlp_wgrad consume them). */
+ *   512 x 16-byte DMA rounds).  Same outputs, same parked tiles (mh_warp_bwd_data / mh_mlp_wgrad consume them).
+ * mh_warp_bwd_data_b3: mh_warp_bwd_data with the TRANSPOSED sliced packs (mh_warp_w3T_bytes() bytes per net: T5, T4..T1,
+ *   T0; packing.py: bwd3_index).  Same dPre tiles, same g_x. */
 int mh_b3_slice(const float *src, void *dst, int32_t n_layers, const int32_t *src_off_host, const int32_t *n_host,
                 const int32_t *dst_off_f4_host, void *stream);
 int64_t mh_warp_w3_bytes(void);
+int64_t mh_warp_w3T_bytes(void);
+int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const float *g_topo, const void *w3T_d, const void *w3T_t,
+                        int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream);
 int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w3_d,
                    const void *w3_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
                    float *out_topo, float *acts, int64_t M, void *stream);

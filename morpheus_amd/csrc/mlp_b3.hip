@@ -64,11 +64,14 @@ __device__ __forceinline__ void b3_stage_wait() {
 
 // acc[t] += W[t] . b : six slice products per k16 step, two output tiles in rotation (consecutive MFMAs never chain on one
 // accumulator), small terms first
-template <int KS, int MT>
+template <int KS, int MT, bool ZERO = false>
 __device__ __forceinline__ void b3_layer(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
                                          f32x16 (&acc)[MT], int lane) {
     constexpr int PL = MT * KS * 64;
     constexpr int NT = MT >= 2 ? 2 : 1;
+    // ZERO: the accumulators are not pre-initialised, the first MFMA of each takes the inline constant 0 as C (backward
+    // layers have no bias)
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; s++) {
 #pragma unroll
@@ -81,7 +84,8 @@ __device__ __forceinline__ void b3_layer(const f32x4 *__restrict__ w, const Frag
                 al[t].f = w[2 * PL + ((mp + t) * KS + s) * 64 + lane];
             }
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+            for (int t = 0; t < NT; t++)
+                acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, (ZERO && s == 0) ? zero : acc[mp + t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[mp + t], 0, 0, 0);
 #pragma unroll
@@ -213,6 +217,133 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_b3_kernel(
     }
 }
 
+// ---- backward-data -------------------------------------------------------------------------------------------------
+// Same chain, transposed packs (T5, T4..T1, T0), ReLU derivative from the sign masks the forward parked; parks dPre tiles in
+// mlp.hip's layout for mh_mlp_wgrad.
+#define B3_T5_F4 1536                                   // 3 planes x 4 tiles x 2 k16 steps x 64 lanes
+#define B3_T0_F4 3072                                   // 3 planes x 2 tiles x 8 k16 steps x 64 lanes
+#define B3_NETT_F4 (B3_T5_F4 + 4 * B3_LH_F4 + B3_T0_F4)  // 29 184 float4 per net
+
+// masked accumulators -> parked dPre tile + the next transposed layer's B operands
+__device__ __forceinline__ void b3_epilogue_bwd(const f32x16 (&acc)[4], uint2 m, float *__restrict__ dt, int pt, int h, Frag (&bh)[8],
+                                                Frag (&bm)[8], Frag (&bl)[8]) {
+    mfma_results_settle();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint32_t mw = (t < 2 ? m.x : m.y) >> (16 * (t & 1));
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[r] = mask_bit(mw, r, acc[t][r]);
+        if (dt) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) dt[(32 * t + acc_row(r, h)) * TILE + pt] = y[r];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split2(y[8 * s2 + 2 * e2], y[8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__restrict__ x, const float *__restrict__ g_deform,
+                                                                 const float *__restrict__ g_topo, const f32x4 *__restrict__ w3T_d,
+                                                                 const f32x4 *__restrict__ w3T_t, int n_bands,
+                                                                 const float *__restrict__ acts, float *__restrict__ dpre,
+                                                                 float *__restrict__ g_x, int64_t M, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * NW + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const bool live = p < M;
+    // the scratch holds whole 128-point blocks: a wave beyond it (tail of the last 256-point workgroup) runs the chain on
+    // the last real tile's masks and stores nothing
+    const bool have = tile_id < n_tiles;
+    const float *atile = acts + (have ? tile_id : n_tiles - 1) * (int64_t)(WARP_ACT_ROWS * TILE);
+    float *dtile = have ? dpre + tile_id * (int64_t)(WARP_DPRE_ROWS * TILE) : nullptr;
+    float gx[3] = {0.f, 0.f, 0.f};
+
+    b3_stage_issue<B3_T5_F4, NW * 64>(w3T_d);
+    for (int net = 0; net < 2; net++) {
+        const f32x4 *wt = net ? w3T_t : w3T_d;
+        const float *g = net ? g_topo : g_deform;
+        const int nout = net ? 2 : 3;
+        float *dt = dtile ? dtile + net * 672 * TILE : nullptr;
+        const uint2 *mk = reinterpret_cast<const uint2 *>(atile + WARP_HID_ROWS * TILE) + net * 5 * 64 + lane;
+        uint2 msk[5];
+#pragma unroll
+        for (int l = 0; l < 5; l++) msk[l] = mk[l * 64];
+        // dPre5: rows 0..nout-1 carry the incoming gradient (no activation on the last layer)
+        float d5[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) d5[r] = 0.f;
+        if (g && live && h == 0) {
+            d5[0] = g[p * nout + 0];
+            d5[1] = g[p * nout + 1];
+            if (nout == 3) d5[2] = g[p * nout + 2];
+        }
+        if (dt) store_acc_rows<1>(dt + 640 * TILE, d5, pt, h);
+        Frag bh[8], bm[8], bl[8];
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++) split2(d5[8 * s + 2 * e2], d5[8 * s + 2 * e2 + 1], bh[s].u[e2], bm[s].u[e2], bl[s].u[e2]);
+        // dH5 = W5^T dPre5
+        f32x16 acc[4];
+        b3_stage_wait();
+        b3_layer<2, 4, true>(lds_b3, bh, bm, bl, acc, lane);
+        __syncthreads();
+        wt += B3_T5_F4;
+        b3_stage_issue<B3_LH_F4, NW * 64>(wt);
+        for (int l = 4; l >= 1; l--) {
+            // output of transposed layer l+1 is dH_{l+1}: mask by H_{l+1}'s ReLU -> dPre_l, park, slice
+            b3_epilogue_bwd(acc, msk[l], dt ? dt + l * 128 * TILE : nullptr, pt, h, bh, bm, bl);
+            b3_stage_wait();
+            b3_layer<8, 4, true>(lds_b3, bh, bm, bl, acc, lane);
+            __syncthreads();
+            wt += B3_LH_F4;
+            if (l > 1)
+                b3_stage_issue<B3_LH_F4, NW * 64>(wt);
+            else if (g_x)
+                b3_stage_issue<B3_T0_F4, NW * 64>(wt);
+            else if (net == 0)
+                b3_stage_issue<B3_T5_F4, NW * 64>(w3T_t);
+        }
+        b3_epilogue_bwd(acc, msk[0], dt, pt, h, bh, bm, bl);
+        if (g_x) {
+            // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5).  Skipped when nobody asks for d/dx
+            f32x16 e[2];
+            b3_stage_wait();
+            b3_layer<8, 2, true>(lds_b3, bh, bm, bl, e, lane);
+            __syncthreads();
+            if (net == 0) b3_stage_issue<B3_T5_F4, NW * 64>(w3T_t);
+            mfma_results_settle();
+            float dsc[18];
+            enc_deriv_parked(atile, pt, h, dsc);
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                const float de = k < 16 ? e[0][k] : e[1][k - 16];
+                gx[k % 3] += de * dsc[k];
+            }
+            // kk 18: (x0 | x1), kk 19: (x2 | -)
+            if (h == 0) {
+                gx[0] += e[1][2];
+                gx[2] += e[1][3];
+            } else {
+                gx[1] += e[1][2];
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
+    if (g_x && live && h == 0) {
+        g_x[p * 3 + 0] = gx[0];
+        g_x[p * 3 + 1] = gx[1];
+        g_x[p * 3 + 2] = gx[2];
+    }
+}
+
 // ---- fp32 fragments (b3 order, one gather of the natural weights on the host side) -> three bf16 planes per layer
 #define B3_MAX_LAYERS 16
 struct B3Layers {
@@ -271,10 +402,28 @@ static int b3_lds_opt_in() {
         if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
                 hipSuccess)
             return MH_ERR_LAUNCH;
         done = 1;
     }
+    return MH_OK;
+}
+
+extern "C" int64_t mh_warp_w3T_bytes(void) { return (int64_t)B3_NETT_F4 * 16; }
+
+extern "C" int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const float *g_topo, const void *w3T_d, const void *w3T_t,
+                                   int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !x || !w3T_d || !w3T_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
+    const int64_t blocks = (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
+    hipLaunchKernelGGL(warp_bwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LH_F4 * 16, mh_stream(stream), x, g_deform,
+                       g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t), (int)n_bands, acts,
+                       dpre, g_x, M, mh_mlp_tiles(M));
+    MH_CHECK_LAUNCH();
     return MH_OK;
 }
 

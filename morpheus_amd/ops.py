@@ -565,12 +565,13 @@ class _PackOperands(torch.autograd.Function):
             # bf16x3 forward fragments (csrc/mlp_b3.hip): the same weights gathered in the 32x32x16 fragment order, then cut
             # into [hi | mid | lo] bf16 planes per layer by one launch
             lib = _lib.load()
-            src = flat[m["fwd3"]]
-            w3 = torch.zeros(jp.fwd3_total_f4 * 4, device=flat.device)
-            so, sp = _i32arr([l[0] for l in jp.b3_layers])
-            no, np_ = _i32arr([l[1] for l in jp.b3_layers])
-            do, dp = _i32arr([l[2] for l in jp.b3_layers])
-            check(lib.mh_b3_slice(ptr(src), ptr(w3), len(jp.b3_layers), sp, np_, dp, stream()), "mh_b3_slice")
+            w3 = torch.zeros((jp.fwd3_total_f4 + jp.bwd3_total_f4) * 4, device=flat.device)
+            for key, layers, base in (("fwd3", jp.b3_layers, 0), ("bwd3", jp.b3T_layers, jp.fwd3_total_f4)):
+                src = flat[m[key]]
+                so, sp = _i32arr([l[0] for l in layers])
+                no, np_ = _i32arr([l[1] for l in layers])
+                do, dp = _i32arr([l[2] + base for l in layers])
+                check(lib.mh_b3_slice(ptr(src), ptr(w3), len(layers), sp, np_, dp, stream()), "mh_b3_slice")
         else:
             w3 = fpack.new_empty(0)
         token = fpack.new_empty(jp.raw_len)
@@ -594,6 +595,7 @@ class MLPOperands:
         self.jp, self.fpack, self.bpack, self.token = jp, fpack, bpack, token
         # bf16x3 slices per net (float32 storage, 4 floats per float4 unit), or None when the fp32-MFMA kernels serve
         self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w3] if w3.numel() else None
+        self.wT3 = [w3[4 * (jp.fwd3_total_f4 + o):4 * (jp.fwd3_total_f4 + o + n)] for o, n in jp.wT3] if w3.numel() else None
         self.w = [jp.take(fpack, sl) for sl in jp.w]
         self.b = [jp.take(fpack, sl) for sl in jp.b]
         self.wT = [jp.take(bpack, sl) for sl in jp.wT]
@@ -639,6 +641,9 @@ class _WarpMLP(torch.autograd.Function):
             check(lib.mh_warp_fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(wd), ptr(wt), ptr(bd), ptr(bt), n_bands,
                                   ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
         TIMER.stop("mh_warp_fwd", _e)
+        ctx.b3 = opnd.wT3 is not None
+        if ctx.b3:
+            wdT, wtT = opnd.wT3
         ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
         ctx.n_bands, ctx.n_slots, ctx.jp = n_bands, bias0_d.shape[0], opnd.jp
         return deform, topo
@@ -653,8 +658,9 @@ class _WarpMLP(torch.autograd.Function):
         g_x = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL -> the kernel skips the W0^T stage
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
-        check(lib.mh_warp_bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts),
-                                   ptr(dpre), ptr(g_x), M, stream()), "mh_warp_bwd_data")
+        bwd_data = lib.mh_warp_bwd_data_b3 if ctx.b3 else lib.mh_warp_bwd_data
+        check(bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
+                       stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)
         raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
                      _WARP_WG[3], n_tiles, dev, "warp")

@@ -219,6 +219,15 @@ class NetPacker:
             self.fwd3_f4.append(f4)
             f4 += -(-(3 * n // 8) // B3_DMA_F4) * B3_DMA_F4
         self.fwd3_total_f4 = f4
+        bwd3 = [_frag_index_b3(self.specs[i].rowmapT, self.specs[i].kmapT, self.specs[i].in_dim, True, sentinel, offs[i])
+                for i in bwd_order]
+        self.bwd3_index = np.concatenate(bwd3)
+        self.bwd3_n = [len(f) for f in bwd3]
+        self.bwd3_f4, f4 = [], 0
+        for n in self.bwd3_n:
+            self.bwd3_f4.append(f4)
+            f4 += -(-(3 * n // 8) // B3_DMA_F4) * B3_DMA_F4
+        self.bwd3_total_f4 = f4
         # bias vector (accumulator-row order, padded to 32*MT) : gather from [b_0 | b_1 | ... | 0]
         b_offs, nb = [], 0
         for s in self.specs:
@@ -343,6 +352,17 @@ class JointPacker:
             wo += p.n_weights
         self.fwd3_index = np.concatenate(f3)
         self.fwd3_total_f4 = f4
+        t3, self.wT3, self.b3T_layers, wo, src, f4 = [], [], [], 0, 0, 0
+        for p in self.packers:
+            t3.append(np.where(p.bwd3_index == p.n_weights, zero, p.bwd3_index + wo))
+            self.wT3.append((f4, p.bwd3_total_f4))
+            for n, o4 in zip(p.bwd3_n, p.bwd3_f4):
+                self.b3T_layers.append((src, n, f4 + o4))
+                src += n
+            f4 += p.bwd3_total_f4
+            wo += p.n_weights
+        self.bwd3_index = np.concatenate(t3)
+        self.bwd3_total_f4 = f4
         # gradients
         raw_dw = sum(p.raw_dw for p in self.packers)
         g, dwo, dbo = [], 0, raw_dw
@@ -374,7 +394,7 @@ class JointPacker:
         if key not in self._dev:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
             self._dev[key] = dict(fwd=t(self.fwd_index), bwd=t(self.bwd_index), grad=t(self.grad_index),
-                                  grad_nob0=t(self.grad_index_nob0), fwd3=t(self.fwd3_index))
+                                  grad_nob0=t(self.grad_index_nob0), fwd3=t(self.fwd3_index), bwd3=t(self.bwd3_index))
         return self._dev[key]
 
     def pack(self, weights: Sequence[Sequence[torch.Tensor]], biases: Sequence[Sequence[torch.Tensor]]):
