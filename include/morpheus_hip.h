@@ -260,6 +260,12 @@ int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats,
                  int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
                  const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
                  float *db_raw, int64_t n_tiles, void *stream);
+/* the same GEMM with exact fp32 products from three bf16 slices on the bf16 matrix pipe (see mh_warp_fwd_b3): both fp32
+ * operands are sliced on the fly, same arguments, same outputs. */
+int mh_mlp_wgrad_b3(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                    int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
+                    const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
+                    float *db_raw, int64_t n_tiles, void *stream);
 
 /* ---- weight-norm parametrisation of every weight-normed layer, one launch each way ---------- */
 /* Replaces nn.utils.weight_norm on the Linear layers of deform_net / topo_net / color_net (models/decoders.py:51-52),

@@ -1287,13 +1287,318 @@ __device__ __forceinline__ void wgrad_body(const float *__restrict__ acts, const
     if (h == 0) db_part[(int64_t)chunk * out_pad + 32 * mt + i] = bsum;
 }
 
+// ---- the same GEMM with exact fp32 products on the bf16 matrix pipe (see mlp_b3.hip) ---------------------------------
+// K = points is a summation index, so the assignment of the tile's 32 points to (k16 step s, lane half g, element e) is
+// free: point 16 g + 8 s + e keeps wg_load_async's pattern (lane (i, g) holds points 16g..16g+15 of row i of BOTH
+// operands).  Each lane cuts its 16 + 16*IT loaded values into bf16 slices (the 4 waves of a block redo the split of the
+// shared act tiles: the kernel is HBM-bound either way) and issues six slice products per (in tile, step).
 template <int IT>
+__device__ __forceinline__ void wg_mma_b3(const WgFrag<IT> &f, f32x16 (&acc)[IT], float &bsum) {
+    Frag ah[2], am[2], al[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+            const float v0 = f.a[2 * s + (e2 >> 1)][2 * (e2 & 1)], v1 = f.a[2 * s + (e2 >> 1)][2 * (e2 & 1) + 1];
+            bsum += v0 + v1;
+            split2(v0, v1, ah[s].u[e2], am[s].u[e2], al[s].u[e2]);
+        }
+#pragma unroll
+    for (int np = 0; np < IT; np += 2) {
+        constexpr int NP_MAX = 2;
+        const int nn = (IT - np) < NP_MAX ? (IT - np) : NP_MAX;
+        Frag bh[NP_MAX][2], bm[NP_MAX][2], bl[NP_MAX][2];
+#pragma unroll
+        for (int t = 0; t < NP_MAX; t++)
+            if (t < nn)
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; e2++)
+                        split2(f.b[np + t][2 * s + (e2 >> 1)][2 * (e2 & 1)], f.b[np + t][2 * s + (e2 >> 1)][2 * (e2 & 1) + 1],
+                               bh[t][s].u[e2], bm[t][s].u[e2], bl[t][s].u[e2]);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+#define WG_B3(A, B)                                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < NP_MAX; t++) if (t < nn)                                                       \
+        acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s].h, B[t][s].h, acc[np + t], 0, 0, 0)
+            WG_B3(al, bh);
+            WG_B3(am, bm);
+            WG_B3(ah, bl);
+            WG_B3(am, bh);
+            WG_B3(ah, bm);
+            WG_B3(ah, bh);
+#undef WG_B3
+        }
+    }
+}
+
+template <int IT>
+__device__ __forceinline__ void wgrad_body_b3(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                              int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off, int dpre_off,
+                                              int out_pad, float *__restrict__ dw_part, float *__restrict__ db_part,
+                                              int64_t n_tiles, int n_chunks, int chunk) {
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t st = n_chunks;
+    f32x16 acc[IT];
+    acc_zero<IT>(acc);
+    float bsum = 0.f;
+    // two register sets (the slices take the room of wgrad_body's third): one tile's loads in flight under the other's
+    // slicing + MFMAs
+    constexpr int NL = 4 + 4 * IT;
+    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
+    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
+#define WG_TILE(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
+#define WG_LOAD(f, k) wg_load_async<IT>(f, acts, dpre, WG_TILE(k), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h)
+    if (n_my > 0) {
+        WgFrag<IT> f0, f1;
+        WG_LOAD(f0, 0);
+        for (int64_t k = 0; k < n_my; k += 2) {
+            WG_LOAD(f1, k + 1);
+            wg_wait<NL>();  // f0 landed
+            wg_mma_b3<IT>(f0, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
+            WG_LOAD(f0, k + 2);
+            wg_wait<NL>();  // f1 landed
+            if (k + 1 < n_my) wg_mma_b3<IT>(f1, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef WG_LOAD
+#undef WG_TILE
+    const int in_pad = 32 * IT;
+    float *dw = dw_part + (int64_t)chunk * out_pad * in_pad;
+#pragma unroll
+    for (int n = 0; n < IT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, h)) * in_pad + 32 * n + i] = acc[n][r];
+    bsum += __shfl_xor(bsum, 32);
+    if (h == 0) db_part[(int64_t)chunk * out_pad + 32 * mt + i] = bsum;
+}
+
+// ---- b3 weight gradients of a 128-row layer with the operand tiles streamed through an LDS ring by LDS-DMA ------------
+// wgrad_body's four waves walk the SAME tile sequence, so a workgroup keeps one tile (32 KB unique) per register set in
+// flight -- with the MFMA time gone (bf16 pipe) that memory-level parallelism bounds the kernel at ~3.5 TB/s (measured:
+// 0.65 ms per 128 x 128 layer, while the one-wave-per-tile out = 32 layers of the same launch sequence run at 6 TB/s).
+// Here the tile (dPre 16 KB + act 4*IT KB) lands ONCE per workgroup in a 4-stage LDS ring, three tiles (96 KB) ahead of
+// the one being multiplied, with no register staging.  LDS-DMA writes lane-linear 16-byte slots, the per-lane GLOBAL
+// address is free: slot (row block rb, quarter j, lane (g, i)) <- floats 16g + 4j .. +3 of row 32 rb + i, so that every
+// fragment read is a conflict-free lane-linear ds_read_b128 and lands exactly in wg_load_async's register pattern.
+template <int IT>
+__global__ __launch_bounds__(256, 1) void wgrad_ring_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                               int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                                               int dpre_off, float *__restrict__ dw_part,
+                                                               float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
+    constexpr int RB = 4 + IT;              // 32-row blocks per tile: 4 of dPre, IT of activations
+    constexpr int STAGE_F4 = RB * 256;      // float4 slots per stage
+    constexpr int NL = RB;                  // DMA instructions per wave and tile (wave w carries quarter w of every block)
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int64_t st = n_chunks;
+    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
+    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
+    f32x16 acc[IT];
+    acc_zero<IT>(acc);
+    float bsum = 0.f;
+    auto issue = [&](int64_t k) {
+        const int64_t t = (chunk + k * st) <= last ? (chunk + k * st) : last;   // prefetches past the end re-read a tile
+        f32x4 *stage = lds_res + (int)(k & 3) * STAGE_F4;
+        const float *dp = dpre + t * dpre_tile_floats + dpre_off + (int64_t)i * TILE + 16 * g + 4 * mt;
+        const float *ap = acts + t * acts_tile_floats + act_off + (int64_t)i * TILE + 16 * g + 4 * mt;
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
+            const float *src = rb < 4 ? dp + rb * 32 * TILE : ap + (rb - 4) * 32 * TILE;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(stage + (rb * 4 + mt) * 64), 16, 0, 0);
+        }
+    };
+    if (n_my > 0) {
+        issue(0);
+        issue(1);
+        issue(2);
+        for (int64_t k = 0; k < n_my; k++) {
+            // my pieces of tile k have landed (tiles k+1, k+2 stay in flight) ...
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+            // ... and after the barrier everyone's have, and everyone is done reading tile k-1, whose stage tile k+3 takes
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue(k + 3);
+            const f32x4 *stage = lds_res + (int)(k & 3) * STAGE_F4;
+            WgFrag<IT> f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) f.a[j] = stage[(mt * 4 + j) * 64 + lane];
+#pragma unroll
+            for (int n = 0; n < IT; n++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) f.b[n][j] = stage[((4 + n) * 4 + j) * 64 + lane];
+            wg_mma_b3<IT>(f, acc, bsum);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int in_pad = 32 * IT;
+    float *dw = dw_part + (int64_t)chunk * 128 * in_pad;
+#pragma unroll
+    for (int n = 0; n < IT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, g)) * in_pad + 32 * n + i] = acc[n][r];
+    bsum += __shfl_xor(bsum, 32);
+    if (g == 0) db_part[(int64_t)chunk * 128 + 32 * mt + i] = bsum;
+}
+
+// ---- b3 weight gradients of a 128-row layer, every operand value sliced ONCE per workgroup ---------------------------
+// The ring kernel above fixed the memory-level parallelism (0.65 -> 0.54 ms per 128 x 128 layer) and exposed the next
+// bound: each of the four waves slices all IT activation tiles itself (440 VALU instructions per tile and wave, serial
+// with its 48 MFMAs on a one-wave SIMD).  Here wave mt loads ONLY its own dPre row block and activation row block mt
+// (8 KB per tile: four register sets deep, 96 KB per CU in flight), keeps its dPre slices in registers (nobody else needs
+// them), and publishes the slices of activation block mt in a double-buffered LDS area, from which all four waves take
+// ready-made B fragments.  Per tile: one barrier, 176 slicing instructions per wave (for tile k+1, independent of and
+// interleavable with tile k's MFMAs), 6 ds_write_b128 + 6*IT ds_read_b128 per wave.
+struct WgRaw {
+    f32x4 a[4], b[4];
+};
+__device__ __forceinline__ void wg_raw_load(WgRaw &f, const float *__restrict__ a, const float *__restrict__ b) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.a[0]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.a[1]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.a[2]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.a[3]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.b[0]) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.b[1]) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.b[2]) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.b[3]) : "v"(b) : "memory");
+}
+struct WgSl {
+    Frag h[2], m[2], l[2];
+};
+__device__ __forceinline__ void wg_slice16(const f32x4 (&v)[4], WgSl &o) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++)
+            split2(v[2 * s + (e2 >> 1)][2 * (e2 & 1)], v[2 * s + (e2 >> 1)][2 * (e2 & 1) + 1], o.h[s].u[e2], o.m[s].u[e2], o.l[s].u[e2]);
+}
+
+template <int IT>
+__global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                                int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                                                int dpre_off, float *__restrict__ dw_part,
+                                                                float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
+    // B slices: [buffer 2][in tile IT][plane 3][step 2][lane 64] float4
+    constexpr int BUF_F4 = IT * 6 * 64;
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int64_t st = n_chunks;
+    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
+    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
+    const int bt = mt & (IT - 1);            // activation block this wave loads (waves >= IT reload one, publish nothing)
+    const float *a0 = dpre + dpre_off + (int64_t)(32 * mt + i) * TILE + 16 * g;
+    const float *b0 = acts + act_off + (int64_t)(32 * bt + i) * TILE + 16 * g;
+    f32x16 acc[IT];
+    acc_zero<IT>(acc);
+    float bsum = 0.f;
+    WgRaw raw[4];
+    WgSl as[2];
+#define WG_T(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
+#define WG_LD(set, k)                                                                \
+    do {                                                                             \
+        const int64_t t_ = WG_T(k);                                                  \
+        wg_raw_load(raw[set], a0 + t_ * dpre_tile_floats, b0 + t_ * acts_tile_floats); \
+    } while (0)
+    // slice raw set `set` (tile k): dPre slices -> as[k & 1], activation slices -> LDS buffer k & 1
+#define WG_SPLIT(set, par)                                                                                          \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) bsum += (raw[set].a[j][0] + raw[set].a[j][1]) + (raw[set].a[j][2] + raw[set].a[j][3]); \
+        wg_slice16(raw[set].a, as[par]);                                                                            \
+        if (mt < IT) {                                                                                              \
+            WgSl bs_;                                                                                               \
+            wg_slice16(raw[set].b, bs_);                                                                            \
+            f32x4 *dst_ = lds_res + (par) * BUF_F4 + mt * 6 * 64 + lane;                                            \
+            _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                         \
+                dst_[(0 * 2 + s) * 64] = bs_.h[s].f;                                                                \
+                dst_[(1 * 2 + s) * 64] = bs_.m[s].f;                                                                \
+                dst_[(2 * 2 + s) * 64] = bs_.l[s].f;                                                                \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+#define WG_MMA(par)                                                                                                 \
+    do {                                                                                                            \
+        const f32x4 *src_ = lds_res + (par) * BUF_F4 + lane;                                                        \
+        _Pragma("unroll") for (int np = 0; np < IT; np += 2) {                                                      \
+            Frag bh_[2][2], bm_[2][2], bl_[2][2];                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 2; t++) _Pragma("unroll") for (int s = 0; s < 2; s++) {           \
+                bh_[t][s].f = src_[((np + t) * 6 + 0 * 2 + s) * 64];                                                \
+                bm_[t][s].f = src_[((np + t) * 6 + 1 * 2 + s) * 64];                                                \
+                bl_[t][s].f = src_[((np + t) * 6 + 2 * 2 + s) * 64];                                                \
+            }                                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                         \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].l[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].m[s].h, bm_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].h[s].h, bl_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].m[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].h[s].h, bm_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].h[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+    // one pipeline step for tile k = k0 + J: raw sets rotate mod 4, slice sets / LDS buffers mod 2
+#define WG_STEP(J)                                                                          \
+    do {                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
+        __builtin_amdgcn_s_barrier();                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        WG_LD((J) & 3, k0 + (J) + 4);                                                       \
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); /* raw tile k+1 landed */         \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (k0 + (J) < n_my) WG_MMA((J) & 1);                                               \
+        WG_SPLIT(((J) + 1) & 3, ((J) + 1) & 1);                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+    if (n_my > 0) {
+        WG_LD(0, 0);
+        WG_LD(1, 1);
+        WG_LD(2, 2);
+        WG_LD(3, 3);
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        WG_SPLIT(0, 0);
+        for (int64_t k0 = 0; k0 < n_my; k0 += 4) {
+            WG_STEP(0);
+            WG_STEP(1);
+            WG_STEP(2);
+            WG_STEP(3);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef WG_STEP
+#undef WG_MMA
+#undef WG_SPLIT
+#undef WG_LD
+#undef WG_T
+    const int in_pad = 32 * IT;
+    float *dw = dw_part + (int64_t)chunk * 128 * in_pad;
+#pragma unroll
+    for (int n = 0; n < IT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, g)) * in_pad + 32 * n + i] = acc[n][r];
+    bsum += __shfl_xor(bsum, 32);
+    if (g == 0) db_part[(int64_t)chunk * 128 + 32 * mt + i] = bsum;
+}
+
+template <int IT, bool B3 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                        int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
                                                        int dpre_off, int out_pad, float *__restrict__ dw_part,
                                                        float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
-    wgrad_body<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, out_pad, dw_part, db_part, n_tiles,
-                   n_chunks, (int)blockIdx.x);
+    if (B3)
+        wgrad_body_b3<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, out_pad, dw_part, db_part, n_tiles,
+                          n_chunks, (int)blockIdx.x);
+    else
+        wgrad_body<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, out_pad, dw_part, db_part, n_tiles,
+                       n_chunks, (int)blockIdx.x);
 }
 
 // All layers of a net group in ONE launch: block b belongs to the layer whose block range holds it.  Used for small
@@ -1308,6 +1613,7 @@ struct WgAll {
     int64_t dw_off[WG_MAX_LAYERS], db_off[WG_MAX_LAYERS];
 };
 
+template <bool B3>
 __global__ __launch_bounds__(256, 1) void wgrad_all_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                            int64_t acts_tile_floats, int64_t dpre_tile_floats,
                                                            float *__restrict__ ws, WgAll d, int64_t n_tiles) {
@@ -1316,12 +1622,20 @@ __global__ __launch_bounds__(256, 1) void wgrad_all_kernel(const float *__restri
     const int chunk = (int)blockIdx.x - d.first_block[l];
     if ((int)(threadIdx.x >> 6) >= d.out_pad[l] / 32) return;      // layers with fewer than four 32-row output tiles
     float *dw = ws + d.dw_off[l], *db = ws + d.db_off[l];
+#define WG_CASE(IT)                                                                                                          \
+    if (B3)                                                                                                                  \
+        wgrad_body_b3<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db,    \
+                          n_tiles, d.chunks[l], chunk);                                                                      \
+    else                                                                                                                     \
+        wgrad_body<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db,       \
+                       n_tiles, d.chunks[l], chunk)
     switch (d.in_tiles[l]) {
-        case 1: wgrad_body<1>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
-        case 2: wgrad_body<2>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
-        case 3: wgrad_body<3>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
-        default: wgrad_body<4>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db, n_tiles, d.chunks[l], chunk); break;
+        case 1: WG_CASE(1); break;
+        case 2: WG_CASE(2); break;
+        case 3: WG_CASE(3); break;
+        default: WG_CASE(4); break;
     }
+#undef WG_CASE
 }
 
 // sum the per-chunk partials of every layer in one launch
@@ -1501,10 +1815,10 @@ extern "C" int64_t mh_mlp_wgrad_workspace_floats(int32_t n_layers, const int32_t
     return tot;
 }
 
-extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
-                            int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                            const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
-                            float *db_raw, int64_t n_tiles, void *stream) {
+static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                      int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
+                      const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
+                      float *db_raw, int64_t n_tiles, void *stream, bool b3) {
     if (n_tiles == 0 || n_layers == 0) return MH_OK;
     if (!acts || !dpre || !act_off_host || !dpre_off_host || !in_feats_host || !out_feats_host || !workspace || !dw_raw ||
         !db_raw || n_layers < 0 || n_layers > WG_MAX_LAYERS || n_tiles < 0)
@@ -1550,12 +1864,44 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
         all.dw_off[l] = dw_poff[l];
         all.db_off[l] = db_poff[l];
         all.first_block[l + 1] = all.first_block[l] + chunks;
-        if (per_layer) {
+        if (per_layer && b3 && out == 128 && (in == 128 || in == 64)) {
+            static int ring_ok = 0;
+            if (!ring_ok) {
+                if (hipFuncSetAttribute((const void *)wgrad_ring_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 4096) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)wgrad_ring_b3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 4096) != hipSuccess)
+                    return MH_ERR_LAUNCH;
+                ring_ok = 1;
+            }
+            static const char *wgk = getenv("MORPHEUS_WGRAD_B3");      // A/B switch: "ring" = raw tiles through an LDS ring
+            if (!(wgk && wgk[0] == 'r')) {
+                if (in == 128)
+                    hipLaunchKernelGGL(wgrad_share_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
+                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+                else
+                    hipLaunchKernelGGL(wgrad_share_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 2 * 2 * 6 * 1024, mh_stream(stream),
+                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+            } else if (in == 128)
+                hipLaunchKernelGGL(wgrad_ring_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 4 * 8 * 4096, mh_stream(stream), acts, dpre,
+                                   acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                                   workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+            else
+                hipLaunchKernelGGL(wgrad_ring_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 4 * 6 * 4096, mh_stream(stream), acts, dpre,
+                                   acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                                   workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+            MH_CHECK_LAUNCH();
+        } else if (per_layer) {
             const dim3 grid((unsigned)chunks), block((unsigned)(out / 32) * 64);
 #define WG_LAUNCH(IT)                                                                                         \
-    hipLaunchKernelGGL(wgrad_kernel<IT>, grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats,     \
-                       dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, workspace + dw_poff[l], \
-                       workspace + db_poff[l], n_tiles, chunks)
+    if (b3)                                                                                                   \
+        hipLaunchKernelGGL((wgrad_kernel<IT, true>), grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats, \
+                           dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, workspace + dw_poff[l], \
+                           workspace + db_poff[l], n_tiles, chunks);                                          \
+    else                                                                                                      \
+        hipLaunchKernelGGL((wgrad_kernel<IT, false>), grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats, \
+                           dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, workspace + dw_poff[l], \
+                           workspace + db_poff[l], n_tiles, chunks)
             switch (in / 32) {
                 case 1: WG_LAUNCH(1); break;
                 case 2: WG_LAUNCH(2); break;
@@ -1579,8 +1925,12 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
         db_out += out;
     }
     if (!per_layer) {
-        hipLaunchKernelGGL(wgrad_all_kernel, dim3((unsigned)all.first_block[n_layers]), dim3(256), 0, mh_stream(stream), acts,
-                           dpre, acts_tile_floats, dpre_tile_floats, workspace, all, n_tiles);
+        if (b3)
+            hipLaunchKernelGGL(wgrad_all_kernel<true>, dim3((unsigned)all.first_block[n_layers]), dim3(256), 0, mh_stream(stream),
+                               acts, dpre, acts_tile_floats, dpre_tile_floats, workspace, all, n_tiles);
+        else
+            hipLaunchKernelGGL(wgrad_all_kernel<false>, dim3((unsigned)all.first_block[n_layers]), dim3(256), 0, mh_stream(stream),
+                               acts, dpre, acts_tile_floats, dpre_tile_floats, workspace, all, n_tiles);
         MH_CHECK_LAUNCH();
     }
     for (int s = 0; s < rd.n; s++) rd.first[s + 1] = rd.first[s] + rd.len[s];
@@ -1589,6 +1939,22 @@ extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_t
                        dw_raw, rd);
     MH_CHECK_LAUNCH();
     return MH_OK;
+}
+
+extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                            int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
+                            const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
+                            float *db_raw, int64_t n_tiles, void *stream) {
+    return wgrad_impl(acts, dpre, acts_tile_floats, dpre_tile_floats, n_layers, act_off_host, dpre_off_host, in_feats_host,
+                      out_feats_host, workspace, dw_raw, db_raw, n_tiles, stream, false);
+}
+
+extern "C" int mh_mlp_wgrad_b3(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                               int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
+                               const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
+                               float *db_raw, int64_t n_tiles, void *stream) {
+    return wgrad_impl(acts, dpre, acts_tile_floats, dpre_tile_floats, n_layers, act_off_host, dpre_off_host, in_feats_host,
+                      out_feats_host, workspace, dw_raw, db_raw, n_tiles, stream, true);
 }
 
 // ---- fused field backward (backward-data + weight gradients, see field_fused_*_kernel) ---------------------------------

@@ -21,13 +21,6 @@
 #include "mlp_dev.h"
 #include <stdlib.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-union Frag {
-    f32x4 f;
-    bf16x8 h;
-    uint32_t u[4];
-};
-
 #define B3_THREADS 512
 #define B3_BLOCK_PTS 256
 #define B3_L0_F4 2560                                  // 3 planes x 4 tiles x 3 k16 steps x 64 lanes = 2304, padded to whole DMA rounds
@@ -36,17 +29,6 @@ union Frag {
 #define B3_NET_F4 (B3_L0_F4 + 4 * B3_LH_F4 + B3_L5_F4)  // 28 672 float4 = 448 KB per net
 
 extern __shared__ f32x4 lds_b3[];
-
-// two fp32 values -> the packed bf16 pairs of their three slices (truncation split, exact)
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
-    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302);
-    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
-    const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-    mid = __builtin_amdgcn_perm(c1, c0, 0x07060302);
-    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
-}
 
 template <int N_F4, int NTHR = B3_THREADS>
 __device__ __forceinline__ void b3_stage_issue(const f32x4 *__restrict__ src) {

@@ -153,3 +153,23 @@ __device__ __forceinline__ void enc_deriv_parked(const float *__restrict__ enc_t
         dsc[k] = h ? -f * other : f * other;
     }
 }
+
+// ---- bf16x3: exact three-way bf16 split of fp32 operands (mlp_b3.hip, the b3 weight-gradient body in mlp.hip) ------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+union Frag {
+    f32x4 f;
+    bf16x8 h;
+    uint32_t u[4];
+};
+
+// two fp32 values -> the packed bf16 pairs of their three slices (truncation split, exact)
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302);
+    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
+    const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(c1, c0, 0x07060302);
+    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+}
+

@@ -512,7 +512,7 @@ def sample_positions(rays_o, rays_d, ray_idx, t_starts, t_ends, ray_start, ray_c
 
 
 # ------------------------------------------------------------------------------------ fused MLPs
-def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag):
+def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False):
     n_layers = len(act_off)
     dw_len = int(sum(i * o for i, o in zip(in_pad, out_pad)))
     db_len = int(sum(out_pad))
@@ -524,8 +524,9 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     raw = torch.empty(dw_len + db_len, device=dev)
     dw_raw, db_raw = raw[:dw_len], raw[dw_len:]
     _e = TIMER.start()
-    check(lib.mh_mlp_wgrad(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw),
-                           ptr(db_raw), n_tiles, stream()), "mh_mlp_wgrad")
+    fn = lib.mh_mlp_wgrad_b3 if b3 else lib.mh_mlp_wgrad
+    check(fn(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw), ptr(db_raw), n_tiles,
+             stream()), "mh_mlp_wgrad")
     TIMER.stop("mh_mlp_wgrad[" + tag + "]", _e)
     return raw          # dw_raw | db_raw, tile-row order (packing.JointPacker.unpack_grads maps it back)
 
@@ -663,7 +664,7 @@ class _WarpMLP(torch.autograd.Function):
                        stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)
         raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
-                     _WARP_WG[3], n_tiles, dev, "warp")
+                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3)
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
             (od, ot) = ctx.jp.bias0_raw
