@@ -27,8 +27,38 @@
 #define B3_LH_F4 6144                                  // 128 x 128
 #define B3_L5_F4 1536                                  // one padded output tile
 #define B3_NET_F4 (B3_L0_F4 + 4 * B3_LH_F4 + B3_L5_F4)  // 28 672 float4 = 448 KB per net
+#define B3_LDS_BYTES (B3_LH_F4 * 16 + 1024)            // one layer's slices + the layer's bias row (forward)
 
 extern __shared__ f32x4 lds_b3[];
+
+#ifdef MH_PHASE_TRACE
+// phase trace for tools/phase_trace_b3.py (never compiled into the product library): wave 0 of every 32nd workgroup stamps
+// s_memtime at the phase boundaries of warp_fwd_b3_kernel's hidden layers of net 0 (8 slots per layer), s_memrealtime in 62/63
+__device__ long long mh_b3_trace[256 * 64];
+#define B3_STAMP(slot)                                                                          \
+    do {                                                                                        \
+        if ((threadIdx.x == 0) && (blockIdx.x % 32 == 0) && (blockIdx.x / 32 < 256))            \
+            mh_b3_trace[(blockIdx.x / 32) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define B3_STAMP_REAL(slot)                                                                     \
+    do {                                                                                        \
+        if ((threadIdx.x == 0) && (blockIdx.x % 32 == 0) && (blockIdx.x / 32 < 256))            \
+            mh_b3_trace[(blockIdx.x / 32) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+extern "C" int mh_b3_trace_read(long long *dst_host) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(mh_b3_trace), sizeof(long long) * 256 * 64) == hipSuccess ? 0 : 2;
+}
+#else
+#define B3_STAMP(slot) do { } while (0)
+#define B3_STAMP_REAL(slot) do { } while (0)
+#endif
+
+// parked tiles are written once and read much later by another kernel
+#ifdef MH_B3_PLAIN_STORES
+#define PARK_STORE(v, p) (*(p) = (v))
+#else
+#define PARK_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 
 template <int N_F4, int NTHR = B3_THREADS>
 __device__ __forceinline__ void b3_stage_issue(const f32x4 *__restrict__ src) {
@@ -38,6 +68,25 @@ __device__ __forceinline__ void b3_stage_issue(const f32x4 *__restrict__ src) {
     for (int k = 0; k < N_F4 / NTHR; k++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * NTHR + threadIdx.x),
                                          (__attribute__((address_space(3))) void *)(lds_b3 + k * NTHR + wave * 64), 16, 0, 0);
+}
+// the layer's bias row (<= 128 floats) rides along: wave 0's lower half fetches 512 bytes into the slot behind the slices,
+// every wave then initialises its accumulators from LDS (broadcast reads, no VMEM latency on the layer's critical path)
+__device__ __forceinline__ void b3_stage_bias(const float *__restrict__ bias, int n_f4 = 32) {
+    if ((int)threadIdx.x < n_f4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const f32x4 *>(bias) + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_b3 + B3_LH_F4 + (threadIdx.x >> 6) * 64), 16, 0, 0);
+}
+template <int MT>
+__device__ __forceinline__ void acc_bias_lds(f32x16 (&acc)[MT], int h) {
+    const f32x4 *b = lds_b3 + B3_LH_F4;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 v = b[8 * t + 2 * r4 + h];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = v[c];
+        }
 }
 __device__ __forceinline__ void b3_stage_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -93,35 +142,165 @@ __device__ __forceinline__ void mfma_results_settle() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// layer epilogue: ReLU, park the tile feature-major (+ its sign mask), slice into the next layer's B operands
-__device__ __forceinline__ void b3_epilogue(const f32x16 (&acc)[4], float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
+// one quarter of a 128 x 128 layer: output tiles T0, T0+1 over k16 steps S0 .. S0+3 (accumulators already hold bias or the
+// earlier steps)
+template <int T0, int S0>
+__device__ __forceinline__ void b3_quarter(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
+                                           f32x16 (&acc)[4], int lane) {
+    constexpr int KS = 8, PL = 4 * KS * 64;
+#pragma unroll
+    for (int s = S0; s < S0 + 4; s++) {
+        Frag ah[2], am[2], al[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            ah[t].f = w[0 * PL + ((T0 + t) * KS + s) * 64 + lane];
+            am[t].f = w[1 * PL + ((T0 + t) * KS + s) * 64 + lane];
+            al[t].f = w[2 * PL + ((T0 + t) * KS + s) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+    }
+}
+
+// ReLU and the sign-mask bit as compiler-visible integer instructions (one v_max_i32; v_min_u32 + v_lshl_add_u32): the float
+// forms cost an extra canonicalising v_max each, mlp_dev.h's inline-asm forms are invisible to the hazard recognizer (above).
+// Bit patterns: x <= -0.0 is a negative int -> 0; positive floats and +NaN keep their bits.
+__device__ __forceinline__ float relu_i(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+__device__ __forceinline__ uint32_t push_nz(uint32_t m, float y /* >= 0 */) { return (m << 1) + min(__float_as_uint(y), 1u); }
+
+// layer epilogue: ReLU in place, park the tile feature-major FIRST (the stores then drain under the ~500 slicing instructions
+// instead of being waited for right after issue), then the sign mask and the next layer's B operand slices
+__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[4], float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
                                             Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = relu_i(acc[t][r]);
+    if (ht) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+    }
     uint32_t mt[4];
-    mfma_results_settle();
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        float y[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) y[r] = relu1(acc[t][r]);
-        if (ht) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) ht[(32 * t + acc_row(r, h)) * TILE + pt] = y[r];
-        }
         uint32_t m = 0;
 #pragma unroll
-        for (int r = 15; r >= 0; r--) m = push_gt0(m, y[r]);
+        for (int r = 15; r >= 0; r--) m = push_nz(m, acc[t][r]);
         mt[t] = m;
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
             for (int e2 = 0; e2 < 4; e2++)
-                split2(y[8 * s2 + 2 * e2], y[8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+                split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2],
+                       bl[2 * t + s2].u[e2]);
     }
     if (mk) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
 }
 
+// one k16 step of output tiles T0, T0+1 (12 MFMAs)
+template <int T0>
+__device__ __forceinline__ void b3_quarter_step(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8],
+                                                const Frag (&bl)[8], f32x16 (&acc)[4], int lane, int s) {
+    constexpr int KS = 8, PL = 4 * KS * 64;
+    Frag ah[2], am[2], al[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        ah[t].f = w[0 * PL + ((T0 + t) * KS + s) * 64 + lane];
+        am[t].f = w[1 * PL + ((T0 + t) * KS + s) * 64 + lane];
+        al[t].f = w[2 * PL + ((T0 + t) * KS + s) * 64 + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+}
+
+// registers 8 s2 .. 8 s2 + 7 of output tile t: ReLU in place, park, their 8 mask bits, the slices of k16 step 2t + s2
+__device__ __forceinline__ void b3_epilogue_eighth(f32x16 (&acc)[4], float *__restrict__ ht, uint32_t (&mt)[4], int pt, int h,
+                                                   Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8], int t, int s2) {
+#pragma unroll
+    for (int r = 8 * s2; r < 8 * s2 + 8; r++) acc[t][r] = relu_i(acc[t][r]);
+    if (ht) {
+#ifdef MH_B3_FAKE_X4
+#pragma unroll
+        for (int q = 2 * s2; q < 2 * s2 + 2; q++) {
+            f32x4 v4 = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+            __builtin_nontemporal_store(v4, reinterpret_cast<f32x4 *>(ht + (32 * t + 8 * q) * TILE) + (threadIdx.x & 63));
+        }
+#else
+#pragma unroll
+        for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+#endif
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 8 * s2 + 7; r >= 8 * s2; r--) m = push_nz(m, acc[t][r]);
+    mt[t] |= m << (8 * s2);
+#pragma unroll
+    for (int e2 = 0; e2 < 4; e2++)
+        split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    // pin the slices HERE: they are only used after the layer's barrier, and hipcc otherwise sinks the ~50 slicing instructions
+    // down to that use -- out of the MFMA stretch they are meant to fill
+    Frag &fh = bh[2 * t + s2], &fm = bm[2 * t + s2], &fl = bl[2 * t + s2];
+    asm volatile("" : "+v"(fh.u[0]), "+v"(fh.u[1]), "+v"(fh.u[2]), "+v"(fh.u[3]), "+v"(fm.u[0]), "+v"(fm.u[1]), "+v"(fm.u[2]),
+                 "+v"(fm.u[3]), "+v"(fl.u[0]), "+v"(fl.u[1]), "+v"(fl.u[2]), "+v"(fl.u[3]), "+v"(mt[t]));
+}
+
+// the epilogue of output tiles T0, T0+1 only: ReLU, park, sign-mask halves, slices of k16 steps 2 T0 .. 2 T0 + 3
+template <int T0>
+__device__ __forceinline__ void b3_epilogue_half(f32x16 (&acc)[4], float *__restrict__ ht, uint32_t (&mt)[4], int pt, int h,
+                                                 Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
+#pragma unroll
+    for (int t = T0; t < T0 + 2; t++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = relu_i(acc[t][r]);
+        if (ht) {
+#ifdef MH_B3_FAKE_X4
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v4 = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                __builtin_nontemporal_store(v4, reinterpret_cast<f32x4 *>(ht + (32 * t + 8 * q) * TILE) + (threadIdx.x & 63));
+            }
+#else
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+#endif
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 15; r >= 0; r--) m = push_nz(m, acc[t][r]);
+        mt[t] = m;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2],
+                       bl[2 * t + s2].u[e2]);
+    }
+}
+
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void warp_fwd_b3_kernel(
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
     const float *__restrict__ bias0_t, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
     const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
@@ -165,24 +344,51 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_b3_kernel(
         __syncthreads();
         wp += B3_L0_F4;
         b3_stage_issue<B3_LH_F4, NW * 64>(wp);
+        b3_stage_bias(bs);
         b3_epilogue(acc, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bm, bl);
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
-            acc_bias<4>(acc, bs + (l - 1) * 128, h);
+            if (net == 0) B3_STAMP((l - 1) * 8 + 0);
+            if (net == 0 && l == 1) B3_STAMP_REAL(62);
             b3_stage_wait();
-            b3_layer<8, 4>(lds_b3, bh, bm, bl, acc, lane);
+            acc_bias_lds<4>(acc, h);
+            if (net == 0) B3_STAMP((l - 1) * 8 + 1);
+            // quarter order: both tile pairs over k16 steps 0..3 first -- those B slices are then dead, and once tiles 0, 1
+            // are complete (third quarter) their epilogue refills exactly these registers UNDER the fourth quarter's MFMAs
+            b3_quarter<0, 0>(lds_b3, bh, bm, bl, acc, lane);
+            b3_quarter<2, 0>(lds_b3, bh, bm, bl, acc, lane);
+            b3_quarter<0, 4>(lds_b3, bh, bm, bl, acc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (net == 0) B3_STAMP((l - 1) * 8 + 2);
+            uint32_t mt[4] = {0u, 0u, 0u, 0u};
+            // fourth quarter in four k16-step chunks, each followed by an eighth of the finished tiles' epilogue (8 values:
+            // ReLU, park, mask bits, one k16 step of slices); the scheduling fences keep the chunks apart, so that the
+            // SIMD's two waves -- not barrier-locked inside a layer -- fill each other's VALU stretches with MFMAs
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
+                b3_epilogue_eighth(acc, ht ? ht + l * 128 * TILE : nullptr, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (net == 0) B3_STAMP((l - 1) * 8 + 3);
             __syncthreads();
+            if (net == 0) B3_STAMP((l - 1) * 8 + 4);
             wp += B3_LH_F4;
             if (l < 4)
                 b3_stage_issue<B3_LH_F4, NW * 64>(wp);
             else
                 b3_stage_issue<B3_L5_F4, NW * 64>(wp);
-            b3_epilogue(acc, ht ? ht + l * 128 * TILE : nullptr, mk ? mk + (net * 5 + l) * 64 + lane : nullptr, pt, h, bh, bm, bl);
+            b3_stage_bias(bs + l * 128, l < 4 ? 32 : 8);   // b5 is one 32-row tile
+            if (net == 0) B3_STAMP((l - 1) * 8 + 5);
+            b3_epilogue_half<2>(acc, ht ? ht + l * 128 * TILE : nullptr, mt, pt, h, bh, bm, bl);
+            if (mk) mk[(net * 5 + l) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+            if (net == 0) B3_STAMP((l - 1) * 8 + 6);
+            if (net == 0 && l == 4) B3_STAMP_REAL(63);
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
         f32x16 o[1];
-        acc_bias<1>(o, bs + 4 * 128, h);
         b3_stage_wait();
+        acc_bias_lds<1>(o, h);
         b3_layer<8, 1>(lds_b3, bh, bm, bl, o, lane);
         __syncthreads();
         if (net == 0) b3_stage_issue<B3_L0_F4, NW * 64>(w3_t);
@@ -218,7 +424,7 @@ __device__ __forceinline__ void b3_epilogue_bwd(const f32x16 (&acc)[4], uint2 m,
         for (int r = 0; r < 16; r++) y[r] = mask_bit(mw, r, acc[t][r]);
         if (dt) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) dt[(32 * t + acc_row(r, h)) * TILE + pt] = y[r];
+            for (int r = 0; r < 16; r++) PARK_STORE(y[r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++)
@@ -226,6 +432,24 @@ __device__ __forceinline__ void b3_epilogue_bwd(const f32x16 (&acc)[4], uint2 m,
             for (int e2 = 0; e2 < 4; e2++)
                 split2(y[8 * s2 + 2 * e2], y[8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
     }
+}
+
+// backward flavour of b3_epilogue_eighth: registers 8 s2 .. 8 s2 + 7 of tile t masked by their ReLU bits -> parked dPre, slices
+__device__ __forceinline__ void b3_epilogue_bwd_eighth(f32x16 (&acc)[4], uint2 m, float *__restrict__ dt, int pt, int h, Frag (&bh)[8],
+                                                       Frag (&bm)[8], Frag (&bl)[8], int t, int s2) {
+    const uint32_t mw = (t < 2 ? m.x : m.y) >> (16 * (t & 1));
+#pragma unroll
+    for (int r = 8 * s2; r < 8 * s2 + 8; r++) acc[t][r] = mask_bit(mw, r, acc[t][r]);
+    if (dt) {
+#pragma unroll
+        for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
+    }
+#pragma unroll
+    for (int e2 = 0; e2 < 4; e2++)
+        split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    Frag &fh = bh[2 * t + s2], &fm = bm[2 * t + s2], &fl = bl[2 * t + s2];
+    asm volatile("" : "+v"(fh.u[0]), "+v"(fh.u[1]), "+v"(fh.u[2]), "+v"(fh.u[3]), "+v"(fm.u[0]), "+v"(fm.u[1]), "+v"(fm.u[2]),
+                 "+v"(fm.u[3]), "+v"(fl.u[0]), "+v"(fl.u[1]), "+v"(fl.u[2]), "+v"(fl.u[3]));
 }
 
 template <int NW>
@@ -278,11 +502,23 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
         __syncthreads();
         wt += B3_T5_F4;
         b3_stage_issue<B3_LH_F4, NW * 64>(wt);
+        // dPre_4 from T5's output (the short first stage: nothing to hide it under)
+        b3_epilogue_bwd(acc, msk[4], dt ? dt + 4 * 128 * TILE : nullptr, pt, h, bh, bm, bl);
         for (int l = 4; l >= 1; l--) {
-            // output of transposed layer l+1 is dH_{l+1}: mask by H_{l+1}'s ReLU -> dPre_l, park, slice
-            b3_epilogue_bwd(acc, msk[l], dt ? dt + l * 128 * TILE : nullptr, pt, h, bh, bm, bl);
+            // dH_l = W_l^T dPre_l in quarters (see the forward kernel): tiles 0, 1 are complete after the third quarter and
+            // their half of dPre_{l-1} (mask by H_l's ReLU bits, park, slice) runs under the fourth quarter's MFMAs
             b3_stage_wait();
-            b3_layer<8, 4, true>(lds_b3, bh, bm, bl, acc, lane);
+            acc_zero<4>(acc);
+            b3_quarter<0, 0>(lds_b3, bh, bm, bl, acc, lane);
+            b3_quarter<2, 0>(lds_b3, bh, bm, bl, acc, lane);
+            b3_quarter<0, 4>(lds_b3, bh, bm, bl, acc, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
+                b3_epilogue_bwd_eighth(acc, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bm, bl, c >> 1, c & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __syncthreads();
             wt += B3_LH_F4;
             if (l > 1)
@@ -291,8 +527,10 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
                 b3_stage_issue<B3_T0_F4, NW * 64>(wt);
             else if (net == 0)
                 b3_stage_issue<B3_T5_F4, NW * 64>(w3T_t);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                b3_epilogue_bwd_eighth(acc, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bm, bl, 2 + (c >> 1), c & 1);
         }
-        b3_epilogue_bwd(acc, msk[0], dt, pt, h, bh, bm, bl);
         if (g_x) {
             // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5).  Skipped when nobody asks for d/dx
             f32x16 e[2];
@@ -381,11 +619,11 @@ extern "C" int64_t mh_warp_w3_bytes(void) { return (int64_t)B3_NET_F4 * 16; }
 static int b3_lds_opt_in() {
     static int done = 0;
     if (!done) {
-        if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
+        if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
+            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LH_F4 * 16) !=
+            hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess)
             return MH_ERR_LAUNCH;
         done = 1;
@@ -402,7 +640,7 @@ extern "C" int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const 
     const int64_t blocks = (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    hipLaunchKernelGGL(warp_bwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LH_F4 * 16, mh_stream(stream), x, g_deform,
+    hipLaunchKernelGGL(warp_bwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x, g_deform,
                        g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t), (int)n_bands, acts,
                        dpre, g_x, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
@@ -421,11 +659,11 @@ extern "C" int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
     if (nw == 4)
-        hipLaunchKernelGGL(warp_fwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LH_F4 * 16, mh_stream(stream), x, slot,
+        hipLaunchKernelGGL(warp_fwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LDS_BYTES, mh_stream(stream), x, slot,
                            bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
                            bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
     else
-        hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LH_F4 * 16, mh_stream(stream), x,
+        hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
                            slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
                            bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
