@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 # algorithmic MACs per sample point
 MACS = dict(deform=77056, topo=76928, sdf=10880, color=8384)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (the bf16x3 warp kernels issue 6 per fp32 MAC)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 L2_PEAK_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 bandwidth
 GRID_FWD_BYTES, GRID_BWD_BYTES = 1164, 2188   # per point per encoder
@@ -381,14 +382,27 @@ def main(argv=None):
                 continue
         return None
 
-    symbol = {"mh_warp_fwd": "warp_fwd_kernel", "mh_warp_bwd_data": "warp_bwd_kernel", "mh_field_fwd": "field_fwd_kernel",
+    b3 = bool(ops.MLP_B3)
+    symbol = {"mh_warp_fwd": "warp_fwd_b3_kernel<8>" if b3 else "warp_fwd_kernel",
+              "mh_warp_bwd_data": "warp_bwd_b3_kernel<8>" if b3 else "warp_bwd_kernel", "mh_field_fwd": "field_fwd_kernel",
               "mh_field_bwd_data": "field_bwd_kernel"}
     full = render_wl and N * S == 128 * 128 * 128
     roofline = None
     if dominant is not None:
         ach = flops[dominant] / (ktab[dominant]["avg_ms"] * 1e-3) / 1e12
-        roofline = dict(kernel=dominant, bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+        on_b3 = b3 and dominant.startswith("mh_warp")
+        # bf16x3 kernels issue 6 bf16 slice products per fp32 MAC on the 2.5 PFLOP/s dense bf16 matrix pipe: the yardstick for
+        # ALGORITHMIC fp32 FLOP/s on that unit is 2500 / 6 (the native fp32 MFMA peak, 157.3, is no longer the ceiling)
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if on_b3 else FP32_MFMA_PEAK_TFLOPS
+        roofline = dict(kernel=dominant, bound="mfma", achieved=round(ach, 2), peak=round(peak, 1),
+                        unit="TFLOP/s", frac=round(ach / peak, 4),
+                        peak_note=("algorithmic fp32 FLOP/s against the dense bf16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 "
+                                   "slice products per MAC: every fp32 operand is cut exactly into three bf16 slices, the six "
+                                   "significant cross products go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation"
+                                   if on_b3 else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"),
+                        issued_tflops=round(6.0 * ach, 1) if on_b3 else round(ach, 2),
+                        issued_frac_of_unit_peak=round(6.0 * ach / BF16_MFMA_PEAK_TFLOPS, 4) if on_b3 else round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        vs_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         traffic=pmc_traffic(symbol.get(dominant, "")) if (full and args.workload == "cfg3") else None,
                         traffic_note="HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), not a live "
                                      "measurement; null when the workload differs from the profiled one",
@@ -396,7 +410,10 @@ def main(argv=None):
         step_flops = 3.0 * (warp_f * (0 if args.workload == "cfg2" else 1) + field_f)
         if args.workload != "cfg3b":
             roofline["whole_step"] = dict(flops=step_flops, tflops=round(step_flops / (ms_step * 1e-3) / 1e12, 2),
-                                          frac=round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
+                                          frac=round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                          frac_note="algorithmic FLOP/s of the whole step over the native fp32 MFMA peak (157.3): "
+                                                    "a speed-of-light figure for an all-fp32-MFMA step, kept for continuity with "
+                                                    "round 1" + ("; the warp nets now run on the bf16 pipe" if b3 else ""))
     roof_hash = None
     if render_wl and ("mh_grid_encode_fwd" in ktab or "mh_grid_encode_fwd2" in ktab):
         # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b).  The two-table launch
@@ -454,6 +471,9 @@ def main(argv=None):
                                                                  not args.no_overlap else "") + ")"),
                    "world_size": world, "backend": backend, "devices_visible": n_dev,
                    "ranks_share_devices": bool(world > 1 and n_dev < world),
+                   "mlp_arithmetic": ("warp nets: fp32 values, exact three-way bf16 split of both operands, six slice products per "
+                                      "MAC on the bf16 matrix pipe, fp32 accumulate (fp32-grade: <= 3 * 2^-24 of a product dropped); "
+                                      "field nets: native fp32 MFMA" if b3 else "native fp32 MFMA (MORPHEUS_MLP=f32)"),
                    "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
         "roofline": roofline, "roofline_hashgrid": roof_hash, "kernels": ktab,
     }

@@ -767,8 +767,13 @@ __device__ __forceinline__ void row_load_async(RowFrag &f, const float *__restri
     asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.v[3]) : "v"(a) : "memory");
 }
 
-__device__ __forceinline__ void fused_wait() {
+// waits for the rows loaded by row_load_async and passes their registers through an empty volatile asm, so that no
+// register-only use of them can be moved above the wait (see landed() further down)
+template <int N>
+__device__ __forceinline__ void fused_wait(RowFrag (&B)[N]) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < N; n++) asm volatile("" : "+v"(B[n].v[0]), "+v"(B[n].v[1]), "+v"(B[n].v[2]), "+v"(B[n].v[3]));
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
 #pragma unroll
         for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw3, j, acc[j >> 4][j & 15]);   // mask C2 -> dQ1
         scr_get(A, scr, i, h);
-        fused_wait();
+        fused_wait(B);
         dw_mma<2>(A, B, w2, b2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- layer c1: input C1 = rows 288..351
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
             float q1[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) q1[j] = mask_bit(mw2, j, acc[j >> 4][j & 15]);   // mask C1 -> dQ0
-            fused_wait();
+            fused_wait(B);
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
@@ -901,7 +906,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
                 o[q] = v;
             }
         }
-        fused_wait();
+        fused_wait(B);
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
             scr_get(A, scr, 32 * mt + i, h);
@@ -1030,7 +1035,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             wt += 1024;
 #pragma unroll
             for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw1, j, acc[j >> 4][j & 15]);   // mask S2 -> dP1
-            fused_wait();
+            fused_wait(B);
 #pragma unroll
             for (int mt = 0; mt < MT2; mt++) {
                 scr_get(A, scr, 32 * (WITH_COLOR ? mt : 1) + i, h);
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             float q0[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) q0[j] = mask_bit(mw0, j, acc[j >> 4][j & 15]);     // mask S1 -> dP0
-            fused_wait();
+            fused_wait(B);
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
@@ -1077,7 +1082,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                 e[2] = e12[1];
             }
             // the weight gradient first (it frees the 48 registers of the activation rows), the sincos stage after it
-            fused_wait();
+            fused_wait(B);
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
@@ -1213,6 +1218,18 @@ __device__ __forceinline__ void wg_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);  // keep register-only MFMAs below the wait (guide rule 18)
 }
+// The compiler takes an inline-asm load's output as valid from the asm statement on, so it may move register-only work on
+// it (a slice conversion, a copy) ABOVE the s_waitcnt that actually makes the data valid: the "memory" clobber orders memory
+// operations, the scheduling fence orders the machine scheduler, neither orders IR-level code motion of pure arithmetic.
+// (Seen: with the round-to-nearest split2 the merged b3 weight-gradient kernel sliced a register set before it had landed.)
+// Passing the registers through an empty volatile asm right after the wait makes every later use depend on that point.
+__device__ __forceinline__ void landed(f32x4 (&v)[4]) { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])); }
+template <int IT>
+__device__ __forceinline__ void landed(WgFrag<IT> &f) {
+    landed(f.a);
+#pragma unroll
+    for (int n = 0; n < IT; n++) landed(f.b[n]);
+}
 
 template <int IT>
 __device__ __forceinline__ void wg_mma(const WgFrag<IT> &f, f32x16 (&acc)[IT], float &bsum) {
@@ -1261,14 +1278,17 @@ __device__ __forceinline__ void wgrad_body(const float *__restrict__ acts, const
         for (int64_t k = 0; k < n_my; k += 3) {
             WG_LOAD(f2, k + 2);
             wg_wait<2 * NL>();  // f0 landed
+            landed(f0);
             wg_mma<IT>(f0, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
             WG_LOAD(f0, k + 3);
             wg_wait<2 * NL>();  // f1 landed
+            landed(f1);
             if (k + 1 < n_my) wg_mma<IT>(f1, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
             WG_LOAD(f1, k + 4);
             wg_wait<2 * NL>();  // f2 landed
+            landed(f2);
             if (k + 2 < n_my) wg_mma<IT>(f2, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1357,10 +1377,12 @@ __device__ __forceinline__ void wgrad_body_b3(const float *__restrict__ acts, co
         for (int64_t k = 0; k < n_my; k += 2) {
             WG_LOAD(f1, k + 1);
             wg_wait<NL>();  // f0 landed
+            landed(f0);
             wg_mma_b3<IT>(f0, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
             WG_LOAD(f0, k + 2);
             wg_wait<NL>();  // f1 landed
+            landed(f1);
             if (k + 1 < n_my) wg_mma_b3<IT>(f1, acc, bsum);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1552,6 +1574,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__r
         __builtin_amdgcn_sched_barrier(0);                                                  \
         WG_LD((J) & 3, k0 + (J) + 4);                                                       \
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); /* raw tile k+1 landed */         \
+        landed(raw[((J) + 1) & 3].a);                                                       \
+        landed(raw[((J) + 1) & 3].b);                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         if (k0 + (J) < n_my) WG_MMA((J) & 1);                                               \
         WG_SPLIT(((J) + 1) & 3, ((J) + 1) & 1);                                             \
@@ -1563,6 +1587,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__r
         WG_LD(2, 2);
         WG_LD(3, 3);
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        landed(raw[0].a);
+        landed(raw[0].b);
         __builtin_amdgcn_sched_barrier(0);
         WG_SPLIT(0, 0);
         for (int64_t k0 = 0; k0 < n_my; k0 += 4) {

@@ -1,13 +1,15 @@
 // The warp networks (deform_net + topo_net, models/model.py:412-437) with EXACT fp32 products issued on the bf16 matrix pipe.
 //
 // gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the vector-ALU rate, 1/16 of the bf16 matrix rate, and blocks the
-// SIMD's VALU issue while it runs.  Here every fp32 operand is cut into three bf16 slices by truncation,
+// SIMD's VALU issue while it runs.  Here every fp32 operand is cut into three bf16 slices (round to nearest,
+// mlp_dev.h: split2),
 //      x = hi + mid + lo   exactly   (8 + 8 + 8 significand bits),
 // and a product W.x is the six cross terms whose weight is >= 2^-16 of the leading one,
 //      Wh.xh + Wh.xm + Wm.xh + Wh.xl + Wm.xm + Wl.xh,
 // each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  What is dropped (Wm.xl, Wl.xm, Wl.xl)
-// is <= 3 * 2^-24 of the product, the size of one fp32 rounding: the result is fp32-grade (tools/micro/mfma_b3.hip: max error
-// of a 128-term layer 1.37e-6 against float64, a fp32 fmaf chain 1.65e-6), for 6/16 of the matrix cycles.
+// is below 2^-24 of the product, less than one fp32 rounding: the result is fp32-grade (tests/test_gpu_ops.py:
+// test_warp_b3_is_fp32_grade holds values and every gradient to the fp32 kernels' own error against float64), for 6/16 of the
+// matrix cycles.
 //
 // Layout facts the kernels rely on (32x32x16 bf16): lane (i = lane & 31, g = lane >> 5) supplies A[m = i][k = 8g..8g+7] and
 // B[k = 8g..8g+7][n = i] as 8 packed bf16 (4 VGPRs); D is the same 32x32 fp32 accumulator layout as the fp32 MFMA,

@@ -162,14 +162,24 @@ union Frag {
     uint32_t u[4];
 };
 
-// two fp32 values -> the packed bf16 pairs of their three slices (truncation split, exact)
+// two fp32 values -> the packed bf16 pairs of their three slices.  Round-to-nearest split (v_cvt_pk_bf16_f32): x - hi and
+// (x - hi) - mid are exact in fp32 and the last residual has at most 8 significant bits, so hi + mid + lo == x exactly, like the
+// truncation split -- but the residuals are half as large and of either sign: what the six-product form drops (mid.lo, lo.mid,
+// lo.lo) is <= ~2^-26 of a product and unbiased, where truncation left a 3 * 2^-24 bias towards zero (measured: the bias
+// gradients' error against float64 8x that of the fp32 kernels with truncation).  Same instruction count.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
-    const uint32_t b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
-    hi = __builtin_amdgcn_perm(b1, b0, 0x07060302);
-    const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);
-    const uint32_t c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-    mid = __builtin_amdgcn_perm(c1, c0, 0x07060302);
-    const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+    union {
+        bf16x2_t b;
+        uint32_t u;
+    } h, m, l;
+    h.b = __builtin_convertvector((f32x2_t){x0, x1}, bf16x2_t);
+    const float r0 = x0 - __uint_as_float(h.u << 16), r1 = x1 - __uint_as_float(h.u & 0xffff0000u);
+    m.b = __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t);
+    const float s0 = r0 - __uint_as_float(m.u << 16), s1 = r1 - __uint_as_float(m.u & 0xffff0000u);
+    l.b = __builtin_convertvector((f32x2_t){s0, s1}, bf16x2_t);
+    hi = h.u;
+    mid = m.u;
+    lo = l.u;
 }
-

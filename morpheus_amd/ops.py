@@ -100,8 +100,9 @@ GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B swit
 # Measured on MI355X (cfg3, same box): 1.05 ms against 2 x 0.43 = 0.86 ms for two launches -- twice the gathers in flight per
 # lane cost more occupancy than the shared index arithmetic saves -- so one launch per table stays the default.
 GRID_FWD_TWO = os.environ.get("MORPHEUS_GRID_FWD", "") == "two"
-# warp nets: "b3" = exact fp32 products from three bf16 slices on the bf16 matrix pipe (csrc/mlp_b3.hip), "f32" = fp32 MFMA
-MLP_B3 = os.environ.get("MORPHEUS_MLP", "f32") == "b3"
+# warp nets: "b3" (default) = exact fp32 products from three bf16 slices on the bf16 matrix pipe (csrc/mlp_b3.hip: values, parked
+# tiles, accumulation and results stay fp32, fp32-grade error), "f32" = the native fp32 MFMA kernels of csrc/mlp.hip (A/B switch)
+MLP_B3 = os.environ.get("MORPHEUS_MLP", "b3") == "b3"
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):

@@ -150,9 +150,12 @@ def _wn(p, pre, l):
 
 @pytest.mark.parametrize("kind", ["a", "b"])
 @pytest.mark.parametrize("max_level", [None, 0.5])
-def test_warp_mlp(kind, max_level):
-    """deform_net + topo_net (fused MFMA kernel) vs the oracle, values and every gradient."""
+@pytest.mark.parametrize("mlp", ["b3", "f32"])
+def test_warp_mlp(kind, max_level, mlp, monkeypatch):
+    """deform_net + topo_net (fused MFMA kernels: bf16x3 on the matrix pipe = the default, and native fp32 MFMA) vs the
+    oracle, values and every gradient."""
     from morpheus_amd import ops
+    monkeypatch.setattr(ops, "MLP_B3", mlp == "b3")
     M = 1000                                              # not a multiple of 128: exercises the ragged tail
     x = synth.hash_tensor((M, 3), 500, 1.0)
     tvals = torch.tensor([37 / 200, 0.5, 0.91])
@@ -611,3 +614,77 @@ def test_sdf_losses_kernel_vs_reference_formula():
         assert_close(fs_g, fs_o, 1e-5, "fs_loss", floor=1e-6)
         assert_close(sl_g, sl_o, 1e-5, "sdf_loss", floor=1e-6)
         assert_close(pg.grad, po.grad, 1e-5, "d/d pred", floor=1e-2 * float(po.grad.abs().max()))
+
+
+def test_warp_b3_is_fp32_grade(monkeypatch):
+    """The bf16x3 warp kernels (three exact bf16 slices per fp32 operand, six slice products, fp32 accumulate) against the
+    native fp32-MFMA kernels and a float64 evaluation of the same networks: forward values, d/dx and every weight gradient.
+    The claim checked: their error against float64 is of the size of the fp32 kernels' own -- forward values within 3x,
+    gradients (sums of ~10^6 slice products per entry; the matrix pipe's internal accumulation is not round-to-nearest)
+    within 6x, i.e. rel-L2 of a few 1e-6 where the fp32 kernels reach a few 1e-7; both two orders below the 1e-4 contract."""
+    from morpheus_amd import ops
+    torch.manual_seed(7)
+    M = 6000                                                # ragged against both the 128- and the 256-point workgroups
+    nets = []
+    for nout in (3, 2):
+        W = [torch.randn(128, 39, device=DEV) * 0.15] + [torch.randn(128, 128, device=DEV) * 0.1 for _ in range(4)] + \
+            [torch.randn(nout, 128, device=DEV) * 0.15]
+        b = [torch.randn(128, device=DEV) * 0.1 for _ in range(5)] + [torch.randn(nout, device=DEV) * 0.1]
+        nets.append(W + b)
+    x = torch.rand(M, 3, device=DEV) * 2 - 1
+    slot = (torch.arange(M, device=DEV) % 3).int()
+    b0 = [torch.randn(3, 128, device=DEV) * 0.3 for _ in range(2)]
+    wd_, wt_ = torch.randn(M, 3, device=DEV), torch.randn(M, 2, device=DEV)
+
+    # float64 evaluation with autograd.  A pre-activation within rounding of zero flips its ReLU bit in any fp32
+    # implementation and moves that point's whole backward signal by O(1); points with a pre-activation closer than 1e-4 to
+    # a kink get zero loss weight in all three runs, so that the comparison measures arithmetic, not kink lottery
+    ps64 = [[p.double().clone().requires_grad_(True) for p in net] for net in nets]
+    x64 = x.double().clone().requires_grad_(True)
+    b64 = [t.double().clone().requires_grad_(True) for t in b0]
+    enc = [x64] + [f(x64 * 2 ** k) for k in range(6) for f in (torch.sin, torch.cos)]
+    e = torch.cat(enc, -1)
+    outs, safe = [], torch.ones(M, dtype=torch.bool, device=DEV)
+    for k, P in enumerate(ps64):
+        z = e @ P[0].t() + b64[k][slot.long()]
+        safe &= (z.detach().abs() > 1e-4).all(dim=1)
+        hcur = torch.relu(z)
+        for l in range(1, 5):
+            z = hcur @ P[l].t() + P[6 + l]
+            safe &= (z.detach().abs() > 1e-4).all(dim=1)
+            hcur = torch.relu(z)
+        outs.append(hcur @ P[5].t() + P[11])
+    assert int(safe.sum()) > M // 2
+    wd_ = wd_ * safe[:, None]
+    wt_ = wt_ * safe[:, None]
+    ((outs[0] * wd_.double()).sum() + (outs[1] * wt_.double()).sum()).backward()
+
+    def run(b3):
+        monkeypatch.setattr(ops, "MLP_B3", b3)
+        ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
+        xg = x.clone().requires_grad_(True)
+        bb = [t.clone().requires_grad_(True) for t in b0]
+        d, t = ops.warp_mlp(xg, slot, bb[0], bb[1], 6, ops.prepare_warp_operands(ps[0], ps[1]))
+        ((d * wd_).sum() + (t * wt_).sum()).backward()
+        return d.detach(), t.detach(), xg.grad, [[p.grad for p in net] for net in ps], [t.grad for t in bb]
+
+    r32, r3 = run(False), run(True)
+    for k, name in ((0, "deform"), (1, "topo")):
+        e32 = float((r32[k].double() - outs[k]).abs().max())
+        e3 = float((r3[k].double() - outs[k]).abs().max())
+        scale = float(outs[k].abs().max())
+        assert e3 <= max(3.0 * e32, 4e-7 * scale), (name, e3, e32, scale)
+
+    def rl2(a, b):
+        return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
+    assert rl2(r3[2], x64.grad) <= max(6 * rl2(r32[2], x64.grad), 5e-6), (rl2(r3[2], x64.grad), rl2(r32[2], x64.grad))
+    n = 0
+    for net3, net32, net64 in zip(r3[3], r32[3], [[p.grad for p in net] for net in ps64]):
+        for ga, gb, gr in zip(net3, net32, net64):
+            if gr is None:
+                continue
+            assert rl2(ga, gr) <= max(6 * rl2(gb, gr), 5e-6), (tuple(gr.shape), rl2(ga, gr), rl2(gb, gr))
+            n += 1
+    assert n == 22
+    for ga, gb, gr in zip(r3[4], r32[4], [t.grad for t in b64]):
+        assert rl2(ga, gr) <= max(6 * rl2(gb, gr), 5e-6)

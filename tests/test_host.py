@@ -235,3 +235,49 @@ def test_raw_gradient_map_with_bias0_dropped():
                 assert torch.equal(ba[net][0], raw[jp.bias0_raw[net]:jp.bias0_raw[net] + 128])
             else:
                 assert torch.equal(ba[net][l], bb[net][l])
+
+
+def test_b3_fragment_index_matches_the_mfma_layout():
+    """packing._frag_index_b3 against a scalar emulation of v_mfma_f32_32x32x16_bf16's operand layout (lane (i, g) supplies
+    A[m = i][k = 8g + e]; the B operand of (s, g, e) is what the chain carries in k-step 8s + e of lane half g): layer 1
+    (accumulator inputs) and layer 0 (frequency-encoding inputs) of the deform net reproduce W . x."""
+    import numpy as np
+    import torch
+    from morpheus_amd.packing import acc_row, kmap_enc20, warp_joint_packer
+    jp = warp_joint_packer()
+    g = torch.Generator().manual_seed(0)
+    nets = []
+    for nout in (3, 2):
+        W = [torch.randn(128, 39, generator=g)] + [torch.randn(128, 128, generator=g) for _ in range(4)] + [torch.randn(nout, 128, generator=g)]
+        b = [torch.randn(128, generator=g) for _ in range(5)] + [torch.randn(nout, generator=g)]
+        nets.append((W, b))
+    flat = jp.flat([n[0] for n in nets], [n[1] for n in nets])
+    src = flat[torch.from_numpy(jp.fwd3_index)].numpy()
+    rng = np.random.default_rng(1)
+    so, n, _ = jp.b3_layers[1]
+    frag = src[so:so + n].reshape(4, 8, 64, 8)
+    X = rng.standard_normal(128).astype(np.float32)
+    out = np.zeros(128)
+    for mt in range(4):
+        for i in range(32):
+            for s in range(8):
+                for gg in range(2):
+                    for e in range(8):
+                        out[32 * mt + i] += frag[mt, s, 32 * gg + i, e] * X[32 * (s >> 1) + acc_row(8 * (s & 1) + e, gg)]
+    assert np.abs(out - nets[0][0][1].numpy() @ X).max() < 1e-4
+    so, n, _ = jp.b3_layers[0]
+    frag = src[so:so + n].reshape(4, 3, 64, 8)
+    enc = rng.standard_normal(39).astype(np.float32)
+    km = kmap_enc20()
+    out = np.zeros(128)
+    for mt in range(4):
+        for i in range(32):
+            for s in range(3):
+                for gg in range(2):
+                    for e in range(8):
+                        kk = 8 * s + e
+                        if kk < 20 and km[kk, gg] >= 0:
+                            out[32 * mt + i] += frag[mt, s, 32 * gg + i, e] * enc[km[kk, gg]]
+    assert np.abs(out - nets[0][0][0].numpy() @ enc).max() < 1e-4
+    # pack geometry the kernels hard-wire (csrc/mlp_b3.hip: B3_NET_F4, B3_NETT_F4)
+    assert jp.w3 == [(0, 28672), (28672, 28672)] and jp.wT3 == [(0, 29184), (29184, 29184)]
