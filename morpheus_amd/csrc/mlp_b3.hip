@@ -27,6 +27,7 @@
 #define B3_BLOCK_PTS 256
 #define B3_L0_F4 2560                                  // 3 planes x 4 tiles x 3 k16 steps x 64 lanes = 2304, padded to whole DMA rounds
 #define B3_LH_F4 6144                                  // 128 x 128
+#define B3_KH_F4 3072                                  // one k-half of it: 3 planes x 4 tiles x 4 k16 steps x 64 lanes (48 KB)
 #define B3_L5_F4 1536                                  // one padded output tile
 #define B3_NET_F4 (B3_L0_F4 + 4 * B3_LH_F4 + B3_L5_F4)  // 28 672 float4 = 448 KB per net
 #define B3_LDS_BYTES (B3_LH_F4 * 16 + 1024)            // one layer's slices + the layer's bias row (forward)
@@ -149,15 +150,17 @@ __device__ __forceinline__ void mfma_results_settle() {
 template <int T0, int S0>
 __device__ __forceinline__ void b3_quarter(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
                                            f32x16 (&acc)[4], int lane) {
-    constexpr int KS = 8, PL = 4 * KS * 64;
+    // a 128 x 128 layer is two k-half blocks [khalf][plane][out tile][k16 step 0..3][lane] of B3_KH_F4 float4 (packing.py)
+    constexpr int PLH = 4 * 4 * 64;
 #pragma unroll
     for (int s = S0; s < S0 + 4; s++) {
         Frag ah[2], am[2], al[2];
+        const f32x4 *wk = w + (S0 / 4) * B3_KH_F4 + ((s & 3)) * 64 + lane;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            ah[t].f = w[0 * PL + ((T0 + t) * KS + s) * 64 + lane];
-            am[t].f = w[1 * PL + ((T0 + t) * KS + s) * 64 + lane];
-            al[t].f = w[2 * PL + ((T0 + t) * KS + s) * 64 + lane];
+            ah[t].f = wk[0 * PLH + (T0 + t) * 256];
+            am[t].f = wk[1 * PLH + (T0 + t) * 256];
+            al[t].f = wk[2 * PLH + (T0 + t) * 256];
         }
 #pragma unroll
         for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
@@ -215,13 +218,14 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[4], float *__restrict_
 template <int T0>
 __device__ __forceinline__ void b3_quarter_step(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8],
                                                 const Frag (&bl)[8], f32x16 (&acc)[4], int lane, int s) {
-    constexpr int KS = 8, PL = 4 * KS * 64;
+    constexpr int PLH = 4 * 4 * 64;
     Frag ah[2], am[2], al[2];
+    const f32x4 *wk = w + (s >> 2) * B3_KH_F4 + (s & 3) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        ah[t].f = w[0 * PL + ((T0 + t) * KS + s) * 64 + lane];
-        am[t].f = w[1 * PL + ((T0 + t) * KS + s) * 64 + lane];
-        al[t].f = w[2 * PL + ((T0 + t) * KS + s) * 64 + lane];
+        ah[t].f = wk[0 * PLH + (T0 + t) * 256];
+        am[t].f = wk[1 * PLH + (T0 + t) * 256];
+        al[t].f = wk[2 * PLH + (T0 + t) * 256];
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
 }
 
 // ---- fp32 fragments (b3 order, one gather of the natural weights on the host side) -> three bf16 planes per layer
-#define B3_MAX_LAYERS 16
+#define B3_MAX_LAYERS 32
 struct B3Layers {
     int n_layers;
     int src_off[B3_MAX_LAYERS];   // floats

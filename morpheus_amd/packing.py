@@ -98,6 +98,16 @@ def _frag_index_b3(row_of_lane: np.ndarray, col_of_k: np.ndarray, n_cols: int, t
     return idx.reshape(-1)
 
 
+def _b3_blocks(idx: np.ndarray, MT: int, KS16: int):
+    """Split a layer's b3 fragment index into the blocks the kernels stage at a time.  A 128 x 128 layer (MT = 4, KS16 = 8)
+    is staged as two k-halves [khalf][out tile][k16 step 0..3][lane][8] of 48 KB of slices each (the phased kernels of
+    csrc/mlp_b3.hip keep three such blocks in LDS); every other layer is one block."""
+    if MT == 4 and KS16 == 8:
+        v = idx.reshape(4, 2, 4, 64, 8).transpose(1, 0, 2, 3, 4)
+        return [v[0].reshape(-1), v[1].reshape(-1)]
+    return [idx]
+
+
 B3_DMA_F4 = 512      # a layer's slices are staged by whole rounds of the 512-thread block (16 bytes per thread and round)
 
 
@@ -211,7 +221,10 @@ class NetPacker:
         self.bwd_index = np.concatenate(bwd)
         # bf16x3 fragments: fp32 gather in b3 order (sliced into three bf16 planes by mh_b3_slice); per layer the float count
         # and the float4 offset of its [hi|mid|lo] planes in the sliced pack (padded to whole DMA rounds)
-        fwd3 = [_frag_index_b3(s.rowmap, s.kmap, s.in_dim, False, sentinel, o) for s, o in zip(self.specs, offs)]
+        fwd3 = []
+        for s, o in zip(self.specs, offs):
+            fwd3 += _b3_blocks(_frag_index_b3(s.rowmap, s.kmap, s.in_dim, False, sentinel, o), s.rowmap.shape[0] // 32,
+                               (s.kmap.shape[0] + 7) // 8)
         self.fwd3_index = np.concatenate(fwd3)
         self.fwd3_n = [len(f) for f in fwd3]
         self.fwd3_f4, f4 = [], 0
@@ -219,8 +232,11 @@ class NetPacker:
             self.fwd3_f4.append(f4)
             f4 += -(-(3 * n // 8) // B3_DMA_F4) * B3_DMA_F4
         self.fwd3_total_f4 = f4
-        bwd3 = [_frag_index_b3(self.specs[i].rowmapT, self.specs[i].kmapT, self.specs[i].in_dim, True, sentinel, offs[i])
-                for i in bwd_order]
+        bwd3 = []
+        for i in bwd_order:
+            sp = self.specs[i]
+            bwd3 += _b3_blocks(_frag_index_b3(sp.rowmapT, sp.kmapT, sp.in_dim, True, sentinel, offs[i]), sp.rowmapT.shape[0] // 32,
+                               (sp.kmapT.shape[0] + 7) // 8)
         self.bwd3_index = np.concatenate(bwd3)
         self.bwd3_n = [len(f) for f in bwd3]
         self.bwd3_f4, f4 = [], 0
