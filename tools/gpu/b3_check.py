@@ -25,9 +25,9 @@ def run(M, n_slots, with_acts, scale=0.15):
     ops.MLP_B3 = True
     op = ops.prepare_warp_operands(pd, pt_)
     assert op.w3 is not None
-    x = torch.rand(M, 3, device=dev) * 2 - 1
+    x = (torch.rand(M, 3, device=dev) * 2 - 1) * (0.0 if scale == 0.0 else 1.0)
     slot = (torch.arange(M, device=dev) % n_slots).int()
-    b0d, b0t = torch.randn(n_slots, 128, device=dev) * 0.3, torch.randn(n_slots, 128, device=dev) * 0.3
+    b0d, b0t = torch.randn(n_slots, 128, device=dev) * 0.3 * (scale != 0.0), torch.randn(n_slots, 128, device=dev) * 0.3 * (scale != 0.0)
     (wd, wt), (bd, bt) = op.w, op.b
     res = {}
     for mode in ("f32", "b3"):
@@ -83,3 +83,6 @@ run(128 * 7 + 5, 2, True)
 run(2097152, 1, True)
 run(2097152, 1, False)
 run(2097152, 1, True, scale=0.3)
+print('--- all-zero weights and inputs (data-dependent power: is the kernel running against the power budget?)')
+run(2097152, 1, True, scale=0.0)
+run(2097152, 1, False, scale=0.0)
