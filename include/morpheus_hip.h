@@ -206,6 +206,12 @@ int mh_warp_fwd(const float *x, const int32_t *slot, const float *bias0_d, const
  *   512 x 16-byte DMA rounds).  Same outputs, same parked tiles (mh_warp_bwd_data / mh_mlp_wgrad consume them).
  * mh_warp_bwd_data_b3: mh_warp_bwd_data with the TRANSPOSED sliced packs (mh_warp_w3T_bytes() bytes per net: T5, T4..T1,
  *   T0; packing.py: bwd3_index).  Same dPre tiles, same g_x. */
+/* mh_field_fwd_b3: mh_field_fwd with the sliced pack of the six field layers (mh_field_w3_bytes() bytes, resident in LDS:
+ *   packing.py field_joint_packer().b3_layers).  Same outputs, same parked tiles (mh_field_bwd_fused consumes them). */
+int64_t mh_field_w3_bytes(void);
+int mh_field_fwd_b3(const float *xc, const float *feat_s, const float *feat_c, const float *topo, const void *w3,
+                    const float *bias, const float *beta, int32_t n_bands, int32_t with_color, float *sdf, float *sigma,
+                    float *albedo, float *acts, int64_t M, void *stream);
 int mh_b3_slice(const float *src, void *dst, int32_t n_layers, const int32_t *src_off_host, const int32_t *n_host,
                 const int32_t *dst_off_f4_host, void *stream);
 int64_t mh_warp_w3_bytes(void);

@@ -1758,20 +1758,6 @@ extern "C" int mh_warp_bwd_data(const float *x, const float *g_deform, const flo
     return MH_OK;
 }
 
-// compute units of the current device, queried once per device (256 on MI355X; partitioned modes expose fewer)
-static int mh_cu_count() {
-    static int cached_dev = -1, cached_cus = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (dev != cached_dev) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached_cus = n;
-        cached_dev = dev;
-    }
-    return cached_cus;
-}
-
 // persistent field kernels: one 8-wave block per CU (the resident weights take 94-98 KB of its LDS)
 static inline unsigned field_blocks(int64_t n_tiles) {
     const int64_t need = (n_tiles + FIELD_THREADS / 64 - 1) / (FIELD_THREADS / 64);

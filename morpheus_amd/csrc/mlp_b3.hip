@@ -782,6 +782,180 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
     }
 }
 
+// ---- canonical field forward (sdf_net + Laplace density, color_net; models/model.py:273-307) on the bf16 pipe ------------
+// Same structure as mlp.hip's field_fwd_kernel: a persistent 8-wave workgroup per CU keeps EVERY layer's weight operand in
+// LDS (here the three bf16 planes of all six layers: 144 KB), a wave owns a 32-point tile through both nets with no barrier
+// at all, and parks the tile in exactly the fp32 kernel's layout (mh_field_bwd_fused consumes it).
+//   sliced pack (packing.py, field_joint_packer().b3_layers), float4 offsets: S0 0 (K = 80: 5 k16 steps, 2 tiles), S1 2048,
+//   S2 3584, C0 5120, C1 6656 (K = 64: 4 steps, 2 tiles), C2 8192 (1 tile); 9216 float4 in all
+#define FB3_S0 0
+#define FB3_S1 2048
+#define FB3_S2 3584
+#define FB3_C0 5120
+#define FB3_C1 6656
+#define FB3_C2 8192
+#define FB3_F4 9216
+#define FB3_THREADS 512
+
+__device__ __forceinline__ float laplace_sigma_b3(float s, float beta) {
+    // density.py:22-31: (1/beta) * (0.5 + 0.5 * sign(s) * expm1(-|s|/beta))
+    const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+}
+
+// 64 activations of a lane (two accumulator tiles): ReLU, park feature-major, sign mask, slices of k16 steps 0..3
+__device__ __forceinline__ void fb3_epilogue(f32x16 (&acc)[2], float *__restrict__ ht, uint32_t *__restrict__ mk, int pt, int h,
+                                             Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 1; t >= 0; t--) {
+#pragma unroll
+        for (int r = 15; r >= 0; r--) {
+            acc[t][r] = relu_i(acc[t][r]);
+            m = push_nz(m, acc[t][r]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (ht) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2],
+                       bl[2 * t + s2].u[e2]);
+    }
+    if (mk) *mk = m;
+}
+
+__global__ __launch_bounds__(FB3_THREADS, 2) void field_fwd_b3_kernel(
+    const float *__restrict__ xc, const float *__restrict__ feat_s, const float *__restrict__ feat_c, const float *__restrict__ topo,
+    const f32x4 *__restrict__ w3, const float *__restrict__ bias, const float *__restrict__ beta_p, int n_bands, int with_color,
+    float *__restrict__ sdf, float *__restrict__ sigma, float *__restrict__ albedo, float *__restrict__ acts, int64_t M,
+    int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    {
+        const int n = with_color ? FB3_F4 : FB3_C0;      // the sdf-only pass (finite-difference taps) needs S0..S2 only
+        for (int i = threadIdx.x; i < n; i += FB3_THREADS) lds_b3[i] = w3[i];
+    }
+    __syncthreads();
+    for (int64_t tile_id = (int64_t)blockIdx.x * (FB3_THREADS / 64) + wave; tile_id < n_tiles;
+         tile_id += (int64_t)gridDim.x * (FB3_THREADS / 64)) {
+        const int64_t p = tile_id * TILE + pt;
+        const bool live = p < M;
+        const int64_t pc = live ? p : M - 1;
+        float xv[3] = {xc[pc * 3 + 0], xc[pc * 3 + 1], xc[pc * 3 + 2]};
+        float *tile = acts ? acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE) : nullptr;
+        uint32_t *mk = tile ? reinterpret_cast<uint32_t *>(tile + FIELD_HID_ROWS * TILE) + lane : nullptr;
+        Frag bh[8], bm[8], bl[8];
+        f32x16 acc[2];
+        {
+            // sdf L0 input, k-step ordered: 20 encoding steps | 16 hash-feature steps (level pairs) | topo | zero pad
+            float bin0[40];
+            enc_bin(xv, h, n_bands, bin0, nullptr);
+            const f32x4 *fs = reinterpret_cast<const f32x4 *>(feat_s + pc * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 v = fs[q];
+#pragma unroll
+                for (int c = 0; c < 4; c++) bin0[20 + 4 * q + c] = v[c];
+            }
+            bin0[36] = topo ? topo[pc * 2 + h] : 0.f;
+            bin0[37] = bin0[38] = bin0[39] = 0.f;
+            if (tile) {
+#pragma unroll
+                for (int k = 0; k < 48; k++) PARK_STORE(k < 40 ? bin0[k] : 0.f, &tile[(2 * k + h) * TILE + pt]);   // rows 80..95 pad
+            }
+#pragma unroll
+            for (int s = 0; s < 5; s++)
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++) split2(bin0[8 * s + 2 * e2], bin0[8 * s + 2 * e2 + 1], bh[s].u[e2], bm[s].u[e2], bl[s].u[e2]);
+        }
+        // sdf L0: 73 -> 64
+        acc_bias<2>(acc, bias, h);
+        b3_layer<5, 2>(lds_b3 + FB3_S0, bh, bm, bl, acc, lane);
+        fb3_epilogue(acc, tile ? tile + 96 * TILE : nullptr, mk ? mk + 0 * 64 : nullptr, pt, h, bh, bm, bl);
+        // sdf L1: 64 -> 64
+        acc_bias<2>(acc, bias + 64, h);
+        b3_layer<4, 2>(lds_b3 + FB3_S1, bh, bm, bl, acc, lane);
+        fb3_epilogue(acc, tile ? tile + 160 * TILE : nullptr, mk ? mk + 1 * 64 : nullptr, pt, h, bh, bm, bl);
+        // sdf L2: 64 -> [geo(32) | sdf], no activation
+        if (!with_color) {
+            // sdf-only pass: the geo tile feeds nothing -- evaluate the tile holding the sdf row only (plane stride of the
+            // two-tile pack: 2 * 4 * 64)
+            f32x16 a1[1];
+            acc_bias<1>(a1, bias + 128 + 32, h);
+            const f32x4 *w = lds_b3 + FB3_S2 + 4 * 64;      // tile 1 of each plane
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                Frag ah, am, al;
+                ah.f = w[0 * 512 + s * 64 + lane];
+                am.f = w[1 * 512 + s * 64 + lane];
+                al.f = w[2 * 512 + s * 64 + lane];
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh[s].h, a1[0], 0, 0, 0);
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bm[s].h, a1[0], 0, 0, 0);
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl[s].h, a1[0], 0, 0, 0);
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bh[s].h, a1[0], 0, 0, 0);
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bm[s].h, a1[0], 0, 0, 0);
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh[s].h, a1[0], 0, 0, 0);
+            }
+            if (h == 0 && live) {
+                const float sv = a1[0][0];
+                sdf[p] = sv;
+                if (sigma) sigma[p] = laplace_sigma_b3(sv, *beta_p);
+            }
+            continue;
+        }
+        acc_bias<2>(acc, bias + 128, h);
+        b3_layer<4, 2>(lds_b3 + FB3_S2, bh, bm, bl, acc, lane);
+        if (h == 0 && live) {
+            const float sv = acc[1][0];
+            sdf[p] = sv;
+            if (sigma) sigma[p] = laplace_sigma_b3(sv, *beta_p);
+        }
+        // color L0: [hash_c(32) | geo(32)] -> 64
+        {
+            float binc[32];
+            const f32x4 *fc = reinterpret_cast<const f32x4 *>(feat_c + pc * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 v = fc[q];
+#pragma unroll
+                for (int c = 0; c < 4; c++) binc[4 * q + c] = v[c];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) binc[16 + r] = acc[0][r];
+            if (tile) {
+#pragma unroll
+                for (int k = 0; k < 32; k++) PARK_STORE(binc[k], &tile[(224 + 2 * k + h) * TILE + pt]);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++) split2(binc[8 * s + 2 * e2], binc[8 * s + 2 * e2 + 1], bh[s].u[e2], bm[s].u[e2], bl[s].u[e2]);
+        }
+        acc_bias<2>(acc, bias + 192, h);
+        b3_layer<4, 2>(lds_b3 + FB3_C0, bh, bm, bl, acc, lane);
+        fb3_epilogue(acc, tile ? tile + 288 * TILE : nullptr, mk ? mk + 2 * 64 : nullptr, pt, h, bh, bm, bl);
+        // color L1
+        acc_bias<2>(acc, bias + 256, h);
+        b3_layer<4, 2>(lds_b3 + FB3_C1, bh, bm, bl, acc, lane);
+        fb3_epilogue(acc, tile ? tile + 352 * TILE : nullptr, mk ? mk + 3 * 64 : nullptr, pt, h, bh, bm, bl);
+        // color L2: 64 -> 3, sigmoid
+        f32x16 o[1];
+        acc_bias<1>(o, bias + 320, h);
+        b3_layer<4, 1>(lds_b3 + FB3_C2, bh, bm, bl, o, lane);
+        if (h == 0 && live) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) albedo[p * 3 + c] = 1.0f / (1.0f + expf(-o[0][c]));
+        }
+    }
+}
+
 // ---- fp32 fragments (b3 order, one gather of the natural weights on the host side) -> three bf16 planes per layer
 #define B3_MAX_LAYERS 32
 struct B3Layers {
@@ -848,6 +1022,30 @@ static int b3_lds_opt_in() {
             return MH_ERR_LAUNCH;
         done = 1;
     }
+    return MH_OK;
+}
+
+extern "C" int64_t mh_field_w3_bytes(void) { return (int64_t)FB3_F4 * 16; }
+
+extern "C" int mh_field_fwd_b3(const float *xc, const float *feat_s, const float *feat_c, const float *topo, const void *w3,
+                               const float *bias, const float *beta, int32_t n_bands, int32_t with_color, float *sdf, float *sigma,
+                               float *albedo, float *acts, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !xc || !feat_s || !w3 || !bias || !sdf || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
+    if (with_color && (!feat_c || !albedo)) return MH_ERR_ARG;
+    const int64_t n_tiles = mh_mlp_tiles(M);   // dead tail tiles are processed too: the backward reads every scratch tile
+    static int ok = 0;
+    if (!ok) {
+        if (hipFuncSetAttribute((const void *)field_fwd_b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB3_F4 * 16) != hipSuccess)
+            return MH_ERR_LAUNCH;
+        ok = 1;
+    }
+    const int64_t need = (n_tiles + FB3_THREADS / 64 - 1) / (FB3_THREADS / 64);
+    const int64_t cus = mh_cu_count();
+    hipLaunchKernelGGL(field_fwd_b3_kernel, dim3((unsigned)(need < cus ? need : cus)), dim3(FB3_THREADS), FB3_F4 * 16,
+                       mh_stream(stream), xc, feat_s, feat_c, topo, reinterpret_cast<const f32x4 *>(w3), bias, beta, (int)n_bands,
+                       (int)with_color, sdf, sigma, albedo, acts, M, n_tiles);
+    MH_CHECK_LAUNCH();
     return MH_OK;
 }
 

@@ -103,6 +103,8 @@ GRID_FWD_TWO = os.environ.get("MORPHEUS_GRID_FWD", "") == "two"
 # warp nets: "b3" (default) = exact fp32 products from three bf16 slices on the bf16 matrix pipe (csrc/mlp_b3.hip: values, parked
 # tiles, accumulation and results stay fp32, fp32-grade error), "f32" = the native fp32 MFMA kernels of csrc/mlp.hip (A/B switch)
 MLP_B3 = os.environ.get("MORPHEUS_MLP", "b3") == "b3"
+# field nets (sdf / colour): forward on the bf16 pipe too (mh_field_fwd_b3); the fused backward stays on the fp32 MFMA
+FIELD_B3 = os.environ.get("MORPHEUS_FIELD_FWD", "b3") == "b3"
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
@@ -613,7 +615,7 @@ def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[t
 def prepare_field_operands(params: Sequence[torch.Tensor]) -> MLPOperands:
     """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
     jp = field_joint_packer()
-    return MLPOperands(jp, *_PackOperands.apply(jp, False, False, len(params), *params))
+    return MLPOperands(jp, *_PackOperands.apply(jp, False, FIELD_B3, len(params), *params))
 
 
 class _WarpMLP(torch.autograd.Function):
@@ -709,8 +711,12 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     sdf, sigma = torch.empty(M, device=dev), torch.empty(M, device=dev)
     albedo = torch.empty(M, 3, device=dev) if with_color else None
     _e = TIMER.start()
-    check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands, int(bool(with_color)),
-                           ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd")
+    if opnd.w3 is not None:
+        check(lib.mh_field_fwd_b3(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(opnd.w3[0]), ptr(b), ptr(beta_c), n_bands,
+                                  int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd_b3")
+    else:
+        check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands, int(bool(with_color)),
+                               ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd")
     TIMER.stop("mh_field_fwd", _e)
     return sdf, sigma, albedo, acts
 
