@@ -254,16 +254,19 @@ def test_b3_fragment_index_matches_the_mfma_layout():
     flat = jp.flat([n[0] for n in nets], [n[1] for n in nets])
     src = flat[torch.from_numpy(jp.fwd3_index)].numpy()
     rng = np.random.default_rng(1)
-    so, n, _ = jp.b3_layers[1]
-    frag = src[so:so + n].reshape(4, 8, 64, 8)
+    # a 128 x 128 layer is staged as two k-half blocks [khalf][out tile][k16 step 0..3][lane][8] (b3_layers[1], [2])
     X = rng.standard_normal(128).astype(np.float32)
     out = np.zeros(128)
-    for mt in range(4):
-        for i in range(32):
-            for s in range(8):
-                for gg in range(2):
-                    for e in range(8):
-                        out[32 * mt + i] += frag[mt, s, 32 * gg + i, e] * X[32 * (s >> 1) + acc_row(8 * (s & 1) + e, gg)]
+    for kh in range(2):
+        so, n, _ = jp.b3_layers[1 + kh]
+        frag = src[so:so + n].reshape(4, 4, 64, 8)
+        for mt in range(4):
+            for i in range(32):
+                for sp in range(4):
+                    s = 4 * kh + sp
+                    for gg in range(2):
+                        for e in range(8):
+                            out[32 * mt + i] += frag[mt, sp, 32 * gg + i, e] * X[32 * (s >> 1) + acc_row(8 * (s & 1) + e, gg)]
     assert np.abs(out - nets[0][0][1].numpy() @ X).max() < 1e-4
     so, n, _ = jp.b3_layers[0]
     frag = src[so:so + n].reshape(4, 3, 64, 8)
