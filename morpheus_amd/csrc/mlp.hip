@@ -1482,15 +1482,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_ring_b3_kernel(const float *__re
 struct WgRaw {
     f32x4 a[4], b[4];
 };
+// plain loads: a lane's four 16-byte pieces share 128-byte lines with the neighbouring lane half, and `nt` loads (stream past
+// the caches: the tiles are read once) re-fetch those lines -- measured 6.4 instead of 4.7 ms for the warp group
+#define WG_NT ""
 __device__ __forceinline__ void wg_raw_load(WgRaw &f, const float *__restrict__ a, const float *__restrict__ b) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.a[0]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.a[1]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.a[2]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.a[3]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.b[0]) : "v"(b) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.b[1]) : "v"(b) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.b[2]) : "v"(b) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.b[3]) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" WG_NT : "=v"(f.a[0]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" WG_NT : "=v"(f.a[1]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" WG_NT : "=v"(f.a[2]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:48" WG_NT : "=v"(f.a[3]) : "v"(a) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" WG_NT : "=v"(f.b[0]) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" WG_NT : "=v"(f.b[1]) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:32" WG_NT : "=v"(f.b[2]) : "v"(b) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:48" WG_NT : "=v"(f.b[3]) : "v"(b) : "memory");
 }
 struct WgSl {
     Frag h[2], m[2], l[2];
