@@ -414,6 +414,16 @@ def main(argv=None):
                                           frac_note="algorithmic FLOP/s of the whole step over the native fp32 MFMA peak (157.3): "
                                                     "a speed-of-light figure for an all-fp32-MFMA step, kept for continuity with "
                                                     "round 1" + ("; the warp nets now run on the bf16 pipe" if b3 else ""))
+    # the warp weight-gradient group is the step's largest item and a streaming kernel: every parked activation and dPre row is
+    # read exactly once (2 x 5.4 KB per point: SURVEY 8d's tile geometry, profiles/r02_pmc_summary.csv confirms the bytes)
+    roof_wgrad = None
+    if render_wl and args.workload != "cfg2" and "mh_mlp_wgrad[warp]" in ktab:
+        wg_bytes = M * 4.0 * (2 * 64 + 2 * 5 * 128 + 2 * (5 * 128 + 32))      # H0 per net + hidden activations + dPre rows
+        wg_gbs = wg_bytes / (ktab["mh_mlp_wgrad[warp]"]["avg_ms"] * 1e-3) / 1e9
+        roof_wgrad = dict(kernel="mh_mlp_wgrad[warp] (12 launches + reduction)", bound="hbm", achieved=round(wg_gbs, 1),
+                          peak=HBM_PEAK_GBS, unit="GB/s", frac=round(wg_gbs / HBM_PEAK_GBS, 4), bytes_per_step=round(wg_bytes),
+                          note="algorithmic = measured bytes (each operand row read once); this box's torch kernels sustain 4.0 "
+                               "(sum) - 5.3 (copy) - 6.8 (fill) TB/s, profiles/r02_micro_hbm_rates.txt")
     roof_hash = None
     if render_wl and ("mh_grid_encode_fwd" in ktab or "mh_grid_encode_fwd2" in ktab):
         # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b).  The two-table launch
@@ -475,7 +485,7 @@ def main(argv=None):
                                       "MAC on the bf16 matrix pipe, fp32 accumulate (fp32-grade: <= 3 * 2^-24 of a product dropped); "
                                       "field nets: native fp32 MFMA" if b3 else "native fp32 MFMA (MORPHEUS_MLP=f32)"),
                    "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
-        "roofline": roofline, "roofline_hashgrid": roof_hash, "kernels": ktab,
+        "roofline": roofline, "roofline_hashgrid": roof_hash, "roofline_weight_gradients": roof_wgrad, "kernels": ktab,
     }
     if "occupied" in wl:
         out["config"]["occupied_fraction"] = round(wl["occupied"], 4)
