@@ -134,7 +134,7 @@ __device__ __forceinline__ void b3_layer(const f32x4 *__restrict__ w, const Frag
     }
 }
 
-// mlp_dev.h's relu1 / push_gt0 are inline asm, and hipcc's hazard recognizer does not see an inline-asm READ of a register
+// mlp_dev.h's push_gt0 (and, until this was found, relu1) is inline asm, and hipcc's hazard recognizer does not see an inline-asm READ of a register
 // an in-flight bf16 MFMA is still writing: the first v_max after the layer's last MFMA would return the stale accumulator
 // (found the hard way: the compiler sinks the layer's last MFMAs past the barrier and the DMA issue, right up to the first
 // asm statement; the fp32 MFMA of mlp.hip runs in the vector ALU's own order and is immune).  So the epilogue opens with the
@@ -178,7 +178,7 @@ __device__ __forceinline__ void b3_quarter(const f32x4 *__restrict__ w, const Fr
 }
 
 // ReLU and the sign-mask bit as compiler-visible integer instructions (one v_max_i32; v_min_u32 + v_lshl_add_u32): the float
-// forms cost an extra canonicalising v_max each, mlp_dev.h's inline-asm forms are invisible to the hazard recognizer (above).
+// forms cost an extra canonicalising v_max each, inline-asm forms are invisible to the hazard recognizer (above).
 // Bit patterns: x <= -0.0 is a negative int -> 0; positive floats and +NaN keep their bits.
 __device__ __forceinline__ float relu_i(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ uint32_t push_nz(uint32_t m, float y /* >= 0 */) { return (m << 1) + min(__float_as_uint(y), 1u); }

@@ -48,13 +48,11 @@ __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT]) {
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
 }
 
-// max(x, 0) as ONE v_max_f32: fmaxf() costs two (hipcc first canonicalises its operand with v_max x, x, x), and on gfx950
-// every VALU instruction of the layer epilogue is serial with the fp32 MFMAs (they share the vector ALU's issue)
-__device__ __forceinline__ float relu1(float x) {
-    float y;
-    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-    return y;
-}
+// max(x, 0) as ONE instruction: fmaxf() costs two (hipcc first canonicalises its operand with v_max x, x, x), and every VALU
+// instruction of a layer epilogue counts (on the fp32 MFMA they are serial with the MFMAs, on the bf16 pipe they cost power).
+// Integer form on the bit pattern (x <= -0.0 is a negative int -> 0; positive floats keep their bits) rather than inline asm:
+// hipcc's hazard recognizer does not see an inline-asm READ of a register an in-flight MFMA is still writing (mlp_b3.hip).
+__device__ __forceinline__ float relu1(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 
 template <int MT, bool RELU>
 __device__ __forceinline__ void acc_to_bin(const f32x16 (&acc)[MT], float (&bin)[16 * MT]) {
