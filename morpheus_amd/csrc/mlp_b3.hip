@@ -11,6 +11,10 @@
 // test_warp_b3_is_fp32_grade holds values and every gradient to the fp32 kernels' own error against float64), for 6/16 of the
 // matrix cycles.
 //
+// Range: the split needs |x| below the bf16 maximum (3.39e38; fp32 reaches 3.40e38) -- above it hi rounds to infinity and the
+// residual is NaN -- and operands below ~1e-33 lose their low slices to the bf16 subnormal range; neither occurs in a network
+// whose activations are O(1).  Infinities and NaNs propagate as NaN.
+//
 // Layout facts the kernels rely on (32x32x16 bf16): lane (i = lane & 31, g = lane >> 5) supplies A[m = i][k = 8g..8g+7] and
 // B[k = 8g..8g+7][n = i] as 8 packed bf16 (4 VGPRs); D is the same 32x32 fp32 accumulator layout as the fp32 MFMA,
 // D[row = (r&3) + 8(r>>2) + 4g][col = i].  So accumulator registers 8s'..8s'+7 of output tile t, sliced and packed pairwise,
