@@ -800,20 +800,91 @@ __device__ __forceinline__ void dw_store(float *__restrict__ dw, const f32x16 (&
         for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, h)) * in_pad + 32 * n + i] = acc[n][r];
 }
 
+// ---- the same two primitives with exact fp32 products on the bf16 matrix pipe (see mlp_b3.hip) ---------------------------
+// weights: [plane hi|mid|lo][out tile][k16 step][lane][8 bf16] (packing.py: bwd3 blocks of the field packer); `bin` holds what
+// the fp32 chain carries per 2-wide k-step, so k16 step s takes bin[8s .. 8s+7]
+template <int KS, int MT>
+__device__ __forceinline__ void mfma_layer_z_b3(const f32x4 *__restrict__ w, const float (&bin)[KS], f32x16 (&acc)[MT], int lane) {
+    static_assert(KS % 8 == 0, "k16 steps");
+    constexpr int S = KS / 8, PL = MT * S * 64;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        Frag bh, bm, bl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) split2(bin[8 * s + 2 * e2], bin[8 * s + 2 * e2 + 1], bh.u[e2], bm.u[e2], bl.u[e2]);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            Frag ah, am, al;
+            ah.f = w[0 * PL + (t * S + s) * 64 + lane];
+            am.f = w[1 * PL + (t * S + s) * 64 + lane];
+            al.f = w[2 * PL + (t * S + s) * 64 + lane];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh.h, s == 0 ? zero : acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bm.h, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl.h, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bh.h, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bm.h, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh.h, acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// K = points: k16 step s, lane half g, element e <-> point 16 g + 8 s + e, i.e. v[2s], v[2s+1] of a RowFrag (both operands)
+__device__ __forceinline__ void row_slices(const RowFrag &f, Frag (&h)[2], Frag (&m)[2], Frag (&l)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++)
+            split2(f.v[2 * s + (e2 >> 1)][2 * (e2 & 1)], f.v[2 * s + (e2 >> 1)][2 * (e2 & 1) + 1], h[s].u[e2], m[s].u[e2], l[s].u[e2]);
+}
+template <int NI>
+__device__ __forceinline__ void dw_mma_b3(const RowFrag &a, const RowFrag (&b)[NI], f32x16 (&acc)[NI], float &bsum) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) bsum += (a.v[j][0] + a.v[j][1]) + (a.v[j][2] + a.v[j][3]);
+    Frag ah[2], am[2], al[2];
+    row_slices(a, ah, am, al);
+#pragma unroll
+    for (int n = 0; n < NI; n++) {
+        Frag bh[2], bm[2], bl[2];
+        row_slices(b[n], bh, bm, bl);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s].h, bh[s].h, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s].h, bm[s].h, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].h, bl[s].h, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s].h, bh[s].h, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].h, bm[s].h, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].h, bh[s].h, acc[n], 0, 0, 0);
+        }
+    }
+}
+// arithmetic selector of the fused kernels: LAYER(KS, MT, w, bin, acc) and DW(NI, A, B, acc, bsum)
+#define FUSED_LAYER(KS, MT, w, bin, acc) do { if (B3) mfma_layer_z_b3<KS, MT>(w, bin, acc, lane); else mfma_layer_z<KS, MT>(w, bin, acc, lane); } while (0)
+#define FUSED_DW(NI, A, B, acc, bsum) do { if (B3) dw_mma_b3<NI>(A, B, acc, bsum); else dw_mma<NI>(A, B, acc, bsum); } while (0)
+// float4 sizes of the transposed blocks in LDS: fp32 fragments / bf16x3 slices (packing.py pads every block to 512)
+#define FUSED_TC2(B3) ((B3) ? 1024 : 512)
+#define FUSED_TC1(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TC0(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TS2(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TS1(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TS0(B3) ((B3) ? 2560 : 1536)
+
 struct FusedPart {            // where this launch's per-wave partial sums go (float offsets into the workspace)
     int64_t dw[3];            // layer-major: [n_chunks][out_pad * in_pad]
     int64_t db[3];            // [n_chunks][out_pad]
 };
 
 // ---- color_net: Q2 (3 rows) <- g_albedo, Q1, Q0; hands d(geo) to the sdf launch ------------------------------------
+template <bool B3>
 __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
     const float *__restrict__ albedo, const float *__restrict__ g_albedo, const float *__restrict__ wpackT,
     const float *__restrict__ acts, float *__restrict__ dgeo_scr, float *__restrict__ g_feat_c, float *__restrict__ ws,
     FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5, i = lane & 31;
-    stage_fused<(2048 + 4096 + 4096) / 4>(wpackT, 0);     // TC2 | TC1 | TC0
-    float *scr = reinterpret_cast<float *>(lds_fused + (2048 + 4096 + 4096) / 4) + wave * SCR_FLOATS;
+    constexpr int W_F4 = FUSED_TC2(B3) + FUSED_TC1(B3) + FUSED_TC0(B3);
+    stage_fused<W_F4>(wpackT, 0);     // TC2 | TC1 | TC0 (fp32 fragments, or their bf16x3 slices)
+    float *scr = reinterpret_cast<float *>(lds_fused + W_F4) + wave * SCR_FLOATS;
     __syncthreads();
     f32x16 w2[2], w1[2][2], w0[2][2];                      // dW of c2 [1 out tile][2 in], c1, c0 [2][2]: 160 registers
     acc_zero<2>(w2);
@@ -849,20 +920,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         row_load_async(B[0], atile, 352 + i, h);
         row_load_async(B[1], atile, 384 + i, h);
         scr_put<1>(scr, d2, pt, h);
-        mfma_layer_z<16, 2>(wt, d2, acc, lane);
-        wt += 512;
+        FUSED_LAYER(16, 2, wt, d2, acc);
+        wt += FUSED_TC2(B3);
 #pragma unroll
         for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw3, j, acc[j >> 4][j & 15]);   // mask C2 -> dQ1
         scr_get(A, scr, i, h);
         fused_wait(B);
-        dw_mma<2>(A, B, w2, b2);
+        FUSED_DW(2, A, B, w2, b2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- layer c1: input C1 = rows 288..351
         row_load_async(B[0], atile, 288 + i, h);
         row_load_async(B[1], atile, 320 + i, h);
         scr_put<2>(scr, dbin, pt, h);
-        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
-        wt += 1024;
+        FUSED_LAYER(32, 2, wt, dbin, acc);
+        wt += FUSED_TC1(B3);
         {
             float q1[32];
 #pragma unroll
@@ -871,7 +942,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
-                dw_mma<2>(A, B, w1[mt], b1[mt]);
+                FUSED_DW(2, A, B, w1[mt], b1[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -881,7 +952,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         row_load_async(B[0], atile, 224 + i, h);
         row_load_async(B[1], atile, 256 + i, h);
         scr_put<2>(scr, dbin, pt, h);
-        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
+        FUSED_LAYER(32, 2, wt, dbin, acc);
         if (live) {
             if (g_feat_c) {
                 f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_c + p * 32 + 16 * h);
@@ -910,7 +981,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
             scr_get(A, scr, 32 * mt + i, h);
-            dw_mma<2>(A, B, w0[mt], b0[mt]);
+            FUSED_DW(2, A, B, w0[mt], b0[mt]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -943,7 +1014,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
 }
 
 // ---- sdf_net (+ Laplace density): P2 <- [d(geo) | g_sdf, g_sigma], P1, P0, d(inputs) ---------------------------------
-template <bool WITH_COLOR>
+template <bool WITH_COLOR, bool B3>
 __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ g_sdf,
     const float *__restrict__ g_sigma, const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands,
@@ -952,8 +1023,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5, i = lane & 31;
-    stage_fused<(4096 + 4096 + 6144) / 4>(wpackT + 2048 + 4096 + 4096, 0);     // TS2 | TS1 | TS0
-    float *scr = reinterpret_cast<float *>(lds_fused + (4096 + 4096 + 6144) / 4) + wave * SCR_FLOATS;
+    constexpr int W_F4 = FUSED_TS2(B3) + FUSED_TS1(B3) + FUSED_TS0(B3);
+    // TS2 | TS1 | TS0 behind the colour net's three blocks (fp32 fragments, or their bf16x3 slices)
+    stage_fused<W_F4>(wpackT + 4 * (FUSED_TC2(B3) + FUSED_TC1(B3) + FUSED_TC0(B3)), 0);
+    float *scr = reinterpret_cast<float *>(lds_fused + W_F4) + wave * SCR_FLOATS;
     __syncthreads();
     constexpr int MT2 = WITH_COLOR ? 2 : 1;                // sdf-only pass: dP2 has ONE non-zero row (tile 1, row 0)
     f32x16 w2[MT2][2], w1[2][2], w0[2][3];                 // 64 (32) + 64 + 96 = 224 (192) registers
@@ -1021,8 +1094,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             row_load_async(B[0], atile, 160 + i, h);
             row_load_async(B[1], atile, 192 + i, h);
             scr_put<2>(scr, d2, pt, h);
-            if (WITH_COLOR) {
-                mfma_layer_z<32, 2>(wt, d2, acc, lane);
+            if (WITH_COLOR || B3) {
+                // (the bf16x3 form of the sdf-only pass runs the whole layer: 48 short MFMAs, d2 is zero but for g_sdf)
+                FUSED_LAYER(32, 2, wt, d2, acc);
             } else {
                 // dH2 = W2[sdf,:]^T g_sdf is the single k-step 16 of the 32 (2 MFMAs instead of 64)
 #pragma unroll
@@ -1032,14 +1106,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], gs, z, 0, 0, 0);
                 }
             }
-            wt += 1024;
+            wt += FUSED_TS2(B3);
 #pragma unroll
             for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw1, j, acc[j >> 4][j & 15]);   // mask S2 -> dP1
             fused_wait(B);
 #pragma unroll
             for (int mt = 0; mt < MT2; mt++) {
                 scr_get(A, scr, 32 * (WITH_COLOR ? mt : 1) + i, h);
-                dw_mma<2>(A, B, w2[mt], b2[WITH_COLOR ? mt : 1]);
+                FUSED_DW(2, A, B, w2[mt], b2[WITH_COLOR ? mt : 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1049,8 +1123,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             row_load_async(B[0], atile, 96 + i, h);
             row_load_async(B[1], atile, 128 + i, h);
             scr_put<2>(scr, dbin, pt, h);
-            mfma_layer_z<32, 2>(wt, dbin, acc, lane);
-            wt += 1024;
+            FUSED_LAYER(32, 2, wt, dbin, acc);
+            wt += FUSED_TS1(B3);
             float q0[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) q0[j] = mask_bit(mw0, j, acc[j >> 4][j & 15]);     // mask S1 -> dP0
@@ -1058,7 +1132,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
-                dw_mma<2>(A, B, w1[mt], b1[mt]);
+                FUSED_DW(2, A, B, w1[mt], b1[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1073,8 +1147,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             scr_put<2>(scr, dbin, pt, h);
             // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
             f32x16 e[3];
-            if (g_xc) {
-                mfma_layer_z<32, 3>(wt, dbin, e, lane);
+            if (g_xc || B3) {
+                FUSED_LAYER(32, 3, wt, dbin, e);
             } else {
                 f32x16 e12[2];
                 mfma_layer_z<32, 2>(wt + 8 * 64, dbin, e12, lane);
@@ -1086,7 +1160,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
-                dw_mma<3>(A, B, w0[mt], b0[mt]);
+                FUSED_DW(3, A, B, w0[mt], b0[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
             float gx[3] = {0.f, 0.f, 0.f};
@@ -1990,21 +2064,26 @@ extern "C" int64_t mh_field_bwd_fused_workspace_floats(int64_t M) {
 }
 extern "C" int64_t mh_field_dgeo_floats(int64_t M) { return n_tiles_for(M) * 64 * 16; }
 
-extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
-                                  const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
-                                  int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
-                                  float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
-                                  float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
+static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
+                                const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
+                                int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
+                                float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
+                                float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream, bool b3) {
     if (M == 0) return MH_OK;
     if (M < 0 || !xc || !sdf || !wpackT || !acts || !workspace || !raw || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && (!albedo || !dgeo_scratch)) return MH_ERR_ARG;
     static int opted = 0;
-    const size_t lds_c = (size_t)(2048 + 4096 + 4096 + 4 * SCR_FLOATS) * sizeof(float);
-    const size_t lds_s = (size_t)(4096 + 4096 + 6144 + 4 * SCR_FLOATS) * sizeof(float);
+    const size_t lds_c = (size_t)(FUSED_TC2(b3) + FUSED_TC1(b3) + FUSED_TC0(b3)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
+    const size_t lds_s = (size_t)(FUSED_TS2(b3) + FUSED_TS1(b3) + FUSED_TS0(b3)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
     if (!opted) {
-        if (hipFuncSetAttribute((const void *)field_fused_color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess)
+        const int big_c = (int)((size_t)(FUSED_TC2(1) + FUSED_TC1(1) + FUSED_TC0(1)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float));
+        const int big_s = (int)((size_t)(FUSED_TS2(1) + FUSED_TS1(1) + FUSED_TS0(1)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float));
+        if (hipFuncSetAttribute((const void *)field_fused_color_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_c) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_color_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_c) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess)
             return MH_ERR_LAUNCH;
         opted = 1;
     }
@@ -2031,18 +2110,22 @@ extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float
         pc.db[k] = db_off[3 + k];
     }
     hipStream_t st = mh_stream(stream);
+#define FUSED_LAUNCH_COLOR(B3)                                                                                              \
+    hipLaunchKernelGGL(field_fused_color_kernel<B3>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT, \
+                       acts, dgeo_scratch, g_feat_c, workspace, pc, gmax_bits, M, n_tiles)
+#define FUSED_LAUNCH_SDF(WC, B3, DGEO)                                                                                       \
+    hipLaunchKernelGGL((field_fused_sdf_kernel<WC, B3>), dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf,      \
+                       g_sigma, wpackT, beta, (int)n_bands, acts, (const float *)(DGEO), g_xc, g_feat_s, g_topo, g_beta_partial, \
+                       workspace, ps, gmax_bits, M, n_tiles)
     if (with_color) {
-        hipLaunchKernelGGL(field_fused_color_kernel, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT,
-                           acts, dgeo_scratch, g_feat_c, workspace, pc, gmax_bits, M, n_tiles);
+        if (b3) FUSED_LAUNCH_COLOR(true); else FUSED_LAUNCH_COLOR(false);
         MH_CHECK_LAUNCH();
-        hipLaunchKernelGGL(field_fused_sdf_kernel<true>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf, g_sigma,
-                           wpackT, beta, (int)n_bands, acts, (const float *)dgeo_scratch, g_xc, g_feat_s, g_topo, g_beta_partial,
-                           workspace, ps, gmax_bits, M, n_tiles);
+        if (b3) FUSED_LAUNCH_SDF(true, true, dgeo_scratch); else FUSED_LAUNCH_SDF(true, false, dgeo_scratch);
     } else {
-        hipLaunchKernelGGL(field_fused_sdf_kernel<false>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf, g_sigma,
-                           wpackT, beta, (int)n_bands, acts, (const float *)nullptr, g_xc, g_feat_s, g_topo, g_beta_partial, workspace,
-                           ps, gmax_bits, M, n_tiles);
+        if (b3) FUSED_LAUNCH_SDF(false, true, nullptr); else FUSED_LAUNCH_SDF(false, false, nullptr);
     }
+#undef FUSED_LAUNCH_COLOR
+#undef FUSED_LAUNCH_SDF
     MH_CHECK_LAUNCH();
     // reduce the per-wave partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format)
     const int n_l = with_color ? 6 : 3;
@@ -2079,6 +2162,27 @@ extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace, raw, rd);
     MH_CHECK_LAUNCH();
     return MH_OK;
+}
+
+extern "C" int64_t mh_field_w3T_bytes(void) { return (int64_t)(FUSED_TC2(1) + FUSED_TC1(1) + FUSED_TC0(1) + FUSED_TS2(1) + FUSED_TS1(1) + FUSED_TS0(1)) * 16; }
+
+extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
+                                  const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
+                                  int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
+                                  float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
+                                  float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
+    return field_bwd_fused_impl(xc, sdf, albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, n_bands, with_color, acts, dgeo_scratch,
+                                workspace, raw, g_xc, g_feat_s, g_feat_c, g_topo, g_beta_partial, gmax_bits, M, stream, false);
+}
+
+extern "C" int mh_field_bwd_fused_b3(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
+                                     const float *g_sigma, const float *g_albedo, const void *w3T, const float *beta,
+                                     int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
+                                     float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
+                                     float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
+    return field_bwd_fused_impl(xc, sdf, albedo, g_sdf, g_sigma, g_albedo, reinterpret_cast<const float *>(w3T), beta, n_bands,
+                                with_color, acts, dgeo_scratch, workspace, raw, g_xc, g_feat_s, g_feat_c, g_topo, g_beta_partial,
+                                gmax_bits, M, stream, true);
 }
 
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }

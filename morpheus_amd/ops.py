@@ -722,10 +722,21 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
 
 
 FIELD_BWD_SPLIT = os.environ.get("MORPHEUS_FIELD_BWD", "") == "split"   # A/B switch: backward-data + mh_mlp_wgrad
+# "b3" = the fused field backward on the bf16 pipe (mh_field_bwd_fused_b3).  Measured, NOT the default: one wave per SIMD holds
+# the 224 weight-gradient accumulators, so the slicing VALU work is serial with its MFMAs and the kernel gains 3 % on cfg3
+# (2.15 -> 2.08 ms) and loses 3 % on the training step's small calls (1.44 -> 1.48 ms)
+FIELD_BWD_B3 = os.environ.get("MORPHEUS_FIELD_BWD", "") == "b3"
+
+
+def _field_wT(opnd):
+    """-> (transposed weight operand for the field backward, is it the bf16x3 pack?)"""
+    if FIELD_BWD_B3 and not FIELD_BWD_SPLIT and opnd.wT3 is not None:
+        return opnd.wT3[0], True
+    return opnd.wT[0], False
 
 
 def _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-                     need_dx, jp):
+                     need_dx, jp, b3=False):
     """mh_field_bwd_fused: backward-data and weight gradients of the field nets in one pass per net (the pre-activation
     gradients stay on the chip).  Same returns as _field_bwd."""
     M, dev = xc.shape[0], xc.device
@@ -743,19 +754,19 @@ def _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_a
     raw = torch.empty(jp.raw_len, device=dev)
     c = lambda t: None if t is None else t.contiguous()
     _e = TIMER.start()
-    check(lib.mh_field_bwd_fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)),
-                                 ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws),
-                                 ptr(raw), ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()),
-          "mh_field_bwd_fused")
+    fused = lib.mh_field_bwd_fused_b3 if b3 else lib.mh_field_bwd_fused
+    check(fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT),
+                ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws), ptr(raw), ptr(g_xc), ptr(g_fs), ptr(g_fc),
+                ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()), "mh_field_bwd_fused")
     TIMER.stop("mh_field_bwd_fused", _e)
     return g_xc, g_fs, g_fc, g_tp, g_bp.sum().reshape(()), raw, gmax
 
 
 def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-               need_dx, jp):
+               need_dx, jp, b3=False):
     if not FIELD_BWD_SPLIT:
         return _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo,
-                                has_fc, need_dx, jp)
+                                has_fc, need_dx, jp, b3)
     return _field_bwd_split(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
                             need_dx, jp)
 
@@ -827,7 +838,8 @@ class _FieldMLP(torch.autograd.Function):
         tp = None if topo is None else topo.detach().contiguous()
         beta_c = beta.detach().reshape(1).contiguous().float()
         sdf, sigma, albedo, acts = _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, any(ctx.needs_input_grad))
-        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo)
+        wT_sel, ctx.bwd_b3 = _field_wT(opnd)
+        ctx.save_for_backward(xc, wT_sel, beta_c, acts, sdf, albedo)
         ctx.cfg = (n_bands, bool(with_color), topo is not None, feat_c is not None)
         ctx.jp = opnd.jp
         if albedo is None:
@@ -842,7 +854,7 @@ class _FieldMLP(torch.autograd.Function):
         n_bands, with_color, has_topo, has_fc = ctx.cfg
         g_xc, g_fs, g_fc, g_tp, g_beta, raw, _ = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
                                                             n_bands, with_color, has_topo, has_fc, ctx.needs_input_grad[0],
-                                                            ctx.jp)
+                                                            ctx.jp, ctx.bwd_b3)
         return (g_xc, g_fs, g_fc, g_tp, g_beta, raw, None, None, None)
 
 
@@ -872,7 +884,8 @@ class _FieldQuery(torch.autograd.Function):
         beta_c = beta.detach().reshape(1).contiguous().float()
         sdf, sigma, albedo, acts = _field_fwd(lib, xc, feats[0], feats[1] if with_color else None, tp, beta_c, n_bands,
                                               with_color, opnd, any(ctx.needs_input_grad))
-        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo, *embs)
+        wT_sel, ctx.bwd_b3 = _field_wT(opnd)
+        ctx.save_for_backward(xc, wT_sel, beta_c, acts, sdf, albedo, *embs)
         ctx.cfg = (n_bands, with_color, topo is not None, o_np, r_np, n_levels, float(bound), L)
         ctx.jp = opnd.jp
         if albedo is None:
@@ -887,7 +900,8 @@ class _FieldQuery(torch.autograd.Function):
         n_bands, with_color, has_topo, o_np, r_np, n_levels, bound, L = ctx.cfg
         need_dx = ctx.needs_input_grad[0]
         g_xc, g_fs, g_fc, g_tp, g_beta, raw, gmax = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
-                                                               n_bands, with_color, has_topo, with_color, need_dx, ctx.jp)
+                                                               n_bands, with_color, has_topo, with_color, need_dx, ctx.jp,
+                                                               ctx.bwd_b3)
         o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
         grads = [g_fs] + ([g_fc] if with_color else [])
         gptrs = [gmax.data_ptr(), gmax.data_ptr() + 4][:len(grads)]
