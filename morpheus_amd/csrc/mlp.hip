@@ -1548,27 +1548,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_ring_b3_kernel(const float *__re
 // ---- b3 weight gradients of a 128-row layer, every operand value sliced ONCE per workgroup ---------------------------
 // The ring kernel above fixed the memory-level parallelism (0.65 -> 0.54 ms per 128 x 128 layer) and exposed the next
 // bound: each of the four waves slices all IT activation tiles itself (440 VALU instructions per tile and wave, serial
-// with its 48 MFMAs on a one-wave SIMD).  Here wave mt loads ONLY its own dPre row block and activation row block mt
-// (8 KB per tile: four register sets deep, 96 KB per CU in flight), keeps its dPre slices in registers (nobody else needs
-// them), and publishes the slices of activation block mt in a double-buffered LDS area, from which all four waves take
-// ready-made B fragments.  Per tile: one barrier, 176 slicing instructions per wave (for tile k+1, independent of and
-// interleavable with tile k's MFMAs), 6 ds_write_b128 + 6*IT ds_read_b128 per wave.
-struct WgRaw {
-    f32x4 a[4], b[4];
-};
-// plain loads: a lane's four 16-byte pieces share 128-byte lines with the neighbouring lane half, and `nt` loads (stream past
-// the caches: the tiles are read once) re-fetch those lines -- measured 6.4 instead of 4.7 ms for the warp group
-#define WG_NT ""
-__device__ __forceinline__ void wg_raw_load(WgRaw &f, const float *__restrict__ a, const float *__restrict__ b) {
-    asm volatile("global_load_dwordx4 %0, %1, off" WG_NT : "=v"(f.a[0]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" WG_NT : "=v"(f.a[1]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" WG_NT : "=v"(f.a[2]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:48" WG_NT : "=v"(f.a[3]) : "v"(a) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off" WG_NT : "=v"(f.b[0]) : "v"(b) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" WG_NT : "=v"(f.b[1]) : "v"(b) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:32" WG_NT : "=v"(f.b[2]) : "v"(b) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:48" WG_NT : "=v"(f.b[3]) : "v"(b) : "memory");
-}
+// with its 48 MFMAs on a one-wave SIMD).  Here the raw tile still lands once per workgroup in an LDS ring by LDS-DMA
+// (three stages: two tiles, 64 KB, ahead), but wave mt reads back ONLY its own dPre row block and activation row block mt,
+// keeps its dPre slices in registers (nobody else needs them) and publishes the slices of activation block mt in a
+// double-buffered LDS area from which all four waves take ready-made B fragments.  Per tile: one barrier, 176 slicing
+// instructions per wave (for tile k+1, independent of tile k's MFMAs), 8 + 6*IT ds_read_b128 and 6 ds_write_b128 per wave.
+// (A first version kept the raw rows in registers, loaded by inline-asm global loads four sets deep: hipcc copied
+// in-flight sets between registers at the loop boundary -- an asm output counts as valid from the asm statement on -- and
+// the kernel returned garbage at sizes no small test reached.  tests/test_gpu_ops.py::test_warp_large_batch_weight_gradients
+// now holds every large-batch kernel to the small-batch forms.  Everything here but the DMA and its waits is visible to
+// the compiler.)
 struct WgSl {
     Frag h[2], m[2], l[2];
 };
@@ -1582,6 +1571,150 @@ __device__ __forceinline__ void wg_slice16(const f32x4 (&v)[4], WgSl &o) {
 
 template <int IT>
 __global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+                                                                int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
+                                                                int dpre_off, float *__restrict__ dw_part,
+                                                                float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
+    constexpr int RB = 4 + IT;              // 32-row blocks per raw tile: 4 of dPre, IT of activations
+    constexpr int STAGE_F4 = RB * 256;      // float4 slots per ring stage
+    constexpr int NST = 3;
+    constexpr int NL = RB;                  // DMA instructions per wave and tile (wave w carries quarter w of every block)
+    constexpr int BUF_F4 = IT * 6 * 64;     // B slices of one tile: [in tile][plane 3][step 2][lane 64] float4
+    f32x4 *const bbuf = lds_res + NST * STAGE_F4;
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int64_t st = n_chunks;
+    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
+    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
+    f32x16 acc[IT];
+    acc_zero<IT>(acc);
+    float bsum = 0.f;
+    WgSl as[2];
+    auto issue = [&](int64_t k) {
+        const int64_t t = (chunk + k * st) <= last ? (chunk + k * st) : last;   // prefetches past the end re-read a tile
+        f32x4 *stage = lds_res + (int)(k % NST) * STAGE_F4;
+        const float *dp = dpre + t * dpre_tile_floats + dpre_off + (int64_t)i * TILE + 16 * g + 4 * mt;
+        const float *ap = acts + t * acts_tile_floats + act_off + (int64_t)i * TILE + 16 * g + 4 * mt;
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
+            const float *src = rb < 4 ? dp + rb * 32 * TILE : ap + (rb - 4) * 32 * TILE;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(stage + (rb * 4 + mt) * 64), 16, 0, 0);
+        }
+    };
+    // raw tile k (ring stage k % 3) -> my dPre slices as[par] (+ the bias-gradient sum of a REAL tile), and -- waves < IT --
+    // the slices of activation block mt into B buffer par
+    auto split = [&](int64_t k, WgSl &a_out, int par) {
+        const f32x4 *stage = lds_res + (int)(k % NST) * STAGE_F4;
+        f32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = stage[(mt * 4 + j) * 64 + lane];
+        if (k < n_my) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bsum += (a[j][0] + a[j][1]) + (a[j][2] + a[j][3]);
+        }
+        wg_slice16(a, a_out);
+        if (mt < IT) {
+            f32x4 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = stage[((4 + mt) * 4 + j) * 64 + lane];
+            WgSl bs;
+            wg_slice16(b, bs);
+            f32x4 *dst = bbuf + par * BUF_F4 + mt * 6 * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                dst[(0 * 2 + s) * 64] = bs.h[s].f;
+                dst[(1 * 2 + s) * 64] = bs.m[s].f;
+                dst[(2 * 2 + s) * 64] = bs.l[s].f;
+            }
+        }
+    };
+    auto mma = [&](const WgSl &a, int par) {
+        const f32x4 *src = bbuf + par * BUF_F4 + lane;
+#pragma unroll
+        for (int np = 0; np < IT; np += 2) {
+            Frag bh[2][2], bm[2][2], bl[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    bh[t][s].f = src[((np + t) * 6 + 0 * 2 + s) * 64];
+                    bm[t][s].f = src[((np + t) * 6 + 1 * 2 + s) * 64];
+                    bl[t][s].f = src[((np + t) * 6 + 2 * 2 + s) * 64];
+                }
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s].h, bh[t][s].h, acc[np + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s].h, bm[t][s].h, acc[np + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s].h, bl[t][s].h, acc[np + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s].h, bh[t][s].h, acc[np + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s].h, bm[t][s].h, acc[np + t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s].h, bh[t][s].h, acc[np + t], 0, 0, 0);
+            }
+        }
+    };
+    // one pipeline step for tile k: (everyone's pieces of raw tile k+1 and B slices of tile k visible, everyone out of
+    // ring stage k % 3 and B buffer (k+1) & 1) -> refill stage k % 3 with tile k+3 -> MFMAs of tile k, slices of tile k+1
+#define WG_STEP(k, PAR)                                                         \
+    do {                                                                        \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");    \
+        __builtin_amdgcn_s_barrier();                                           \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+        issue((k) + 3);                                                         \
+        if ((k) < n_my) mma(as[PAR], PAR);                                      \
+        split((k) + 1, as[1 - (PAR)], 1 - (PAR));                               \
+        __builtin_amdgcn_sched_barrier(0);                                      \
+    } while (0)
+    if (n_my > 0) {
+        issue(0);
+        issue(1);
+        issue(2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        split(0, as[0], 0);
+        for (int64_t k = 0; k < n_my; k += 2) {
+            WG_STEP(k, 0);
+            WG_STEP(k + 1, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef WG_STEP
+    const int in_pad = 32 * IT;
+    float *dw = dw_part + (int64_t)chunk * 128 * in_pad;
+#pragma unroll
+    for (int n = 0; n < IT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, g)) * in_pad + 32 * n + i] = acc[n][r];
+    bsum += __shfl_xor(bsum, 32);
+    if (g == 0) db_part[(int64_t)chunk * 128 + 32 * mt + i] = bsum;
+}
+
+// ---- the same slice-once scheme with the raw rows prefetched into REGISTERS by ordinary (compiler-visible) loads ------
+// wave mt loads only its own dPre row block and activation row block mt (8 KB per tile), four register sets deep; hipcc
+// tracks these loads itself (its s_waitcnt before a set's first use counts the younger sets), the scheduling fences keep the
+// loads at the head of each step.  No LDS-DMA issue cost, 96 KB per CU in flight.  (MORPHEUS_WGRAD_B3=regs)
+struct WgRaw {
+    f32x4 a[4], b[4];
+};
+__device__ __forceinline__ void wg_raw_load(WgRaw &f, const float *__restrict__ a, const float *__restrict__ b) {
+    const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a), *b4 = reinterpret_cast<const f32x4 *>(b);
+#pragma unroll
+    for (int j = 0; j < 4; j++) f.a[j] = a4[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) f.b[j] = b4[j];
+}
+#ifndef WG_REG_SETS
+#define WG_REG_SETS 4
+#endif
+template <int IT>
+__global__ __launch_bounds__(256, 1) void wgrad_regs_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                                 int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
                                                                 int dpre_off, float *__restrict__ dw_part,
                                                                 float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
@@ -1599,7 +1732,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__r
     f32x16 acc[IT];
     acc_zero<IT>(acc);
     float bsum = 0.f;
-    WgRaw raw[4];
+    constexpr int NS = WG_REG_SETS;           // register sets of raw rows: NS - 1 tiles (8 KB per wave each) in flight
+    WgRaw raw[NS];
     WgSl as[2];
 #define WG_T(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
 #define WG_LD(set, k)                                                                \
@@ -1608,9 +1742,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__r
         wg_raw_load(raw[set], a0 + t_ * dpre_tile_floats, b0 + t_ * acts_tile_floats); \
     } while (0)
     // slice raw set `set` (tile k): dPre slices -> as[k & 1], activation slices -> LDS buffer k & 1
-#define WG_SPLIT(set, par)                                                                                          \
+#define WG_SPLIT(set, par, REAL)                                                                                          \
     do {                                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) bsum += (raw[set].a[j][0] + raw[set].a[j][1]) + (raw[set].a[j][2] + raw[set].a[j][3]); \
+        if (REAL) { _Pragma("unroll") for (int j = 0; j < 4; j++) bsum += (raw[set].a[j][0] + raw[set].a[j][1]) + (raw[set].a[j][2] + raw[set].a[j][3]); } \
         wg_slice16(raw[set].a, as[par]);                                                                            \
         if (mt < IT) {                                                                                              \
             WgSl bs_;                                                                                               \
@@ -1646,35 +1780,34 @@ __global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__r
     // one pipeline step for tile k = k0 + J: raw sets rotate mod 4, slice sets / LDS buffers mod 2
 #define WG_STEP(J)                                                                          \
     do {                                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                  \
-        __builtin_amdgcn_s_barrier();                                                       \
+        __syncthreads();                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        WG_LD((J) & 3, k0 + (J) + 4);                                                       \
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); /* raw tile k+1 landed */         \
-        landed(raw[((J) + 1) & 3].a);                                                       \
-        landed(raw[((J) + 1) & 3].b);                                                       \
+        WG_LD((J) % NS, k0 + (J) + NS);                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                  \
         if (k0 + (J) < n_my) WG_MMA((J) & 1);                                               \
-        WG_SPLIT(((J) + 1) & 3, ((J) + 1) & 1);                                             \
+        WG_SPLIT(((J) + 1) % NS, ((J) + 1) & 1, (k0 + (J) + 1 < n_my));                                             \
         __builtin_amdgcn_sched_barrier(0);                                                  \
     } while (0)
     if (n_my > 0) {
-        WG_LD(0, 0);
-        WG_LD(1, 1);
-        WG_LD(2, 2);
-        WG_LD(3, 3);
-        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        landed(raw[0].a);
-        landed(raw[0].b);
+#pragma unroll
+        for (int q = 0; q < NS; q++) WG_LD(q, q);
         __builtin_amdgcn_sched_barrier(0);
-        WG_SPLIT(0, 0);
-        for (int64_t k0 = 0; k0 < n_my; k0 += 4) {
+        WG_SPLIT(0, 0, true);
+        // the set index has period NS, the slice / B-buffer parity period 2: one loop trip = lcm(NS, 2) steps
+        for (int64_t k0 = 0; k0 < n_my; k0 += (NS % 2 ? 2 * NS : NS)) {
             WG_STEP(0);
             WG_STEP(1);
             WG_STEP(2);
             WG_STEP(3);
+            if (NS > 4) {
+                WG_STEP(4);
+                WG_STEP(5);
+                WG_STEP(6);
+                WG_STEP(7);
+                WG_STEP(8);
+                WG_STEP(9);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #undef WG_STEP
 #undef WG_MMA
@@ -1957,18 +2090,31 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
             static int ring_ok = 0;
             if (!ring_ok) {
                 if (hipFuncSetAttribute((const void *)wgrad_ring_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 4096) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)wgrad_ring_b3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 4096) != hipSuccess)
+                    hipFuncSetAttribute((const void *)wgrad_ring_b3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 4096) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)wgrad_share_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 8 * 256 + 2 * 4 * 6 * 64) * 16) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)wgrad_share_b3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 6 * 256 + 2 * 2 * 6 * 64) * 16) != hipSuccess)
                     return MH_ERR_LAUNCH;
                 ring_ok = 1;
             }
-            static const char *wgk = getenv("MORPHEUS_WGRAD_B3");      // A/B switch: "ring" = raw tiles through an LDS ring
-            if (!(wgk && wgk[0] == 'r')) {
+            // default: slice-once with the raw rows prefetched into registers; A/B switches: "share" = the same scheme with the raw
+            // tile through an LDS-DMA ring (measured 5.54 vs 5.28 ms), "ring" = LDS-DMA ring, every wave slices all (5.50)
+            static const char *wgk = getenv("MORPHEUS_WGRAD_B3");
+            if (!wgk || (wgk[0] == 'r' && wgk[1] == 'e')) {
                 if (in == 128)
-                    hipLaunchKernelGGL(wgrad_share_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
+                    hipLaunchKernelGGL(wgrad_regs_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
                                        acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
                                        workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
                 else
-                    hipLaunchKernelGGL(wgrad_share_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 2 * 2 * 6 * 1024, mh_stream(stream),
+                    hipLaunchKernelGGL(wgrad_regs_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 2 * 2 * 6 * 1024, mh_stream(stream),
+                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+            } else if (wgk[0] == 's') {
+                if (in == 128)
+                    hipLaunchKernelGGL(wgrad_share_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), (3 * 8 * 256 + 2 * 4 * 6 * 64) * 16, mh_stream(stream),
+                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+                else
+                    hipLaunchKernelGGL(wgrad_share_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), (3 * 6 * 256 + 2 * 2 * 6 * 64) * 16, mh_stream(stream),
                                        acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
                                        workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
             } else if (in == 128)

@@ -688,3 +688,45 @@ def test_warp_b3_is_fp32_grade(monkeypatch):
     assert n == 22
     for ga, gb, gr in zip(r3[4], r32[4], [t.grad for t in b64]):
         assert rl2(ga, gr) <= max(6 * rl2(gb, gr), 5e-6)
+
+
+@pytest.mark.parametrize("mlp", ["b3", "f32"])
+def test_warp_large_batch_weight_gradients(mlp, monkeypatch):
+    """The large-batch kernels of the warp path (from 16 384 tiles on mh_mlp_wgrad(_b3) launches one kernel per layer: the
+    slice-once-per-workgroup b3 kernel / the three-register-set fp32 kernel; the 8-wave forward / backward run hundreds of
+    workgroups per CU) against the small-batch forms the oracle tests pin: one call on 600 000 points must give the same
+    outputs, d/dx and parameter gradients as the same points fed in six chunks (same terms, different kernels and order)."""
+    from morpheus_amd import ops
+    monkeypatch.setattr(ops, "MLP_B3", mlp == "b3")
+    torch.manual_seed(3)
+    M, CH = 600_000, 100_000
+    nets = []
+    for nout in (3, 2):
+        W = [torch.randn(128, 39, device=DEV) * 0.15] + [torch.randn(128, 128, device=DEV) * 0.1 for _ in range(4)] + \
+            [torch.randn(nout, 128, device=DEV) * 0.15]
+        b = [torch.randn(128, device=DEV) * 0.1 for _ in range(5)] + [torch.randn(nout, device=DEV) * 0.1]
+        nets.append(W + b)
+    x = torch.rand(M, 3, device=DEV) * 2 - 1
+    b0 = [torch.randn(1, 128, device=DEV) * 0.3 for _ in range(2)]
+    wd_, wt_ = torch.randn(M, 3, device=DEV), torch.randn(M, 2, device=DEV)
+
+    def run(chunks):
+        ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
+        bb = [t.clone().requires_grad_(True) for t in b0]
+        xg = x.clone().requires_grad_(True)
+        opnd = ops.prepare_warp_operands(ps[0], ps[1])
+        outs = []
+        for a in range(0, M, chunks):
+            d, t = ops.warp_mlp(xg[a:a + chunks], None, bb[0], bb[1], 6, opnd)
+            outs.append((d, t))
+        d = torch.cat([o[0] for o in outs]); t = torch.cat([o[1] for o in outs])
+        ((d * wd_).sum() + (t * wt_).sum()).backward()
+        return d.detach(), t.detach(), xg.grad, [g for net in ps for g in (p.grad for p in net) if g is not None] + [t.grad for t in bb]
+
+    big, small = run(M), run(CH)
+    assert torch.equal(big[0], small[0]) and torch.equal(big[1], small[1])          # per-point results do not depend on the batch
+    assert torch.equal(big[2], small[2])
+    assert len(big[3]) == len(small[3]) == 26
+    for ga, gb in zip(big[3], small[3]):
+        scale = float(gb.abs().max()) + 1e-20
+        assert float((ga - gb).abs().max()) / scale <= 2e-5, (tuple(gb.shape), float((ga - gb).abs().max()) / scale)

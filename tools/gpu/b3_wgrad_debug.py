@@ -36,3 +36,14 @@ for l, (i, o) in enumerate(zip(geo[2], geo[3])):
     a, b = r3[off:off + n], r32[off:off + n]
     print(f"layer {l}: in {i} out {o}: nan {int(torch.isnan(a).sum())}  max |b3-f32| {float((a - b).abs().nan_to_num(0).max()):.3e}  max|f32| {float(b.abs().max()):.3e}")
     off += n
+print("---- error pattern of layer 1 (raw [out 128][in 128]) by 32 x 32 block, and of its bias gradient")
+off = geo[2][0] * geo[3][0]
+a = r3[off:off + 16384].view(128, 128); b = r32[off:off + 16384].view(128, 128)
+for ot in range(4):
+    print("out tile", ot, [f"{float((a[32*ot:32*ot+32, 32*it:32*it+32] - b[32*ot:32*ot+32, 32*it:32*it+32]).abs().max()):.2e}" for it in range(4)])
+dw_total = sum(i * o for i, o in zip(geo[2], geo[3]))
+db3, db32 = r3[dw_total:], r32[dw_total:]
+print("db layer0..1 max err", float((db3[:256] - db32[:256]).abs().max()), "max", float(db32[:256].abs().max()))
+# ratio test: is b3 a multiple of f32 somewhere?
+ratio = (a / b)[b.abs() > 1.0]
+print("ratio b3/f32 quantiles", [float(ratio.quantile(q)) for q in (0.01, 0.25, 0.5, 0.75, 0.99)])
