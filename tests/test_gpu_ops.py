@@ -730,3 +730,49 @@ def test_warp_large_batch_weight_gradients(mlp, monkeypatch):
     for ga, gb in zip(big[3], small[3]):
         scale = float(gb.abs().max()) + 1e-20
         assert float((ga - gb).abs().max()) / scale <= 2e-5, (tuple(gb.shape), float((ga - gb).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("with_color", [True, False])
+@pytest.mark.parametrize("bwd", ["f32", "b3"])
+def test_field_large_batch_gradients(with_color, bwd, monkeypatch):
+    """The persistent field kernels loop over many tiles per wave only at large batches (a 777-point test gives every wave
+    at most one tile): 400 000 points in one call against the same points in 40 chunks of 10 000 -- outputs and input
+    gradients bit for bit, parameter gradients to summation order."""
+    from morpheus_amd import ops
+    monkeypatch.setattr(ops, "FIELD_BWD_B3", bwd == "b3")      # the opt-in bf16x3 form of the fused backward is held to it too
+    torch.manual_seed(5)
+    M, CH = 400_000, 10_000
+    pg = _state("b", DEV, grad=False)
+    x = torch.rand(M, 3, device=DEV) * 2 - 1
+    fs, fc = torch.randn(M, 32, device=DEV) * 0.1, torch.randn(M, 32, device=DEV) * 0.1
+    topo = torch.randn(M, 2, device=DEV) * 0.3
+    ws, wg, wc = torch.randn(M, device=DEV), torch.randn(M, device=DEV) * 0.01, torch.randn(M, 3, device=DEV)
+
+    def run(chunk):
+        Ws = [pg[f"sdf_net.net.{l}.weight"].clone().requires_grad_(True) for l in range(3)]
+        Wc = [of.wn_weight(pg[f"color_net.net.{l}.weight_g"], pg[f"color_net.net.{l}.weight_v"]).clone().requires_grad_(True) for l in range(3)]
+        bs = [pg[f"sdf_net.net.{l}.bias"].clone().requires_grad_(True) for l in range(3)]
+        bc = [pg[f"color_net.net.{l}.bias"].clone().requires_grad_(True) for l in range(3)]
+        beta = (pg["sdf2density.beta"].abs() + 1e-4).clone().requires_grad_(True)
+        leaves = [t.clone().requires_grad_(True) for t in (x, fs, fc, topo)]
+        opnd = ops.prepare_field_operands(Ws + Wc + bs + bc)
+        outs = []
+        for a in range(0, M, chunk):
+            sl = slice(a, a + chunk)
+            outs.append(ops.field_mlp(leaves[0][sl], leaves[1][sl], leaves[2][sl] if with_color else None, leaves[3][sl], beta, 6,
+                                      with_color, opnd))
+        sdf = torch.cat([o[0] for o in outs]); sig = torch.cat([o[1] for o in outs])
+        loss = (sdf * ws).sum() + (sig * wg).sum()
+        if with_color:
+            loss = loss + (torch.cat([o[2] for o in outs]) * wc).sum()
+        loss.backward()
+        params = Ws + (Wc if with_color else []) + bs + (bc if with_color else []) + [beta]
+        return (sdf.detach(), sig.detach()), [t.grad for t in leaves if t.grad is not None], [p.grad for p in params]
+
+    big, small = run(M), run(CH)
+    assert torch.equal(big[0][0], small[0][0]) and torch.equal(big[0][1], small[0][1])
+    for ga, gb in zip(big[1], small[1]):
+        assert torch.equal(ga, gb)
+    for ga, gb in zip(big[2], small[2]):
+        scale = float(gb.abs().max()) + 1e-20
+        assert float((ga - gb).abs().max()) / scale <= 2e-5, (tuple(gb.shape), float((ga - gb).abs().max()) / scale)
