@@ -1710,11 +1710,16 @@ __device__ __forceinline__ void wg_raw_load(WgRaw &f, const float *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; j++) f.b[j] = b4[j];
 }
+// measured on cfg3 (warp group, same box): 4 sets / one workgroup per CU 5.28 ms, 5 sets 5.25, 3 sets / TWO workgroups per CU
+// (240 registers, 2 x 48 KB of LDS: the second workgroup's MFMAs fill the first one's slicing and barrier time) 4.95
 #ifndef WG_REG_SETS
-#define WG_REG_SETS 4
+#define WG_REG_SETS 3
+#endif
+#ifndef WG_REG_WAVES
+#define WG_REG_WAVES 2        // waves per SIMD the register budget is sized for = workgroups per CU
 #endif
 template <int IT>
-__global__ __launch_bounds__(256, 1) void wgrad_regs_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
+__global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_regs_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                                 int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
                                                                 int dpre_off, float *__restrict__ dw_part,
                                                                 float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
@@ -1799,9 +1804,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_regs_b3_kernel(const float *__re
             WG_STEP(1);
             WG_STEP(2);
             WG_STEP(3);
-            if (NS > 4) {
+            if ((NS % 2 ? 2 * NS : NS) > 4) {
                 WG_STEP(4);
                 WG_STEP(5);
+            }
+            if ((NS % 2 ? 2 * NS : NS) > 6) {
                 WG_STEP(6);
                 WG_STEP(7);
                 WG_STEP(8);
@@ -2024,7 +2031,8 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
 
 static inline int wg_chunks(int out_pad, int64_t n_tiles) {
     // 4 waves per CU per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
-    int64_t c = (int64_t)(4 * mh_cu_count()) / (out_pad / 32);
+    // large batches (the per-layer launches, from 16 384 tiles on): WG_REG_WAVES workgroups per CU (wgrad_regs_b3_kernel)
+    int64_t c = (int64_t)(4 * (n_tiles >= 16384 ? WG_REG_WAVES : 1) * mh_cu_count()) / (out_pad / 32);
     if (c > n_tiles) c = n_tiles;
     return (int)(c < 1 ? 1 : c);
 }
