@@ -2032,7 +2032,7 @@ extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float 
 static inline int wg_chunks(int out_pad, int64_t n_tiles) {
     // 4 waves per CU per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
     // large batches (the per-layer launches, from 16 384 tiles on): WG_REG_WAVES workgroups per CU (wgrad_regs_b3_kernel)
-    int64_t c = (int64_t)(4 * (n_tiles >= 16384 ? WG_REG_WAVES : 1) * mh_cu_count()) / (out_pad / 32);
+    int64_t c = (int64_t)(4 * ((n_tiles >= 16384 && out_pad == 128) ? WG_REG_WAVES : 1) * mh_cu_count()) / (out_pad / 32);
     if (c > n_tiles) c = n_tiles;
     return (int)(c < 1 ? 1 : c);
 }
