@@ -251,16 +251,8 @@ __device__ __forceinline__ void b3_epilogue_eighth(f32x16 (&acc)[4], float *__re
 #pragma unroll
     for (int r = 8 * s2; r < 8 * s2 + 8; r++) acc[t][r] = relu_i(acc[t][r]);
     if (ht) {
-#ifdef MH_B3_FAKE_X4
-#pragma unroll
-        for (int q = 2 * s2; q < 2 * s2 + 2; q++) {
-            f32x4 v4 = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-            __builtin_nontemporal_store(v4, reinterpret_cast<f32x4 *>(ht + (32 * t + 8 * q) * TILE) + (threadIdx.x & 63));
-        }
-#else
 #pragma unroll
         for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
-#endif
     }
     uint32_t m = 0;
 #pragma unroll
@@ -285,16 +277,8 @@ __device__ __forceinline__ void b3_epilogue_half(f32x16 (&acc)[4], float *__rest
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = relu_i(acc[t][r]);
         if (ht) {
-#ifdef MH_B3_FAKE_X4
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                f32x4 v4 = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-                __builtin_nontemporal_store(v4, reinterpret_cast<f32x4 *>(ht + (32 * t + 8 * q) * TILE) + (threadIdx.x & 63));
-            }
-#else
 #pragma unroll
             for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
-#endif
         }
         uint32_t m = 0;
 #pragma unroll
@@ -1017,8 +1001,6 @@ static int b3_lds_opt_in() {
     if (!done) {
         if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
-                hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_fwd_b3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B3P_LDS_BYTES) !=
@@ -1076,20 +1058,15 @@ extern "C" int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *
     if (M < 0 || !x || !bias0_d || !bias0_t || !w3_d || !w3_t || !bias_d || !bias_t || !out_deform || !out_topo || n_bands < 0 ||
         n_bands > 6)
         return MH_ERR_ARG;
-    static const int nw = getenv("MH_B3_WAVES") ? atoi(getenv("MH_B3_WAVES")) : 8;   // debug: 4 = one wave per SIMD
-    const int64_t blocks = (M + nw * 32 - 1) / (nw * 32);
+    const int64_t blocks = (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
     // "phased" = the two waves of a SIMD half a layer apart (warp_fwd_b3p_kernel): measured SLOWER than the lockstep kernel
     // (4.20 vs 3.70 ms with parking, 2.99 vs 2.65 without, same box) -- these kernels run against the chip's power budget
     // (effective clock 1.8 GHz in the phase trace), where overlap buys nothing and every extra barrier / DMA round costs
     static const char *sched = getenv("MORPHEUS_B3_FWD");
-    if (sched && sched[0] == 'p' && nw == 8)
+    if (sched && sched[0] == 'p')
         hipLaunchKernelGGL(warp_fwd_b3p_kernel, dim3((unsigned)blocks), dim3(B3_THREADS), B3P_LDS_BYTES, mh_stream(stream), x, slot,
-                           bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
-                           bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
-    else if (nw == 4)
-        hipLaunchKernelGGL(warp_fwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LDS_BYTES, mh_stream(stream), x, slot,
                            bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
                            bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
     else

@@ -125,11 +125,7 @@ __device__ __forceinline__ void enc_bin(const float (&x)[3], int h, int n_bands,
         const int band = k / 3, dim = k % 3;
         const float f = (float)(1 << band);
         float s, c;
-#ifdef MH_FAKE_SINCOS
-        s = x[dim] * f; c = 1.f - s;      // timing experiment only: what does the exact sincosf cost?
-#else
         sincosf(x[dim] * f, &s, &c);
-#endif
         const bool on = band < n_bands;
         bin[k] = on ? (h ? c : s) : 0.f;
         if (dsc) dsc[k] = on ? (h ? -f * s : f * c) : 0.f;
