@@ -18,6 +18,7 @@
  *   mh_sample_uniform           nerfacc OccGridEstimator.sampling call site morpheus.py:628-638
  *                               (benchmark sampler of SURVEY 8d; marcher is next-tier)
  *   mh_generate_rays            datasets/utils.py:28-65 + datasets/dataset.py:363-366
+ *   mh_rays_sample_uniform      the two above + the pixel draw of datasets/dataset.py:412-423, one launch
  *   mh_warp_* / mh_field_*      models/model.py:412-437 (warp), :273-307 (get_sigma_albedo),
  *                               models/decoders.py:59-64, models/encodings.py:35-57,
  *                               models/density.py:22-31 -- plain PyTorch in the reference
@@ -111,6 +112,15 @@ int mh_generate_rays(float fx, float fy, float cx, float cy, const float *c2w_ho
 int mh_sample_uniform(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, int32_t S,
                       float bound, int32_t *ray_idx, float *t_starts, float *t_ends, float *xyz,
                       int32_t *ray_start, int32_t *ray_cnt, void *stream);
+
+/* The two above in one launch (BASELINE.json north_star "fused ray-generate + stratified sampler"): ray r looks
+ * through pixel pix[r] (int32 [N] on the device; NULL = pixel r, N <= H*W) -- the per-iteration pixel draw of
+ * datasets/dataset.py:412-423.  Writes rays_o/rays_d [N,3] and every mh_sample_uniform output, bit-identical to
+ * mh_generate_rays + gather + mh_sample_uniform. */
+int mh_rays_sample_uniform(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
+                           const int32_t *pix, const float *jitter, int32_t N, int32_t S, float bound,
+                           float *rays_o, float *rays_d, int32_t *ray_idx, float *t_starts, float *t_ends,
+                           float *xyz, int32_t *ray_start, int32_t *ray_cnt, void *stream);
 
 /* Occupancy-grid marcher (nerfacc OccGridEstimator.sampling call shape, morpheus.py:628-638): fixed `step`,
  * one jitter per ray (NULL = none), binary grid [R,R,R] uint8 over the AABB [-bound,bound]^3.  Interval k of a ray:

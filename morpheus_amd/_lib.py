@@ -29,6 +29,8 @@ _SIGS = {
     "mh_composite_bwd": (ctypes.c_int, [_P] * 13 + [_I32, _P]),
     "mh_generate_rays": (ctypes.c_int, [_F, _F, _F, _F, _P, _I32, _I32, _P, _P, _P]),
     "mh_sample_uniform": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "mh_rays_sample_uniform": (ctypes.c_int, [_F, _F, _F, _F, _P, _I32, _I32, _P, _P, _I32, _I32, _F, _P, _P, _P, _P,
+                                              _P, _P, _P, _P, _P]),
     "mh_march_count": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _P, _P]),
     "mh_march_fill": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _P, _P, _P, _P, _P]),
     "mh_march_cap": (_I32, [_F, _F]),

@@ -21,20 +21,52 @@ struct Pose {
     float t[3];
 };
 
-__global__ __launch_bounds__(256) void generate_rays_kernel(float fx, float fy, float cx, float cy, Pose pose, int H,
-                                                            int W, float *__restrict__ rays_o, float *__restrict__ rays_d) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= H * W) return;
+// one pinhole ray: pixel idx = j*W + i -> camera direction ((i+.5-cx)/fx, -(j+.5-cy)/fy, -1) rotated by R
+__device__ __forceinline__ void pixel_ray(float fx, float fy, float cx, float cy, const Pose &pose, int W, int idx,
+                                          float *o, float *d) {
     const int j = idx / W, i = idx - j * W;
     const float d0 = (((float)i + 0.5f) - cx) / fx;
     const float d1 = -((((float)j + 0.5f) - cy) / fy);
     const float d2 = -1.0f;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        float v = (d0 * pose.r[a * 3 + 0] + d1 * pose.r[a * 3 + 1]) + d2 * pose.r[a * 3 + 2];
-        rays_d[idx * 3 + a] = v;
-        rays_o[idx * 3 + a] = pose.t[a];
+        d[a] = (d0 * pose.r[a * 3 + 0] + d1 * pose.r[a * 3 + 1]) + d2 * pose.r[a * 3 + 2];
+        o[a] = pose.t[a];
     }
+}
+
+__global__ __launch_bounds__(256) void generate_rays_kernel(float fx, float fy, float cx, float cy, Pose pose, int H,
+                                                            int W, float *__restrict__ rays_o, float *__restrict__ rays_d) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    float o[3], d[3];
+    pixel_ray(fx, fy, cx, cy, pose, W, idx, o, d);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        rays_d[idx * 3 + a] = d[a];
+        rays_o[idx * 3 + a] = o[a];
+    }
+}
+
+// slab clip + the i-th stratified interval of one ray (shared by the two uniform-sampler kernels)
+__device__ __forceinline__ void uniform_interval(const float *o, const float *d, float bound, int S, int i, float u,
+                                                 float *ts, float *te) {
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float ta = (-bound - o[a]) / d[a];
+        const float tb = (bound - o[a]) / d[a];
+        tmin = fmaxf(tmin, fminf(ta, tb));
+        tmax = fminf(tmax, fmaxf(ta, tb));
+    }
+    tmin = fmaxf(tmin, 0.0f);
+    if (!(tmax > tmin)) {
+        tmin = 0.f;
+        tmax = 0.f;
+    }
+    const float dt = (tmax - tmin) / (float)(S + 1);
+    *ts = tmin + ((float)i + u) * dt;
+    *te = tmin + (((float)i + 1.0f) + u) * dt;
 }
 
 __global__ __launch_bounds__(256) void sample_uniform_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
@@ -48,26 +80,13 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(const float *__rest
     const int r = (int)(gid / S);
     const int i = (int)(gid - (int64_t)r * S);
     float o[3], d[3];
-    float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         o[a] = rays_o[r * 3 + a];
         d[a] = rays_d[r * 3 + a];
-        const float ta = (-bound - o[a]) / d[a];
-        const float tb = (bound - o[a]) / d[a];
-        tmin = fmaxf(tmin, fminf(ta, tb));
-        tmax = fminf(tmax, fmaxf(ta, tb));
     }
-    tmin = fmaxf(tmin, 0.0f);
-    const bool hit = tmax > tmin;
-    if (!hit) {
-        tmin = 0.f;
-        tmax = 0.f;
-    }
-    const float dt = (tmax - tmin) / (float)(S + 1);
-    const float u = jitter[r];
-    const float ts = tmin + ((float)i + u) * dt;
-    const float te = tmin + (((float)i + 1.0f) + u) * dt;
+    float ts, te;
+    uniform_interval(o, d, bound, S, i, jitter[r], &ts, &te);
     ray_idx[gid] = r;
     t_starts[gid] = ts;
     t_ends[gid] = te;
@@ -77,6 +96,46 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(const float *__rest
         for (int a = 0; a < 3; a++) xyz[gid * 3 + a] = o[a] + d[a] * tm;
     }
     if (i == 0) {
+        ray_start[r] = (int32_t)((int64_t)r * S);
+        ray_cnt[r] = S;
+    }
+}
+
+// Ray generation fused with the uniform sampler (BASELINE.json north_star: "fused ray-generate + stratified sampler"):
+// ray r looks through pixel pix[r] (NULL -> r, the whole image) of the pinhole camera; every sample thread rebuilds
+// its ray from the 12 pose floats instead of reading a rays buffer, thread i == 0 of a ray also writes rays_o/rays_d
+// for the renderer.  The per-iteration pixel draw is dataset.py:412-423 (index = randint(0, H*W, (ray_num,)),
+// rays[:, index]).  Same operation sequence as the two kernels above -> bit-identical outputs.
+__global__ __launch_bounds__(256) void rays_sample_uniform_kernel(float fx, float fy, float cx, float cy, Pose pose, int W,
+                                                                  const int32_t *__restrict__ pix,
+                                                                  const float *__restrict__ jitter, int N, int S, float bound,
+                                                                  float *__restrict__ rays_o, float *__restrict__ rays_d,
+                                                                  int32_t *__restrict__ ray_idx, float *__restrict__ t_starts,
+                                                                  float *__restrict__ t_ends, float *__restrict__ xyz,
+                                                                  int32_t *__restrict__ ray_start, int32_t *__restrict__ ray_cnt) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)N * S;
+    if (gid >= total) return;
+    const int r = (int)(gid / S);
+    const int i = (int)(gid - (int64_t)r * S);
+    float o[3], d[3];
+    pixel_ray(fx, fy, cx, cy, pose, W, pix ? pix[r] : r, o, d);
+    float ts, te;
+    uniform_interval(o, d, bound, S, i, jitter[r], &ts, &te);
+    ray_idx[gid] = r;
+    t_starts[gid] = ts;
+    t_ends[gid] = te;
+    if (xyz) {
+        const float tm = (ts + te) / 2.0f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) xyz[gid * 3 + a] = o[a] + d[a] * tm;
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            rays_o[r * 3 + a] = o[a];
+            rays_d[r * 3 + a] = d[a];
+        }
         ray_start[r] = (int32_t)((int64_t)r * S);
         ray_cnt[r] = S;
     }
@@ -216,17 +275,41 @@ __global__ __launch_bounds__(256) void march_pack_kernel(const int32_t *__restri
     }
 }
 
-extern "C" int mh_generate_rays(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
-                                float *rays_o, float *rays_d, void *stream) {
-    if (!c2w_host || !rays_o || !rays_d || H <= 0 || W <= 0) return MH_ERR_ARG;
+static Pose pose_from_c2w(const float *c2w_host) {
     Pose p;
     for (int a = 0; a < 3; a++) {
         for (int b = 0; b < 3; b++) p.r[a * 3 + b] = c2w_host[a * 4 + b];
         p.t[a] = c2w_host[a * 4 + 3];
     }
+    return p;
+}
+
+extern "C" int mh_generate_rays(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
+                                float *rays_o, float *rays_d, void *stream) {
+    if (!c2w_host || !rays_o || !rays_d || H <= 0 || W <= 0) return MH_ERR_ARG;
+    const Pose p = pose_from_c2w(c2w_host);
     const int n = H * W;
     hipLaunchKernelGGL(generate_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, mh_stream(stream), fx, fy, cx, cy, p,
                        (int)H, (int)W, rays_o, rays_d);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_rays_sample_uniform(float fx, float fy, float cx, float cy, const float *c2w_host, int32_t H, int32_t W,
+                                      const int32_t *pix, const float *jitter, int32_t N, int32_t S, float bound,
+                                      float *rays_o, float *rays_d, int32_t *ray_idx, float *t_starts, float *t_ends,
+                                      float *xyz, int32_t *ray_start, int32_t *ray_cnt, void *stream) {
+    if (N == 0) return MH_OK;
+    if (!c2w_host || !jitter || !rays_o || !rays_d || !ray_idx || !t_starts || !t_ends || !ray_start || !ray_cnt ||
+        H <= 0 || W <= 0 || N < 0 || S <= 0)
+        return MH_ERR_ARG;
+    if (!pix && (int64_t)N > (int64_t)H * W) return MH_ERR_ARG;   // whole-image mode: ray r is pixel r
+    const int64_t total = (int64_t)N * S;
+    if (total > 0x7fffffffLL) return MH_ERR_ARG;
+    const Pose p = pose_from_c2w(c2w_host);
+    hipLaunchKernelGGL(rays_sample_uniform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mh_stream(stream),
+                       fx, fy, cx, cy, p, (int)W, pix, jitter, (int)N, (int)S, bound, rays_o, rays_d, ray_idx, t_starts,
+                       t_ends, xyz, ray_start, ray_cnt);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

@@ -285,6 +285,35 @@ def sample_uniform(rays_o, rays_d, jitter, S: int, bound: float, with_xyz: bool 
     return ri, ts, te, xyz, rs, rc
 
 
+def rays_sample_uniform(fx, fy, cx, cy, c2w, H: int, W: int, pix, jitter, S: int, bound: float, with_xyz: bool = False):
+    """Ray generation + uniform sampler in one launch (`mh_rays_sample_uniform`).  `pix`: int32 [N] pixel indices
+    (j*W+i) on the device, the draw of datasets/dataset.py:412-423; None = the whole image.
+    -> rays_o, rays_d [N,3], then the `sample_uniform` tuple."""
+    require_gpu(jitter)
+    lib = _lib.load()
+    c2w = np.ascontiguousarray(np.asarray(c2w, dtype=np.float32).reshape(4, 4))
+    j, dev = jitter.contiguous(), jitter.device
+    N = j.shape[0]
+    if pix is not None:
+        require_gpu(pix)
+        if pix.dtype != torch.int32 or pix.shape != (N,):
+            raise ValueError("pix must be int32 [N], one pixel index per jitter value")
+        pix = pix.contiguous()
+    elif N > H * W:
+        raise ValueError("whole-image mode renders at most H*W rays")
+    o, d = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+    ri = torch.empty(N * S, dtype=torch.int32, device=dev)
+    ts, te = torch.empty(N * S, device=dev), torch.empty(N * S, device=dev)
+    xyz = torch.empty(N * S, 3, device=dev) if with_xyz else None
+    rs, rc = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+    _e = TIMER.start()
+    check(lib.mh_rays_sample_uniform(float(fx), float(fy), float(cx), float(cy), c2w.ctypes.data_as(ctypes.c_void_p), H, W,
+                                     ptr(pix), ptr(j), N, S, float(bound), ptr(o), ptr(d), ptr(ri), ptr(ts), ptr(te),
+                                     ptr(xyz), ptr(rs), ptr(rc), stream()), "mh_rays_sample_uniform")
+    TIMER.stop("mh_rays_sample_uniform", _e)
+    return o, d, ri, ts, te, xyz, rs, rc
+
+
 MARCH_TWO_PASS = os.environ.get("MORPHEUS_MARCH", "") == "two_pass"   # A/B switch: thread-per-ray count + fill
 
 

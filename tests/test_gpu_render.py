@@ -413,6 +413,40 @@ def test_generate_rays_kernel_vs_reference_golden():
             assert np.array_equal(d.cpu().numpy().reshape(H, W, 3), g[f"raygen_{tag}|rays_d"][b]), (tag, b)
 
 
+def test_fused_raygen_sampler_is_the_two_kernels_bit_for_bit():
+    """mh_rays_sample_uniform (north_star's fused ray-generate + stratified sampler) against mh_generate_rays + the
+    per-iteration pixel draw (dataset.py:412-423) + mh_sample_uniform, and -- through the first of those -- the
+    reference-generated ray fixture; a random pixel subset with repeats, and the whole image."""
+    import numpy as np
+    from morpheus_amd import ops
+    dev = torch.device(DEV)
+    g = load_golden("extras.npz")
+    H, W, S, bound = 20, 28, 24, 1.0
+    pose = synth.look_at_pose(75.0, 130.0, 1.3)
+    K = (np.float32(1.2 * W), np.float32(1.2 * W), 0.5 * W, 0.5 * H)
+    o_all, d_all = ops.generate_rays(*K, pose, H, W, dev)
+    gen = torch.Generator().manual_seed(7)
+    cases = {"subset": torch.randint(0, H * W, (300,), generator=gen).to(torch.int32).to(dev), "image": None}
+    for tag, pix in cases.items():
+        N = H * W if pix is None else pix.shape[0]
+        jit = torch.rand(N, generator=gen).to(dev)
+        sel = slice(None) if pix is None else pix.long()
+        o_ref, d_ref = o_all[sel].contiguous(), d_all[sel].contiguous()
+        want = ops.sample_uniform(o_ref, d_ref, jit, S, bound, with_xyz=True)
+        got = ops.rays_sample_uniform(*K, pose, H, W, pix, jit, S, bound, with_xyz=True)
+        assert torch.equal(got[0], o_ref) and torch.equal(got[1], d_ref), tag
+        for name, a, b in zip(("ray_idx", "t_starts", "t_ends", "xyz", "ray_start", "ray_cnt"), got[2:], want):
+            assert torch.equal(a, b), (tag, name)
+        assert float((got[4] - got[3]).min()) >= 0.0 and int(got[7].sum()) == N * S
+    assert np.array_equal(got[1].cpu().numpy().reshape(H, W, 3), g["raygen_rect|rays_d"][1])
+    no_xyz = ops.rays_sample_uniform(*K, pose, H, W, None, jit, S, bound)
+    assert no_xyz[5] is None and torch.equal(no_xyz[3], got[3])
+    with pytest.raises(ValueError):
+        ops.rays_sample_uniform(*K, pose, H, W, cases["subset"].long(), jit[:300], S, bound)   # int64 pixels
+    with pytest.raises(ValueError):
+        ops.rays_sample_uniform(*K, pose, H, W, None, torch.rand(H * W + 1).to(dev), S, bound)
+
+
 def test_full_size_canonical_properties():
     """BASELINE configs[1] at full size (16384 rays x 128 samples, cano=True: hash grids + sdf/colour nets + compositor):
     deterministic forward, opacity = sum of weights in [0,1], first 256 rays equal to the reference-generated golden,
