@@ -809,3 +809,23 @@ def test_grid_large_batch_gradients():
     assert torch.equal(gx1, gx2)
     scale = float(ge2.abs().max())
     assert float((ge1 - ge2).abs().max()) / scale <= 1e-5, float((ge1 - ge2).abs().max()) / scale
+
+
+@pytest.mark.parametrize("env", [{"MORPHEUS_WGRAD_B3": "share"}, {"MORPHEUS_WGRAD_B3": "ring"}, {"MORPHEUS_B3_FWD": "phased"},
+                                 {"MORPHEUS_WGRAD": "merged"}, {"MORPHEUS_WGRAD": "per_layer"}],
+                         ids=lambda e: "-".join(f"{k}={v}" for k, v in e.items()))
+def test_ab_switch_kernels_stay_correct(env):
+    """The opt-in A/B kernels DESIGN.md section 3 quotes (LDS-ring weight-gradient kernels, the phased forward
+    schedule, forced merged / per-layer weight-gradient launches) are read once per process by the library, so each
+    runs the warp-net parity, accuracy and large-batch tests in a child interpreter with the switch set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pick = "test_warp_mlp and b3-None-a or test_warp_b3_is_fp32_grade or test_warp_large_batch_weight_gradients and b3"
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
+                          "-k", pick, "-p", "no:cacheprovider"], cwd=root, env={**os.environ, **env}, capture_output=True,
+                         text=True, timeout=600)
+    tail = (run.stdout + run.stderr)[-3000:]
+    assert run.returncode == 0, tail
+    assert "3 passed" in run.stdout, tail
