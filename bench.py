@@ -382,26 +382,33 @@ def main(argv=None):
                 continue
         return None
 
-    b3 = bool(ops.MLP_B3)
-    symbol = {"mh_warp_fwd": "warp_fwd_b3_kernel<8>" if b3 else "warp_fwd_kernel",
-              "mh_warp_bwd_data": "warp_bwd_b3_kernel<8>" if b3 else "warp_bwd_kernel", "mh_field_fwd": "field_fwd_kernel",
+    mode = ops._warp_mode()                     # "h2" / "b3" / "" (native fp32 MFMA)
+    b3 = mode != ""                             # the warp nets run on the 16-bit matrix pipe with sliced operands
+    sfx = {"h2": "warp_fwd_h2_kernel", "b3": "warp_fwd_b3_kernel<8>", "": "warp_fwd_kernel"}[mode]
+    symbol = {"mh_warp_fwd": sfx, "mh_warp_bwd_data": sfx.replace("fwd", "bwd"), "mh_field_fwd": "field_fwd_kernel",
               "mh_field_bwd_data": "field_bwd_kernel"}
     full = render_wl and N * S == 128 * 128 * 128
     roofline = None
     if dominant is not None:
         ach = flops[dominant] / (ktab[dominant]["avg_ms"] * 1e-3) / 1e12
         on_b3 = b3 and dominant.startswith("mh_warp")
-        # bf16x3 kernels issue 6 bf16 slice products per fp32 MAC on the 2.5 PFLOP/s dense bf16 matrix pipe: the yardstick for
-        # ALGORITHMIC fp32 FLOP/s on that unit is 2500 / 6 (the native fp32 MFMA peak, 157.3, is no longer the ceiling)
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if on_b3 else FP32_MFMA_PEAK_TFLOPS
+        # sliced kernels issue `prod` 16-bit slice products per fp32 MAC on the 2.5 PFLOP/s dense bf16 / fp16 matrix pipe: the
+        # yardstick for ALGORITHMIC fp32 FLOP/s on that unit is 2500 / prod (the native fp32 MFMA peak, 157.3, is no longer
+        # the ceiling).  b3: three bf16 slices, six products; h2: two fp16 slices, three products.
+        prod = {"h2": 3.0, "b3": 6.0}.get(mode, 1.0) if on_b3 else 1.0
+        peak = BF16_MFMA_PEAK_TFLOPS / prod if on_b3 else FP32_MFMA_PEAK_TFLOPS
+        notes = {"b3": "algorithmic fp32 FLOP/s against the dense bf16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 "
+                       "slice products per MAC: every fp32 operand is cut exactly into three bf16 slices, the six "
+                       "significant cross products go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation",
+                 "h2": "algorithmic fp32 FLOP/s against the dense fp16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 3 "
+                       "slice products per MAC: every fp32 operand is cut into two fp16 slices at a power-of-two scale (22 "
+                       "significand bits), the three significant cross products go through v_mfma_f32_32x32x16_f16 with "
+                       "fp32 accumulation; fp32-grade by test_warp_sliced_arithmetic_is_fp32_grade"}
         roofline = dict(kernel=dominant, bound="mfma", achieved=round(ach, 2), peak=round(peak, 1),
                         unit="TFLOP/s", frac=round(ach / peak, 4),
-                        peak_note=("algorithmic fp32 FLOP/s against the dense bf16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 "
-                                   "slice products per MAC: every fp32 operand is cut exactly into three bf16 slices, the six "
-                                   "significant cross products go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation"
-                                   if on_b3 else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"),
-                        issued_tflops=round(6.0 * ach, 1) if on_b3 else round(ach, 2),
-                        issued_frac_of_unit_peak=round(6.0 * ach / BF16_MFMA_PEAK_TFLOPS, 4) if on_b3 else round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        peak_note=(notes[mode] if on_b3 else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"),
+                        issued_tflops=round(prod * ach, 1) if on_b3 else round(ach, 2),
+                        issued_frac_of_unit_peak=round(prod * ach / BF16_MFMA_PEAK_TFLOPS, 4) if on_b3 else round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         vs_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         traffic=pmc_traffic(symbol.get(dominant, "")) if (full and args.workload == "cfg3") else None,
                         traffic_note="HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), not a live "
@@ -413,7 +420,7 @@ def main(argv=None):
                                           frac=round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                                           frac_note="algorithmic FLOP/s of the whole step over the native fp32 MFMA peak (157.3): "
                                                     "a speed-of-light figure for an all-fp32-MFMA step, kept for continuity with "
-                                                    "round 1" + ("; the warp nets now run on the bf16 pipe" if b3 else ""))
+                                                    "round 1" + ("; the warp nets now run on the 16-bit matrix pipe" if b3 else ""))
     # the warp weight-gradient group is the step's largest item and a streaming kernel: every parked activation and dPre row is
     # read exactly once (2 x 5.4 KB per point: SURVEY 8d's tile geometry, profiles/r02_pmc_summary.csv confirms the bytes)
     roof_wgrad = None
@@ -481,9 +488,15 @@ def main(argv=None):
                                                                  not args.no_overlap else "") + ")"),
                    "world_size": world, "backend": backend, "devices_visible": n_dev,
                    "ranks_share_devices": bool(world > 1 and n_dev < world),
-                   "mlp_arithmetic": ("warp nets: fp32 values, exact three-way bf16 split of both operands, six slice products per "
-                                      "MAC on the bf16 matrix pipe, fp32 accumulate (fp32-grade: <= 3 * 2^-24 of a product dropped); "
-                                      "field nets: native fp32 MFMA" if b3 else "native fp32 MFMA (MORPHEUS_MLP=f32)"),
+                   "mlp_arithmetic": {"b3": "warp nets: fp32 values, exact three-way bf16 split of both operands, six slice "
+                                            "products per MAC on the bf16 matrix pipe, fp32 accumulate (fp32-grade: <= 3 * 2^-24 of a "
+                                            "product dropped); field nets: forward the same, backward native fp32 MFMA",
+                                      "h2": "warp nets forward / backward-data: fp32 values, two fp16 slices per operand at per-layer / "
+                                            "per-point power-of-two scales (22 significand bits), three slice products per MAC on the "
+                                            "fp16 matrix pipe, fp32 accumulate (fp32-grade: measured error against float64 equal to "
+                                            "the fp32-MFMA kernels'); weight gradients and the field forward: bf16 x 3 slices; field "
+                                            "backward native fp32 MFMA (MORPHEUS_MLP=h2)",
+                                      "": "native fp32 MFMA (MORPHEUS_MLP=f32)"}[mode],
                    "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
         "roofline": roofline, "roofline_hashgrid": roof_hash, "roofline_weight_gradients": roof_wgrad, "kernels": ktab,
     }

@@ -231,6 +231,29 @@ int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const float *g_to
 int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w3_d,
                    const void *w3_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
                    float *out_topo, float *acts, int64_t M, void *stream);
+/* ---- the same with two fp16 slices per operand (csrc/mlp_h2.hip) -------------------------------------------------
+ * x . 2^k = h + l (fp16 each, 22 significand bits together), three slice products Wh.xh + Wh.xl + Wl.xh per fp32 product
+ * through v_mfma_f32_32x32x16_f16 with fp32 accumulation: half the matrix work of the bf16x3 form at fp32-grade error
+ * (tests/test_gpu_ops.py::test_warp_sliced_arithmetic_is_fp32_grade).  Power-of-two scales keep the slices inside fp16's
+ * exponent range: one per layer for the weights, one per point for activations and gradients (computed in the kernels).
+ *
+ * mh_h2_slice: fp32 fragments in the 32x32x16 order (the gathers of mh_b3_slice), block after block -> per block two fp16
+ *   planes [h | l] at the layer's scale; first the layers' largest |w| go (fp32 bits) into dst word table_word[layer] -- the
+ *   table the kernels read their weight exponents from.  layer[b] = layer of block b (blocks of a layer consecutive in
+ *   src); src_off / n in floats (n % 8 == 0), dst_off in 16-byte units; host arrays (<= 32 blocks).
+ * mh_warp_fwd_h2 / mh_warp_bwd_data_h2: mh_warp_fwd / mh_warp_bwd_data with one net's sliced pack (mh_warp_w2_bytes() /
+ *   mh_warp_w2T_bytes() bytes: blocks in whole 512 x 16-byte DMA rounds, then one round holding the scale table).  Same
+ *   outputs, same parked tiles and dPre tiles (fp32; mh_mlp_wgrad_b3 consumes them). */
+int mh_h2_slice(const float *src, void *dst, int32_t n_blocks, const int32_t *src_off_host, const int32_t *n_host,
+                const int32_t *dst_off_f4_host, const int32_t *layer_host, int32_t n_layers, const int32_t *table_word_host,
+                void *stream);
+int64_t mh_warp_w2_bytes(void);
+int64_t mh_warp_w2T_bytes(void);
+int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w2_d,
+                   const void *w2_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
+                   float *out_topo, float *acts, int64_t M, void *stream);
+int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const float *g_topo, const void *w2T_d, const void *w2T_t,
+                        int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream);
 /* backward-data: consumes g_deform [M,3], g_topo [M,2] (either may be NULL = zero), acts from the
  * forward and the TRANSPOSED packs; writes g_x [M,3] (d/dx through the frequency encoding; pass NULL when the
  * sample positions carry no gradient and the first-layer transposed GEMM is skipped) and

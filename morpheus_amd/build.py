@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 SO = os.path.join(OUT_DIR, "libmorpheus_hip.so")
-SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_b3.hip", "optim.hip", "wnorm.hip", "normal.hip"]
+SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_b3.hip", "mlp_h2.hip", "optim.hip", "wnorm.hip", "normal.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "morpheus_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MH_EXTRA_FLAGS", "").split()
 

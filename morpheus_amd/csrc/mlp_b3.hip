@@ -8,7 +8,7 @@
 //      Wh.xh + Wh.xm + Wm.xh + Wh.xl + Wm.xm + Wl.xh,
 // each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  What is dropped (Wm.xl, Wl.xm, Wl.xl)
 // is below 2^-24 of the product, less than one fp32 rounding: the result is fp32-grade (tests/test_gpu_ops.py:
-// test_warp_b3_is_fp32_grade holds values and every gradient to the fp32 kernels' own error against float64), for 6/16 of the
+// test_warp_sliced_arithmetic_is_fp32_grade holds values and every gradient to the fp32 kernels' own error against float64), for 6/16 of the
 // matrix cycles.
 //
 // Range: the split needs |x| below the bf16 maximum (3.39e38; fp32 reaches 3.40e38) -- above it hi rounds to infinity and the
@@ -58,13 +58,6 @@ extern "C" int mh_b3_trace_read(long long *dst_host) {
 #else
 #define B3_STAMP(slot) do { } while (0)
 #define B3_STAMP_REAL(slot) do { } while (0)
-#endif
-
-// parked tiles are written once and read much later by another kernel
-#ifdef MH_B3_PLAIN_STORES
-#define PARK_STORE(v, p) (*(p) = (v))
-#else
-#define PARK_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
 
 template <int N_F4, int NTHR = B3_THREADS>
@@ -180,12 +173,6 @@ __device__ __forceinline__ void b3_quarter(const f32x4 *__restrict__ w, const Fr
         for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
     }
 }
-
-// ReLU and the sign-mask bit as compiler-visible integer instructions (one v_max_i32; v_min_u32 + v_lshl_add_u32): the float
-// forms cost an extra canonicalising v_max each, inline-asm forms are invisible to the hazard recognizer (above).
-// Bit patterns: x <= -0.0 is a negative int -> 0; positive floats and +NaN keep their bits.
-__device__ __forceinline__ float relu_i(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
-__device__ __forceinline__ uint32_t push_nz(uint32_t m, float y /* >= 0 */) { return (m << 1) + min(__float_as_uint(y), 1u); }
 
 // layer epilogue: ReLU in place, park the tile feature-major FIRST (the stores then drain under the ~500 slicing instructions
 // instead of being waited for right after issue), then the sign mask and the next layer's B operand slices

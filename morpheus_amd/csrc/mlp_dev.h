@@ -160,6 +160,19 @@ union Frag {
     uint32_t u[4];
 };
 
+// parked tiles are written once and read much later by another kernel
+#ifdef MH_B3_PLAIN_STORES
+#define PARK_STORE(v, p) (*(p) = (v))
+#else
+#define PARK_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
+// ReLU and the sign-mask bit as compiler-visible integer instructions (one v_max_i32; v_min_u32 + v_lshl_add_u32): the float
+// forms cost an extra canonicalising v_max each, inline-asm forms are invisible to the hazard recognizer (mlp_b3.hip:
+// mfma_results_settle).  Bit patterns: x <= -0.0 is a negative int -> 0; positive floats and +NaN keep their bits.
+__device__ __forceinline__ float relu_i(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+__device__ __forceinline__ uint32_t push_nz(uint32_t m, float y /* >= 0 */) { return (m << 1) + min(__float_as_uint(y), 1u); }
+
 // two fp32 values -> the packed bf16 pairs of their three slices.  Round-to-nearest split (v_cvt_pk_bf16_f32): x - hi and
 // (x - hi) - mid are exact in fp32 and the last residual has at most 8 significant bits, so hi + mid + lo == x exactly, like the
 // truncation split -- but the residuals are half as large and of either sign: what the six-product form drops (mid.lo, lo.mid,

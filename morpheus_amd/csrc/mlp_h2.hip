@@ -1,0 +1,571 @@
+// The warp networks (deform_net + topo_net, models/model.py:412-437) with fp32-grade products from TWO fp16 slices per operand.
+//
+// Same idea as mlp_b3.hip -- fp32 operands cut into narrow slices, slice products exact on the 16-bit matrix pipe, fp32
+// accumulation -- at half the matrix work: fp16 carries 11 significand bits, so
+//      x . 2^k = h + l + r,   h = fp16(x . 2^k),  l = fp16(x . 2^k - h),  |r| <= 2^-22 |x . 2^k|
+// and a product W.x is THREE slice products, Wh.xh + Wh.xl + Wl.xh, through v_mfma_f32_32x32x16_f16 (what is dropped, Wl.xl
+// and the residuals r, is <= ~2^-22 of a product and unbiased; measured on layer-shaped data the representation error is
+// 7e-8 relative, a third of the accumulation error a plain fp32 GEMM has: tools/h2_error_model.py, and
+// tests/test_gpu_ops.py::test_warp_sliced_arithmetic_is_fp32_grade holds the kernels to the fp32 kernels' own error).
+//
+// fp16 has five exponent bits, so the slices only work at the right scale; every operand carries a power-of-two scale that
+// puts its largest magnitude in [2^14, 2^15) -- an exact operation in both directions:
+//   * weights: one exponent per layer, from the layer's largest |w| (h2_amax_kernel -> a table behind the net's slices);
+//   * activations / gradients: one exponent PER POINT, from the largest magnitude of the point's feature vector (the two
+//     lanes that hold a point's column exchange their maxima).  An element then keeps all 22 bits while it is within 2^-17
+//     of its vector's maximum, and an absolute error of 2^-39 of that maximum below.
+// Accumulators run in the scaled domain (bias pre-scaled by 2^(kw + kx), results scaled back by v_ldexp_f32 on the way to
+// the parked tile); infinities and NaNs propagate as NaN, zero vectors clamp their exponent.
+//
+// Everything else is mlp_b3.hip's scheme: register-resident chain (accumulator registers 8s'..8s'+7 of output tile t are the
+// B operand of k16 step 2t + s' of the next layer), parked tiles and ReLU sign masks bit-for-bit in mlp.hip's layout (the
+// weight-gradient kernels read them as fp32), weight slices [plane h|l][out tile][k16 step][lane][8 fp16] staged by LDS-DMA.
+// A 128 x 128 layer is 64 KB of slices: TWO layers fit in LDS, so layer l+1 is fetched while layer l computes and a layer
+// costs one workgroup barrier.
+#include "mlp_dev.h"
+
+#define H2_THREADS 512
+#define H2_BLOCK_PTS 256
+#define H2_L0_F4 1536                                    // 2 planes x 4 tiles x 3 k16 steps x 64 lanes
+#define H2_LH_F4 4096                                    // 128 x 128: two k-half blocks [khalf][plane][tile][k16 step 0..3][lane]
+#define H2_KH_F4 2048
+#define H2_L5_F4 1024                                    // one padded output tile, 8 k16 steps
+#define H2_TAB_F4 (H2_L0_F4 + 4 * H2_LH_F4 + H2_L5_F4)   // the net's scale table (largest |w| per layer, fp32 bits) sits here
+#define H2_NET_F4 (H2_TAB_F4 + 512)
+#define H2_T5_F4 1024                                    // 2 planes x 4 tiles x 2 k16 steps x 64 lanes
+#define H2_T0_F4 2048                                    // 2 planes x 2 tiles x 8 k16 steps x 64 lanes
+#define H2_TABT_F4 (H2_T5_F4 + 4 * H2_LH_F4 + H2_T0_F4)
+#define H2_NETT_F4 (H2_TABT_F4 + 512)
+#define H2_BUF_F4 (H2_LH_F4 + 64)                        // one staged layer + its bias row
+#define H2_LDS_BYTES (2 * H2_BUF_F4 * 16)                // 133 120
+#define H2_TOP 141                                       // 127 + 14: biased exponent e -> shift H2_TOP - e puts 2^(e-127) at 2^14
+#define H2_W_CLAMP 60
+#define H2_FWD_CLAMP 40                                  // per-point shifts: forward (|bias| . 2^(60 + 40) must stay finite)
+#define H2_BWD_CLAMP 100                                 // backward: loss gradients down to ~1e-26 reach full scale
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+union FragH {
+    f32x4 f;
+    f16x8 h;
+    uint32_t u[4];
+};
+
+extern __shared__ f32x4 lds_h2[];
+
+__device__ __forceinline__ int h2_wexp(uint32_t amax_bits) { return min(H2_TOP - (int)(amax_bits >> 23), H2_W_CLAMP); }
+
+// two ALREADY SCALED fp32 values -> their packed fp16 slices (round to nearest: v_cvt_pk_f16_f32; x - h is exact in fp32)
+__device__ __forceinline__ void split_h(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+    const f32x2_t v = {x0, x1};
+    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
+    const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// the point's shift from the largest magnitude (fp32 bits, sign cleared) among this lane's values: the partner lane (other
+// half of the point's column) holds the rest.  Shift so that the maximum lands in [2^14, 2^15), at most `cap`.
+__device__ __forceinline__ int h2_point_shift(int amax_bits, int cap) {
+    amax_bits = max(amax_bits, __shfl_xor(amax_bits, 32));
+    return min(H2_TOP - (amax_bits >> 23), cap);
+}
+
+template <int N_F4>
+__device__ __forceinline__ void h2_stage(int buf, const f32x4 *__restrict__ src) {
+    static_assert(N_F4 % H2_THREADS == 0, "whole rounds of the block");
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N_F4 / H2_THREADS; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * H2_THREADS + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_h2 + buf * H2_BUF_F4 + k * H2_THREADS + wave * 64),
+                                         16, 0, 0);
+}
+__device__ __forceinline__ void h2_stage_bias(int buf, const float *__restrict__ bias, int n_f4) {
+    if ((int)threadIdx.x < n_f4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const f32x4 *>(bias) + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_h2 + buf * H2_BUF_F4 + H2_LH_F4 + (threadIdx.x >> 6) * 64),
+                                         16, 0, 0);
+}
+// my DMA pieces (and parking stores) are done; behind the barrier everyone's are visible and everyone has left the other buffer
+__device__ __forceinline__ void h2_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// accumulators <- bias row (LDS, accumulator-row order) . 2^ks
+template <int MT>
+__device__ __forceinline__ void h2_acc_bias_lds(f32x16 (&acc)[MT], int buf, int h, int ks) {
+    const f32x4 *b = lds_h2 + buf * H2_BUF_F4 + H2_LH_F4;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 v = b[8 * t + 2 * r4 + h];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = __builtin_ldexpf(v[c], ks);
+        }
+}
+
+// acc[t] += W[t] . b : three slice products per k16 step, two output tiles in rotation, small terms first
+template <int KS, int MT, bool ZERO = false>
+__device__ __forceinline__ void h2_layer(const f32x4 *__restrict__ w, const FragH (&bh)[8], const FragH (&bl)[8], f32x16 (&acc)[MT],
+                                         int lane) {
+    constexpr int PL = MT * KS * 64;
+    constexpr int NT = MT >= 2 ? 2 : 1;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+#pragma unroll
+        for (int mp = 0; mp < MT; mp += NT) {
+            FragH ah[NT], al[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                ah[t].f = w[0 * PL + ((mp + t) * KS + s) * 64 + lane];
+                al[t].f = w[1 * PL + ((mp + t) * KS + s) * 64 + lane];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t].h, bh[s].h, (ZERO && s == 0) ? zero : acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].h, bl[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+        }
+    }
+}
+
+// a 128 x 128 layer from its two k-half blocks
+__device__ __forceinline__ void h2_hidden(const f32x4 *__restrict__ w, const FragH (&bh)[8], const FragH (&bl)[8], f32x16 (&acc)[4],
+                                          int lane) {
+    constexpr int PLH = 4 * 4 * 64;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const f32x4 *wk = w + (s >> 2) * H2_KH_F4 + (s & 3) * 64 + lane;
+#pragma unroll
+        for (int mp = 0; mp < 4; mp += 2) {
+            FragH ah[2], al[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                ah[t].f = wk[0 * PLH + (mp + t) * 256];
+                al[t].f = wk[1 * PLH + (mp + t) * 256];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].h, bl[s].h, acc[mp + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+        }
+    }
+}
+
+// forward layer epilogue.  acc = 2^ks (W x + b).  ReLU; y = acc . 2^-ks is parked (feature-major) and gives the sign mask; the
+// point's next shift d comes from the largest acc; acc . 2^d = y . 2^(ks + d) is cut into the next layer's B operand slices.
+// Returns the point's new exponent kx = ks + d (the next layer adds its weight exponent).
+__device__ __forceinline__ int h2_epilogue(f32x16 (&acc)[4], int ks, float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
+                                           FragH (&bh)[8], FragH (&bl)[8]) {
+    int mi = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc[t][r] = relu_i(acc[t][r]);
+            mi = max(mi, __float_as_int(acc[t][r]));
+        }
+    uint32_t mt[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[r] = __builtin_ldexpf(acc[t][r], -ks);
+        if (ht) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(y[r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 15; r >= 0; r--) m = push_nz(m, y[r]);
+        mt[t] = m;
+    }
+    if (mk) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+    const int d = h2_point_shift(mi, H2_FWD_CLAMP - ks);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split_h(__builtin_ldexpf(acc[t][8 * s2 + 2 * e2], d), __builtin_ldexpf(acc[t][8 * s2 + 2 * e2 + 1], d),
+                        bh[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    return d + ks;
+}
+
+__global__ __launch_bounds__(H2_THREADS, 2) void warp_fwd_h2_kernel(
+    const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
+    const float *__restrict__ bias0_t, const f32x4 *__restrict__ w2_d, const f32x4 *__restrict__ w2_t,
+    const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
+    float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * (H2_THREADS / 64) + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const int64_t pc = p < M ? p : M - 1;
+    float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
+    const int sl = slot ? slot[pc] : 0;
+    // the scratch holds whole 128-point blocks (mh_mlp_tiles); a 256-point workgroup's tail tiles beyond it park nothing
+    float *tile = (acts && tile_id < n_tiles) ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
+
+    int cb = 0;                                           // LDS buffer of the layer about to run
+    h2_stage<H2_L0_F4>(cb, w2_d);
+    float bin0[24];
+    enc_bin(xv, h, n_bands, bin0, nullptr);
+#pragma unroll
+    for (int k = 20; k < 24; k++) bin0[k] = 0.f;
+    if (tile) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) tile[(2 * k + h) * TILE + pt] = k < 20 ? bin0[k] : 0.f;  // k-step ordered, rows 40..63 pad
+    }
+    uint2 *mk = tile ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
+    int m0 = 0;
+#pragma unroll
+    for (int k = 0; k < 20; k++) m0 = max(m0, __float_as_int(bin0[k]) & 0x7fffffff);
+    const int kx0 = h2_point_shift(m0, H2_FWD_CLAMP);
+
+    for (int net = 0; net < 2; net++) {
+        const f32x4 *wp = net ? w2_t : w2_d;
+        const uint32_t *tab = reinterpret_cast<const uint32_t *>(wp + H2_TAB_F4);
+        const float *bs = net ? bias_t : bias_d;
+        const float *b0 = (net ? bias0_t : bias0_d) + (int64_t)sl * 128;
+        float *ht = tile ? tile + (64 + net * 640) * TILE : nullptr;
+        f32x16 acc[4];
+        FragH bh[8], bl[8];
+        // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split_h(__builtin_ldexpf(bin0[8 * s + 2 * e2], kx0), __builtin_ldexpf(bin0[8 * s + 2 * e2 + 1], kx0), bh[s].u[e2],
+                        bl[s].u[e2]);
+        int ks = h2_wexp(tab[0]) + kx0;
+        acc_bias<4>(acc, b0, h);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = __builtin_ldexpf(acc[t][r], ks);
+        h2_wait();
+        h2_stage<H2_LH_F4>(cb ^ 1, wp + H2_L0_F4);
+        h2_stage_bias(cb ^ 1, bs, 32);
+        h2_layer<3, 4>(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
+        cb ^= 1;
+        int kx = h2_epilogue(acc, ks, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bl);
+        // layers 1..4: 128 -> 128
+        for (int l = 1; l <= 4; l++) {
+            ks = h2_wexp(tab[l]) + kx;
+            h2_wait();
+            if (l < 4) {
+                h2_stage<H2_LH_F4>(cb ^ 1, wp + H2_L0_F4 + l * H2_LH_F4);
+                h2_stage_bias(cb ^ 1, bs + l * 128, 32);
+            } else {
+                h2_stage<H2_L5_F4>(cb ^ 1, wp + H2_L0_F4 + 4 * H2_LH_F4);
+                h2_stage_bias(cb ^ 1, bs + 4 * 128, 8);   // b5 is one 32-row tile
+            }
+            h2_acc_bias_lds<4>(acc, cb, h, ks);
+            h2_hidden(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
+            cb ^= 1;
+            kx = h2_epilogue(acc, ks, ht ? ht + l * 128 * TILE : nullptr, mk ? mk + (net * 5 + l) * 64 + lane : nullptr, pt, h, bh, bl);
+        }
+        // layer 5: 128 -> 3 | 2 (one padded tile)
+        ks = h2_wexp(tab[5]) + kx;
+        f32x16 o[1];
+        h2_wait();
+        if (net == 0) h2_stage<H2_L0_F4>(cb ^ 1, w2_t);
+        h2_acc_bias_lds<1>(o, cb, h, ks);
+        h2_layer<8, 1>(lds_h2 + cb * H2_BUF_F4, bh, bl, o, lane);
+        cb ^= 1;
+        if (h == 0 && p < M) {
+            if (net == 0) {
+                out_deform[p * 3 + 0] = __builtin_ldexpf(o[0][0], -ks);
+                out_deform[p * 3 + 1] = __builtin_ldexpf(o[0][1], -ks);
+                out_deform[p * 3 + 2] = __builtin_ldexpf(o[0][2], -ks);
+            } else {
+                out_topo[p * 2 + 0] = __builtin_ldexpf(o[0][0], -ks);
+                out_topo[p * 2 + 1] = __builtin_ldexpf(o[0][1], -ks);
+            }
+        }
+    }
+}
+
+// ---- backward-data -------------------------------------------------------------------------------------------------
+// Same chain, transposed packs (T5, T4..T1, T0), ReLU derivative from the sign masks the forward parked; parks dPre tiles in
+// mlp.hip's layout for mh_mlp_wgrad.  acc = 2^ks W^T dPre: masked, y = acc . 2^-ks parked, acc . 2^d sliced.
+__device__ __forceinline__ int h2_epilogue_bwd(f32x16 (&acc)[4], int ks, uint2 m, float *__restrict__ dt, int pt, int h, FragH (&bh)[8],
+                                               FragH (&bl)[8]) {
+    int mi = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const uint32_t mw = (t < 2 ? m.x : m.y) >> (16 * (t & 1));
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc[t][r] = mask_bit(mw, r, acc[t][r]);
+            mi = max(mi, __float_as_int(acc[t][r]) & 0x7fffffff);
+        }
+    }
+    if (dt) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(__builtin_ldexpf(acc[t][r], -ks), &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
+    }
+    const int d = h2_point_shift(mi, H2_BWD_CLAMP - ks);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split_h(__builtin_ldexpf(acc[t][8 * s2 + 2 * e2], d), __builtin_ldexpf(acc[t][8 * s2 + 2 * e2 + 1], d),
+                        bh[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    return d + ks;
+}
+
+__global__ __launch_bounds__(H2_THREADS, 2) void warp_bwd_h2_kernel(const float *__restrict__ x, const float *__restrict__ g_deform,
+                                                                    const float *__restrict__ g_topo, const f32x4 *__restrict__ w2T_d,
+                                                                    const f32x4 *__restrict__ w2T_t, int n_bands,
+                                                                    const float *__restrict__ acts, float *__restrict__ dpre,
+                                                                    float *__restrict__ g_x, int64_t M, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    const int64_t tile_id = (int64_t)blockIdx.x * (H2_THREADS / 64) + wave;
+    const int64_t p = tile_id * TILE + pt;
+    const bool live = p < M;
+    // the scratch holds whole 128-point blocks: a wave beyond it (tail of the last 256-point workgroup) runs the chain on
+    // the last real tile's masks and stores nothing
+    const bool have = tile_id < n_tiles;
+    const float *atile = acts + (have ? tile_id : n_tiles - 1) * (int64_t)(WARP_ACT_ROWS * TILE);
+    float *dtile = have ? dpre + tile_id * (int64_t)(WARP_DPRE_ROWS * TILE) : nullptr;
+    float gx[3] = {0.f, 0.f, 0.f};
+
+    int cb = 0;
+    h2_stage<H2_T5_F4>(cb, w2T_d);
+    for (int net = 0; net < 2; net++) {
+        const f32x4 *wt = net ? w2T_t : w2T_d;
+        const uint32_t *tab = reinterpret_cast<const uint32_t *>(wt + H2_TABT_F4);
+        const float *g = net ? g_topo : g_deform;
+        const int nout = net ? 2 : 3;
+        float *dt = dtile ? dtile + net * 672 * TILE : nullptr;
+        const uint2 *mk = reinterpret_cast<const uint2 *>(atile + WARP_HID_ROWS * TILE) + net * 5 * 64 + lane;
+        uint2 msk[5];
+#pragma unroll
+        for (int l = 0; l < 5; l++) msk[l] = mk[l * 64];
+        // dPre5: rows 0..nout-1 carry the incoming gradient (no activation on the last layer)
+        float d5[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) d5[r] = 0.f;
+        if (g && live && h == 0) {
+            d5[0] = g[p * nout + 0];
+            d5[1] = g[p * nout + 1];
+            if (nout == 3) d5[2] = g[p * nout + 2];
+        }
+        if (dt) store_acc_rows<1>(dt + 640 * TILE, d5, pt, h);
+        int m5 = max(max(__float_as_int(d5[0]) & 0x7fffffff, __float_as_int(d5[1]) & 0x7fffffff), __float_as_int(d5[2]) & 0x7fffffff);
+        int kx = h2_point_shift(m5, H2_BWD_CLAMP);
+        FragH bh[8], bl[8];
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split_h(__builtin_ldexpf(d5[8 * s + 2 * e2], kx), __builtin_ldexpf(d5[8 * s + 2 * e2 + 1], kx), bh[s].u[e2], bl[s].u[e2]);
+        // dH5 = W5^T dPre5
+        int ks = h2_wexp(tab[0]) + kx;
+        f32x16 acc[4];
+        h2_wait();
+        h2_stage<H2_LH_F4>(cb ^ 1, wt + H2_T5_F4);
+        h2_layer<2, 4, true>(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
+        cb ^= 1;
+        kx = h2_epilogue_bwd(acc, ks, msk[4], dt ? dt + 4 * 128 * TILE : nullptr, pt, h, bh, bl);
+        for (int l = 4; l >= 1; l--) {
+            // dH_l = W_l^T dPre_l, then dPre_{l-1} = dH_l masked by H_l's ReLU bits
+            ks = h2_wexp(tab[5 - l]) + kx;
+            h2_wait();
+            if (l > 1)
+                h2_stage<H2_LH_F4>(cb ^ 1, wt + H2_T5_F4 + (5 - l) * H2_LH_F4);
+            else if (g_x)
+                h2_stage<H2_T0_F4>(cb ^ 1, wt + H2_T5_F4 + 4 * H2_LH_F4);
+            else if (net == 0)
+                h2_stage<H2_T5_F4>(cb ^ 1, w2T_t);
+            acc_zero<4>(acc);
+            h2_hidden(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
+            cb ^= 1;
+            kx = h2_epilogue_bwd(acc, ks, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bl);
+        }
+        if (g_x) {
+            // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5).  Skipped when nobody asks for d/dx
+            ks = h2_wexp(tab[5]) + kx;
+            f32x16 e[2];
+            h2_wait();
+            if (net == 0) h2_stage<H2_T5_F4>(cb ^ 1, w2T_t);
+            h2_layer<8, 2, true>(lds_h2 + cb * H2_BUF_F4, bh, bl, e, lane);
+            cb ^= 1;
+            float dsc[18];
+            enc_deriv_parked(atile, pt, h, dsc);
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                const float de = __builtin_ldexpf(k < 16 ? e[0][k] : e[1][k - 16], -ks);
+                gx[k % 3] += de * dsc[k];
+            }
+            // kk 18: (x0 | x1), kk 19: (x2 | -)
+            if (h == 0) {
+                gx[0] += __builtin_ldexpf(e[1][2], -ks);
+                gx[2] += __builtin_ldexpf(e[1][3], -ks);
+            } else {
+                gx[1] += __builtin_ldexpf(e[1][2], -ks);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
+    if (g_x && live && h == 0) {
+        g_x[p * 3 + 0] = gx[0];
+        g_x[p * 3 + 1] = gx[1];
+        g_x[p * 3 + 2] = gx[2];
+    }
+}
+
+// ---- weight slices --------------------------------------------------------------------------------------------------
+// One pass finds each layer's largest |w| (fp32 bits into the net's table), the next cuts the layers -- gathered in fragment
+// order by the caller (packing.py: fwd3 / bwd3 maps, shared with mlp_b3.hip) -- into [h | l] fp16 planes at the layer's scale.
+#define H2_MAX_BLOCKS 32
+struct H2Groups {
+    int src_off[H2_MAX_BLOCKS];   // floats
+    int n[H2_MAX_BLOCKS];         // floats of the whole layer (all its blocks are consecutive in src)
+    int tab[H2_MAX_BLOCKS];       // index (32-bit words) of the layer's table entry in dst
+};
+struct H2Blocks {
+    int n_blocks;
+    int src_off[H2_MAX_BLOCKS];   // floats
+    int n8[H2_MAX_BLOCKS];        // groups of 8 floats (= float4 of fp16 per plane)
+    int dst_off[H2_MAX_BLOCKS];   // float4 units
+    int g_end[H2_MAX_BLOCKS];     // running end of the blocks' group ranges
+    int tab[H2_MAX_BLOCKS];       // the block's layer's table entry
+};
+
+__global__ __launch_bounds__(256) void h2_amax_kernel(const float *__restrict__ src, uint32_t *__restrict__ dst, H2Groups G) {
+    __shared__ int part[4];
+    const int g = blockIdx.x;
+    const float *s = src + G.src_off[g];
+    int m = 0;
+    for (int i = threadIdx.x; i < G.n[g]; i += 256) m = max(m, __float_as_int(s[i]) & 0x7fffffff);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) dst[G.tab[g]] = (uint32_t)max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
+__global__ void h2_slice_kernel(const float *__restrict__ src, f32x4 *__restrict__ dst, H2Blocks L) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= L.g_end[L.n_blocks - 1]) return;
+    int l = 0;
+    while (g >= L.g_end[l]) l++;
+    const int i = g - (l ? L.g_end[l - 1] : 0);
+    const int k = h2_wexp(reinterpret_cast<const uint32_t *>(dst)[L.tab[l]]);
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(src + L.src_off[l] + 8 * i);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(src + L.src_off[l] + 8 * i + 4);
+    FragH fh, fl;
+    split_h(__builtin_ldexpf(a[0], k), __builtin_ldexpf(a[1], k), fh.u[0], fl.u[0]);
+    split_h(__builtin_ldexpf(a[2], k), __builtin_ldexpf(a[3], k), fh.u[1], fl.u[1]);
+    split_h(__builtin_ldexpf(b[0], k), __builtin_ldexpf(b[1], k), fh.u[2], fl.u[2]);
+    split_h(__builtin_ldexpf(b[2], k), __builtin_ldexpf(b[3], k), fh.u[3], fl.u[3]);
+    f32x4 *d = dst + L.dst_off[l] + i;
+    d[0] = fh.f;
+    d[L.n8[l]] = fl.f;
+}
+
+// src: the layers' weights gathered in fragment order, block after block; block b: n[b] floats at src_off[b] -> planes at
+// float4 offset dst_off_f4[b] of dst; layer[b] = the block's layer (0..n_layers-1, blocks of a layer consecutive);
+// table_word[layer] = 32-bit word index in dst that receives the layer's largest |w|.
+extern "C" int mh_h2_slice(const float *src, void *dst, int32_t n_blocks, const int32_t *src_off_host, const int32_t *n_host,
+                           const int32_t *dst_off_f4_host, const int32_t *layer_host, int32_t n_layers,
+                           const int32_t *table_word_host, void *stream) {
+    if (n_blocks == 0) return MH_OK;
+    if (!src || !dst || n_blocks < 0 || n_blocks > H2_MAX_BLOCKS || n_layers <= 0 || n_layers > n_blocks || !src_off_host ||
+        !n_host || !dst_off_f4_host || !layer_host || !table_word_host)
+        return MH_ERR_ARG;
+    H2Blocks L;
+    H2Groups G;
+    L.n_blocks = n_blocks;
+    int end = 0, prev = -1;
+    for (int b = 0; b < n_blocks; b++) {
+        const int ly = layer_host[b];
+        if (n_host[b] <= 0 || n_host[b] % 8 || src_off_host[b] % 4 || src_off_host[b] < 0 || dst_off_f4_host[b] < 0 || ly < 0 ||
+            ly >= n_layers || (ly != prev && ly != prev + 1) || table_word_host[ly] < 0)
+            return MH_ERR_ARG;
+        if (ly != prev) {
+            G.src_off[ly] = src_off_host[b];
+            G.n[ly] = 0;
+            G.tab[ly] = table_word_host[ly];
+        } else if (src_off_host[b] != G.src_off[ly] + G.n[ly]) {
+            return MH_ERR_ARG;   // a layer's blocks must be consecutive in src
+        }
+        G.n[ly] += n_host[b];
+        prev = ly;
+        L.src_off[b] = src_off_host[b];
+        L.n8[b] = n_host[b] / 8;
+        L.dst_off[b] = dst_off_f4_host[b];
+        L.tab[b] = table_word_host[ly];
+        end += n_host[b] / 8;
+        L.g_end[b] = end;
+    }
+    if (prev != n_layers - 1) return MH_ERR_ARG;
+    hipLaunchKernelGGL(h2_amax_kernel, dim3(n_layers), dim3(256), 0, mh_stream(stream), src, reinterpret_cast<uint32_t *>(dst), G);
+    hipLaunchKernelGGL(h2_slice_kernel, dim3((end + 255) / 256), dim3(256), 0, mh_stream(stream), src, reinterpret_cast<f32x4 *>(dst), L);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int64_t mh_warp_w2_bytes(void) { return (int64_t)H2_NET_F4 * 16; }
+extern "C" int64_t mh_warp_w2T_bytes(void) { return (int64_t)H2_NETT_F4 * 16; }
+
+static int h2_lds_opt_in() {
+    static int done = 0;
+    if (!done) {
+        if (hipFuncSetAttribute((const void *)warp_fwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_bwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
+            return MH_ERR_LAUNCH;
+        done = 1;
+    }
+    return MH_OK;
+}
+
+extern "C" int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w2_d,
+                              const void *w2_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
+                              float *out_topo, float *acts, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !x || !bias0_d || !bias0_t || !w2_d || !w2_t || !bias_d || !bias_t || !out_deform || !out_topo || n_bands < 0 ||
+        n_bands > 6)
+        return MH_ERR_ARG;
+    const int64_t blocks = (M + H2_BLOCK_PTS - 1) / H2_BLOCK_PTS;
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    if (h2_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
+    hipLaunchKernelGGL(warp_fwd_h2_kernel, dim3((unsigned)blocks), dim3(H2_THREADS), H2_LDS_BYTES, mh_stream(stream), x, slot, bias0_d,
+                       bias0_t, reinterpret_cast<const f32x4 *>(w2_d), reinterpret_cast<const f32x4 *>(w2_t), bias_d, bias_t,
+                       (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const float *g_topo, const void *w2T_d, const void *w2T_t,
+                                   int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !x || !w2T_d || !w2T_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
+    const int64_t blocks = (M + H2_BLOCK_PTS - 1) / H2_BLOCK_PTS;
+    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
+    if (h2_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
+    hipLaunchKernelGGL(warp_bwd_h2_kernel, dim3((unsigned)blocks), dim3(H2_THREADS), H2_LDS_BYTES, mh_stream(stream), x, g_deform, g_topo,
+                       reinterpret_cast<const f32x4 *>(w2T_d), reinterpret_cast<const f32x4 *>(w2T_t), (int)n_bands, acts, dpre, g_x, M,
+                       mh_mlp_tiles(M));
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}

@@ -103,6 +103,13 @@ GRID_FWD_TWO = os.environ.get("MORPHEUS_GRID_FWD", "") == "two"
 # warp nets: "b3" (default) = exact fp32 products from three bf16 slices on the bf16 matrix pipe (csrc/mlp_b3.hip: values, parked
 # tiles, accumulation and results stay fp32, fp32-grade error), "f32" = the native fp32 MFMA kernels of csrc/mlp.hip (A/B switch)
 MLP_B3 = os.environ.get("MORPHEUS_MLP", "b3") == "b3"
+# "h2" = the same scheme with two fp16 slices per operand and three slice products (csrc/mlp_h2.hip): half the matrix work,
+# per-layer / per-point power-of-two scales keep the slices inside fp16's exponent range; weight gradients as in "b3"
+MLP_H2 = os.environ.get("MORPHEUS_MLP", "b3") == "h2"
+
+
+def _warp_mode() -> str:
+    return "h2" if MLP_H2 else ("b3" if MLP_B3 else "")
 # field nets (sdf / colour): forward on the bf16 pipe too (mh_field_fwd_b3); the fused backward stays on the fp32 MFMA
 FIELD_B3 = os.environ.get("MORPHEUS_FIELD_FWD", "b3") == "b3"
 
@@ -594,7 +601,21 @@ class _PackOperands(torch.autograd.Function):
         flat = jp.flat(weights, biases)
         m = jp.on(flat.device)
         fpack, bpack = flat[m["fwd"]], flat[m["bwd"]]
-        if b3:
+        if b3 == "h2":
+            # fp16x2 slices (csrc/mlp_h2.hip): same gathers, [h | l] planes per block at the layer's scale + the scale tables
+            lib = _lib.load()
+            w3 = torch.zeros((jp.fwd2_total_f4 + jp.bwd2_total_f4) * 4, device=flat.device)
+            for key, blocks, table, base in (("fwd3", jp.h2_blocks, jp.h2_table, 0),
+                                             ("bwd3", jp.h2T_blocks, jp.h2T_table, jp.fwd2_total_f4)):
+                src = flat[m[key]]
+                so, sp = _i32arr([b[0] for b in blocks])
+                no, np_ = _i32arr([b[1] for b in blocks])
+                do, dp = _i32arr([b[2] for b in blocks])
+                lo, lp = _i32arr([b[3] for b in blocks])
+                to, tp = _i32arr(table)
+                check(lib.mh_h2_slice(ptr(src), ptr(w3[4 * base:]), len(blocks), sp, np_, dp, lp, len(table), tp, stream()),
+                      "mh_h2_slice")
+        elif b3:
             # bf16x3 forward fragments (csrc/mlp_b3.hip): the same weights gathered in the 32x32x16 fragment order, then cut
             # into [hi | mid | lo] bf16 planes per layer by one launch
             lib = _lib.load()
@@ -624,11 +645,16 @@ class _PackOperands(torch.autograd.Function):
 class MLPOperands:
     """Prepared operands of the warp nets (deform_net + topo_net) or of the field nets (sdf_net + color_net)."""
 
-    def __init__(self, jp, fpack, bpack, w3, token):
+    def __init__(self, jp, fpack, bpack, w3, token, mode=""):
         self.jp, self.fpack, self.bpack, self.token = jp, fpack, bpack, token
-        # bf16x3 slices per net (float32 storage, 4 floats per float4 unit), or None when the fp32-MFMA kernels serve
-        self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w3] if w3.numel() else None
-        self.wT3 = [w3[4 * (jp.fwd3_total_f4 + o):4 * (jp.fwd3_total_f4 + o + n)] for o, n in jp.wT3] if w3.numel() else None
+        self.mode = mode if w3.numel() else ""             # "b3" / "h2": which sliced kernels the operands are cut for
+        # slices per net (float32 storage, 4 floats per float4 unit), or None when the fp32-MFMA kernels serve
+        if self.mode == "h2":
+            self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w2]
+            self.wT3 = [w3[4 * (jp.fwd2_total_f4 + o):4 * (jp.fwd2_total_f4 + o + n)] for o, n in jp.wT2]
+        else:
+            self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w3] if w3.numel() else None
+            self.wT3 = [w3[4 * (jp.fwd3_total_f4 + o):4 * (jp.fwd3_total_f4 + o + n)] for o, n in jp.wT3] if w3.numel() else None
         self.w = [jp.take(fpack, sl) for sl in jp.w]
         self.b = [jp.take(fpack, sl) for sl in jp.b]
         self.wT = [jp.take(bpack, sl) for sl in jp.wT]
@@ -638,13 +664,15 @@ def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[t
     """params_{d,t}: W0x [128,39], W1..W4 [128,128], W5 [n_out,128], b0 (its gradient travels through bias0), b1..b5."""
     jp = warp_joint_packer()
     flat = list(params_d[:6]) + list(params_t[:6]) + list(params_d[6:]) + list(params_t[6:])
-    return MLPOperands(jp, *_PackOperands.apply(jp, True, MLP_B3, len(flat), *flat))
+    mode = _warp_mode()
+    return MLPOperands(jp, *_PackOperands.apply(jp, True, mode, len(flat), *flat), mode=mode)
 
 
 def prepare_field_operands(params: Sequence[torch.Tensor]) -> MLPOperands:
     """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
     jp = field_joint_packer()
-    return MLPOperands(jp, *_PackOperands.apply(jp, False, FIELD_B3, len(params), *params))
+    mode = "b3" if FIELD_B3 else ""
+    return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), *params), mode=mode)
 
 
 class _WarpMLP(torch.autograd.Function):
@@ -668,13 +696,14 @@ class _WarpMLP(torch.autograd.Function):
         slot_c = None if slot is None else slot.contiguous()
         _e = TIMER.start()
         if opnd.w3 is not None:
-            check(lib.mh_warp_fwd_b3(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
-                                     n_bands, ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd_b3")
+            fwd = lib.mh_warp_fwd_h2 if opnd.mode == "h2" else lib.mh_warp_fwd_b3
+            check(fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
+                      n_bands, ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd_" + opnd.mode)
         else:
             check(lib.mh_warp_fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(wd), ptr(wt), ptr(bd), ptr(bt), n_bands,
                                   ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
         TIMER.stop("mh_warp_fwd", _e)
-        ctx.b3 = opnd.wT3 is not None
+        ctx.b3, ctx.mode = opnd.wT3 is not None, opnd.mode
         if ctx.b3:
             wdT, wtT = opnd.wT3
         ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
@@ -691,7 +720,7 @@ class _WarpMLP(torch.autograd.Function):
         g_x = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL -> the kernel skips the W0^T stage
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
-        bwd_data = lib.mh_warp_bwd_data_b3 if ctx.b3 else lib.mh_warp_bwd_data
+        bwd_data = (lib.mh_warp_bwd_data_h2 if ctx.mode == "h2" else lib.mh_warp_bwd_data_b3) if ctx.b3 else lib.mh_warp_bwd_data
         check(bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
                        stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)

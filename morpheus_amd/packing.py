@@ -108,6 +108,15 @@ def _b3_blocks(idx: np.ndarray, MT: int, KS16: int):
     return [idx]
 
 
+def _h2_offsets(block_floats):
+    """float4 offsets of the blocks' [h | l] fp16 planes (whole DMA rounds each), of the scale table behind them, and the total."""
+    offs, f4 = [], 0
+    for n in block_floats:
+        offs.append(f4)
+        f4 += -(-(2 * n // 8) // B3_DMA_F4) * B3_DMA_F4
+    return offs, f4, f4 + B3_DMA_F4
+
+
 B3_DMA_F4 = 512      # a layer's slices are staged by whole rounds of the 512-thread block (16 bytes per thread and round)
 
 
@@ -221,10 +230,12 @@ class NetPacker:
         self.bwd_index = np.concatenate(bwd)
         # bf16x3 fragments: fp32 gather in b3 order (sliced into three bf16 planes by mh_b3_slice); per layer the float count
         # and the float4 offset of its [hi|mid|lo] planes in the sliced pack (padded to whole DMA rounds)
-        fwd3 = []
-        for s, o in zip(self.specs, offs):
-            fwd3 += _b3_blocks(_frag_index_b3(s.rowmap, s.kmap, s.in_dim, False, sentinel, o), s.rowmap.shape[0] // 32,
-                               (s.kmap.shape[0] + 7) // 8)
+        fwd3, self.fwd3_layer = [], []          # fwd3_layer: which layer of the chain a staged block belongs to
+        for li, (s, o) in enumerate(zip(self.specs, offs)):
+            blocks = _b3_blocks(_frag_index_b3(s.rowmap, s.kmap, s.in_dim, False, sentinel, o), s.rowmap.shape[0] // 32,
+                                (s.kmap.shape[0] + 7) // 8)
+            fwd3 += blocks
+            self.fwd3_layer += [li] * len(blocks)
         self.fwd3_index = np.concatenate(fwd3)
         self.fwd3_n = [len(f) for f in fwd3]
         self.fwd3_f4, f4 = [], 0
@@ -232,11 +243,13 @@ class NetPacker:
             self.fwd3_f4.append(f4)
             f4 += -(-(3 * n // 8) // B3_DMA_F4) * B3_DMA_F4
         self.fwd3_total_f4 = f4
-        bwd3 = []
-        for i in bwd_order:
+        bwd3, self.bwd3_layer = [], []
+        for li, i in enumerate(bwd_order):
             sp = self.specs[i]
-            bwd3 += _b3_blocks(_frag_index_b3(sp.rowmapT, sp.kmapT, sp.in_dim, True, sentinel, offs[i]), sp.rowmapT.shape[0] // 32,
-                               (sp.kmapT.shape[0] + 7) // 8)
+            blocks = _b3_blocks(_frag_index_b3(sp.rowmapT, sp.kmapT, sp.in_dim, True, sentinel, offs[i]), sp.rowmapT.shape[0] // 32,
+                                (sp.kmapT.shape[0] + 7) // 8)
+            bwd3 += blocks
+            self.bwd3_layer += [li] * len(blocks)
         self.bwd3_index = np.concatenate(bwd3)
         self.bwd3_n = [len(f) for f in bwd3]
         self.bwd3_f4, f4 = [], 0
@@ -244,6 +257,10 @@ class NetPacker:
             self.bwd3_f4.append(f4)
             f4 += -(-(3 * n // 8) // B3_DMA_F4) * B3_DMA_F4
         self.bwd3_total_f4 = f4
+        # fp16x2 slices (csrc/mlp_h2.hip): the same gathers, two planes per block, and behind the net's blocks one DMA round
+        # that holds the per-layer scale table (largest |w| of layer i in 32-bit word i)
+        self.fwd2_f4, self.fwd2_tab_f4, self.fwd2_total_f4 = _h2_offsets(self.fwd3_n)
+        self.bwd2_f4, self.bwd2_tab_f4, self.bwd2_total_f4 = _h2_offsets(self.bwd3_n)
         # bias vector (accumulator-row order, padded to 32*MT) : gather from [b_0 | b_1 | ... | 0]
         b_offs, nb = [], 0
         for s in self.specs:
@@ -379,6 +396,10 @@ class JointPacker:
             wo += p.n_weights
         self.bwd3_index = np.concatenate(t3)
         self.bwd3_total_f4 = f4
+        # fp16x2 slices of all nets (mh_h2_slice): blocks (src float offset, floats, dst float4, layer id) and the table word of
+        # every layer, for the forward and the transposed chains; w2 / wT2 = (float4 offset, float4 count) per net
+        self.w2, self.h2_blocks, self.h2_table, self.fwd2_total_f4 = self._h2_plan("fwd")
+        self.wT2, self.h2T_blocks, self.h2T_table, self.bwd2_total_f4 = self._h2_plan("bwd")
         # gradients
         raw_dw = sum(p.raw_dw for p in self.packers)
         g, dwo, dbo = [], 0, raw_dw
@@ -404,6 +425,21 @@ class JointPacker:
             pos += p.n_biases
         self.grad_index_nob0 = gz
         self._dev: Dict[Tuple[str, int], Dict[str, torch.Tensor]] = {}
+
+    def _h2_plan(self, which: str):
+        nets, blocks, table, src, f4, layer0 = [], [], [], 0, 0, 0
+        for p in self.packers:
+            ns, o4s, lys = getattr(p, which + "3_n"), getattr(p, which + "2_f4"), getattr(p, which + "3_layer")
+            tab_f4, total = getattr(p, which + "2_tab_f4"), getattr(p, which + "2_total_f4")
+            nets.append((f4, total))
+            for n, o4, ly in zip(ns, o4s, lys):
+                blocks.append((src, n, f4 + o4, layer0 + ly))
+                src += n
+            n_layers = max(lys) + 1
+            table += [4 * (f4 + tab_f4) + i for i in range(n_layers)]
+            layer0 += n_layers
+            f4 += total
+        return nets, blocks, table, f4
 
     def on(self, device: torch.device) -> Dict[str, torch.Tensor]:
         key = (device.type, device.index or 0)

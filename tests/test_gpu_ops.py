@@ -16,6 +16,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _set_mlp(monkeypatch, ops, mode):
+    """warp-net arithmetic: "b3" (bf16 x 3 slices), "h2" (fp16 x 2 slices) or "f32" (native fp32 MFMA)"""
+    monkeypatch.setattr(ops, "MLP_B3", mode == "b3")
+    monkeypatch.setattr(ops, "MLP_H2", mode == "h2")
+
+
 def _grid_setup(scale=0.1):
     offs, s = synth.grid_offsets()
     emb = synth.hash_tensor((int(offs[-1]), 2), 9001, scale)
@@ -150,12 +156,12 @@ def _wn(p, pre, l):
 
 @pytest.mark.parametrize("kind", ["a", "b"])
 @pytest.mark.parametrize("max_level", [None, 0.5])
-@pytest.mark.parametrize("mlp", ["b3", "f32"])
+@pytest.mark.parametrize("mlp", ["b3", "h2", "f32"])
 def test_warp_mlp(kind, max_level, mlp, monkeypatch):
-    """deform_net + topo_net (fused MFMA kernels: bf16x3 on the matrix pipe = the default, and native fp32 MFMA) vs the
-    oracle, values and every gradient."""
+    """deform_net + topo_net (fused MFMA kernels: sliced operands on the 16-bit matrix pipe -- bf16 x 3 and fp16 x 2 -- and
+    native fp32 MFMA) vs the oracle, values and every gradient."""
     from morpheus_amd import ops
-    monkeypatch.setattr(ops, "MLP_B3", mlp == "b3")
+    _set_mlp(monkeypatch, ops, mlp)
     M = 1000                                              # not a multiple of 128: exercises the ragged tail
     x = synth.hash_tensor((M, 3), 500, 1.0)
     tvals = torch.tensor([37 / 200, 0.5, 0.91])
@@ -616,8 +622,10 @@ def test_sdf_losses_kernel_vs_reference_formula():
         assert_close(pg.grad, po.grad, 1e-5, "d/d pred", floor=1e-2 * float(po.grad.abs().max()))
 
 
-def test_warp_b3_is_fp32_grade(monkeypatch):
-    """The bf16x3 warp kernels (three exact bf16 slices per fp32 operand, six slice products, fp32 accumulate) against the
+@pytest.mark.parametrize("sliced", ["b3", "h2"])
+def test_warp_sliced_arithmetic_is_fp32_grade(sliced, monkeypatch):
+    """The sliced warp kernels -- b3: three exact bf16 slices per fp32 operand, six slice products; h2: two fp16 slices at a
+    per-layer / per-point power-of-two scale, three slice products; fp32 accumulate in both -- against the
     native fp32-MFMA kernels and a float64 evaluation of the same networks: forward values, d/dx and every weight gradient.
     The claim checked: their error against float64 is of the size of the fp32 kernels' own -- forward values within 3x,
     gradients (sums of ~10^6 slice products per entry; the matrix pipe's internal accumulation is not round-to-nearest)
@@ -659,8 +667,8 @@ def test_warp_b3_is_fp32_grade(monkeypatch):
     wt_ = wt_ * safe[:, None]
     ((outs[0] * wd_.double()).sum() + (outs[1] * wt_.double()).sum()).backward()
 
-    def run(b3):
-        monkeypatch.setattr(ops, "MLP_B3", b3)
+    def run(mode):
+        _set_mlp(monkeypatch, ops, mode)
         ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
         xg = x.clone().requires_grad_(True)
         bb = [t.clone().requires_grad_(True) for t in b0]
@@ -668,7 +676,7 @@ def test_warp_b3_is_fp32_grade(monkeypatch):
         ((d * wd_).sum() + (t * wt_).sum()).backward()
         return d.detach(), t.detach(), xg.grad, [[p.grad for p in net] for net in ps], [t.grad for t in bb]
 
-    r32, r3 = run(False), run(True)
+    r32, r3 = run("f32"), run(sliced)
     for k, name in ((0, "deform"), (1, "topo")):
         e32 = float((r32[k].double() - outs[k]).abs().max())
         e3 = float((r3[k].double() - outs[k]).abs().max())
@@ -690,14 +698,14 @@ def test_warp_b3_is_fp32_grade(monkeypatch):
         assert rl2(ga, gr) <= max(6 * rl2(gb, gr), 5e-6)
 
 
-@pytest.mark.parametrize("mlp", ["b3", "f32"])
+@pytest.mark.parametrize("mlp", ["b3", "h2", "f32"])
 def test_warp_large_batch_weight_gradients(mlp, monkeypatch):
     """The large-batch kernels of the warp path (from 16 384 tiles on mh_mlp_wgrad(_b3) launches one kernel per layer: the
     slice-once-per-workgroup b3 kernel / the three-register-set fp32 kernel; the 8-wave forward / backward run hundreds of
     workgroups per CU) against the small-batch forms the oracle tests pin: one call on 600 000 points must give the same
     outputs, d/dx and parameter gradients as the same points fed in six chunks (same terms, different kernels and order)."""
     from morpheus_amd import ops
-    monkeypatch.setattr(ops, "MLP_B3", mlp == "b3")
+    _set_mlp(monkeypatch, ops, mlp)
     torch.manual_seed(3)
     M, CH = 600_000, 100_000
     nets = []
@@ -822,7 +830,7 @@ def test_ab_switch_kernels_stay_correct(env):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pick = "test_warp_mlp and b3-None-a or test_warp_b3_is_fp32_grade or test_warp_large_batch_weight_gradients and b3"
+    pick = "test_warp_mlp and b3-None-a or test_warp_sliced_arithmetic_is_fp32_grade and b3 or test_warp_large_batch_weight_gradients and b3"
     run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
                           "-k", pick, "-p", "no:cacheprovider"], cwd=root, env={**os.environ, **env}, capture_output=True,
                          text=True, timeout=600)
