@@ -384,9 +384,9 @@ def main(argv=None):
 
     mode = ops._warp_mode()                     # "h2" / "b3" / "" (native fp32 MFMA)
     b3 = mode != ""                             # the warp nets run on the 16-bit matrix pipe with sliced operands
-    sfx = {"h2": "warp_fwd_h2_kernel", "b3": "warp_fwd_b3_kernel<8>", "": "warp_fwd_kernel"}[mode]
-    symbol = {"mh_warp_fwd": sfx, "mh_warp_bwd_data": sfx.replace("fwd", "bwd"), "mh_field_fwd": "field_fwd_kernel",
-              "mh_field_bwd_data": "field_bwd_kernel"}
+    fsym = {"h2": "warp_fwd_h2_kernel<4>", "b3": "warp_fwd_b3_kernel<8>", "": "warp_fwd_kernel"}[mode]
+    bsym = {"h2": "warp_bwd_h2_kernel<8>", "b3": "warp_bwd_b3_kernel<8>", "": "warp_bwd_kernel"}[mode]
+    symbol = {"mh_warp_fwd": fsym, "mh_warp_bwd_data": bsym, "mh_field_fwd": "field_fwd_kernel", "mh_field_bwd_data": "field_bwd_kernel"}
     full = render_wl and N * S == 128 * 128 * 128
     roofline = None
     if dominant is not None:
@@ -490,12 +490,12 @@ def main(argv=None):
                    "ranks_share_devices": bool(world > 1 and n_dev < world),
                    "mlp_arithmetic": {"b3": "warp nets: fp32 values, exact three-way bf16 split of both operands, six slice "
                                             "products per MAC on the bf16 matrix pipe, fp32 accumulate (fp32-grade: <= 3 * 2^-24 of a "
-                                            "product dropped); field nets: forward the same, backward native fp32 MFMA",
+                                            "product dropped); field nets: forward the same, backward native fp32 MFMA (MORPHEUS_MLP=b3)",
                                       "h2": "warp nets forward / backward-data: fp32 values, two fp16 slices per operand at per-layer / "
                                             "per-point power-of-two scales (22 significand bits), three slice products per MAC on the "
                                             "fp16 matrix pipe, fp32 accumulate (fp32-grade: measured error against float64 equal to "
                                             "the fp32-MFMA kernels'); weight gradients and the field forward: bf16 x 3 slices; field "
-                                            "backward native fp32 MFMA (MORPHEUS_MLP=h2)",
+                                            "backward native fp32 MFMA (the default, MORPHEUS_MLP=h2)",
                                       "": "native fp32 MFMA (MORPHEUS_MLP=f32)"}[mode],
                    "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
         "roofline": roofline, "roofline_hashgrid": roof_hash, "roofline_weight_gradients": roof_wgrad, "kernels": ktab,

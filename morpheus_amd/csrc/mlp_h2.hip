@@ -23,9 +23,8 @@
 // A 128 x 128 layer is 64 KB of slices: TWO layers fit in LDS, so layer l+1 is fetched while layer l computes and a layer
 // costs one workgroup barrier.
 #include "mlp_dev.h"
+#include <stdlib.h>
 
-#define H2_THREADS 512
-#define H2_BLOCK_PTS 256
 #define H2_L0_F4 1536                                    // 2 planes x 4 tiles x 3 k16 steps x 64 lanes
 #define H2_LH_F4 4096                                    // 128 x 128: two k-half blocks [khalf][plane][tile][k16 step 0..3][lane]
 #define H2_KH_F4 2048
@@ -53,6 +52,28 @@ union FragH {
 
 extern __shared__ f32x4 lds_h2[];
 
+#ifdef MH_PHASE_TRACE
+// phase trace for tools/phase_trace_h2.py (never compiled into the product library): wave 0 of every 32nd workgroup stamps
+// s_memtime at the phase boundaries of the forward kernel's hidden layers of net 0 (8 slots per layer), s_memrealtime in 62/63
+__device__ long long mh_h2_trace[256 * 64];
+#define H2_STAMP(slot)                                                                          \
+    do {                                                                                        \
+        if ((threadIdx.x == 0) && (blockIdx.x % 64 == 0) && (blockIdx.x / 64 < 256))            \
+            mh_h2_trace[(blockIdx.x / 64) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define H2_STAMP_REAL(slot)                                                                     \
+    do {                                                                                        \
+        if ((threadIdx.x == 0) && (blockIdx.x % 64 == 0) && (blockIdx.x / 64 < 256))            \
+            mh_h2_trace[(blockIdx.x / 64) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+extern "C" int mh_h2_trace_read(long long *dst_host) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(mh_h2_trace), sizeof(long long) * 256 * 64) == hipSuccess ? 0 : 2;
+}
+#else
+#define H2_STAMP(slot) do { } while (0)
+#define H2_STAMP_REAL(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ int h2_wexp(uint32_t amax_bits) { return min(H2_TOP - (int)(amax_bits >> 23), H2_W_CLAMP); }
 
 // two ALREADY SCALED fp32 values -> their packed fp16 slices (round to nearest: v_cvt_pk_f16_f32; x - h is exact in fp32)
@@ -72,40 +93,30 @@ __device__ __forceinline__ int h2_point_shift(int amax_bits, int cap) {
     return min(H2_TOP - (amax_bits >> 23), cap);
 }
 
-template <int N_F4>
+template <int N_F4, int NW>
 __device__ __forceinline__ void h2_stage(int buf, const f32x4 *__restrict__ src) {
-    static_assert(N_F4 % H2_THREADS == 0, "whole rounds of the block");
+    constexpr int NTHR = NW * 64;
+    static_assert(N_F4 % NTHR == 0, "whole rounds of the block");
     const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < N_F4 / H2_THREADS; k++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * H2_THREADS + threadIdx.x),
-                                         (__attribute__((address_space(3))) void *)(lds_h2 + buf * H2_BUF_F4 + k * H2_THREADS + wave * 64),
+    for (int k = 0; k < N_F4 / NTHR; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * NTHR + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_h2 + buf * H2_BUF_F4 + k * NTHR + wave * 64),
                                          16, 0, 0);
 }
-__device__ __forceinline__ void h2_stage_bias(int buf, const float *__restrict__ bias, int n_f4) {
+// the layer's bias row (<= 128 floats) rides along, into one of the buffer's two 32-float4 slots (layers alternate slots: with
+// ONE weight buffer the next layer's fetch is in flight while this layer's epilogue still reads its bias)
+__device__ __forceinline__ void h2_stage_bias(int buf, int slot, const float *__restrict__ bias, int n_f4) {
     if ((int)threadIdx.x < n_f4)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const f32x4 *>(bias) + threadIdx.x),
-                                         (__attribute__((address_space(3))) void *)(lds_h2 + buf * H2_BUF_F4 + H2_LH_F4 + (threadIdx.x >> 6) * 64),
+                                         (__attribute__((address_space(3))) void *)(lds_h2 + buf * H2_BUF_F4 + H2_LH_F4 + slot * 32 +
+                                                                                    (threadIdx.x >> 6) * 64),
                                          16, 0, 0);
 }
 // my DMA pieces (and parking stores) are done; behind the barrier everyone's are visible and everyone has left the other buffer
 __device__ __forceinline__ void h2_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-}
-
-// accumulators <- bias row (LDS, accumulator-row order) . 2^ks
-template <int MT>
-__device__ __forceinline__ void h2_acc_bias_lds(f32x16 (&acc)[MT], int buf, int h, int ks) {
-    const f32x4 *b = lds_h2 + buf * H2_BUF_F4 + H2_LH_F4;
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const f32x4 v = b[8 * t + 2 * r4 + h];
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = __builtin_ldexpf(v[c], ks);
-        }
 }
 
 // acc[t] += W[t] . b : three slice products per k16 step, two output tiles in rotation, small terms first
@@ -136,10 +147,12 @@ __device__ __forceinline__ void h2_layer(const f32x4 *__restrict__ w, const Frag
     }
 }
 
-// a 128 x 128 layer from its two k-half blocks
+// a 128 x 128 layer from its two k-half blocks; the accumulators start from the inline constant 0 (the bias joins in the
+// epilogue's fma, backward layers have none)
 __device__ __forceinline__ void h2_hidden(const f32x4 *__restrict__ w, const FragH (&bh)[8], const FragH (&bl)[8], f32x16 (&acc)[4],
                                           int lane) {
     constexpr int PLH = 4 * 4 * 64;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const f32x4 *wk = w + (s >> 2) * H2_KH_F4 + (s & 3) * 64 + lane;
@@ -152,7 +165,7 @@ __device__ __forceinline__ void h2_hidden(const f32x4 *__restrict__ w, const Fra
                 al[t].f = wk[1 * PLH + (mp + t) * 256];
             }
 #pragma unroll
-            for (int t = 0; t < 2; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t].h, bh[s].h, acc[mp + t], 0, 0, 0);
+            for (int t = 0; t < 2; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t].h, bh[s].h, s == 0 ? zero : acc[mp + t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 2; t++) acc[mp + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t].h, bl[s].h, acc[mp + t], 0, 0, 0);
 #pragma unroll
@@ -161,7 +174,7 @@ __device__ __forceinline__ void h2_hidden(const f32x4 *__restrict__ w, const Fra
     }
 }
 
-// forward layer epilogue.  acc = 2^ks (W x + b).  ReLU; y = acc . 2^-ks is parked (feature-major) and gives the sign mask; the
+// layer-0 epilogue (the per-slot bias row went into the accumulators).  acc = 2^ks (W x + b).  ReLU; y = acc . 2^-ks is parked (feature-major) and gives the sign mask; the
 // point's next shift d comes from the largest acc; acc . 2^d = y . 2^(ks + d) is cut into the next layer's B operand slices.
 // Returns the point's new exponent kx = ks + d (the next layer adds its weight exponent).
 __device__ __forceinline__ int h2_epilogue(f32x16 (&acc)[4], int ks, float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
@@ -202,14 +215,70 @@ __device__ __forceinline__ int h2_epilogue(f32x16 (&acc)[4], int ks, float *__re
     return d + ks;
 }
 
-__global__ __launch_bounds__(H2_THREADS, 2) void warp_fwd_h2_kernel(
+// hidden-layer epilogue.  acc = 2^ks W x, the bias is NOT inside: y = relu(acc . 2^-ks + b) is one fma (the product is an exact
+// power-of-two scaling, the sum rounds once) and one integer max; y is parked and gives the sign mask; the point's next
+// exponent kx comes from the largest y; y . 2^kx is cut into the next layer's B operand slices.  Returns kx.
+__device__ __forceinline__ int h2_epilogue_hidden(f32x16 (&acc)[4], int ks, const f32x4 *__restrict__ brow, float *__restrict__ ht,
+                                                  uint2 *__restrict__ mk, int pt, int h, FragH (&bh)[8], FragH (&bl)[8], int stamp = -1) {
+    const float sc = __builtin_ldexpf(1.0f, -ks);
+    int mi = 0;
+    uint32_t mt[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 b = brow[8 * t + 2 * r4 + h];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float y = relu_i(__builtin_fmaf(acc[t][4 * r4 + c], sc, b[c]));
+                acc[t][4 * r4 + c] = y;
+                mi = max(mi, __float_as_int(y));
+            }
+        }
+        if (ht) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+        }
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 15; r >= 0; r--) m = push_nz(m, acc[t][r]);
+        mt[t] = m;
+    }
+    if (mk) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+    if (stamp >= 0) {
+        asm volatile("" ::"v"(mt[0]), "v"(mt[3]), "v"(mi));   // trace build only: the stamp waits for the values above
+        H2_STAMP(stamp);
+    }
+    const int kx = h2_point_shift(mi, H2_FWD_CLAMP);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split_h(__builtin_ldexpf(acc[t][8 * s2 + 2 * e2], kx), __builtin_ldexpf(acc[t][8 * s2 + 2 * e2 + 1], kx),
+                        bh[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    if (stamp >= 0) {
+        asm volatile("" ::"v"(bl[7].u[3]), "v"(bl[0].u[0]), "v"(bh[3].u[1]));
+        H2_STAMP(stamp + 1);
+    }
+    return kx;
+}
+
+// NW = 8: one 256-point workgroup per CU, two LDS buffers (layer l+1 is fetched while layer l computes), one barrier per
+// layer.  NW = 4: TWO independent 128-point workgroups per CU with one buffer each (2 x 65 KB); the next layer's fetch has
+// to wait for the layer's last LDS read and then hides under the epilogue -- but the SIMD's two waves now belong to different
+// workgroups, share no barrier and drift apart: one's MFMA stretch runs under the other's epilogue.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void warp_fwd_h2_kernel(
     const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
     const float *__restrict__ bias0_t, const f32x4 *__restrict__ w2_d, const f32x4 *__restrict__ w2_t,
     const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
     float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
+    constexpr bool TWO = NW == 8;                         // two LDS buffers
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
-    const int64_t tile_id = (int64_t)blockIdx.x * (H2_THREADS / 64) + wave;
+    const int64_t tile_id = (int64_t)blockIdx.x * NW + wave;
     const int64_t p = tile_id * TILE + pt;
     const int64_t pc = p < M ? p : M - 1;
     float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
@@ -218,7 +287,7 @@ __global__ __launch_bounds__(H2_THREADS, 2) void warp_fwd_h2_kernel(
     float *tile = (acts && tile_id < n_tiles) ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
 
     int cb = 0;                                           // LDS buffer of the layer about to run
-    h2_stage<H2_L0_F4>(cb, w2_d);
+    h2_stage<H2_L0_F4, NW>(cb, w2_d);
     float bin0[24];
     enc_bin(xv, h, n_bands, bin0, nullptr);
 #pragma unroll
@@ -241,6 +310,18 @@ __global__ __launch_bounds__(H2_THREADS, 2) void warp_fwd_h2_kernel(
         float *ht = tile ? tile + (64 + net * 640) * TILE : nullptr;
         f32x16 acc[4];
         FragH bh[8], bl[8];
+        // the fetch of the layer after stage `l` (0..5), into buffer `buf`
+        auto fetch_after = [&](int l, int buf) {
+            if (l < 4) {
+                h2_stage<H2_LH_F4, NW>(buf, wp + H2_L0_F4 + l * H2_LH_F4);
+                h2_stage_bias(buf, (l + 1) & 1, bs + l * 128, 32);
+            } else if (l == 4) {
+                h2_stage<H2_L5_F4, NW>(buf, wp + H2_L0_F4 + 4 * H2_LH_F4);
+                h2_stage_bias(buf, 1, bs + 4 * 128, 8);     // b5 is one 32-row tile
+            } else if (net == 0) {
+                h2_stage<H2_L0_F4, NW>(buf, w2_t);
+            }
+        };
         // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot
 #pragma unroll
         for (int s = 0; s < 3; s++)
@@ -255,43 +336,60 @@ __global__ __launch_bounds__(H2_THREADS, 2) void warp_fwd_h2_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = __builtin_ldexpf(acc[t][r], ks);
         h2_wait();
-        h2_stage<H2_LH_F4>(cb ^ 1, wp + H2_L0_F4);
-        h2_stage_bias(cb ^ 1, bs, 32);
+        if (TWO) fetch_after(0, cb ^ 1);
         h2_layer<3, 4>(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
-        cb ^= 1;
+        if (TWO) {
+            cb ^= 1;
+        } else {
+            __syncthreads();
+            fetch_after(0, cb);
+        }
         int kx = h2_epilogue(acc, ks, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bl);
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
+            if (net == 0) H2_STAMP((l - 1) * 8 + 0);
+            if (net == 0 && l == 1) H2_STAMP_REAL(62);
             ks = h2_wexp(tab[l]) + kx;
             h2_wait();
-            if (l < 4) {
-                h2_stage<H2_LH_F4>(cb ^ 1, wp + H2_L0_F4 + l * H2_LH_F4);
-                h2_stage_bias(cb ^ 1, bs + l * 128, 32);
-            } else {
-                h2_stage<H2_L5_F4>(cb ^ 1, wp + H2_L0_F4 + 4 * H2_LH_F4);
-                h2_stage_bias(cb ^ 1, bs + 4 * 128, 8);   // b5 is one 32-row tile
-            }
-            h2_acc_bias_lds<4>(acc, cb, h, ks);
+            if (net == 0) H2_STAMP((l - 1) * 8 + 1);
+            if (TWO) fetch_after(l, cb ^ 1);
+            if (net == 0) H2_STAMP((l - 1) * 8 + 2);
             h2_hidden(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
-            cb ^= 1;
-            kx = h2_epilogue(acc, ks, ht ? ht + l * 128 * TILE : nullptr, mk ? mk + (net * 5 + l) * 64 + lane : nullptr, pt, h, bh, bl);
+            if (net == 0) H2_STAMP((l - 1) * 8 + 3);
+            const f32x4 *brow = lds_h2 + cb * H2_BUF_F4 + H2_LH_F4 + (l & 1) * 32;
+            if (TWO) {
+                cb ^= 1;
+            } else {
+                __syncthreads();
+                fetch_after(l, cb);
+            }
+            if (net == 0) H2_STAMP((l - 1) * 8 + 4);
+            kx = h2_epilogue_hidden(acc, ks, brow, ht ? ht + l * 128 * TILE : nullptr, mk ? mk + (net * 5 + l) * 64 + lane : nullptr, pt, h,
+                                    bh, bl, net == 0 ? (l - 1) * 8 + 5 : -1);
+            if (net == 0 && l == 4) H2_STAMP_REAL(63);
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
         ks = h2_wexp(tab[5]) + kx;
         f32x16 o[1];
         h2_wait();
-        if (net == 0) h2_stage<H2_L0_F4>(cb ^ 1, w2_t);
-        h2_acc_bias_lds<1>(o, cb, h, ks);
-        h2_layer<8, 1>(lds_h2 + cb * H2_BUF_F4, bh, bl, o, lane);
-        cb ^= 1;
+        if (TWO) fetch_after(5, cb ^ 1);
+        h2_layer<8, 1, true>(lds_h2 + cb * H2_BUF_F4, bh, bl, o, lane);
+        const f32x4 b5 = lds_h2[cb * H2_BUF_F4 + H2_LH_F4 + 32 + h];   // rows 0..3 of the padded tile (slot 1)
+        if (TWO) {
+            cb ^= 1;
+        } else {
+            __syncthreads();
+            fetch_after(5, cb);
+        }
+        const float sc = __builtin_ldexpf(1.0f, -ks);
         if (h == 0 && p < M) {
             if (net == 0) {
-                out_deform[p * 3 + 0] = __builtin_ldexpf(o[0][0], -ks);
-                out_deform[p * 3 + 1] = __builtin_ldexpf(o[0][1], -ks);
-                out_deform[p * 3 + 2] = __builtin_ldexpf(o[0][2], -ks);
+                out_deform[p * 3 + 0] = __builtin_fmaf(o[0][0], sc, b5[0]);
+                out_deform[p * 3 + 1] = __builtin_fmaf(o[0][1], sc, b5[1]);
+                out_deform[p * 3 + 2] = __builtin_fmaf(o[0][2], sc, b5[2]);
             } else {
-                out_topo[p * 2 + 0] = __builtin_ldexpf(o[0][0], -ks);
-                out_topo[p * 2 + 1] = __builtin_ldexpf(o[0][1], -ks);
+                out_topo[p * 2 + 0] = __builtin_fmaf(o[0][0], sc, b5[0]);
+                out_topo[p * 2 + 1] = __builtin_fmaf(o[0][1], sc, b5[1]);
             }
         }
     }
@@ -330,14 +428,16 @@ __device__ __forceinline__ int h2_epilogue_bwd(f32x16 (&acc)[4], int ks, uint2 m
     return d + ks;
 }
 
-__global__ __launch_bounds__(H2_THREADS, 2) void warp_bwd_h2_kernel(const float *__restrict__ x, const float *__restrict__ g_deform,
-                                                                    const float *__restrict__ g_topo, const f32x4 *__restrict__ w2T_d,
-                                                                    const f32x4 *__restrict__ w2T_t, int n_bands,
-                                                                    const float *__restrict__ acts, float *__restrict__ dpre,
-                                                                    float *__restrict__ g_x, int64_t M, int64_t n_tiles) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void warp_bwd_h2_kernel(const float *__restrict__ x, const float *__restrict__ g_deform,
+                                                                 const float *__restrict__ g_topo, const f32x4 *__restrict__ w2T_d,
+                                                                 const f32x4 *__restrict__ w2T_t, int n_bands,
+                                                                 const float *__restrict__ acts, float *__restrict__ dpre,
+                                                                 float *__restrict__ g_x, int64_t M, int64_t n_tiles) {
+    constexpr bool TWO = NW == 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
-    const int64_t tile_id = (int64_t)blockIdx.x * (H2_THREADS / 64) + wave;
+    const int64_t tile_id = (int64_t)blockIdx.x * NW + wave;
     const int64_t p = tile_id * TILE + pt;
     const bool live = p < M;
     // the scratch holds whole 128-point blocks: a wave beyond it (tail of the last 256-point workgroup) runs the chain on
@@ -348,7 +448,7 @@ __global__ __launch_bounds__(H2_THREADS, 2) void warp_bwd_h2_kernel(const float 
     float gx[3] = {0.f, 0.f, 0.f};
 
     int cb = 0;
-    h2_stage<H2_T5_F4>(cb, w2T_d);
+    h2_stage<H2_T5_F4, NW>(cb, w2T_d);
     for (int net = 0; net < 2; net++) {
         const f32x4 *wt = net ? w2T_t : w2T_d;
         const uint32_t *tab = reinterpret_cast<const uint32_t *>(wt + H2_TABT_F4);
@@ -359,6 +459,15 @@ __global__ __launch_bounds__(H2_THREADS, 2) void warp_bwd_h2_kernel(const float 
         uint2 msk[5];
 #pragma unroll
         for (int l = 0; l < 5; l++) msk[l] = mk[l * 64];
+        // the fetch of the stage after chain position j (0 = T5, 1..4 = T4..T1, 5 = T0), into buffer `buf`
+        auto fetch_after = [&](int j, int buf) {
+            if (j < 4)
+                h2_stage<H2_LH_F4, NW>(buf, wt + H2_T5_F4 + j * H2_LH_F4);
+            else if (j == 4 && g_x)
+                h2_stage<H2_T0_F4, NW>(buf, wt + H2_T5_F4 + 4 * H2_LH_F4);
+            else if (net == 0)
+                h2_stage<H2_T5_F4, NW>(buf, w2T_t);
+        };
         // dPre5: rows 0..nout-1 carry the incoming gradient (no activation on the last layer)
         float d5[16];
 #pragma unroll
@@ -381,23 +490,27 @@ __global__ __launch_bounds__(H2_THREADS, 2) void warp_bwd_h2_kernel(const float 
         int ks = h2_wexp(tab[0]) + kx;
         f32x16 acc[4];
         h2_wait();
-        h2_stage<H2_LH_F4>(cb ^ 1, wt + H2_T5_F4);
+        if (TWO) fetch_after(0, cb ^ 1);
         h2_layer<2, 4, true>(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
-        cb ^= 1;
+        if (TWO) {
+            cb ^= 1;
+        } else {
+            __syncthreads();
+            fetch_after(0, cb);
+        }
         kx = h2_epilogue_bwd(acc, ks, msk[4], dt ? dt + 4 * 128 * TILE : nullptr, pt, h, bh, bl);
         for (int l = 4; l >= 1; l--) {
             // dH_l = W_l^T dPre_l, then dPre_{l-1} = dH_l masked by H_l's ReLU bits
             ks = h2_wexp(tab[5 - l]) + kx;
             h2_wait();
-            if (l > 1)
-                h2_stage<H2_LH_F4>(cb ^ 1, wt + H2_T5_F4 + (5 - l) * H2_LH_F4);
-            else if (g_x)
-                h2_stage<H2_T0_F4>(cb ^ 1, wt + H2_T5_F4 + 4 * H2_LH_F4);
-            else if (net == 0)
-                h2_stage<H2_T5_F4>(cb ^ 1, w2T_t);
-            acc_zero<4>(acc);
+            if (TWO) fetch_after(5 - l, cb ^ 1);
             h2_hidden(lds_h2 + cb * H2_BUF_F4, bh, bl, acc, lane);
-            cb ^= 1;
+            if (TWO) {
+                cb ^= 1;
+            } else {
+                __syncthreads();
+                fetch_after(5 - l, cb);
+            }
             kx = h2_epilogue_bwd(acc, ks, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bl);
         }
         if (g_x) {
@@ -405,9 +518,14 @@ __global__ __launch_bounds__(H2_THREADS, 2) void warp_bwd_h2_kernel(const float 
             ks = h2_wexp(tab[5]) + kx;
             f32x16 e[2];
             h2_wait();
-            if (net == 0) h2_stage<H2_T5_F4>(cb ^ 1, w2T_t);
+            if (TWO) fetch_after(5, cb ^ 1);
             h2_layer<8, 2, true>(lds_h2 + cb * H2_BUF_F4, bh, bl, e, lane);
-            cb ^= 1;
+            if (TWO) {
+                cb ^= 1;
+            } else {
+                __syncthreads();
+                fetch_after(5, cb);
+            }
             float dsc[18];
             enc_deriv_parked(atile, pt, h, dsc);
 #pragma unroll
@@ -528,11 +646,25 @@ extern "C" int mh_h2_slice(const float *src, void *dst, int32_t n_blocks, const 
 extern "C" int64_t mh_warp_w2_bytes(void) { return (int64_t)H2_NET_F4 * 16; }
 extern "C" int64_t mh_warp_w2T_bytes(void) { return (int64_t)H2_NETT_F4 * 16; }
 
+// workgroup shape: 8 = one 8-wave workgroup per CU with two LDS buffers, 4 = two independent 4-wave workgroups per CU with one
+// buffer each.  Measured at 2 M points: forward 2.59 (8) / 2.53 ms (4), backward-data 2.39 (8) / 2.58 ms (4) -> the defaults;
+// MORPHEUS_H2_WAVES=4|8 forces both (A/B switch).
+static int h2_waves(bool fwd) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("MORPHEUS_H2_WAVES");
+        forced = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : 0);
+    }
+    return forced ? forced : (fwd ? 4 : 8);
+}
+
 static int h2_lds_opt_in() {
     static int done = 0;
     if (!done) {
-        if (hipFuncSetAttribute((const void *)warp_fwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_bwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)warp_fwd_h2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_bwd_h2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_fwd_h2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_BUF_F4 * 16) != hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_bwd_h2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_BUF_F4 * 16) != hipSuccess)
             return MH_ERR_LAUNCH;
         done = 1;
     }
@@ -546,12 +678,17 @@ extern "C" int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *
     if (M < 0 || !x || !bias0_d || !bias0_t || !w2_d || !w2_t || !bias_d || !bias_t || !out_deform || !out_topo || n_bands < 0 ||
         n_bands > 6)
         return MH_ERR_ARG;
-    const int64_t blocks = (M + H2_BLOCK_PTS - 1) / H2_BLOCK_PTS;
+    const int nw = h2_waves(true);
+    const int64_t blocks = (M + nw * TILE - 1) / (nw * TILE);
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (h2_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    hipLaunchKernelGGL(warp_fwd_h2_kernel, dim3((unsigned)blocks), dim3(H2_THREADS), H2_LDS_BYTES, mh_stream(stream), x, slot, bias0_d,
-                       bias0_t, reinterpret_cast<const f32x4 *>(w2_d), reinterpret_cast<const f32x4 *>(w2_t), bias_d, bias_t,
-                       (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    const f32x4 *wd = reinterpret_cast<const f32x4 *>(w2_d), *wt = reinterpret_cast<const f32x4 *>(w2_t);
+    if (nw == 8)
+        hipLaunchKernelGGL(warp_fwd_h2_kernel<8>, dim3((unsigned)blocks), dim3(512), H2_LDS_BYTES, mh_stream(stream), x, slot, bias0_d,
+                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    else
+        hipLaunchKernelGGL(warp_fwd_h2_kernel<4>, dim3((unsigned)blocks), dim3(256), H2_BUF_F4 * 16, mh_stream(stream), x, slot, bias0_d,
+                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
@@ -560,12 +697,17 @@ extern "C" int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const 
                                    int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !x || !w2T_d || !w2T_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
-    const int64_t blocks = (M + H2_BLOCK_PTS - 1) / H2_BLOCK_PTS;
+    const int nw = h2_waves(false);
+    const int64_t blocks = (M + nw * TILE - 1) / (nw * TILE);
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (h2_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    hipLaunchKernelGGL(warp_bwd_h2_kernel, dim3((unsigned)blocks), dim3(H2_THREADS), H2_LDS_BYTES, mh_stream(stream), x, g_deform, g_topo,
-                       reinterpret_cast<const f32x4 *>(w2T_d), reinterpret_cast<const f32x4 *>(w2T_t), (int)n_bands, acts, dpre, g_x, M,
-                       mh_mlp_tiles(M));
+    const f32x4 *wd = reinterpret_cast<const f32x4 *>(w2T_d), *wt = reinterpret_cast<const f32x4 *>(w2T_t);
+    if (nw == 8)
+        hipLaunchKernelGGL(warp_bwd_h2_kernel<8>, dim3((unsigned)blocks), dim3(512), H2_LDS_BYTES, mh_stream(stream), x, g_deform, g_topo,
+                           wd, wt, (int)n_bands, acts, dpre, g_x, M, mh_mlp_tiles(M));
+    else
+        hipLaunchKernelGGL(warp_bwd_h2_kernel<4>, dim3((unsigned)blocks), dim3(256), H2_BUF_F4 * 16, mh_stream(stream), x, g_deform, g_topo,
+                           wd, wt, (int)n_bands, acts, dpre, g_x, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

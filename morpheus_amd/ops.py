@@ -100,12 +100,18 @@ GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B swit
 # Measured on MI355X (cfg3, same box): 1.05 ms against 2 x 0.43 = 0.86 ms for two launches -- twice the gathers in flight per
 # lane cost more occupancy than the shared index arithmetic saves -- so one launch per table stays the default.
 GRID_FWD_TWO = os.environ.get("MORPHEUS_GRID_FWD", "") == "two"
-# warp nets: "b3" (default) = exact fp32 products from three bf16 slices on the bf16 matrix pipe (csrc/mlp_b3.hip: values, parked
-# tiles, accumulation and results stay fp32, fp32-grade error), "f32" = the native fp32 MFMA kernels of csrc/mlp.hip (A/B switch)
-MLP_B3 = os.environ.get("MORPHEUS_MLP", "b3") == "b3"
-# "h2" = the same scheme with two fp16 slices per operand and three slice products (csrc/mlp_h2.hip): half the matrix work,
-# per-layer / per-point power-of-two scales keep the slices inside fp16's exponent range; weight gradients as in "b3"
-MLP_H2 = os.environ.get("MORPHEUS_MLP", "b3") == "h2"
+# warp nets (MORPHEUS_MLP): fp32 values, parked tiles, accumulation and results in every mode; what differs is how a product
+# reaches the matrix cores.
+#   "h2" (default) = two fp16 slices per operand at per-layer / per-point power-of-two scales (22 significand bits), three
+#          slice products per MAC through v_mfma_f32_32x32x16_f16 (csrc/mlp_h2.hip); weight gradients on the "b3" kernels
+#   "b3" = three bf16 slices per operand (exact split), six slice products per MAC (csrc/mlp_b3.hip)
+#   "f32" = the native fp32 MFMA kernels of csrc/mlp.hip
+# Both sliced forms are held to the fp32 kernels' own error against float64 (test_warp_sliced_arithmetic_is_fp32_grade).
+_MLP_MODE = os.environ.get("MORPHEUS_MLP", "h2")
+if _MLP_MODE not in ("h2", "b3", "f32"):
+    raise ValueError(f"MORPHEUS_MLP={_MLP_MODE!r}: expected h2, b3 or f32")
+MLP_B3 = _MLP_MODE == "b3"
+MLP_H2 = _MLP_MODE == "h2"
 
 
 def _warp_mode() -> str:

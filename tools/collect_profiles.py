@@ -77,7 +77,7 @@ def main():
     os.makedirs(PROF, exist_ok=True)
     for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b"),
                     ("bench_train_real.log", "train_real"), ("bench_density128.log", "density128"), ("bench_n2.log", "n2_one_gpu_gloo"),
-                    ("bench_cfg3_f32.log", "cfg3_fp32_mfma_kernels")):
+                    ("bench_cfg3_f32.log", "cfg3_fp32_mfma_kernels"), ("bench_cfg3_b3.log", "cfg3_bf16x3_kernels")):
         line = json_line(os.path.join(OUT, log))
         if line:
             open(os.path.join(PROF, f"{tag}_bench_{wl}.json"), "w").write(line)
@@ -93,7 +93,8 @@ def main():
         if lines:
             open(os.path.join(PROF, f"{tag}_parity_report.jsonl"), "w").writelines(lines)
             print("parity", len(lines), "records")
-    for log, name in (("phase_trace.log", "phase_trace_warp_fwd_fp32_mfma.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd.txt"),
+    for log, name in (("phase_trace.log", "phase_trace_warp_fwd_fp32_mfma.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd_bf16x3.txt"),
+                      ("phase_trace_h2.log", "phase_trace_warp_fwd.txt"),
                       ("hbm_rates.log", "micro_hbm_rates.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
                       ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt")):
         src = os.path.join(OUT, log)
