@@ -254,6 +254,12 @@ int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *bias0_d, co
                    float *out_topo, float *acts, int64_t M, void *stream);
 int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const float *g_topo, const void *w2T_d, const void *w2T_t,
                         int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream);
+/* mh_field_fwd_h2: mh_field_fwd with the fp16x2 pack of the six field layers and their two scale tables (mh_field_w2_bytes()
+ *   bytes, resident in LDS; packing.py field_joint_packer().h2_blocks).  Same outputs, same parked tiles. */
+int64_t mh_field_w2_bytes(void);
+int mh_field_fwd_h2(const float *xc, const float *feat_s, const float *feat_c, const float *topo, const void *w2,
+                    const float *bias, const float *beta, int32_t n_bands, int32_t with_color, float *sdf, float *sigma,
+                    float *albedo, float *acts, int64_t M, void *stream);
 /* backward-data: consumes g_deform [M,3], g_topo [M,2] (either may be NULL = zero), acts from the
  * forward and the TRANSPOSED packs; writes g_x [M,3] (d/dx through the frequency encoding; pass NULL when the
  * sample positions carry no gradient and the first-layer transposed GEMM is skipped) and

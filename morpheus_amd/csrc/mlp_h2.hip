@@ -551,6 +551,213 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_h2_kernel(const float *__
     }
 }
 
+// ---- canonical field forward (sdf_net + Laplace density, color_net; models/model.py:273-307) --------------------------------
+// mlp_b3.hip's field_fwd_b3_kernel with two fp16 slices: a persistent 8-wave workgroup per CU keeps every layer's [h | l] planes
+// in LDS (96 KB + the scale table), a wave owns a 32-point tile through both nets with no barrier, and parks the tile in
+// exactly the fp32 kernel's layout (mh_field_bwd_fused consumes it).
+//   sliced pack (packing.py, field_joint_packer().h2_blocks), float4 offsets: S0 0 (K = 80: 5 k16 steps, 2 tiles), S1 1536,
+//   S2 2560, C0 3584, C1 4608 (K = 64: 4 steps, 2 tiles), C2 5632 (1 tile), the six layers' scale table 6144; 6656 in all
+#define FH2_S0 0
+#define FH2_S1 1536
+#define FH2_S2 2560
+#define FH2_C0 3584
+#define FH2_C1 4608
+#define FH2_C2 5632
+#define FH2_TAB 6144
+#define FH2_F4 6656
+#define FH2_THREADS 512
+
+__device__ __forceinline__ float laplace_sigma_h2(float s, float beta) {
+    // density.py:22-31: (1/beta) * (0.5 + 0.5 * sign(s) * expm1(-|s|/beta))
+    const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
+    return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+}
+
+// 64 pre-activations of a lane (two accumulator tiles, acc = 2^ks W x): y = relu(acc . 2^-ks + b), park feature-major, sign mask,
+// the point's next exponent, slices of k16 steps 0..3.  bias: the layer's row in accumulator order (global, L1-resident)
+__device__ __forceinline__ int fh2_epilogue(f32x16 (&acc)[2], int ks, const float *__restrict__ bias, float *__restrict__ ht,
+                                            uint32_t *__restrict__ mk, int pt, int h, FragH (&bh)[8], FragH (&bl)[8]) {
+    const float sc = __builtin_ldexpf(1.0f, -ks);
+    int mi = 0;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 32 * t + 8 * r4 + 4 * h);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float y = relu_i(__builtin_fmaf(acc[t][4 * r4 + c], sc, b[c]));
+                acc[t][4 * r4 + c] = y;
+                mi = max(mi, __float_as_int(y));
+            }
+        }
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 1; t >= 0; t--)
+#pragma unroll
+        for (int r = 15; r >= 0; r--) m = push_nz(m, acc[t][r]);
+    if (ht) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+    }
+    if (mk) *mk = m;
+    const int kx = h2_point_shift(mi, H2_FWD_CLAMP);
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int e2 = 0; e2 < 4; e2++)
+                split_h(__builtin_ldexpf(acc[t][8 * s2 + 2 * e2], kx), __builtin_ldexpf(acc[t][8 * s2 + 2 * e2 + 1], kx),
+                        bh[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+    return kx;
+}
+
+__global__ __launch_bounds__(FH2_THREADS, 2) void field_fwd_h2_kernel(
+    const float *__restrict__ xc, const float *__restrict__ feat_s, const float *__restrict__ feat_c, const float *__restrict__ topo,
+    const f32x4 *__restrict__ w2, const float *__restrict__ bias, const float *__restrict__ beta_p, int n_bands, int with_color,
+    float *__restrict__ sdf, float *__restrict__ sigma, float *__restrict__ albedo, float *__restrict__ acts, int64_t M,
+    int64_t n_tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt = lane & 31, h = lane >> 5;
+    {
+        const int n = with_color ? FH2_F4 : FH2_C0;      // the sdf-only pass (finite-difference taps) needs S0..S2 only
+        for (int i = threadIdx.x; i < n; i += FH2_THREADS) lds_h2[i] = w2[i];
+    }
+    // weight exponents of the six layers (uniform: scalar loads)
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(w2 + FH2_TAB);
+    const int kws0 = h2_wexp(tab[0]), kws1 = h2_wexp(tab[1]), kws2 = h2_wexp(tab[2]);
+    const int kwc0 = h2_wexp(tab[3]), kwc1 = h2_wexp(tab[4]), kwc2 = h2_wexp(tab[5]);
+    __syncthreads();
+    for (int64_t tile_id = (int64_t)blockIdx.x * (FH2_THREADS / 64) + wave; tile_id < n_tiles;
+         tile_id += (int64_t)gridDim.x * (FH2_THREADS / 64)) {
+        const int64_t p = tile_id * TILE + pt;
+        const bool live = p < M;
+        const int64_t pc = live ? p : M - 1;
+        float xv[3] = {xc[pc * 3 + 0], xc[pc * 3 + 1], xc[pc * 3 + 2]};
+        float *tile = acts ? acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE) : nullptr;
+        uint32_t *mk = tile ? reinterpret_cast<uint32_t *>(tile + FIELD_HID_ROWS * TILE) + lane : nullptr;
+        FragH bh[8], bl[8];
+        f32x16 acc[2];
+        int kx;
+        {
+            // sdf L0 input, k-step ordered: 20 encoding steps | 16 hash-feature steps (level pairs) | topo | zero pad
+            float bin0[40];
+            enc_bin(xv, h, n_bands, bin0, nullptr);
+            const f32x4 *fs = reinterpret_cast<const f32x4 *>(feat_s + pc * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 v = fs[q];
+#pragma unroll
+                for (int c = 0; c < 4; c++) bin0[20 + 4 * q + c] = v[c];
+            }
+            bin0[36] = topo ? topo[pc * 2 + h] : 0.f;
+            bin0[37] = bin0[38] = bin0[39] = 0.f;
+            if (tile) {
+#pragma unroll
+                for (int k = 0; k < 48; k++) PARK_STORE(k < 40 ? bin0[k] : 0.f, &tile[(2 * k + h) * TILE + pt]);   // rows 80..95 pad
+            }
+            int m0 = 0;
+#pragma unroll
+            for (int k = 0; k < 37; k++) m0 = max(m0, __float_as_int(bin0[k]) & 0x7fffffff);
+            kx = h2_point_shift(m0, H2_FWD_CLAMP);
+#pragma unroll
+            for (int s = 0; s < 5; s++)
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++)
+                    split_h(__builtin_ldexpf(bin0[8 * s + 2 * e2], kx), __builtin_ldexpf(bin0[8 * s + 2 * e2 + 1], kx), bh[s].u[e2],
+                            bl[s].u[e2]);
+        }
+        // sdf L0: 73 -> 64
+        int ks = kws0 + kx;
+        h2_layer<5, 2, true>(lds_h2 + FH2_S0, bh, bl, acc, lane);
+        kx = fh2_epilogue(acc, ks, bias, tile ? tile + 96 * TILE : nullptr, mk ? mk + 0 * 64 : nullptr, pt, h, bh, bl);
+        // sdf L1: 64 -> 64
+        ks = kws1 + kx;
+        h2_layer<4, 2, true>(lds_h2 + FH2_S1, bh, bl, acc, lane);
+        kx = fh2_epilogue(acc, ks, bias + 64, tile ? tile + 160 * TILE : nullptr, mk ? mk + 1 * 64 : nullptr, pt, h, bh, bl);
+        // sdf L2: 64 -> [geo(32) | sdf], no activation
+        ks = kws2 + kx;
+        const float sc2 = __builtin_ldexpf(1.0f, -ks);
+        if (!with_color) {
+            // sdf-only pass: the geo tile feeds nothing -- evaluate the tile holding the sdf row only (plane stride of the
+            // two-tile pack: 2 * 4 * 64)
+            f32x16 a1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const f32x4 *w = lds_h2 + FH2_S2 + 4 * 64;      // tile 1 of each plane
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                FragH ah, al;
+                ah.f = w[0 * 512 + s * 64 + lane];
+                al.f = w[1 * 512 + s * 64 + lane];
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bh[s].h, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bl[s].h, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bh[s].h, a1, 0, 0, 0);
+            }
+            if (h == 0 && live) {
+                const float sv = __builtin_fmaf(a1[0], sc2, bias[128 + 32]);
+                sdf[p] = sv;
+                if (sigma) sigma[p] = laplace_sigma_h2(sv, *beta_p);
+            }
+            continue;
+        }
+        h2_layer<4, 2, true>(lds_h2 + FH2_S2, bh, bl, acc, lane);
+        if (h == 0 && live) {
+            const float sv = __builtin_fmaf(acc[1][0], sc2, bias[128 + 32]);
+            sdf[p] = sv;
+            if (sigma) sigma[p] = laplace_sigma_h2(sv, *beta_p);
+        }
+        // color L0: [hash_c(32) | geo(32)] -> 64
+        {
+            float binc[32];
+            const f32x4 *fc = reinterpret_cast<const f32x4 *>(feat_c + pc * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 v = fc[q];
+#pragma unroll
+                for (int c = 0; c < 4; c++) binc[4 * q + c] = v[c];
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 128 + 8 * r4 + 4 * h);
+#pragma unroll
+                for (int c = 0; c < 4; c++) binc[16 + 4 * r4 + c] = __builtin_fmaf(acc[0][4 * r4 + c], sc2, b[c]);
+            }
+            if (tile) {
+#pragma unroll
+                for (int k = 0; k < 32; k++) PARK_STORE(binc[k], &tile[(224 + 2 * k + h) * TILE + pt]);
+            }
+            int mc = 0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) mc = max(mc, __float_as_int(binc[k]) & 0x7fffffff);
+            kx = h2_point_shift(mc, H2_FWD_CLAMP);
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++)
+                    split_h(__builtin_ldexpf(binc[8 * s + 2 * e2], kx), __builtin_ldexpf(binc[8 * s + 2 * e2 + 1], kx), bh[s].u[e2],
+                            bl[s].u[e2]);
+        }
+        ks = kwc0 + kx;
+        h2_layer<4, 2, true>(lds_h2 + FH2_C0, bh, bl, acc, lane);
+        kx = fh2_epilogue(acc, ks, bias + 192, tile ? tile + 288 * TILE : nullptr, mk ? mk + 2 * 64 : nullptr, pt, h, bh, bl);
+        // color L1
+        ks = kwc1 + kx;
+        h2_layer<4, 2, true>(lds_h2 + FH2_C1, bh, bl, acc, lane);
+        kx = fh2_epilogue(acc, ks, bias + 256, tile ? tile + 352 * TILE : nullptr, mk ? mk + 3 * 64 : nullptr, pt, h, bh, bl);
+        // color L2: 64 -> 3, sigmoid
+        ks = kwc2 + kx;
+        f32x16 o[1];
+        h2_layer<4, 1, true>(lds_h2 + FH2_C2, bh, bl, o, lane);
+        if (h == 0 && live) {
+            const float sc = __builtin_ldexpf(1.0f, -ks);
+#pragma unroll
+            for (int c = 0; c < 3; c++) albedo[p * 3 + c] = 1.0f / (1.0f + expf(-__builtin_fmaf(o[0][c], sc, bias[320 + c])));
+        }
+    }
+}
+
 // ---- weight slices --------------------------------------------------------------------------------------------------
 // One pass finds each layer's largest |w| (fp32 bits into the net's table), the next cuts the layers -- gathered in fragment
 // order by the caller (packing.py: fwd3 / bwd3 maps, shared with mlp_b3.hip) -- into [h | l] fp16 planes at the layer's scale.
@@ -708,6 +915,30 @@ extern "C" int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const 
     else
         hipLaunchKernelGGL(warp_bwd_h2_kernel<4>, dim3((unsigned)blocks), dim3(256), H2_BUF_F4 * 16, mh_stream(stream), x, g_deform, g_topo,
                            wd, wt, (int)n_bands, acts, dpre, g_x, M, mh_mlp_tiles(M));
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int64_t mh_field_w2_bytes(void) { return (int64_t)FH2_F4 * 16; }
+
+extern "C" int mh_field_fwd_h2(const float *xc, const float *feat_s, const float *feat_c, const float *topo, const void *w2,
+                               const float *bias, const float *beta, int32_t n_bands, int32_t with_color, float *sdf, float *sigma,
+                               float *albedo, float *acts, int64_t M, void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !xc || !feat_s || !w2 || !bias || !sdf || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
+    if (with_color && (!feat_c || !albedo)) return MH_ERR_ARG;
+    const int64_t n_tiles = mh_mlp_tiles(M);   // dead tail tiles are processed too: the backward reads every scratch tile
+    static int ok = 0;
+    if (!ok) {
+        if (hipFuncSetAttribute((const void *)field_fwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FH2_F4 * 16) != hipSuccess)
+            return MH_ERR_LAUNCH;
+        ok = 1;
+    }
+    const int64_t need = (n_tiles + FH2_THREADS / 64 - 1) / (FH2_THREADS / 64);
+    const int64_t cus = mh_cu_count();
+    hipLaunchKernelGGL(field_fwd_h2_kernel, dim3((unsigned)(need < cus ? need : cus)), dim3(FH2_THREADS), FH2_F4 * 16,
+                       mh_stream(stream), xc, feat_s, feat_c, topo, reinterpret_cast<const f32x4 *>(w2), bias, beta, (int)n_bands,
+                       (int)with_color, sdf, sigma, albedo, acts, M, n_tiles);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

@@ -117,7 +117,11 @@ MLP_H2 = _MLP_MODE == "h2"
 def _warp_mode() -> str:
     return "h2" if MLP_H2 else ("b3" if MLP_B3 else "")
 # field nets (sdf / colour): forward on the bf16 pipe too (mh_field_fwd_b3); the fused backward stays on the fp32 MFMA
-FIELD_B3 = os.environ.get("MORPHEUS_FIELD_FWD", "b3") == "b3"
+_FIELD_MODE = os.environ.get("MORPHEUS_FIELD_FWD", "h2")   # "h2" (default: mh_field_fwd_h2) | "b3" (mh_field_fwd_b3) | "f32"
+if _FIELD_MODE not in ("h2", "b3", "f32"):
+    raise ValueError(f"MORPHEUS_FIELD_FWD={_FIELD_MODE!r}: expected h2, b3 or f32")
+FIELD_B3 = _FIELD_MODE == "b3"
+FIELD_H2 = _FIELD_MODE == "h2"
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
@@ -677,7 +681,8 @@ def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[t
 def prepare_field_operands(params: Sequence[torch.Tensor]) -> MLPOperands:
     """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
     jp = field_joint_packer()
-    mode = "b3" if FIELD_B3 else ""
+    # the bf16x3 form of the fused backward (opt-in) needs the transposed bf16x3 slices: it pins the operands to "b3"
+    mode = "b3" if (FIELD_B3 or (FIELD_BWD_B3 and not FIELD_BWD_SPLIT)) else ("h2" if FIELD_H2 else "")
     return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), *params), mode=mode)
 
 
@@ -776,8 +781,9 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     albedo = torch.empty(M, 3, device=dev) if with_color else None
     _e = TIMER.start()
     if opnd.w3 is not None:
-        check(lib.mh_field_fwd_b3(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(opnd.w3[0]), ptr(b), ptr(beta_c), n_bands,
-                                  int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd_b3")
+        fwd = lib.mh_field_fwd_h2 if opnd.mode == "h2" else lib.mh_field_fwd_b3
+        check(fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(opnd.w3[0]), ptr(b), ptr(beta_c), n_bands,
+                  int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd_" + opnd.mode)
     else:
         check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands, int(bool(with_color)),
                                ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd")
@@ -794,7 +800,7 @@ FIELD_BWD_B3 = os.environ.get("MORPHEUS_FIELD_BWD", "") == "b3"
 
 def _field_wT(opnd):
     """-> (transposed weight operand for the field backward, is it the bf16x3 pack?)"""
-    if FIELD_BWD_B3 and not FIELD_BWD_SPLIT and opnd.wT3 is not None:
+    if FIELD_BWD_B3 and not FIELD_BWD_SPLIT and opnd.wT3 is not None and opnd.mode == "b3":
         return opnd.wT3[0], True
     return opnd.wT[0], False
 

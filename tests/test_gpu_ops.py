@@ -202,10 +202,13 @@ def test_warp_mlp(kind, max_level, mlp, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["a", "b"])
 @pytest.mark.parametrize("with_color", [True, False])
-def test_field_mlp(kind, with_color):
-    """sdf_net + Laplace density + color_net (fused MFMA kernel) vs the oracle, given identical
-    hash features (the hash grid itself is checked above)."""
+@pytest.mark.parametrize("fwd", ["h2", "b3", "f32"])
+def test_field_mlp(kind, with_color, fwd, monkeypatch):
+    """sdf_net + Laplace density + color_net (fused MFMA kernels; forward with fp16 x 2 slices = the default, bf16 x 3 slices,
+    native fp32 MFMA) vs the oracle, given identical hash features (the hash grid itself is checked above)."""
     from morpheus_amd import ops
+    monkeypatch.setattr(ops, "FIELD_H2", fwd == "h2")
+    monkeypatch.setattr(ops, "FIELD_B3", fwd == "b3")
     M = 777
     x = synth.hash_tensor((M, 3), 600, 1.0)
     fs, fc = synth.hash_tensor((M, 32), 601, 0.1), synth.hash_tensor((M, 32), 602, 0.1)

@@ -284,3 +284,28 @@ def test_b3_fragment_index_matches_the_mfma_layout():
     assert np.abs(out - nets[0][0][0].numpy() @ enc).max() < 1e-4
     # pack geometry the kernels hard-wire (csrc/mlp_b3.hip: B3_NET_F4, B3_NETT_F4)
     assert jp.w3 == [(0, 28672), (28672, 28672)] and jp.wT3 == [(0, 29184), (29184, 29184)]
+
+
+def test_h2_pack_geometry_matches_the_kernels(lib):
+    """The fp16x2 packs (csrc/mlp_h2.hip) reuse the bf16x3 gathers; what the kernels hard-wire is the block geometry: two planes
+    per block in whole 512-float4 DMA rounds, one round with the layers' scale table behind every net, both k-halves of a
+    128 x 128 layer in ONE scale group, and the byte sizes the C-ABI reports."""
+    from morpheus_amd.packing import field_joint_packer, warp_joint_packer
+    jp = warp_joint_packer()
+    assert jp.w2 == [(0, 19456), (19456, 19456)] and jp.wT2 == [(0, 19968), (19968, 19968)]
+    assert lib.mh_warp_w2_bytes() == 19456 * 16 and lib.mh_warp_w2T_bytes() == 19968 * 16
+    # forward net 0: L0 (1536 float4), four layers of two 2048-float4 k-half blocks, L5 (1024), then the table
+    assert [b[2] for b in jp.h2_blocks[:10]] == [0, 1536, 3584, 5632, 7680, 9728, 11776, 13824, 15872, 17920]
+    assert [b[3] for b in jp.h2_blocks[:10]] == [0, 1, 1, 2, 2, 3, 3, 4, 4, 5]
+    assert jp.h2_table[:6] == [4 * 18944 + i for i in range(6)] and jp.h2_table[6:] == [4 * (19456 + 18944) + i for i in range(6)]
+    # transposed chain: T5 (1024), T4..T1, T0 (2048), table at 19456
+    assert [b[2] for b in jp.h2T_blocks[:10]] == [0, 1024, 3072, 5120, 7168, 9216, 11264, 13312, 15360, 17408]
+    assert jp.h2T_table[:6] == [4 * 19456 + i for i in range(6)]
+    for blocks in (jp.h2_blocks, jp.h2T_blocks):
+        src = 0
+        for so, n, d4, ly in blocks:                      # the gathered source is consumed block after block
+            assert so == src and n % 8 == 0 and d4 % 512 == 0
+            src += n
+    fp = field_joint_packer()
+    assert fp.w2 == [(0, 6656)] and lib.mh_field_w2_bytes() == 6656 * 16
+    assert [b[2] for b in fp.h2_blocks] == [0, 1536, 2560, 3584, 4608, 5632] and fp.h2_table == [4 * 6144 + i for i in range(6)]
