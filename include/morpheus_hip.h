@@ -251,9 +251,21 @@ int64_t mh_warp_w2_bytes(void);
 int64_t mh_warp_w2T_bytes(void);
 int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w2_d,
                    const void *w2_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
-                   float *out_topo, float *acts, int64_t M, void *stream);
+                   float *out_topo, float *acts, uint32_t *amax, int64_t M, void *stream);
 int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const float *g_topo, const void *w2T_d, const void *w2T_t,
-                        int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream);
+                        int32_t n_bands, const float *acts, float *dpre, float *g_x, uint32_t *amax, int64_t M, void *stream);
+/* amax (NULL = not recorded): mh_h2_amax_words() device words (64 copies of a 32-word table, one per workgroup residue, against
+ * atomic contention), zeroed by the caller before the forward; the kernels atomicMax the largest magnitude (fp32 bits) of
+ * every row block they park into it -- word 0: the encoding rows, 1 + 5 net + j: the output of layer j (0..4),
+ * 16 + 6 net + l: dPre_l.  mh_mlp_wgrad_h2 takes its per-tensor scales from it (maximum over the copies):
+ * mh_mlp_wgrad_b3 whose 128-row layers run, from 16 384 tiles on, on two fp16 slices per operand; a_slot[l] / b_slot[l] = the table
+ * words of layer l's dPre and of its input activations (negative: the layer stays on the bf16 x 3 kernel). */
+int64_t mh_h2_amax_words(void);
+int mh_mlp_wgrad_h2(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
+                    int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
+                    const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
+                    float *db_raw, int64_t n_tiles, const uint32_t *amax, const int32_t *a_slot_host,
+                    const int32_t *b_slot_host, void *stream);
 /* mh_field_fwd_h2: mh_field_fwd with the fp16x2 pack of the six field layers and their two scale tables (mh_field_w2_bytes()
  *   bytes, resident in LDS; packing.py field_joint_packer().h2_blocks).  Same outputs, same parked tiles. */
 int64_t mh_field_w2_bytes(void);

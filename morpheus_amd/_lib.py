@@ -61,11 +61,13 @@ _SIGS = {
     "mh_warp_w3_bytes": (_I64, []),
     "mh_h2_slice": (ctypes.c_int, [_P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P]),
     "mh_warp_w2_bytes": (_I64, []),
+    "mh_h2_amax_words": (_I64, []),
     "mh_field_w2_bytes": (_I64, []),
     "mh_field_fwd_h2": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_warp_w2T_bytes": (_I64, []),
-    "mh_warp_fwd_h2": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _I64, _P]),
-    "mh_warp_bwd_data_h2": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
+    "mh_warp_fwd_h2": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _P, _I64, _P]),
+    "mh_warp_bwd_data_h2": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _P, _I64, _P]),
+    "mh_mlp_wgrad_h2": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "mh_field_w3_bytes": (_I64, []),
     "mh_field_fwd_b3": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_warp_w3T_bytes": (_I64, []),

@@ -37,20 +37,13 @@
 #define H2_NETT_F4 (H2_TABT_F4 + 512)
 #define H2_BUF_F4 (H2_LH_F4 + 64)                        // one staged layer + its bias row
 #define H2_LDS_BYTES (2 * H2_BUF_F4 * 16)                // 133 120
-#define H2_TOP 141                                       // 127 + 14: biased exponent e -> shift H2_TOP - e puts 2^(e-127) at 2^14
-#define H2_W_CLAMP 60
-#define H2_FWD_CLAMP 40                                  // per-point shifts: forward (|bias| . 2^(60 + 40) must stay finite)
-#define H2_BWD_CLAMP 100                                 // backward: loss gradients down to ~1e-26 reach full scale
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-union FragH {
-    f32x4 f;
-    f16x8 h;
-    uint32_t u[4];
-};
-
 extern __shared__ f32x4 lds_h2[];
+
+// amax table (H2_AMAX_COPIES x 32 words, zeroed by the caller before the forward): largest magnitude of every parked row block,
+// for the weight-gradient kernel's per-tensor scales (mlp_dev.h: h2_note_amax).  Word 0: encoding rows; 1 + 5 net + j: output of
+// layer j (0..4); 16 + 6 net + l: dPre_l
+#define H2_AMAX_H(net, j) (1 + 5 * (net) + (j))
+#define H2_AMAX_D(net, l) (16 + 6 * (net) + (l))
 
 #ifdef MH_PHASE_TRACE
 // phase trace for tools/phase_trace_h2.py (never compiled into the product library): wave 0 of every 32nd workgroup stamps
@@ -73,25 +66,6 @@ extern "C" int mh_h2_trace_read(long long *dst_host) {
 #define H2_STAMP(slot) do { } while (0)
 #define H2_STAMP_REAL(slot) do { } while (0)
 #endif
-
-__device__ __forceinline__ int h2_wexp(uint32_t amax_bits) { return min(H2_TOP - (int)(amax_bits >> 23), H2_W_CLAMP); }
-
-// two ALREADY SCALED fp32 values -> their packed fp16 slices (round to nearest: v_cvt_pk_f16_f32; x - h is exact in fp32)
-__device__ __forceinline__ void split_h(float x0, float x1, uint32_t &hi, uint32_t &lo) {
-    const f32x2_t v = {x0, x1};
-    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
-    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
-    const f16x2_t l = __builtin_convertvector(r, f16x2_t);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-
-// the point's shift from the largest magnitude (fp32 bits, sign cleared) among this lane's values: the partner lane (other
-// half of the point's column) holds the rest.  Shift so that the maximum lands in [2^14, 2^15), at most `cap`.
-__device__ __forceinline__ int h2_point_shift(int amax_bits, int cap) {
-    amax_bits = max(amax_bits, __shfl_xor(amax_bits, 32));
-    return min(H2_TOP - (amax_bits >> 23), cap);
-}
 
 template <int N_F4, int NW>
 __device__ __forceinline__ void h2_stage(int buf, const f32x4 *__restrict__ src) {
@@ -178,7 +152,7 @@ __device__ __forceinline__ void h2_hidden(const f32x4 *__restrict__ w, const Fra
 // point's next shift d comes from the largest acc; acc . 2^d = y . 2^(ks + d) is cut into the next layer's B operand slices.
 // Returns the point's new exponent kx = ks + d (the next layer adds its weight exponent).
 __device__ __forceinline__ int h2_epilogue(f32x16 (&acc)[4], int ks, float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
-                                           FragH (&bh)[8], FragH (&bl)[8]) {
+                                           FragH (&bh)[8], FragH (&bl)[8], uint32_t *__restrict__ amax, int slot) {
     int mi = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -203,6 +177,7 @@ __device__ __forceinline__ int h2_epilogue(f32x16 (&acc)[4], int ks, float *__re
         mt[t] = m;
     }
     if (mk) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+    if (amax) h2_note_amax(amax, slot, __float_as_int(__builtin_ldexpf(__int_as_float(mi), -ks)));
     const int d = h2_point_shift(mi, H2_FWD_CLAMP - ks);
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -219,7 +194,8 @@ __device__ __forceinline__ int h2_epilogue(f32x16 (&acc)[4], int ks, float *__re
 // power-of-two scaling, the sum rounds once) and one integer max; y is parked and gives the sign mask; the point's next
 // exponent kx comes from the largest y; y . 2^kx is cut into the next layer's B operand slices.  Returns kx.
 __device__ __forceinline__ int h2_epilogue_hidden(f32x16 (&acc)[4], int ks, const f32x4 *__restrict__ brow, float *__restrict__ ht,
-                                                  uint2 *__restrict__ mk, int pt, int h, FragH (&bh)[8], FragH (&bl)[8], int stamp = -1) {
+                                                  uint2 *__restrict__ mk, int pt, int h, FragH (&bh)[8], FragH (&bl)[8],
+                                                  uint32_t *__restrict__ amax, int slot, int stamp = -1) {
     const float sc = __builtin_ldexpf(1.0f, -ks);
     int mi = 0;
     uint32_t mt[4];
@@ -249,6 +225,7 @@ __device__ __forceinline__ int h2_epilogue_hidden(f32x16 (&acc)[4], int ks, cons
         asm volatile("" ::"v"(mt[0]), "v"(mt[3]), "v"(mi));   // trace build only: the stamp waits for the values above
         H2_STAMP(stamp);
     }
+    if (amax) h2_note_amax(amax, slot, mi);
     const int kx = h2_point_shift(mi, H2_FWD_CLAMP);
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -274,7 +251,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_h2_kernel(
     const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
     const float *__restrict__ bias0_t, const f32x4 *__restrict__ w2_d, const f32x4 *__restrict__ w2_t,
     const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
-    float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
+    float *__restrict__ out_topo, float *__restrict__ acts, uint32_t *__restrict__ amax, int64_t M, int64_t n_tiles) {
     constexpr bool TWO = NW == 8;                         // two LDS buffers
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
@@ -300,6 +277,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_h2_kernel(
     int m0 = 0;
 #pragma unroll
     for (int k = 0; k < 20; k++) m0 = max(m0, __float_as_int(bin0[k]) & 0x7fffffff);
+    if (amax) h2_note_amax(amax, 0, m0);
     const int kx0 = h2_point_shift(m0, H2_FWD_CLAMP);
 
     for (int net = 0; net < 2; net++) {
@@ -344,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_h2_kernel(
             __syncthreads();
             fetch_after(0, cb);
         }
-        int kx = h2_epilogue(acc, ks, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bl);
+        int kx = h2_epilogue(acc, ks, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bl, amax, H2_AMAX_H(net, 0));
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
             if (net == 0) H2_STAMP((l - 1) * 8 + 0);
@@ -365,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_h2_kernel(
             }
             if (net == 0) H2_STAMP((l - 1) * 8 + 4);
             kx = h2_epilogue_hidden(acc, ks, brow, ht ? ht + l * 128 * TILE : nullptr, mk ? mk + (net * 5 + l) * 64 + lane : nullptr, pt, h,
-                                    bh, bl, net == 0 ? (l - 1) * 8 + 5 : -1);
+                                    bh, bl, amax, H2_AMAX_H(net, l), net == 0 ? (l - 1) * 8 + 5 : -1);
             if (net == 0 && l == 4) H2_STAMP_REAL(63);
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
@@ -399,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_h2_kernel(
 // Same chain, transposed packs (T5, T4..T1, T0), ReLU derivative from the sign masks the forward parked; parks dPre tiles in
 // mlp.hip's layout for mh_mlp_wgrad.  acc = 2^ks W^T dPre: masked, y = acc . 2^-ks parked, acc . 2^d sliced.
 __device__ __forceinline__ int h2_epilogue_bwd(f32x16 (&acc)[4], int ks, uint2 m, float *__restrict__ dt, int pt, int h, FragH (&bh)[8],
-                                               FragH (&bl)[8]) {
+                                               FragH (&bl)[8], uint32_t *__restrict__ amax, int slot) {
     int mi = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -416,6 +394,7 @@ __device__ __forceinline__ int h2_epilogue_bwd(f32x16 (&acc)[4], int ks, uint2 m
 #pragma unroll
             for (int r = 0; r < 16; r++) PARK_STORE(__builtin_ldexpf(acc[t][r], -ks), &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
     }
+    if (amax) h2_note_amax(amax, slot, __float_as_int(__builtin_ldexpf(__int_as_float(mi), -ks)));
     const int d = h2_point_shift(mi, H2_BWD_CLAMP - ks);
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -433,7 +412,8 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_h2_kernel(const float *__
                                                                  const float *__restrict__ g_topo, const f32x4 *__restrict__ w2T_d,
                                                                  const f32x4 *__restrict__ w2T_t, int n_bands,
                                                                  const float *__restrict__ acts, float *__restrict__ dpre,
-                                                                 float *__restrict__ g_x, int64_t M, int64_t n_tiles) {
+                                                                 float *__restrict__ g_x, uint32_t *__restrict__ amax, int64_t M,
+                                                                 int64_t n_tiles) {
     constexpr bool TWO = NW == 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
@@ -498,7 +478,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_h2_kernel(const float *__
             __syncthreads();
             fetch_after(0, cb);
         }
-        kx = h2_epilogue_bwd(acc, ks, msk[4], dt ? dt + 4 * 128 * TILE : nullptr, pt, h, bh, bl);
+        kx = h2_epilogue_bwd(acc, ks, msk[4], dt ? dt + 4 * 128 * TILE : nullptr, pt, h, bh, bl, amax, H2_AMAX_D(net, 4));
         for (int l = 4; l >= 1; l--) {
             // dH_l = W_l^T dPre_l, then dPre_{l-1} = dH_l masked by H_l's ReLU bits
             ks = h2_wexp(tab[5 - l]) + kx;
@@ -511,7 +491,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_h2_kernel(const float *__
                 __syncthreads();
                 fetch_after(5 - l, cb);
             }
-            kx = h2_epilogue_bwd(acc, ks, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bl);
+            kx = h2_epilogue_bwd(acc, ks, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bl, amax, H2_AMAX_D(net, l - 1));
         }
         if (g_x) {
             // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5).  Skipped when nobody asks for d/dx
@@ -880,7 +860,7 @@ static int h2_lds_opt_in() {
 
 extern "C" int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w2_d,
                               const void *w2_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
-                              float *out_topo, float *acts, int64_t M, void *stream) {
+                              float *out_topo, float *acts, uint32_t *amax, int64_t M, void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !x || !bias0_d || !bias0_t || !w2_d || !w2_t || !bias_d || !bias_t || !out_deform || !out_topo || n_bands < 0 ||
         n_bands > 6)
@@ -892,16 +872,17 @@ extern "C" int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *
     const f32x4 *wd = reinterpret_cast<const f32x4 *>(w2_d), *wt = reinterpret_cast<const f32x4 *>(w2_t);
     if (nw == 8)
         hipLaunchKernelGGL(warp_fwd_h2_kernel<8>, dim3((unsigned)blocks), dim3(512), H2_LDS_BYTES, mh_stream(stream), x, slot, bias0_d,
-                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, amax, M, mh_mlp_tiles(M));
     else
         hipLaunchKernelGGL(warp_fwd_h2_kernel<4>, dim3((unsigned)blocks), dim3(256), H2_BUF_F4 * 16, mh_stream(stream), x, slot, bias0_d,
-                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, amax, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
 
 extern "C" int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const float *g_topo, const void *w2T_d, const void *w2T_t,
-                                   int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream) {
+                                   int32_t n_bands, const float *acts, float *dpre, float *g_x, uint32_t *amax, int64_t M,
+                                   void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !x || !w2T_d || !w2T_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
     const int nw = h2_waves(false);
@@ -911,10 +892,10 @@ extern "C" int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const 
     const f32x4 *wd = reinterpret_cast<const f32x4 *>(w2T_d), *wt = reinterpret_cast<const f32x4 *>(w2T_t);
     if (nw == 8)
         hipLaunchKernelGGL(warp_bwd_h2_kernel<8>, dim3((unsigned)blocks), dim3(512), H2_LDS_BYTES, mh_stream(stream), x, g_deform, g_topo,
-                           wd, wt, (int)n_bands, acts, dpre, g_x, M, mh_mlp_tiles(M));
+                           wd, wt, (int)n_bands, acts, dpre, g_x, amax, M, mh_mlp_tiles(M));
     else
         hipLaunchKernelGGL(warp_bwd_h2_kernel<4>, dim3((unsigned)blocks), dim3(256), H2_BUF_F4 * 16, mh_stream(stream), x, g_deform, g_topo,
-                           wd, wt, (int)n_bands, acts, dpre, g_x, M, mh_mlp_tiles(M));
+                           wd, wt, (int)n_bands, acts, dpre, g_x, amax, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
@@ -942,3 +923,5 @@ extern "C" int mh_field_fwd_h2(const float *xc, const float *feat_s, const float
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
+
+extern "C" int64_t mh_h2_amax_words(void) { return (int64_t)H2_AMAX_COPIES * 32; }

@@ -561,7 +561,8 @@ def sample_positions(rays_o, rays_d, ray_idx, t_starts, t_ends, ray_start, ray_c
 
 
 # ------------------------------------------------------------------------------------ fused MLPs
-def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False):
+def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False, amax=None,
+           slots=None):
     n_layers = len(act_off)
     dw_len = int(sum(i * o for i, o in zip(in_pad, out_pad)))
     db_len = int(sum(out_pad))
@@ -573,9 +574,17 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     raw = torch.empty(dw_len + db_len, device=dev)
     dw_raw, db_raw = raw[:dw_len], raw[dw_len:]
     _e = TIMER.start()
-    fn = lib.mh_mlp_wgrad_b3 if b3 else lib.mh_mlp_wgrad
-    check(fn(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw), ptr(db_raw), n_tiles,
-             stream()), "mh_mlp_wgrad")
+    if amax is not None:
+        # fp16 x 2 slices at the per-tensor scales the h2 forward / backward recorded (large-batch 128-row layers; the C side
+        # keeps the rest on the bf16 x 3 kernels)
+        sa_np, sa_p = _i32arr(slots[0])
+        sb_np, sb_p = _i32arr(slots[1])
+        check(lib.mh_mlp_wgrad_h2(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw),
+                                  ptr(db_raw), n_tiles, ptr(amax), sa_p, sb_p, stream()), "mh_mlp_wgrad_h2")
+    else:
+        fn = lib.mh_mlp_wgrad_b3 if b3 else lib.mh_mlp_wgrad
+        check(fn(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw), ptr(db_raw), n_tiles,
+                 stream()), "mh_mlp_wgrad")
     TIMER.stop("mh_mlp_wgrad[" + tag + "]", _e)
     return raw          # dw_raw | db_raw, tile-row order (packing.JointPacker.unpack_grads maps it back)
 
@@ -706,10 +715,15 @@ class _WarpMLP(torch.autograd.Function):
         b0d, b0t = bias0_d.detach().contiguous(), bias0_t.detach().contiguous()
         slot_c = None if slot is None else slot.contiguous()
         _e = TIMER.start()
-        if opnd.w3 is not None:
-            fwd = lib.mh_warp_fwd_h2 if opnd.mode == "h2" else lib.mh_warp_fwd_b3
-            check(fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
-                      n_bands, ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd_" + opnd.mode)
+        amax = None
+        if opnd.mode == "h2":
+            # the kernels record the largest magnitude of every parked block: per-tensor scales of the weight-gradient kernel
+            amax = torch.zeros(lib.mh_h2_amax_words(), dtype=torch.int32, device=dev) if (need_grad and WGRAD_H2) else None
+            check(lib.mh_warp_fwd_h2(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
+                                     n_bands, ptr(deform), ptr(topo), ptr(acts), ptr(amax), M, stream()), "mh_warp_fwd_h2")
+        elif opnd.w3 is not None:
+            check(lib.mh_warp_fwd_b3(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
+                                     n_bands, ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd_b3")
         else:
             check(lib.mh_warp_fwd(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(wd), ptr(wt), ptr(bd), ptr(bt), n_bands,
                                   ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd")
@@ -717,26 +731,30 @@ class _WarpMLP(torch.autograd.Function):
         ctx.b3, ctx.mode = opnd.wT3 is not None, opnd.mode
         if ctx.b3:
             wdT, wtT = opnd.wT3
-        ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
+        ctx.save_for_backward(x, slot_c, wdT, wtT, acts, amax)
         ctx.n_bands, ctx.n_slots, ctx.jp = n_bands, bias0_d.shape[0], opnd.jp
         return deform, topo
 
     @staticmethod
     def backward(ctx, g_deform, g_topo):
         lib = _lib.load()
-        x, slot, wdT, wtT, acts = ctx.saved_tensors
+        x, slot, wdT, wtT, acts, amax = ctx.saved_tensors
         M, dev = x.shape[0], x.device
         n_tiles = lib.mh_mlp_tiles(M)
         dpre = torch.empty(lib.mh_warp_dpre_floats(M), device=dev)
         g_x = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL -> the kernel skips the W0^T stage
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
-        bwd_data = (lib.mh_warp_bwd_data_h2 if ctx.mode == "h2" else lib.mh_warp_bwd_data_b3) if ctx.b3 else lib.mh_warp_bwd_data
-        check(bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
-                       stream()), "mh_warp_bwd_data")
+        if ctx.mode == "h2":
+            check(lib.mh_warp_bwd_data_h2(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre),
+                                          ptr(g_x), ptr(amax), M, stream()), "mh_warp_bwd_data_h2")
+        else:
+            bwd_data = lib.mh_warp_bwd_data_b3 if ctx.b3 else lib.mh_warp_bwd_data
+            check(bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
+                           stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)
         raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
-                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3)
+                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3, amax=amax, slots=_WARP_WG_SLOTS)
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
             (od, ot) = ctx.jp.bias0_raw
@@ -766,6 +784,10 @@ def _warp_wg_geometry():
 
 
 _WARP_WG = _warp_wg_geometry()
+# amax-table words (csrc/mlp_h2.hip: H2_AMAX_*) of the warp layers' dPre and input activations; the 32-row last layers stay bf16 x 3
+_WARP_WG_SLOTS = ([(16 + 6 * net + l) if l < 5 else -1 for net in range(2) for l in range(6)],
+                  [(0 if l == 0 else 1 + 5 * net + (l - 1)) if l < 5 else -1 for net in range(2) for l in range(6)])
+WGRAD_H2 = os.environ.get("MORPHEUS_WGRAD_H2", "1") != "0"    # A/B switch: 0 keeps the h2 mode's weight gradients on bf16 x 3
 
 
 def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, opnd: MLPOperands):

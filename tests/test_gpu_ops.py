@@ -840,3 +840,46 @@ def test_ab_switch_kernels_stay_correct(env):
     tail = (run.stdout + run.stderr)[-3000:]
     assert run.returncode == 0, tail
     assert "3 passed" in run.stdout, tail
+
+
+def test_warp_weight_gradient_kernel_on_fp16_slices(monkeypatch):
+    """wgrad_regs_h2_kernel (large batches of the h2 mode: two fp16 slices per operand at ONE power-of-two scale per parked tensor,
+    taken from the amax table the forward / backward kernels fill) against the bf16 x 3 kernel on the very same parked
+    tensors: every weight gradient within 5e-6 rel-L2 -- the distance the bf16 x 3 kernel itself keeps from float64 -- with
+    loss gradients spread over eight decades (a per-tensor scale must not lose the small ones), bias gradients identical
+    (both sum the raw fp32 rows), and the amax table must hold the tensors' true maxima."""
+    from morpheus_amd import ops, _lib
+    _set_mlp(monkeypatch, ops, "h2")
+    torch.manual_seed(11)
+    M = 600_000                                             # 18 750 tiles: the per-layer large-batch launches
+    nets = []
+    for nout in (3, 2):
+        W = [torch.randn(128, 39, device=DEV) * 0.15] + [torch.randn(128, 128, device=DEV) * 0.1 for _ in range(4)] + \
+            [torch.randn(nout, 128, device=DEV) * 0.15]
+        b = [torch.randn(128, device=DEV) * 0.1 for _ in range(5)] + [torch.randn(nout, device=DEV) * 0.1]
+        nets.append(W + b)
+    x = torch.rand(M, 3, device=DEV) * 2 - 1
+    b0 = [torch.randn(1, 128, device=DEV) * 0.3 for _ in range(2)]
+    decades = 10.0 ** (-8.0 * torch.rand(M, 1, device=DEV))
+    g = (torch.randn(M, 3, device=DEV) * decades, torch.randn(M, 2, device=DEV) * decades)
+
+    def run(wgrad_h2):
+        monkeypatch.setattr(ops, "WGRAD_H2", wgrad_h2)
+        ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
+        d, t = ops.warp_mlp(x, None, b0[0], b0[1], 6, ops.prepare_warp_operands(ps[0], ps[1]))
+        torch.autograd.backward([d, t], [g[0], g[1]])
+        return d.detach(), [p.grad for net in ps for p in net]
+
+    (d_h, g_h), (d_b, g_b) = run(True), run(False)
+    assert torch.equal(d_h, d_b)                            # recording the maxima does not touch the values
+    n = 0
+    for k, (a, b) in enumerate(zip(g_h, g_b)):
+        if b is None:
+            continue
+        if a.dim() == 1 or a.shape[0] < 128:                # biases, and the 32-row last layers (bf16 x 3 in both runs)
+            assert torch.equal(a, b), k
+        else:
+            rel = float((a - b).norm() / b.norm())
+            assert rel <= 5e-6, (k, tuple(b.shape), rel)
+            n += 1
+    assert n == 10

@@ -78,6 +78,39 @@ for name, r in res.items():
     print(f"{name}: fwd max err / max |out| deform {fe[0]:.2e} topo {fe[1]:.2e};  d/dx rel-L2 {ge:.2e};  nan {bool(torch.isnan(r[0]).any())}")
     print("    param grad rel-L2:", " ".join("-" if b is None else f"{float((a.double() - b).norm() / b.norm()):.1e}" for a, b in zip(r[3], g64)))
 
+# ---- 2b. large batch: the weight-gradient kernels with per-tensor scales, against float64 ---------------------------------
+if os.environ.get("H2_BIG", "1") == "1":
+    Mq = 600_000
+    xq = torch.rand(Mq, 3, device=DEV) * 2 - 1
+    bq = [t[:1].contiguous() for t in b0]
+    gq = (torch.randn(Mq, 3, device=DEV) * torch.rand(Mq, 1, device=DEV) ** 8, torch.randn(Mq, 2, device=DEV) * torch.rand(Mq, 1, device=DEV) ** 8)
+    p64 = [[p.double().clone().requires_grad_(True) for p in net] for net in nets]
+    e64 = torch.cat([xq.double()] + [f(xq.double() * 2 ** k) for k in range(6) for f in (torch.sin, torch.cos)], -1)
+    o64 = []
+    for k, P in enumerate(p64):
+        hh = torch.relu(e64 @ P[0].t() + bq[k].double())
+        for l in range(1, 5):
+            hh = torch.relu(hh @ P[l].t() + P[6 + l])
+        o64.append(hh @ P[5].t() + P[11])
+    ((o64[0] * gq[0].double()).sum() + (o64[1] * gq[1].double()).sum()).backward()
+    gq64 = [p.grad for net in p64 for p in net]
+    del e64, o64, hh
+    for mode, wg in (("f32", False), ("b3", False), ("h2", False), ("h2", True)):
+        set_mode(mode)
+        ops.WGRAD_H2 = wg
+        ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
+        d, t = ops.warp_mlp(xq, None, bq[0], bq[1], 6, ops.prepare_warp_operands(ps[0], ps[1]))
+        torch.autograd.backward([d, t], [gq[0], gq[1]])
+        gs = [p.grad for net in ps for p in net]
+        if mode == "h2" and not wg:
+            g_ref = gs
+        if mode == "h2" and wg:
+            print("   h2 weight-gradient kernel against the bf16x3 one on the same parked tensors, rel-L2:",
+                  " ".join("-" if b is None else f"{float((a - b).norm() / b.norm()):.1e}" for a, b in zip(gs, g_ref)))
+        print(f"{mode}{'+h2 wgrad' if wg else ''}: 600k points, heavy-tailed loss gradients; param grad rel-L2 vs float64:",
+              " ".join("-" if b is None else f"{float((a.double() - b).norm() / b.norm()):.1e}" for a, b in zip(gs, gq64)))
+    ops.WGRAD_H2 = True
+
 # ---- 3. timing -----------------------------------------------------------------------------------------------------
 if os.environ.get("H2_TIME", "1") == "1":
     Mb = 16384 * 128
