@@ -414,6 +414,24 @@ def main(argv=None):
                         traffic_note="HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), not a live "
                                      "measurement; null when the workload differs from the profiled one",
                         flops_per_launch=flops[dominant], avg_launch_ms=ktab[dominant]["avg_ms"])
+        if dominant == "mh_warp_fwd" and ktab[dominant].get("calls_per_step", 1.0) == 1.0:
+            # the training forward parks every layer's activations for the weight gradients: 1344 fp32 rows + 40 rows of ReLU sign
+            # masks per 32-point tile (csrc/mlp_dev.h: WARP_ACT_ROWS), x in, 5 floats out -- 5568 B per point, written once.
+            # With the fp16 x 2 slices the kernel sits closer to THAT roof than to the matrix pipe's; report the nearer one as
+            # the bound and keep the other view beside it.
+            park_bytes = M * (4.0 * (64 + 2 * 640) + 4.0 * 40 + 12.0 + 20.0)
+            gbs = park_bytes / (ktab[dominant]["avg_ms"] * 1e-3) / 1e9
+            if gbs / HBM_PEAK_GBS > roofline["frac"]:
+                mfma_view = {k: roofline[k] for k in ("bound", "achieved", "peak", "unit", "frac", "peak_note", "issued_tflops",
+                                                      "issued_frac_of_unit_peak", "vs_fp32_mfma_peak", "flops_per_launch")}
+                roofline = dict(kernel=dominant, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=roofline["traffic"], traffic_note=roofline["traffic_note"],
+                                bytes_per_launch=round(park_bytes), avg_launch_ms=ktab[dominant]["avg_ms"],
+                                note="algorithmic bytes = the parked activation tile (5568 B per point, written once; reads are "
+                                     "the 12 B of x and the L2-resident weight slices); a pure streaming WRITE reaches 6.8 TB/s on "
+                                     "this box (profiles/r02_micro_hbm_rates.txt), and the kernel's clock sits at 1.6 GHz while it "
+                                     "parks against 1.9 GHz when it does not (profiles/r02_phase_trace_warp_fwd.txt)",
+                                mfma=mfma_view)
         step_flops = 3.0 * (warp_f * (0 if args.workload == "cfg2" else 1) + field_f)
         if args.workload != "cfg3b":
             roofline["whole_step"] = dict(flops=step_flops, tflops=round(step_flops / (ms_step * 1e-3) / 1e12, 2),

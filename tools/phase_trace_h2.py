@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from morpheus_amd import ops
 lib = ctypes.CDLL(os.path.join(ROOT, "morpheus_amd", "_build", "libmorpheus_trace.so"))
 P, I32, I64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
-lib.mh_warp_fwd_h2.argtypes = [P] * 8 + [I32, P, P, P, I64, P]
+lib.mh_warp_fwd_h2.argtypes = [P] * 8 + [I32, P, P, P, P, I64, P]
 lib.mh_warp_acts_floats.restype = I64
 lib.mh_warp_acts_floats.argtypes = [I64]
 M = 128 * 128 * 128
@@ -34,7 +34,7 @@ for it in range(int(os.environ.get("MH_TRACE_ITERS", "4"))):
     e0.record()
     rc = lib.mh_warp_fwd_h2(x.data_ptr(), None, b0d.data_ptr(), b0t.data_ptr(), op.w3[0].data_ptr(), op.w3[1].data_ptr(),
                             op.b[0].data_ptr(), op.b[1].data_ptr(), 6, deform.data_ptr(), topo.data_ptr(),
-                            None if acts is None else acts.data_ptr(), M, st)
+                            None if acts is None else acts.data_ptr(), None, M, st)
     e1.record(); torch.cuda.synchronize(); assert rc == 0
 print("kernel ms", e0.elapsed_time(e1), "(stamped build, MORPHEUS_H2_WAVES=%s, parking %s)" % (os.environ.get("MORPHEUS_H2_WAVES", "default"), acts is not None))
 buf = (ctypes.c_longlong * (256 * 64))()
