@@ -508,12 +508,15 @@ def main(argv=None):
                    "ranks_share_devices": bool(world > 1 and n_dev < world),
                    "mlp_arithmetic": {"b3": "warp nets: fp32 values, exact three-way bf16 split of both operands, six slice "
                                             "products per MAC on the bf16 matrix pipe, fp32 accumulate (fp32-grade: <= 3 * 2^-24 of a "
-                                            "product dropped); field nets: forward the same, backward native fp32 MFMA (MORPHEUS_MLP=b3)",
-                                      "h2": "warp nets forward / backward-data: fp32 values, two fp16 slices per operand at per-layer / "
-                                            "per-point power-of-two scales (22 significand bits), three slice products per MAC on the "
-                                            "fp16 matrix pipe, fp32 accumulate (fp32-grade: measured error against float64 equal to "
-                                            "the fp32-MFMA kernels'); weight gradients and the field forward: bf16 x 3 slices; field "
-                                            "backward native fp32 MFMA (the default, MORPHEUS_MLP=h2)",
+                                            "product dropped); field forward: fp16 x 2 slices unless MORPHEUS_FIELD_FWD says otherwise, "
+                                            "field backward native fp32 MFMA (MORPHEUS_MLP=b3)",
+                                      "h2": "warp nets (forward, backward-data, large-batch weight gradients) and the field forward: fp32 "
+                                            "values, two fp16 slices per operand at power-of-two scales (per layer for weights, per point "
+                                            "for activations / gradients, per tensor for the weight-gradient operands; 22 significand "
+                                            "bits), three slice products per MAC on the fp16 matrix pipe, fp32 accumulate -- fp32-grade: "
+                                            "measured error against float64 equal to the fp32-MFMA kernels'; 32-row layers' and small "
+                                            "batches' weight gradients: bf16 x 3 slices; field backward: native fp32 MFMA (the default, "
+                                            "MORPHEUS_MLP=h2)",
                                       "": "native fp32 MFMA (MORPHEUS_MLP=f32)"}[mode],
                    "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
         "roofline": roofline, "roofline_hashgrid": roof_hash, "roofline_weight_gradients": roof_wgrad, "kernels": ktab,

@@ -823,17 +823,21 @@ def test_grid_large_batch_gradients():
 
 
 @pytest.mark.parametrize("env", [{"MORPHEUS_WGRAD_B3": "share"}, {"MORPHEUS_WGRAD_B3": "ring"}, {"MORPHEUS_B3_FWD": "phased"},
-                                 {"MORPHEUS_WGRAD": "merged"}, {"MORPHEUS_WGRAD": "per_layer"}],
+                                 {"MORPHEUS_WGRAD": "merged"}, {"MORPHEUS_WGRAD": "per_layer"}, {"MORPHEUS_H2_WAVES": "8"},
+                                 {"MORPHEUS_H2_WAVES": "4"}],
                          ids=lambda e: "-".join(f"{k}={v}" for k, v in e.items()))
 def test_ab_switch_kernels_stay_correct(env):
-    """The opt-in A/B kernels DESIGN.md section 3 quotes (LDS-ring weight-gradient kernels, the phased forward
-    schedule, forced merged / per-layer weight-gradient launches) are read once per process by the library, so each
-    runs the warp-net parity, accuracy and large-batch tests in a child interpreter with the switch set."""
+    """The opt-in A/B kernels DESIGN.md section 3 quotes (LDS-ring weight-gradient kernels, the phased bf16 x 3 forward, forced
+    merged / per-layer weight-gradient launches, the two workgroup shapes of the fp16 x 2 kernels) are read once per process
+    by the library, so each runs the warp-net parity, accuracy and large-batch tests of its arithmetic mode in a child
+    interpreter with the switch set."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pick = "test_warp_mlp and b3-None-a or test_warp_sliced_arithmetic_is_fp32_grade and b3 or test_warp_large_batch_weight_gradients and b3"
+    mode = "h2" if any(k.startswith("MORPHEUS_H2") for k in env) else "b3"
+    pick = (f"test_warp_mlp and {mode}-None-a or test_warp_sliced_arithmetic_is_fp32_grade and {mode} or "
+            f"test_warp_large_batch_weight_gradients and {mode}")
     run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
                           "-k", pick, "-p", "no:cacheprovider"], cwd=root, env={**os.environ, **env}, capture_output=True,
                          text=True, timeout=600)
