@@ -14,14 +14,18 @@
 //   * activations / gradients: one exponent PER POINT, from the largest magnitude of the point's feature vector (the two
 //     lanes that hold a point's column exchange their maxima).  An element then keeps all 22 bits while it is within 2^-17
 //     of its vector's maximum, and an absolute error of 2^-39 of that maximum below.
-// Accumulators run in the scaled domain (bias pre-scaled by 2^(kw + kx), results scaled back by v_ldexp_f32 on the way to
-// the parked tile); infinities and NaNs propagate as NaN, zero vectors clamp their exponent.
+//   * the weight-gradient kernel's operands (mlp.hip: wgrad_regs_h2_kernel): one exponent per parked TENSOR -- it contracts
+//     over points -- from the maxima these kernels record while parking (amax table, mlp_dev.h: h2_note_amax).
+// Accumulators run in the scaled domain, 2^(kw + kx) W x; a hidden layer's epilogue forms y = relu(acc . 2^-(kw + kx) + b) in one
+// fma (the bias never enters the scaled domain; layer 0, whose bias row is per frame slot, pre-scales it into the
+// accumulators instead), parks y as fp32 and cuts y . 2^kx' into the next operand.  Infinities and NaNs propagate as NaN, a
+// zero vector clamps its exponent, the clamps keep every 2^-(kw + kx) a normal float.
 //
 // Everything else is mlp_b3.hip's scheme: register-resident chain (accumulator registers 8s'..8s'+7 of output tile t are the
 // B operand of k16 step 2t + s' of the next layer), parked tiles and ReLU sign masks bit-for-bit in mlp.hip's layout (the
 // weight-gradient kernels read them as fp32), weight slices [plane h|l][out tile][k16 step][lane][8 fp16] staged by LDS-DMA.
-// A 128 x 128 layer is 64 KB of slices: TWO layers fit in LDS, so layer l+1 is fetched while layer l computes and a layer
-// costs one workgroup barrier.
+// A 128 x 128 layer is 64 KB of slices: TWO layers fit in LDS, so either layer l+1 is fetched while layer l computes and a
+// layer costs one workgroup barrier (8-wave workgroup), or two independent 4-wave workgroups share a CU (see the kernels).
 #include "mlp_dev.h"
 #include <stdlib.h>
 
@@ -46,7 +50,7 @@ extern __shared__ f32x4 lds_h2[];
 #define H2_AMAX_D(net, l) (16 + 6 * (net) + (l))
 
 #ifdef MH_PHASE_TRACE
-// phase trace for tools/phase_trace_h2.py (never compiled into the product library): wave 0 of every 32nd workgroup stamps
+// phase trace for tools/phase_trace_h2.py (never compiled into the product library): wave 0 of every 64th workgroup stamps
 // s_memtime at the phase boundaries of the forward kernel's hidden layers of net 0 (8 slots per layer), s_memrealtime in 62/63
 __device__ long long mh_h2_trace[256 * 64];
 #define H2_STAMP(slot)                                                                          \
