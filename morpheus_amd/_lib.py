@@ -9,7 +9,11 @@ import os
 
 import torch
 
-from .build import SO
+from .build import SO as _BUILT_SO
+
+# MORPHEUS_HIP_LIB: load another build of the SAME library (an A/B variant compiled with extra -D flags, tools/gpu/*.sh);
+# the default is the in-tree build, and there is still no fallback to anything that is not this library
+SO = os.environ.get("MORPHEUS_HIP_LIB") or _BUILT_SO
 
 _P = ctypes.c_void_p
 _I32, _I64, _F = ctypes.c_int32, ctypes.c_int64, ctypes.c_float

@@ -1705,10 +1705,21 @@ struct WgRaw {
 };
 __device__ __forceinline__ void wg_raw_load(WgRaw &f, const float *__restrict__ a, const float *__restrict__ b) {
     const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a), *b4 = reinterpret_cast<const f32x4 *>(b);
+#ifdef WG_NT_LOADS   // A/B, measured: weight gradients 4.2 -> 6.6 ms.  Every parked row is read once by one wave, but a lane takes
+                     // its 64 bytes of a row as four consecutive dwordx4 loads, i.e. an instruction touches 32 bytes of each of 32
+                     // lines and the other three find the line in the cache -- which a non-temporal load does not leave there.
+                     // (A streaming read gains 10 % from nt, tools/micro/hbm_read.hip; using it here needs lane-linear loads,
+                     // i.e. the A operand through LDS as well.)
+#pragma unroll
+    for (int j = 0; j < 4; j++) f.a[j] = __builtin_nontemporal_load(a4 + j);
+#pragma unroll
+    for (int j = 0; j < 4; j++) f.b[j] = __builtin_nontemporal_load(b4 + j);
+#else
 #pragma unroll
     for (int j = 0; j < 4; j++) f.a[j] = a4[j];
 #pragma unroll
     for (int j = 0; j < 4; j++) f.b[j] = b4[j];
+#endif
 }
 // measured on cfg3 (warp group, same box): 4 sets / one workgroup per CU 5.28 ms, 5 sets 5.25, 3 sets / TWO workgroups per CU
 // (240 registers, 2 x 48 KB of LDS: the second workgroup's MFMAs fill the first one's slicing and barrier time) 4.95
