@@ -309,3 +309,41 @@ def test_h2_pack_geometry_matches_the_kernels(lib):
     fp = field_joint_packer()
     assert fp.w2 == [(0, 6656)] and lib.mh_field_w2_bytes() == 6656 * 16
     assert [b[2] for b in fp.h2_blocks] == [0, 1536, 2560, 3584, 4608, 5632] and fp.h2_table == [4 * 6144 + i for i in range(6)]
+
+
+def test_fp16_slice_arithmetic_model():
+    """The arithmetic claim behind csrc/mlp_h2.hip, on the CPU (numpy float16 rounds to nearest like v_cvt_pk_f16_f32): at a
+    power-of-two scale that puts a vector's maximum in [2^14, 2^15), x = (h + l) / 2^k to 2^-22 |x| for elements within 2^-17 of
+    the maximum and to 2^-39 of the maximum below; and on layer-shaped data the three-slice-product GEMM is closer to the
+    float64 result than a plain fp32 GEMM is."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(4096) * 10.0 ** rng.uniform(-9, 1, 4096)).astype(np.float32)
+    amax = np.abs(x).max()
+    k = 141 - ((np.float32(amax).view(np.uint32) >> 23) & 0xFF)          # H2_TOP - biased exponent
+    xs = np.ldexp(x, int(k)).astype(np.float32)
+    assert 2.0 ** 14 <= np.abs(xs).max() < 2.0 ** 15
+    h = xs.astype(np.float16)
+    l = (xs - h.astype(np.float32)).astype(np.float16)
+    err = np.abs((h.astype(np.float64) + l.astype(np.float64)) / 2.0 ** int(k) - x.astype(np.float64))
+    bound = np.maximum(2.0 ** -22 * np.abs(x.astype(np.float64)), 2.0 ** -39 * float(amax))
+    assert (err <= bound).all()
+    K, M, N = 128, 128, 2048
+    W = (rng.standard_normal((M, K)) * np.sqrt(2.0 / K)).astype(np.float32)
+    X = np.maximum(rng.standard_normal((K, N)), 0).astype(np.float32) * np.float32(0.3)
+    ref = W.astype(np.float64) @ X.astype(np.float64)
+
+    def slices(a, axis):
+        m = np.abs(a).max(axis=axis, keepdims=True)
+        s = 2.0 ** (14 - np.floor(np.log2(np.maximum(m, 1e-30))))
+        a_s = (a * s).astype(np.float32)
+        hh = a_s.astype(np.float16)
+        ll = (a_s - hh.astype(np.float32)).astype(np.float16)
+        return hh.astype(np.float64) / s, ll.astype(np.float64) / s
+
+    Wh, Wl = slices(W, None)                                            # one scale per layer
+    Xh, Xl = slices(X, 0)                                               # one scale per point (column)
+    sliced = Wh @ Xh + Wh @ Xl + Wl @ Xh
+    rel = lambda a: float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
+    e_h2, e_f32 = rel(sliced), rel((W @ X).astype(np.float64))
+    assert e_h2 < 1.5e-7 and e_h2 < e_f32, (e_h2, e_f32)
