@@ -4,8 +4,11 @@
  * Drop-in native boundary for the render_rays hot path of HengyiWang/MorpheuS.
  * Every entry point takes raw device pointers + sizes + an explicit hipStream_t
  * (passed as void*), returns an int status (0 = ok), never throws, never
- * allocates or frees, keeps no thread-local or global mutable state (forward
- * and backward arrive on different host threads), and launches only on the
+ * allocates or frees, keeps no thread-local state and no global state that a
+ * call's result depends on (forward and backward arrive on different host
+ * threads; the only host statics are idempotent per-DEVICE caches -- a device's
+ * CU count, "dynamic-LDS limit of kernel k raised on device d" -- indexed by
+ * the current device, csrc/common.h), and launches only on the
  * stream it is given (the reference launched on the legacy default stream --
  * gridencoder.cu:386 -- a defect this ABI deliberately does not reproduce).
  * All buffers are caller-owned, contiguous, fp32 unless stated.
@@ -60,11 +63,6 @@ const char *mh_status_string(int status);
 int mh_grid_encode_fwd(const float *x, const float *emb, const int32_t *offsets_host,
                        const int32_t *res_host, float *out, int64_t M, int32_t L, int32_t n_levels,
                        float bound, int32_t group, void *stream);
-/* Two tables of identical level geometry at the same points in one launch (the sdf and colour encoders, model.py:144-157):
- * cell location, row indices and corner weights are computed once; results are bit-identical to two mh_grid_encode_fwd calls. */
-int mh_grid_encode_fwd2(const float *x, const float *emb_a, const float *emb_b, const int32_t *offsets_host,
-                        const int32_t *res_host, float *out_a, float *out_b, int64_t M, int32_t L, int32_t n_levels,
-                        float bound, void *stream);
 /* grad: [M, L*2]; grad_emb: [rows,2] ACCUMULATED into (caller zeroes it, as grid.py:84 does);
  * grad_x: NULL or [M,3], receives d/dx (the 1/(2*bound) chain factor included).  The slope uses
  * the kernel's dy_dx definition, which ignores the border clamp (gridencoder.cu:205-247). */
@@ -82,7 +80,7 @@ int mh_grid_encode_bwd(const float *grad, const float *x, const float *emb,
  * mh_grid_encode_bwd_binned: one workgroup per brick accumulates all levels in LDS, then flushes the
  * touched vertices with one global atomic each. L must be 16. grad_x (optional) is fully written.
  * gmax_bits: NULL, or a DEVICE word holding max |grad| as raw float bits (the producer of `grad` may compute it on
- * the fly, see mh_field_bwd_data); NULL costs one extra pass over `grad`. */
+ * the fly, see mh_field_bwd_fused); NULL costs one extra pass over `grad`. */
 int64_t mh_grid_bin_workspace_ints(void);
 int32_t mh_grid_bin_bricks(void);
 int32_t mh_grid_bin_index_ints(void);
@@ -129,20 +127,12 @@ int mh_rays_sample_uniform(float fx, float fy, float cx, float cy, const float *
 /* Occupancy-grid marcher (nerfacc OccGridEstimator.sampling call shape, morpheus.py:628-638): fixed `step`,
  * one jitter per ray (NULL = none), binary grid [R,R,R] uint8 over the AABB [-bound,bound]^3.  Interval k of a ray:
  * ts = t_near + u*step + k*step, te = min(ts+step, t_far), kept iff the cell of its midpoint is occupied.
- * Pass 1 writes ray_cnt [N]; the caller scans it into ray_start [N] (exclusive) and allocates; pass 2 fills
- * the packed ray_idx / t_starts / t_ends. */
-int mh_march_count(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step, float bound,
-                   int32_t R, const uint8_t *binary, int32_t *ray_cnt, void *stream);
-int mh_march_fill(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step, float bound,
-                  int32_t R, const uint8_t *binary, const int32_t *ray_start, int32_t *ray_idx, float *t_starts,
-                  float *t_ends, void *stream);
-
-/* Single-pass form of the same marcher, one wavefront per ray (64 steps per iteration, ballot/popcount compaction):
+ * One wavefront per ray (64 steps per iteration, ballot/popcount compaction), single pass:
  * mh_march_slots writes ray_cnt [N] and the kept intervals of ray r to slot_ts/slot_te [r*cap .. r*cap+cnt), cap >=
  * mh_march_cap(step, bound) (steps on the AABB diagonal for unit-or-longer directions); *overflow (device int, zeroed by
- * the caller) is set if some ray needed more than cap slots -- the caller then falls back to count/fill.  After the
- * exclusive scan of ray_cnt, mh_march_pack copies the slot rows to the packed ray_idx / t_starts / t_ends.  Results are
- * bit-identical to mh_march_count + mh_march_fill. */
+ * the caller) is set if some ray needed more than cap slots -- the caller then marches again with a longer slot row.
+ * After the exclusive scan of ray_cnt into ray_start, mh_march_pack copies the slot rows to the packed ray_idx /
+ * t_starts / t_ends. */
 int32_t mh_march_cap(float step, float bound);
 int mh_march_slots(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step, float bound,
                    int32_t R, const uint8_t *binary, int32_t cap, int32_t *ray_cnt, float *slot_ts, float *slot_te,
@@ -290,24 +280,11 @@ int mh_warp_bwd_data(const float *x, const float *g_deform, const float *g_topo,
  *   (a pointer, so the host never synchronises to read the learnable beta);
  *   with_color = 0 skips color_net (FD-normal taps, occupancy queries). */
 int64_t mh_field_acts_floats(int64_t M);
-int64_t mh_field_dpre_floats(int64_t M);
 int64_t mh_field_wpack_floats(void);
 int64_t mh_field_wpackT_floats(void);
 int mh_field_fwd(const float *xc, const float *feat_s, const float *feat_c, const float *topo,
                  const float *wpack, const float *bias, const float *beta, int32_t n_bands, int32_t with_color,
                  float *sdf, float *sigma, float *albedo, float *acts, int64_t M, void *stream);
-/* backward-data: g_sdf, g_sigma [M], g_albedo [M,3] (any may be NULL) -> g_xc [M,3] (freq path only;
- * the hash path's d/dx comes from mh_grid_encode_bwd), g_feat_s, g_feat_c [M,32], g_topo [M,2],
- * g_beta_partial [mh_mlp_tiles(M)] (per-tile partial sums of dL/dbeta), dpre scratch.
- * sdf / albedo are the forward's outputs (Laplace and sigmoid derivatives are formed from them).
- * gmax_bits: NULL, or 2 DEVICE words zeroed by the caller that receive max |g_feat_s| and max |g_feat_c| as raw float
- * bits (atomicMax) -- what mh_grid_encode_bwd_binned needs for its fixed-point accumulation. */
-int mh_field_bwd_data(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
-                      const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
-                      int32_t n_bands, int32_t with_color, const float *acts, float *dpre, float *g_xc,
-                      float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial, uint32_t *gmax_bits,
-                      int64_t M, void *stream);
-
 /* weight gradients: for `n_layers` (<= 16) layers described by HOST arrays (offsets in floats into the
  * acts / dpre tiles, feature counts padded to multiples of 32):
  *   dW_l[out][in] = sum_pts dpre_l[out][pt] * act_l[in][pt],  db_l[out] = sum_pts dpre_l[out][pt]
@@ -339,27 +316,23 @@ int mh_weight_norm_bwd(int32_t n_layers, const float *const *v_host, const float
                        const float *const *dw_host, float *const *dv_host, float *const *dg_host,
                        const int32_t *rows_host, const int32_t *cols_host, void *stream);
 
-/* Fused form of mh_field_bwd_data + mh_mlp_wgrad for the field nets: one pass per net keeps the weight-gradient
- * accumulators in registers, so the pre-activation gradients never reach HBM (no `dpre` buffer).  Same inputs / outputs as
- * mh_field_bwd_data, plus: dgeo_scratch [mh_field_dgeo_floats(M)] (d(geo) handed from the colour launch to the sdf launch;
- * may be NULL when with_color == 0), workspace [mh_field_bwd_fused_workspace_floats(M)] (per-wave partial sums), and
- * raw [24 928] = the weight gradient in mh_mlp_wgrad's tile-row format for the layer list s0, s1, s2, c0, c1, c2
- * (dW tiles | db tiles; the colour part is zero-filled when with_color == 0). */
+/* Backward of the field nets: backward-data AND weight gradients in one pass per net; the weight-gradient accumulators
+ * stay in registers, so the pre-activation gradients never reach HBM (no `dpre` buffer).
+ *   g_sdf, g_sigma [M], g_albedo [M,3] (any may be NULL) -> g_xc [M,3] or NULL (freq path only; the hash path's d/dx comes
+ *   from mh_grid_encode_bwd), g_feat_s, g_feat_c [M,32], g_topo [M,2], g_beta_partial [mh_mlp_tiles(M)] (per-tile partial
+ *   sums of dL/dbeta).  sdf / albedo are the forward's outputs (Laplace and sigmoid derivatives are formed from them).
+ *   gmax_bits: NULL, or 2 DEVICE words zeroed by the caller that receive max |g_feat_s| and max |g_feat_c| as raw float
+ *   bits (atomicMax) -- what mh_grid_encode_bwd_binned needs for its fixed-point accumulation.
+ *   dgeo_scratch [mh_field_dgeo_floats(M)] (d(geo) handed from the colour launch to the sdf launch; may be NULL when
+ *   with_color == 0), workspace [mh_field_bwd_fused_workspace_floats(M)] (per-wave partial sums), and
+ *   raw [24 928] = the weight gradient in mh_mlp_wgrad's tile-row format for the layer list s0, s1, s2, c0, c1, c2
+ *   (dW tiles | db tiles; the colour part is zero-filled when with_color == 0). */
 int64_t mh_field_bwd_fused_workspace_floats(int64_t M);
 int64_t mh_field_dgeo_floats(int64_t M);
 int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf, const float *g_sigma,
                        const float *g_albedo, const float *wpackT, const float *beta, int32_t n_bands, int32_t with_color,
                        const float *acts, float *dgeo_scratch, float *workspace, float *raw, float *g_xc, float *g_feat_s,
                        float *g_feat_c, float *g_topo, float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream);
-/* the same pass with exact fp32 products from three bf16 slices on the bf16 matrix pipe (see mh_warp_fwd_b3); w3T = the
- * sliced TRANSPOSED pack of the six field layers (packing.py field_joint_packer().b3T_layers: TC2 | TC1 | TC0 | TS2 | TS1 | TS0,
- * mh_field_w3T_bytes() bytes).  Same arguments otherwise, same outputs. */
-int64_t mh_field_w3T_bytes(void);
-int mh_field_bwd_fused_b3(const float *xc, const float *sdf, const float *albedo, const float *g_sdf, const float *g_sigma,
-                       const float *g_albedo, const void *w3T, const float *beta, int32_t n_bands, int32_t with_color,
-                       const float *acts, float *dgeo_scratch, float *workspace, float *raw, float *g_xc, float *g_feat_s,
-                       float *g_feat_c, float *g_topo, float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream);
-
 /* ---- optimiser step over the flat parameter bucket (the step after the path) ---- */
 /* Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9,0.99), eps=1e-15).step() of morpheus.py:154-155,
  * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned.

@@ -22,7 +22,6 @@ _SIGS = {
     "mh_abi_version": (ctypes.c_int, []),
     "mh_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mh_grid_encode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _I32, _P]),
-    "mh_grid_encode_fwd2": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_grid_encode_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_grid_bin_workspace_ints": (_I64, []),
     "mh_grid_bin_bricks": (_I32, []),
@@ -35,8 +34,6 @@ _SIGS = {
     "mh_sample_uniform": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _F, _P, _P, _P, _P, _P, _P, _P]),
     "mh_rays_sample_uniform": (ctypes.c_int, [_F, _F, _F, _F, _P, _I32, _I32, _P, _P, _I32, _I32, _F, _P, _P, _P, _P,
                                               _P, _P, _P, _P, _P]),
-    "mh_march_count": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _P, _P]),
-    "mh_march_fill": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _P, _P, _P, _P, _P]),
     "mh_march_cap": (_I32, [_F, _F]),
     "mh_march_slots": (ctypes.c_int, [_P, _P, _P, _I32, _F, _F, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "mh_march_pack": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P]),
@@ -56,7 +53,6 @@ _SIGS = {
     "mh_warp_wpack_floats": (_I64, []),
     "mh_warp_wpackT_floats": (_I64, []),
     "mh_field_acts_floats": (_I64, [_I64]),
-    "mh_field_dpre_floats": (_I64, [_I64]),
     "mh_field_wpack_floats": (_I64, []),
     "mh_field_wpackT_floats": (_I64, []),
     "mh_warp_fwd": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _I64, _P]),
@@ -78,12 +74,9 @@ _SIGS = {
     "mh_warp_bwd_data_b3": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_warp_fwd_b3": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_field_fwd": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
-    "mh_field_bwd_data": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 8 + [_I64, _P]),
     "mh_field_bwd_fused_workspace_floats": (_I64, [_I64]),
     "mh_field_dgeo_floats": (_I64, [_I64]),
     "mh_field_bwd_fused": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 10 + [_I64, _P]),
-    "mh_field_bwd_fused_b3": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 10 + [_I64, _P]),
-    "mh_field_w3T_bytes": (_I64, []),
     "mh_mlp_wgrad_workspace_floats": (_I64, [_I32, _P, _P, _I64]),
     "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mh_mlp_wgrad_b3": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),

@@ -19,17 +19,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int mh_lane() { return threadIdx.x & 63; }
 
+// Per-device host state.  The library keeps NO state that depends on which device a call runs on in plain statics: what
+// is cached (a device's CU count, "this kernel's dynamic-LDS limit was raised on this device") is indexed by the current
+// device, so one process may drive several GPUs (the product runs one process per GPU; this is belt and braces).  The
+// guarded actions are idempotent, so the benign race of two threads doing one twice needs no lock.
+#define MH_MAX_DEVICES 64
+static inline int mh_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+    return dev < MH_MAX_DEVICES ? dev : MH_MAX_DEVICES - 1;   // devices beyond the table share its last entry's slot (re-done harmlessly)
+}
+struct MhOncePerDevice {
+    unsigned char done[MH_MAX_DEVICES];
+    bool need(int dev) const { return dev >= MH_MAX_DEVICES - 1 || !done[dev]; }
+    void mark(int dev) { done[dev] = 1; }
+};
+
 // compute units of the current device, queried once per device (256 on MI355X; partitioned modes expose fewer)
 static inline int mh_cu_count() {
-    static int cached_dev = -1, cached_cus = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (dev != cached_dev) {
+    static int cus[MH_MAX_DEVICES];
+    const int dev = mh_device();
+    if (cus[dev] <= 0 || dev == MH_MAX_DEVICES - 1) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached_cus = n;
-        cached_dev = dev;
+        cus[dev] = n;
     }
-    return cached_cus;
+    return cus[dev];
 }
-

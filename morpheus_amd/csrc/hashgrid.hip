@@ -60,18 +60,14 @@ __device__ __forceinline__ bool grid_locate(const float *__restrict__ x, int64_t
     return inb;
 }
 
-// TWO: a second table of the same geometry (the colour encoder next to the sdf encoder, model.py:144-157) is evaluated at
-// the same points in the same launch: cell location, the 8 row indices and the corner weights are computed once.
-template <bool TWO>
-__global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__ x, const float2 *__restrict__ emb,
-                                                       const float2 *__restrict__ emb_b, GridMeta meta,
-                                                       float2 *__restrict__ out, float2 *__restrict__ out_b, int64_t M, int L,
-                                                       int n_levels, float bound, float two_bound) {
+__global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__ x, const float2 *__restrict__ emb, GridMeta meta,
+                                                       float2 *__restrict__ out, int64_t M, int L, int n_levels, float bound,
+                                                       float two_bound) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = gid / L;
     const int l = (int)(gid - p * L);
     if (p >= M) return;
-    float2 r = make_float2(0.f, 0.f), rb = make_float2(0.f, 0.f);
+    float2 r = make_float2(0.f, 0.f);
     if (l < n_levels) {
         const uint32_t res = (uint32_t)meta.res[l];
         const uint32_t T = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
@@ -81,30 +77,22 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__
         float f[3];
         if (grid_locate(x, p, bound, two_bound, res, g, f)) {
             const float2 *tab = emb + meta.offsets[l];
-            const float2 *tab_b = TWO ? emb_b + meta.offsets[l] : nullptr;
             const uint32_t g1x = min(g[0] + 1, res - 1), g1y = min(g[1] + 1, res - 1), g1z = min(g[2] + 1, res - 1);
-            float2 v[8], vb[8];
+            float2 v[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 uint32_t cx = (c & 1) ? g1x : g[0], cy = (c & 2) ? g1y : g[1], cz = (c & 4) ? g1z : g[2];
-                const uint32_t row = grid_row(cx, cy, cz, res, T, dense, pow2);
-                v[c] = tab[row];
-                if (TWO) vb[c] = tab_b[row];
+                v[c] = tab[grid_row(cx, cy, cz, res, T, dense, pow2)];
             }
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 float w = ((c & 1) ? f[0] : 1.f - f[0]) * ((c & 2) ? f[1] : 1.f - f[1]) * ((c & 4) ? f[2] : 1.f - f[2]);
                 r.x = fmaf(w, v[c].x, r.x);
                 r.y = fmaf(w, v[c].y, r.y);
-                if (TWO) {
-                    rb.x = fmaf(w, vb[c].x, rb.x);
-                    rb.y = fmaf(w, vb[c].y, rb.y);
-                }
             }
         }
     }
     out[gid] = r;
-    if (TWO) out_b[gid] = rb;
 }
 
 // Grouped forward: every G consecutive points are known to lie close together (the six finite-difference taps of one
@@ -558,27 +546,9 @@ extern "C" int mh_grid_encode_fwd(const float *x, const float *emb, const int32_
     const int64_t threads = M * L;
     const int64_t blocks = (threads + 255) / 256;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
-    hipLaunchKernelGGL(grid_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), x,
-                       reinterpret_cast<const float2 *>(emb), (const float2 *)nullptr, meta, reinterpret_cast<float2 *>(out),
-                       (float2 *)nullptr, M, (int)L, (int)n_levels, bound, 2.0f * bound);
-    MH_CHECK_LAUNCH();
-    return MH_OK;
-}
-
-extern "C" int mh_grid_encode_fwd2(const float *x, const float *emb_a, const float *emb_b, const int32_t *offsets_host,
-                                   const int32_t *res_host, float *out_a, float *out_b, int64_t M, int32_t L,
-                                   int32_t n_levels, float bound, void *stream) {
-    if (M == 0) return MH_OK;
-    if (!x || !emb_a || !emb_b || !out_a || !out_b || M < 0 || n_levels < 0 || n_levels > L || !(bound > 0.f)) return MH_ERR_ARG;
-    GridMeta meta;
-    int st = fill_meta(meta, offsets_host, res_host, L);
-    if (st) return st;
-    const int64_t blocks = (M * L + 255) / 256;
-    if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
-    hipLaunchKernelGGL(grid_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), x,
-                       reinterpret_cast<const float2 *>(emb_a), reinterpret_cast<const float2 *>(emb_b), meta,
-                       reinterpret_cast<float2 *>(out_a), reinterpret_cast<float2 *>(out_b), M, (int)L, (int)n_levels, bound,
-                       2.0f * bound);
+    hipLaunchKernelGGL(grid_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, mh_stream(stream), x,
+                       reinterpret_cast<const float2 *>(emb), meta, reinterpret_cast<float2 *>(out), M, (int)L, (int)n_levels,
+                       bound, 2.0f * bound);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

@@ -500,223 +500,12 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
     }  // tile loop
 }
 
-__global__ __launch_bounds__(FIELD_THREADS, 1) void field_bwd_kernel(
-    const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ albedo,
-    const float *__restrict__ g_sdf, const float *__restrict__ g_sigma, const float *__restrict__ g_albedo,
-    const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands, int with_color, const float *__restrict__ acts,
-    float *__restrict__ dpre, float *__restrict__ g_xc, float *__restrict__ g_feat_s, float *__restrict__ g_feat_c,
-    float *__restrict__ g_topo, float *__restrict__ g_beta_partial, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pt = lane & 31, h = lane >> 5;
-    uint32_t max_s = 0, max_c = 0;  // running max |feature gradient| (float bits) for the hash-grid backward's fixed point
-    if (with_color)
-        stage_resident<FIELD_WPACKT / 4>(wpackT, 0);
-    else
-        stage_resident<(2 * 4096 + 6144) / 4>(wpackT + 2048 + 2 * 4096, (2048 + 2 * 4096) / 4);
-    __syncthreads();
-    const float beta = *beta_p;
-    for (int64_t tile_id = (int64_t)blockIdx.x * (FIELD_THREADS / 64) + wave; tile_id < n_tiles;
-         tile_id += (int64_t)gridDim.x * (FIELD_THREADS / 64)) {
-    const int64_t p = tile_id * TILE + pt;
-    const bool live = p < M;
-    const int64_t pc = live ? p : M - 1;
-    float xv[3] = {xc[pc * 3 + 0], xc[pc * 3 + 1], xc[pc * 3 + 2]};
-    const float *atile = acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE);
-    float *dtile = dpre + tile_id * (int64_t)(FIELD_DPRE_ROWS * TILE);
-    const f32x4 *wt = lds_res;
-    f32x16 acc[2];
-    float dbin[32];
-    float dgeo[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) dgeo[r] = 0.f;
-
-    if (with_color) {
-        // dQ2 = g_albedo * a * (1 - a)
-        float d2[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) d2[r] = 0.f;
-        if (g_albedo && live && h == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float a = albedo[p * 3 + c];
-                d2[c] = g_albedo[p * 3 + c] * a * (1.0f - a);
-            }
-        }
-        store_acc_rows<1>(dtile + 320 * TILE, d2, pt, h);
-        mfma_layer_z<16, 2>(wt, d2, acc, lane);
-        wt += 512;
-        // mask C2 -> dQ1
-        {
-            const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[3 * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw, j, acc[j >> 4][j & 15]);
-        }
-        store_acc_rows<2>(dtile + 256 * TILE, dbin, pt, h);
-        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
-        wt += 1024;
-        // mask C1 -> dQ0
-        {
-            const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[2 * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw, j, acc[j >> 4][j & 15]);
-        }
-        store_acc_rows<2>(dtile + 192 * TILE, dbin, pt, h);
-        mfma_layer_z<32, 2>(wt, dbin, acc, lane);
-        wt += 1024;
-        if (g_feat_c && live) {
-            f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_c + p * 32 + 16 * h);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                f32x4 v;
-#pragma unroll
-                for (int c = 0; c < 4; c++) v[c] = acc[0][4 * q + c];
-                o[q] = v;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) max_c = max(max_c, __float_as_uint(fabsf(acc[0][r])));
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) dgeo[r] = acc[1][r];
-    } else {
-        wt += (2048 + 4096 + 4096) / 4;
-    }
-    // dP2 = [dgeo | d sdf]
-    float gs = 0.f, gbeta = 0.f;
-    if (live && h == 0) {
-        const float s = sdf[p];
-        if (g_sdf) gs = g_sdf[p];
-        if (g_sigma) {
-            const float gsg = g_sigma[p];
-            const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
-            const float a = fabsf(s) / beta;
-            const float ex = expf(-a);
-            gs += gsg * (-(0.5f / (beta * beta)) * sg * sg * ex);
-            // d sigma / d beta
-            gbeta = gsg * (-(1.0f / (beta * beta)) * (0.5f + 0.5f * sg * expm1f(-a)) +
-                           (1.0f / beta) * (0.5f * sg * ex * (fabsf(s) / (beta * beta))));
-        }
-    }
-    if (g_beta_partial) {
-        float tot = gbeta;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-        if (lane == 0) g_beta_partial[tile_id] = tot;
-    }
-    {
-        float d2[32];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            d2[r] = dgeo[r];
-            d2[16 + r] = 0.f;
-        }
-        d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
-        if (with_color) {
-            store_acc_rows<2>(dtile + 128 * TILE, d2, pt, h);
-            mfma_layer_z<32, 2>(wt, d2, acc, lane);
-        } else {
-            // sdf-only pass (finite-difference taps): dP2 has ONE non-zero row, the sdf output -- tile 1, row 0, i.e.
-            // k-step 16 of the 32.  dH2 = W2[sdf,:]^T g_sdf is that single k-step (2 MFMAs instead of 64), and only
-            // tile 1 of dP2 is parked (mh_mlp_wgrad is pointed at it with a 32-row out tile by the caller)
-            float t1[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) t1[r] = d2[16 + r];
-            store_acc_rows<1>(dtile + (128 + 32) * TILE, t1, pt, h);
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const f32x4 a = wt[(t * 8 + 4) * 64 + lane];
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; r++) z[r] = 0.f;
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], gs, z, 0, 0, 0);
-            }
-        }
-        wt += 1024;
-    }
-    // mask S2 -> dP1
-    {
-        const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[1 * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
-    }
-    store_acc_rows<2>(dtile + 64 * TILE, dbin, pt, h);
-    mfma_layer_z<32, 2>(wt, dbin, acc, lane);
-    wt += 1024;
-    // mask S1 -> dP0
-    {
-        const uint32_t mw = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE)[0 * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < 32; j++) dbin[j] = ((mw >> j) & 1u) ? acc[j >> 4][j & 15] : 0.f;
-    }
-    store_acc_rows<2>(dtile, dbin, pt, h);
-    // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
-    f32x16 e[3];
-    float gx[3] = {0.f, 0.f, 0.f};
-    if (g_xc) {
-        mfma_layer_z<32, 3>(wt, dbin, e, lane);
-        float dsc[18];
-        enc_deriv_parked(atile, pt, h, dsc);
-#pragma unroll
-        for (int k = 0; k < 18; k++) {
-            const float de = k < 16 ? e[0][k] : e[1][k - 16];
-            gx[k % 3] += de * dsc[k];
-        }
-        if (h == 0) {
-            gx[0] += e[1][2];
-            gx[2] += e[1][3];
-        } else {
-            gx[1] += e[1][2];
-        }
-#pragma unroll
-        for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
-    } else {
-        // nobody asks for d/d(position) (canonical rendering, finite-difference taps): the encoding tile of W0^T and the
-        // 18 sincos derivatives are skipped; tiles 1 (topo) and 2 (hash features) are contiguous in the pack
-        f32x16 e12[2];
-        mfma_layer_z<32, 2>(wt + 8 * 64, dbin, e12, lane);
-        e[1] = e12[0];
-        e[2] = e12[1];
-    }
-    if (live) {
-        if (g_xc && h == 0) {
-            g_xc[p * 3 + 0] = gx[0];
-            g_xc[p * 3 + 1] = gx[1];
-            g_xc[p * 3 + 2] = gx[2];
-        }
-        if (g_topo) g_topo[p * 2 + h] = e[1][4];
-        if (g_feat_s) {
-            f32x4 *o = reinterpret_cast<f32x4 *>(g_feat_s + p * 32 + 16 * h);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                f32x4 v;
-#pragma unroll
-                for (int c = 0; c < 4; c++) v[c] = e[2][4 * q + c];
-                o[q] = v;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) max_s = max(max_s, __float_as_uint(fabsf(e[2][r])));
-        }
-    }
-    }  // tile loop
-    if (gmax) {
-        // one pair of atomics per wave for the whole launch (the blocks are persistent)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
-            max_c = max(max_c, (uint32_t)__shfl_xor((int)max_c, o));
-        }
-        if (lane == 0) {
-            if (max_s) atomicMax(gmax + 0, max_s);
-            if (max_c) atomicMax(gmax + 1, max_c);
-        }
-    }
-}
-
 // =====================================================================================
 // canonical field, FUSED backward: backward-data AND weight gradients in one pass, dPre never leaves the chip.
 //
-// The split form above writes every layer's pre-activation gradient (1.4 KB per point) and mh_mlp_wgrad reads it back
-// together with the parked activations (3.1 KB per point): 9.7 GB of HBM traffic per step at the benchmark size, which
-// bounds both kernels (field nets: 3.9 ms per step against a 1.5 ms MFMA floor).  Here a wave keeps the weight-gradient
+// A split form (backward-data kernel + mh_mlp_wgrad, removed in round 3) wrote every layer's pre-activation gradient
+// (1.4 KB per point) and read it back together with the parked activations (3.1 KB per point): 9.7 GB of HBM traffic per
+// step at the benchmark size (2.76 ms against 2.13 ms for this form).  Here a wave keeps the weight-gradient
 // accumulators of its net IN REGISTERS across all its tiles -- the field nets are small enough: sdf_net 14 336 floats =
 // 224 registers per lane, color_net 10 240 = 160 (the warp nets' 77 824 per net are not) -- so per
 // tile and layer it (1) starts the loads of the layer's parked input activations H_l (feature-major rows = the B operand
@@ -800,74 +589,15 @@ __device__ __forceinline__ void dw_store(float *__restrict__ dw, const f32x16 (&
         for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, h)) * in_pad + 32 * n + i] = acc[n][r];
 }
 
-// ---- the same two primitives with exact fp32 products on the bf16 matrix pipe (see mlp_b3.hip) ---------------------------
-// weights: [plane hi|mid|lo][out tile][k16 step][lane][8 bf16] (packing.py: bwd3 blocks of the field packer); `bin` holds what
-// the fp32 chain carries per 2-wide k-step, so k16 step s takes bin[8s .. 8s+7]
-template <int KS, int MT>
-__device__ __forceinline__ void mfma_layer_z_b3(const f32x4 *__restrict__ w, const float (&bin)[KS], f32x16 (&acc)[MT], int lane) {
-    static_assert(KS % 8 == 0, "k16 steps");
-    constexpr int S = KS / 8, PL = MT * S * 64;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        Frag bh, bm, bl;
-#pragma unroll
-        for (int e2 = 0; e2 < 4; e2++) split2(bin[8 * s + 2 * e2], bin[8 * s + 2 * e2 + 1], bh.u[e2], bm.u[e2], bl.u[e2]);
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            Frag ah, am, al;
-            ah.f = w[0 * PL + (t * S + s) * 64 + lane];
-            am.f = w[1 * PL + (t * S + s) * 64 + lane];
-            al.f = w[2 * PL + (t * S + s) * 64 + lane];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh.h, s == 0 ? zero : acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bm.h, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl.h, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bh.h, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bm.h, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh.h, acc[t], 0, 0, 0);
-        }
-    }
-}
-
-// K = points: k16 step s, lane half g, element e <-> point 16 g + 8 s + e, i.e. v[2s], v[2s+1] of a RowFrag (both operands)
-__device__ __forceinline__ void row_slices(const RowFrag &f, Frag (&h)[2], Frag (&m)[2], Frag (&l)[2]) {
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int e2 = 0; e2 < 4; e2++)
-            split2(f.v[2 * s + (e2 >> 1)][2 * (e2 & 1)], f.v[2 * s + (e2 >> 1)][2 * (e2 & 1) + 1], h[s].u[e2], m[s].u[e2], l[s].u[e2]);
-}
-template <int NI>
-__device__ __forceinline__ void dw_mma_b3(const RowFrag &a, const RowFrag (&b)[NI], f32x16 (&acc)[NI], float &bsum) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) bsum += (a.v[j][0] + a.v[j][1]) + (a.v[j][2] + a.v[j][3]);
-    Frag ah[2], am[2], al[2];
-    row_slices(a, ah, am, al);
-#pragma unroll
-    for (int n = 0; n < NI; n++) {
-        Frag bh[2], bm[2], bl[2];
-        row_slices(b[n], bh, bm, bl);
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s].h, bh[s].h, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s].h, bm[s].h, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].h, bl[s].h, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[s].h, bh[s].h, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].h, bm[s].h, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].h, bh[s].h, acc[n], 0, 0, 0);
-        }
-    }
-}
-// arithmetic selector of the fused kernels: LAYER(KS, MT, w, bin, acc) and DW(NI, A, B, acc, bsum)
-#define FUSED_LAYER(KS, MT, w, bin, acc) do { if (B3) mfma_layer_z_b3<KS, MT>(w, bin, acc, lane); else mfma_layer_z<KS, MT>(w, bin, acc, lane); } while (0)
-#define FUSED_DW(NI, A, B, acc, bsum) do { if (B3) dw_mma_b3<NI>(A, B, acc, bsum); else dw_mma<NI>(A, B, acc, bsum); } while (0)
-// float4 sizes of the transposed blocks in LDS: fp32 fragments / bf16x3 slices (packing.py pads every block to 512)
-#define FUSED_TC2(B3) ((B3) ? 1024 : 512)
-#define FUSED_TC1(B3) ((B3) ? 1536 : 1024)
-#define FUSED_TC0(B3) ((B3) ? 1536 : 1024)
-#define FUSED_TS2(B3) ((B3) ? 1536 : 1024)
-#define FUSED_TS1(B3) ((B3) ? 1536 : 1024)
-#define FUSED_TS0(B3) ((B3) ? 2560 : 1536)
+#define FUSED_LAYER(KS, MT, w, bin, acc) mfma_layer_z<KS, MT>(w, bin, acc, lane)
+#define FUSED_DW(NI, A, B, acc, bsum) dw_mma<NI>(A, B, acc, bsum)
+// float4 sizes of the transposed fp32 fragment blocks in LDS (packing.py pads every block to 512)
+#define FUSED_TC2 512
+#define FUSED_TC1 1024
+#define FUSED_TC0 1024
+#define FUSED_TS2 1024
+#define FUSED_TS1 1024
+#define FUSED_TS0 1536
 
 struct FusedPart {            // where this launch's per-wave partial sums go (float offsets into the workspace)
     int64_t dw[3];            // layer-major: [n_chunks][out_pad * in_pad]
@@ -875,14 +605,13 @@ struct FusedPart {            // where this launch's per-wave partial sums go (f
 };
 
 // ---- color_net: Q2 (3 rows) <- g_albedo, Q1, Q0; hands d(geo) to the sdf launch ------------------------------------
-template <bool B3>
 __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
     const float *__restrict__ albedo, const float *__restrict__ g_albedo, const float *__restrict__ wpackT,
     const float *__restrict__ acts, float *__restrict__ dgeo_scr, float *__restrict__ g_feat_c, float *__restrict__ ws,
     FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5, i = lane & 31;
-    constexpr int W_F4 = FUSED_TC2(B3) + FUSED_TC1(B3) + FUSED_TC0(B3);
+    constexpr int W_F4 = FUSED_TC2 + FUSED_TC1 + FUSED_TC0;
     stage_fused<W_F4>(wpackT, 0);     // TC2 | TC1 | TC0 (fp32 fragments, or their bf16x3 slices)
     float *scr = reinterpret_cast<float *>(lds_fused + W_F4) + wave * SCR_FLOATS;
     __syncthreads();
@@ -921,7 +650,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         row_load_async(B[1], atile, 384 + i, h);
         scr_put<1>(scr, d2, pt, h);
         FUSED_LAYER(16, 2, wt, d2, acc);
-        wt += FUSED_TC2(B3);
+        wt += FUSED_TC2;
 #pragma unroll
         for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw3, j, acc[j >> 4][j & 15]);   // mask C2 -> dQ1
         scr_get(A, scr, i, h);
@@ -933,7 +662,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         row_load_async(B[1], atile, 320 + i, h);
         scr_put<2>(scr, dbin, pt, h);
         FUSED_LAYER(32, 2, wt, dbin, acc);
-        wt += FUSED_TC1(B3);
+        wt += FUSED_TC1;
         {
             float q1[32];
 #pragma unroll
@@ -1014,7 +743,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
 }
 
 // ---- sdf_net (+ Laplace density): P2 <- [d(geo) | g_sdf, g_sigma], P1, P0, d(inputs) ---------------------------------
-template <bool WITH_COLOR, bool B3>
+template <bool WITH_COLOR>
 __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ g_sdf,
     const float *__restrict__ g_sigma, const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands,
@@ -1023,9 +752,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5, i = lane & 31;
-    constexpr int W_F4 = FUSED_TS2(B3) + FUSED_TS1(B3) + FUSED_TS0(B3);
+    constexpr int W_F4 = FUSED_TS2 + FUSED_TS1 + FUSED_TS0;
     // TS2 | TS1 | TS0 behind the colour net's three blocks (fp32 fragments, or their bf16x3 slices)
-    stage_fused<W_F4>(wpackT + 4 * (FUSED_TC2(B3) + FUSED_TC1(B3) + FUSED_TC0(B3)), 0);
+    stage_fused<W_F4>(wpackT + 4 * (FUSED_TC2 + FUSED_TC1 + FUSED_TC0), 0);
     float *scr = reinterpret_cast<float *>(lds_fused + W_F4) + wave * SCR_FLOATS;
     __syncthreads();
     constexpr int MT2 = WITH_COLOR ? 2 : 1;                // sdf-only pass: dP2 has ONE non-zero row (tile 1, row 0)
@@ -1094,7 +823,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             row_load_async(B[0], atile, 160 + i, h);
             row_load_async(B[1], atile, 192 + i, h);
             scr_put<2>(scr, d2, pt, h);
-            if (WITH_COLOR || B3) {
+            if (WITH_COLOR) {
                 // (the bf16x3 form of the sdf-only pass runs the whole layer: 48 short MFMAs, d2 is zero but for g_sdf)
                 FUSED_LAYER(32, 2, wt, d2, acc);
             } else {
@@ -1106,7 +835,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], gs, z, 0, 0, 0);
                 }
             }
-            wt += FUSED_TS2(B3);
+            wt += FUSED_TS2;
 #pragma unroll
             for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw1, j, acc[j >> 4][j & 15]);   // mask S2 -> dP1
             fused_wait(B);
@@ -1124,7 +853,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             row_load_async(B[1], atile, 128 + i, h);
             scr_put<2>(scr, dbin, pt, h);
             FUSED_LAYER(32, 2, wt, dbin, acc);
-            wt += FUSED_TS1(B3);
+            wt += FUSED_TS1;
             float q0[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) q0[j] = mask_bit(mw0, j, acc[j >> 4][j & 15]);     // mask S1 -> dP0
@@ -1147,7 +876,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             scr_put<2>(scr, dbin, pt, h);
             // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
             f32x16 e[3];
-            if (g_xc || B3) {
+            if (g_xc) {
                 FUSED_LAYER(32, 3, wt, dbin, e);
             } else {
                 f32x16 e12[2];
@@ -1474,90 +1203,14 @@ __device__ __forceinline__ void wgrad_body_b3(const float *__restrict__ acts, co
     if (h == 0) db_part[(int64_t)chunk * out_pad + 32 * mt + i] = bsum;
 }
 
-// ---- b3 weight gradients of a 128-row layer with the operand tiles streamed through an LDS ring by LDS-DMA ------------
-// wgrad_body's four waves walk the SAME tile sequence, so a workgroup keeps one tile (32 KB unique) per register set in
-// flight -- with the MFMA time gone (bf16 pipe) that memory-level parallelism bounds the kernel at ~3.5 TB/s (measured:
-// 0.65 ms per 128 x 128 layer, while the one-wave-per-tile out = 32 layers of the same launch sequence run at 6 TB/s).
-// Here the tile (dPre 16 KB + act 4*IT KB) lands ONCE per workgroup in a 4-stage LDS ring, three tiles (96 KB) ahead of
-// the one being multiplied, with no register staging.  LDS-DMA writes lane-linear 16-byte slots, the per-lane GLOBAL
-// address is free: slot (row block rb, quarter j, lane (g, i)) <- floats 16g + 4j .. +3 of row 32 rb + i, so that every
-// fragment read is a conflict-free lane-linear ds_read_b128 and lands exactly in wg_load_async's register pattern.
-template <int IT>
-__global__ __launch_bounds__(256, 1) void wgrad_ring_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
-                                                               int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
-                                                               int dpre_off, float *__restrict__ dw_part,
-                                                               float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
-    constexpr int RB = 4 + IT;              // 32-row blocks per tile: 4 of dPre, IT of activations
-    constexpr int STAGE_F4 = RB * 256;      // float4 slots per stage
-    constexpr int NL = RB;                  // DMA instructions per wave and tile (wave w carries quarter w of every block)
-    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
-    const int i = lane & 31, g = lane >> 5;
-    const int chunk = blockIdx.x;
-    const int64_t st = n_chunks;
-    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
-    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
-    f32x16 acc[IT];
-    acc_zero<IT>(acc);
-    float bsum = 0.f;
-    auto issue = [&](int64_t k) {
-        const int64_t t = (chunk + k * st) <= last ? (chunk + k * st) : last;   // prefetches past the end re-read a tile
-        f32x4 *stage = lds_res + (int)(k & 3) * STAGE_F4;
-        const float *dp = dpre + t * dpre_tile_floats + dpre_off + (int64_t)i * TILE + 16 * g + 4 * mt;
-        const float *ap = acts + t * acts_tile_floats + act_off + (int64_t)i * TILE + 16 * g + 4 * mt;
-#pragma unroll
-        for (int rb = 0; rb < RB; rb++) {
-            const float *src = rb < 4 ? dp + rb * 32 * TILE : ap + (rb - 4) * 32 * TILE;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(stage + (rb * 4 + mt) * 64), 16, 0, 0);
-        }
-    };
-    if (n_my > 0) {
-        issue(0);
-        issue(1);
-        issue(2);
-        for (int64_t k = 0; k < n_my; k++) {
-            // my pieces of tile k have landed (tiles k+1, k+2 stay in flight) ...
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-            // ... and after the barrier everyone's have, and everyone is done reading tile k-1, whose stage tile k+3 takes
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            issue(k + 3);
-            const f32x4 *stage = lds_res + (int)(k & 3) * STAGE_F4;
-            WgFrag<IT> f;
-#pragma unroll
-            for (int j = 0; j < 4; j++) f.a[j] = stage[(mt * 4 + j) * 64 + lane];
-#pragma unroll
-            for (int n = 0; n < IT; n++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) f.b[n][j] = stage[((4 + n) * 4 + j) * 64 + lane];
-            wg_mma_b3<IT>(f, acc, bsum);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const int in_pad = 32 * IT;
-    float *dw = dw_part + (int64_t)chunk * 128 * in_pad;
-#pragma unroll
-    for (int n = 0; n < IT; n++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, g)) * in_pad + 32 * n + i] = acc[n][r];
-    bsum += __shfl_xor(bsum, 32);
-    if (g == 0) db_part[(int64_t)chunk * 128 + 32 * mt + i] = bsum;
-}
-
 // ---- b3 weight gradients of a 128-row layer, every operand value sliced ONCE per workgroup ---------------------------
-// The ring kernel above fixed the memory-level parallelism (0.65 -> 0.54 ms per 128 x 128 layer) and exposed the next
-// bound: each of the four waves slices all IT activation tiles itself (440 VALU instructions per tile and wave, serial
-// with its 48 MFMAs on a one-wave SIMD).  Here the raw tile still lands once per workgroup in an LDS ring by LDS-DMA
-// (three stages: two tiles, 64 KB, ahead), but wave mt reads back ONLY its own dPre row block and activation row block mt,
-// keeps its dPre slices in registers (nobody else needs them) and publishes the slices of activation block mt in a
-// double-buffered LDS area from which all four waves take ready-made B fragments.  Per tile: one barrier, 176 slicing
-// instructions per wave (for tile k+1, independent of tile k's MFMAs), 8 + 6*IT ds_read_b128 and 6 ds_write_b128 per wave.
-// (A first version kept the raw rows in registers, loaded by inline-asm global loads four sets deep: hipcc copied
-// in-flight sets between registers at the loop boundary -- an asm output counts as valid from the asm statement on -- and
-// the kernel returned garbage at sizes no small test reached.  tests/test_gpu_ops.py::test_warp_large_batch_weight_gradients
-// now holds every large-batch kernel to the small-batch forms.  Everything here but the DMA and its waits is visible to
-// the compiler.)
+// wgrad_body_b3's four waves walk the SAME tile sequence and each slices all IT activation tiles itself (440 VALU
+// instructions per tile and wave, serial with its 48 MFMAs on a one-wave SIMD).  In the large-batch kernel below wave mt
+// loads ONLY its own dPre row block and activation row block mt, keeps its dPre slices in registers (nobody else needs
+// them) and publishes the slices of activation block mt in a double-buffered LDS area from which all four waves take
+// ready-made B fragments: one barrier and 176 slicing instructions per wave and tile.  (Forms that were measured and
+// removed -- raw tiles through an LDS-DMA ring with every wave slicing everything, 5.4-5.5 ms for the warp group; the same
+// ring with slice-once, 5.54 ms; asm-loaded register sets, wrong at large batches -- are described in DESIGN.md section 3.)
 struct WgSl {
     Frag h[2], m[2], l[2];
 };
@@ -1569,137 +1222,9 @@ __device__ __forceinline__ void wg_slice16(const f32x4 (&v)[4], WgSl &o) {
             split2(v[2 * s + (e2 >> 1)][2 * (e2 & 1)], v[2 * s + (e2 >> 1)][2 * (e2 & 1) + 1], o.h[s].u[e2], o.m[s].u[e2], o.l[s].u[e2]);
 }
 
-template <int IT>
-__global__ __launch_bounds__(256, 1) void wgrad_share_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
-                                                                int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
-                                                                int dpre_off, float *__restrict__ dw_part,
-                                                                float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
-    constexpr int RB = 4 + IT;              // 32-row blocks per raw tile: 4 of dPre, IT of activations
-    constexpr int STAGE_F4 = RB * 256;      // float4 slots per ring stage
-    constexpr int NST = 3;
-    constexpr int NL = RB;                  // DMA instructions per wave and tile (wave w carries quarter w of every block)
-    constexpr int BUF_F4 = IT * 6 * 64;     // B slices of one tile: [in tile][plane 3][step 2][lane 64] float4
-    f32x4 *const bbuf = lds_res + NST * STAGE_F4;
-    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
-    const int i = lane & 31, g = lane >> 5;
-    const int chunk = blockIdx.x;
-    const int64_t st = n_chunks;
-    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
-    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
-    f32x16 acc[IT];
-    acc_zero<IT>(acc);
-    float bsum = 0.f;
-    WgSl as[2];
-    auto issue = [&](int64_t k) {
-        const int64_t t = (chunk + k * st) <= last ? (chunk + k * st) : last;   // prefetches past the end re-read a tile
-        f32x4 *stage = lds_res + (int)(k % NST) * STAGE_F4;
-        const float *dp = dpre + t * dpre_tile_floats + dpre_off + (int64_t)i * TILE + 16 * g + 4 * mt;
-        const float *ap = acts + t * acts_tile_floats + act_off + (int64_t)i * TILE + 16 * g + 4 * mt;
-#pragma unroll
-        for (int rb = 0; rb < RB; rb++) {
-            const float *src = rb < 4 ? dp + rb * 32 * TILE : ap + (rb - 4) * 32 * TILE;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(stage + (rb * 4 + mt) * 64), 16, 0, 0);
-        }
-    };
-    // raw tile k (ring stage k % 3) -> my dPre slices as[par] (+ the bias-gradient sum of a REAL tile), and -- waves < IT --
-    // the slices of activation block mt into B buffer par
-    auto split = [&](int64_t k, WgSl &a_out, int par) {
-        const f32x4 *stage = lds_res + (int)(k % NST) * STAGE_F4;
-        f32x4 a[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) a[j] = stage[(mt * 4 + j) * 64 + lane];
-        if (k < n_my) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) bsum += (a[j][0] + a[j][1]) + (a[j][2] + a[j][3]);
-        }
-        wg_slice16(a, a_out);
-        if (mt < IT) {
-            f32x4 b[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = stage[((4 + mt) * 4 + j) * 64 + lane];
-            WgSl bs;
-            wg_slice16(b, bs);
-            f32x4 *dst = bbuf + par * BUF_F4 + mt * 6 * 64 + lane;
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                dst[(0 * 2 + s) * 64] = bs.h[s].f;
-                dst[(1 * 2 + s) * 64] = bs.m[s].f;
-                dst[(2 * 2 + s) * 64] = bs.l[s].f;
-            }
-        }
-    };
-    auto mma = [&](const WgSl &a, int par) {
-        const f32x4 *src = bbuf + par * BUF_F4 + lane;
-#pragma unroll
-        for (int np = 0; np < IT; np += 2) {
-            Frag bh[2][2], bm[2][2], bl[2][2];
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int s = 0; s < 2; s++) {
-                    bh[t][s].f = src[((np + t) * 6 + 0 * 2 + s) * 64];
-                    bm[t][s].f = src[((np + t) * 6 + 1 * 2 + s) * 64];
-                    bl[t][s].f = src[((np + t) * 6 + 2 * 2 + s) * 64];
-                }
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-#pragma unroll
-                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s].h, bh[t][s].h, acc[np + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s].h, bm[t][s].h, acc[np + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s].h, bl[t][s].h, acc[np + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s].h, bh[t][s].h, acc[np + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s].h, bm[t][s].h, acc[np + t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s].h, bh[t][s].h, acc[np + t], 0, 0, 0);
-            }
-        }
-    };
-    // one pipeline step for tile k: (everyone's pieces of raw tile k+1 and B slices of tile k visible, everyone out of
-    // ring stage k % 3 and B buffer (k+1) & 1) -> refill stage k % 3 with tile k+3 -> MFMAs of tile k, slices of tile k+1
-#define WG_STEP(k, PAR)                                                         \
-    do {                                                                        \
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NL) : "memory");    \
-        __builtin_amdgcn_s_barrier();                                           \
-        __builtin_amdgcn_sched_barrier(0);                                      \
-        issue((k) + 3);                                                         \
-        if ((k) < n_my) mma(as[PAR], PAR);                                      \
-        split((k) + 1, as[1 - (PAR)], 1 - (PAR));                               \
-        __builtin_amdgcn_sched_barrier(0);                                      \
-    } while (0)
-    if (n_my > 0) {
-        issue(0);
-        issue(1);
-        issue(2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        split(0, as[0], 0);
-        for (int64_t k = 0; k < n_my; k += 2) {
-            WG_STEP(k, 0);
-            WG_STEP(k + 1, 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#undef WG_STEP
-    const int in_pad = 32 * IT;
-    float *dw = dw_part + (int64_t)chunk * 128 * in_pad;
-#pragma unroll
-    for (int n = 0; n < IT; n++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, g)) * in_pad + 32 * n + i] = acc[n][r];
-    bsum += __shfl_xor(bsum, 32);
-    if (g == 0) db_part[(int64_t)chunk * 128 + 32 * mt + i] = bsum;
-}
-
-// ---- the same slice-once scheme with the raw rows prefetched into REGISTERS by ordinary (compiler-visible) loads ------
-// wave mt loads only its own dPre row block and activation row block mt (8 KB per tile), four register sets deep; hipcc
-// tracks these loads itself (its s_waitcnt before a set's first use counts the younger sets), the scheduling fences keep the
-// loads at the head of each step.  No LDS-DMA issue cost, 96 KB per CU in flight.  (MORPHEUS_WGRAD_B3=regs)
+// The raw rows are prefetched into REGISTERS by ordinary (compiler-visible) loads: wave mt loads only its own dPre row block
+// and activation row block mt (8 KB per tile), WG_REG_SETS register sets deep; hipcc tracks these loads itself (its s_waitcnt
+// before a set's first use counts the younger sets), the scheduling fences keep the loads at the head of each step.
 struct WgRaw {
     f32x4 a[4], b[4];
 };
@@ -2072,7 +1597,6 @@ extern "C" int64_t mh_warp_dpre_floats(int64_t M) { return n_tiles_for(M) * (int
 extern "C" int64_t mh_warp_wpack_floats(void) { return WARP_NET_WPACK; }
 extern "C" int64_t mh_warp_wpackT_floats(void) { return WARP_NET_WPACKT; }
 extern "C" int64_t mh_field_acts_floats(int64_t M) { return n_tiles_for(M) * (int64_t)(FIELD_ACT_ROWS * TILE); }
-extern "C" int64_t mh_field_dpre_floats(int64_t M) { return n_tiles_for(M) * (int64_t)(FIELD_DPRE_ROWS * TILE); }
 extern "C" int64_t mh_field_wpack_floats(void) { return FIELD_WPACK; }
 extern "C" int64_t mh_field_wpackT_floats(void) { return FIELD_WPACKT; }
 extern "C" int64_t mh_mlp_tiles(int64_t M) { return n_tiles_for(M); }
@@ -2122,14 +1646,13 @@ static inline unsigned field_blocks(int64_t n_tiles) {
 
 // the resident-weight kernels need more than the default 64 KB of dynamic LDS: opt in once per kernel, not per launch
 static int field_lds_opt_in() {
-    static int done = 0;
-    if (!done) {
+    static MhOncePerDevice done;
+    const int dev = mh_device();
+    if (done.need(dev)) {
         if (hipFuncSetAttribute((const void *)field_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(FIELD_WPACK * sizeof(float))) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(FIELD_WPACKT * sizeof(float))) != hipSuccess)
+                                (int)(FIELD_WPACK * sizeof(float))) != hipSuccess)
             return MH_ERR_LAUNCH;
-        done = 1;
+        done.mark(dev);
     }
     return MH_OK;
 }
@@ -2149,28 +1672,11 @@ extern "C" int mh_field_fwd(const float *xc, const float *feat_s, const float *f
     return MH_OK;
 }
 
-extern "C" int mh_field_bwd_data(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
-                                 const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
-                                 int32_t n_bands, int32_t with_color, const float *acts, float *dpre, float *g_xc,
-                                 float *g_feat_s, float *g_feat_c, float *g_topo, float *g_beta_partial,
-                                 uint32_t *gmax_bits, int64_t M, void *stream) {
-    if (M == 0) return MH_OK;
-    if (M < 0 || !xc || !sdf || !wpackT || !acts || !dpre || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
-    if (with_color && !albedo) return MH_ERR_ARG;
-    const int64_t n_tiles = n_tiles_for(M);  // dead tail tiles are processed too: wgrad reads every scratch tile
-    const size_t lds = (size_t)FIELD_WPACKT * sizeof(float);
-    if (field_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    hipLaunchKernelGGL(field_bwd_kernel, dim3(field_blocks(n_tiles)), dim3(FIELD_THREADS), lds, mh_stream(stream), xc, sdf,
-                       albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, (int)n_bands, (int)with_color, acts, dpre, g_xc, g_feat_s,
-                       g_feat_c, g_topo, g_beta_partial, gmax_bits, M, n_tiles);
-    MH_CHECK_LAUNCH();
-    return MH_OK;
-}
-
+#define WG_PER_LAYER_TILES 16384      // from this many 32-point tiles on: one launch per layer, large-batch kernels
 static inline int wg_chunks(int out_pad, int64_t n_tiles) {
     // 4 waves per CU per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
     // large batches (the per-layer launches, from 16 384 tiles on): WG_REG_WAVES workgroups per CU (wgrad_regs_b3_kernel)
-    int64_t c = (int64_t)(4 * ((n_tiles >= 16384 && out_pad == 128) ? WG_REG_WAVES : 1) * mh_cu_count()) / (out_pad / 32);
+    int64_t c = (int64_t)(4 * ((n_tiles >= WG_PER_LAYER_TILES && out_pad == 128) ? WG_REG_WAVES : 1) * mh_cu_count()) / (out_pad / 32);
     if (c > n_tiles) c = n_tiles;
     return (int)(c < 1 ? 1 : c);
 }
@@ -2216,9 +1722,8 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
     // One launch per layer for big batches, ONE launch for all layers for small ones (measured on MI355X, same box):
     // at 2 M points the merged launch is slower (warp nets 6.6 vs 6.0 ms: workgroups of different layers stream
     // different 2 GB regions at once), at the 2 k-140 k-point calls of a training step it is faster (1.11 vs 1.28 ms
-    // per step: the twelve launches are mostly ramp-up and drain).  MORPHEUS_WGRAD=per_layer / merged forces either.
-    static const char *wg_mode = getenv("MORPHEUS_WGRAD");
-    const bool per_layer = wg_mode ? (wg_mode[0] == 'p') : (n_tiles >= 16384);
+    // per step: the twelve launches are mostly ramp-up and drain).
+    const bool per_layer = n_tiles >= WG_PER_LAYER_TILES;
     WgAll all;
     all.n = n_layers;
     all.first_block[0] = 0;
@@ -2234,19 +1739,7 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
         all.db_off[l] = db_poff[l];
         all.first_block[l + 1] = all.first_block[l] + chunks;
         if (per_layer && b3 && out == 128 && (in == 128 || in == 64)) {
-            static int ring_ok = 0;
-            if (!ring_ok) {
-                if (hipFuncSetAttribute((const void *)wgrad_ring_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8 * 4096) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)wgrad_ring_b3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 6 * 4096) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)wgrad_share_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 8 * 256 + 2 * 4 * 6 * 64) * 16) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)wgrad_share_b3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (3 * 6 * 256 + 2 * 2 * 6 * 64) * 16) != hipSuccess)
-                    return MH_ERR_LAUNCH;
-                ring_ok = 1;
-            }
-            // default: slice-once with the raw rows prefetched into registers; A/B switches: "share" = the same scheme with the raw
-            // tile through an LDS-DMA ring (measured 5.54 vs 5.28 ms), "ring" = LDS-DMA ring, every wave slices all (5.50)
-            static const char *wgk = getenv("MORPHEUS_WGRAD_B3");
-            if (amax && a_slot_host && b_slot_host && a_slot_host[l] >= 0 && b_slot_host[l] >= 0 && !wgk) {
+            if (amax && a_slot_host && b_slot_host && a_slot_host[l] >= 0 && b_slot_host[l] >= 0) {
                 // fp16 x 2 slices at the tensors' recorded scales (LDS: two planes per B tile)
                 if (in == 128)
                     hipLaunchKernelGGL(wgrad_regs_h2_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 4 * 1024, mh_stream(stream),
@@ -2258,31 +1751,13 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
                                        acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
                                        workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks, amax, (int)a_slot_host[l],
                                        (int)b_slot_host[l]);
-            } else if (!wgk || (wgk[0] == 'r' && wgk[1] == 'e')) {
-                if (in == 128)
-                    hipLaunchKernelGGL(wgrad_regs_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
-                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
-                else
-                    hipLaunchKernelGGL(wgrad_regs_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 2 * 2 * 6 * 1024, mh_stream(stream),
-                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
-            } else if (wgk[0] == 's') {
-                if (in == 128)
-                    hipLaunchKernelGGL(wgrad_share_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), (3 * 8 * 256 + 2 * 4 * 6 * 64) * 16, mh_stream(stream),
-                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
-                else
-                    hipLaunchKernelGGL(wgrad_share_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), (3 * 6 * 256 + 2 * 2 * 6 * 64) * 16, mh_stream(stream),
-                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
             } else if (in == 128)
-                hipLaunchKernelGGL(wgrad_ring_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 4 * 8 * 4096, mh_stream(stream), acts, dpre,
-                                   acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                hipLaunchKernelGGL(wgrad_regs_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
+                                   acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
                                    workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
             else
-                hipLaunchKernelGGL(wgrad_ring_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 4 * 6 * 4096, mh_stream(stream), acts, dpre,
-                                   acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
+                hipLaunchKernelGGL(wgrad_regs_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 2 * 2 * 6 * 1024, mh_stream(stream),
+                                   acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
                                    workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
             MH_CHECK_LAUNCH();
         } else if (per_layer) {
@@ -2388,24 +1863,20 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
                                 const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
                                 int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
                                 float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
-                                float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream, bool b3) {
+                                float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !xc || !sdf || !wpackT || !acts || !workspace || !raw || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && (!albedo || !dgeo_scratch)) return MH_ERR_ARG;
-    static int opted = 0;
-    const size_t lds_c = (size_t)(FUSED_TC2(b3) + FUSED_TC1(b3) + FUSED_TC0(b3)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
-    const size_t lds_s = (size_t)(FUSED_TS2(b3) + FUSED_TS1(b3) + FUSED_TS0(b3)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
-    if (!opted) {
-        const int big_c = (int)((size_t)(FUSED_TC2(1) + FUSED_TC1(1) + FUSED_TC0(1)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float));
-        const int big_s = (int)((size_t)(FUSED_TS2(1) + FUSED_TS1(1) + FUSED_TS0(1)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float));
-        if (hipFuncSetAttribute((const void *)field_fused_color_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_c) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_color_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_c) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess)
+    static MhOncePerDevice opted;
+    const size_t lds_c = (size_t)(FUSED_TC2 + FUSED_TC1 + FUSED_TC0) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
+    const size_t lds_s = (size_t)(FUSED_TS2 + FUSED_TS1 + FUSED_TS0) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
+    const int dev = mh_device();
+    if (opted.need(dev)) {
+        if (hipFuncSetAttribute((const void *)field_fused_color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess)
             return MH_ERR_LAUNCH;
-        opted = 1;
+        opted.mark(dev);
     }
     const int64_t n_tiles = n_tiles_for(M);
     const int blocks = fused_blocks(n_tiles);
@@ -2430,21 +1901,18 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
         pc.db[k] = db_off[3 + k];
     }
     hipStream_t st = mh_stream(stream);
-#define FUSED_LAUNCH_COLOR(B3)                                                                                              \
-    hipLaunchKernelGGL(field_fused_color_kernel<B3>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT, \
-                       acts, dgeo_scratch, g_feat_c, workspace, pc, gmax_bits, M, n_tiles)
-#define FUSED_LAUNCH_SDF(WC, B3, DGEO)                                                                                       \
-    hipLaunchKernelGGL((field_fused_sdf_kernel<WC, B3>), dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf,      \
+#define FUSED_LAUNCH_SDF(WC, DGEO)                                                                                           \
+    hipLaunchKernelGGL((field_fused_sdf_kernel<WC>), dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf,      \
                        g_sigma, wpackT, beta, (int)n_bands, acts, (const float *)(DGEO), g_xc, g_feat_s, g_topo, g_beta_partial, \
                        workspace, ps, gmax_bits, M, n_tiles)
     if (with_color) {
-        if (b3) FUSED_LAUNCH_COLOR(true); else FUSED_LAUNCH_COLOR(false);
+        hipLaunchKernelGGL(field_fused_color_kernel, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT,
+                           acts, dgeo_scratch, g_feat_c, workspace, pc, gmax_bits, M, n_tiles);
         MH_CHECK_LAUNCH();
-        if (b3) FUSED_LAUNCH_SDF(true, true, dgeo_scratch); else FUSED_LAUNCH_SDF(true, false, dgeo_scratch);
+        FUSED_LAUNCH_SDF(true, dgeo_scratch);
     } else {
-        if (b3) FUSED_LAUNCH_SDF(false, true, nullptr); else FUSED_LAUNCH_SDF(false, false, nullptr);
+        FUSED_LAUNCH_SDF(false, nullptr);
     }
-#undef FUSED_LAUNCH_COLOR
 #undef FUSED_LAUNCH_SDF
     MH_CHECK_LAUNCH();
     // reduce the per-wave partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format)
@@ -2484,25 +1952,13 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
     return MH_OK;
 }
 
-extern "C" int64_t mh_field_w3T_bytes(void) { return (int64_t)(FUSED_TC2(1) + FUSED_TC1(1) + FUSED_TC0(1) + FUSED_TS2(1) + FUSED_TS1(1) + FUSED_TS0(1)) * 16; }
-
 extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
                                   const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
                                   int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
                                   float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
                                   float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
     return field_bwd_fused_impl(xc, sdf, albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, n_bands, with_color, acts, dgeo_scratch,
-                                workspace, raw, g_xc, g_feat_s, g_feat_c, g_topo, g_beta_partial, gmax_bits, M, stream, false);
-}
-
-extern "C" int mh_field_bwd_fused_b3(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
-                                     const float *g_sigma, const float *g_albedo, const void *w3T, const float *beta,
-                                     int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
-                                     float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
-                                     float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
-    return field_bwd_fused_impl(xc, sdf, albedo, g_sdf, g_sigma, g_albedo, reinterpret_cast<const float *>(w3T), beta, n_bands,
-                                with_color, acts, dgeo_scratch, workspace, raw, g_xc, g_feat_s, g_feat_c, g_topo, g_beta_partial,
-                                gmax_bits, M, stream, true);
+                                workspace, raw, g_xc, g_feat_s, g_feat_c, g_topo, g_beta_partial, gmax_bits, M, stream);
 }
 
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }

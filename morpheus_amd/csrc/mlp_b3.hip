@@ -386,218 +386,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     }
 }
 
-// ---- phased forward: the SIMD's two waves run half a layer apart ---------------------------------------------------
-// warp_fwd_b3_kernel's eight waves move in lockstep: per layer, MFMA pipe work 12.3 k cycles per SIMD inside 21 k -- while
-// every wave is in its exposed epilogue, DMA issue or stage wait, the matrix pipe idles (profiles/r02_phase_trace_warp_fwd.txt).
-// Here waves 4..7 (group B) run ONE PHASE behind waves 0..3 (group A); a phase is one staged block = one k-half of a hidden
-// layer (96 MFMAs per wave), and a wave's exposed work (the second tile pair's epilogue, accumulator init) sits at the START
-// of a phase, where its SIMD partner -- in the other half of the layer -- has MFMAs to run.  One workgroup barrier per phase;
-// block p+1 is DMA'd during phase p into a ring of three 48 KB regions (block p is being read by A, block p-1 by B), so no
-// wave ever waits for a DMA it has just issued.
-#define B3P_REGIONS 3
-#define B3P_BIAS_F4 (B3P_REGIONS * B3_KH_F4)                       // bias slots (64 float4 each) behind the regions
-#define B3P_LDS_BYTES ((B3P_REGIONS * B3_KH_F4 + B3P_REGIONS * 64) * 16)
-#define B3P_BLOCKS 20                                               // per net: L0, 4 x (k-half 0, k-half 1), L5
-
-// all waves: DMA global block q (+ the bias row of the layer it opens) into region q % 3
-__device__ __forceinline__ void b3p_issue(int q, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
-                                          const float *__restrict__ bias_d, const float *__restrict__ bias_t) {
-    if (q >= B3P_BLOCKS) return;
-    const int net = q >= 10, i = q - 10 * net;
-    const f32x4 *src = (net ? w3_t : w3_d) + (i == 0 ? 0 : B3_L0_F4 + (i - 1) * B3_KH_F4);
-    const int pieces = i == 0 ? B3_L0_F4 / B3_THREADS : (i == 9 ? B3_L5_F4 / B3_THREADS : B3_KH_F4 / B3_THREADS);
-    const int wave = threadIdx.x >> 6, reg = q % B3P_REGIONS;
-#pragma unroll
-    for (int k = 0; k < B3_KH_F4 / B3_THREADS; k++)
-        if (k < pieces)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * B3_THREADS + threadIdx.x),
-                                             (__attribute__((address_space(3))) void *)(lds_b3 + reg * B3_KH_F4 + k * B3_THREADS + wave * 64),
-                                             16, 0, 0);
-    if (i & 1) {   // i = 1, 3, 5, 7: k-half 0 of hidden layer (i + 1) / 2 -> bias row (i - 1) / 2;  i = 9: L5 -> row 4 (32 floats)
-        const float *b = (net ? bias_t : bias_d) + ((i - 1) / 2) * 128;
-        if ((int)threadIdx.x < (i == 9 ? 8 : 32))
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const f32x4 *>(b) + threadIdx.x),
-                                             (__attribute__((address_space(3))) void *)(lds_b3 + B3P_BIAS_F4 + reg * 64 + (threadIdx.x >> 6) * 64),
-                                             16, 0, 0);
-    }
-}
-// phase boundary: my DMA pieces (and parking stores) are done, everyone's are visible and everyone has left the region that
-// block p + 1 now overwrites
-__device__ __forceinline__ void b3p_begin(int p, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
-                                          const float *__restrict__ bias_d, const float *__restrict__ bias_t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    b3p_issue(p + 1, w3_d, w3_t, bias_d, bias_t);
-}
-template <int MT>
-__device__ __forceinline__ void b3p_acc_bias(f32x16 (&acc)[MT], int reg, int h) {
-    const f32x4 *b = lds_b3 + B3P_BIAS_F4 + reg * 64;
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const f32x4 v = b[8 * t + 2 * r4 + h];
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = v[c];
-        }
-}
-// 48 MFMAs: output tiles T0, T0+1 over the four k16 steps of the k-half block at `wk`; B slices 4 * KHALF + 0..3
-template <int T0, int KHALF>
-__device__ __forceinline__ void b3p_quarter(const f32x4 *__restrict__ wk, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
-                                            f32x16 (&acc)[4], int lane) {
-    constexpr int PLH = 4 * 4 * 64;
-#pragma unroll
-    for (int sp = 0; sp < 4; sp++) {
-        constexpr int dummy = 0;
-        const int s = 4 * KHALF + sp;
-        Frag ah[2], am[2], al[2];
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            ah[t].f = wk[0 * PLH + (T0 + t) * 256 + sp * 64 + lane];
-            am[t].f = wk[1 * PLH + (T0 + t) * 256 + sp * 64 + lane];
-            al[t].f = wk[2 * PLH + (T0 + t) * 256 + sp * 64 + lane];
-        }
-#pragma unroll
-        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
-        (void)dummy;
-    }
-}
-// one k16 step (local index sp of k-half 1) of output tiles 2, 3: 12 MFMAs
-__device__ __forceinline__ void b3p_step_t23(const f32x4 *__restrict__ wk, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
-                                             f32x16 (&acc)[4], int lane, int sp) {
-    constexpr int PLH = 4 * 4 * 64;
-    const int s = 4 + sp;
-    Frag ah[2], am[2], al[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        ah[t].f = wk[0 * PLH + (2 + t) * 256 + sp * 64 + lane];
-        am[t].f = wk[1 * PLH + (2 + t) * 256 + sp * 64 + lane];
-        al[t].f = wk[2 * PLH + (2 + t) * 256 + sp * 64 + lane];
-    }
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[2 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[2 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl[s].h, acc[2 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh[s].h, acc[2 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm[s].h, acc[2 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[2 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[2 + t], 0, 0, 0);
-}
-
-__global__ __launch_bounds__(B3_THREADS, 2) void warp_fwd_b3p_kernel(
-    const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
-    const float *__restrict__ bias0_t, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
-    const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
-    float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pt = lane & 31, h = lane >> 5;
-    const int grp = wave >> 2;                                    // 0: group A (leads), 1: group B (one phase behind)
-    const int64_t tile_id = (int64_t)blockIdx.x * 8 + wave;
-    const int64_t p = tile_id * TILE + pt;
-    const int64_t pc = p < M ? p : M - 1;
-    float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
-    const int sl = slot ? slot[pc] : 0;
-    float *tile = (acts && tile_id < n_tiles) ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
-
-    b3p_issue(0, w3_d, w3_t, bias_d, bias_t);
-    uint2 *mk = tile ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
-    int ph = 0;                                                    // the global phase this wave enters next
-    if (grp) b3p_begin(ph++, w3_d, w3_t, bias_d, bias_t);          // group B sits out phase 0
-#define REGION(phase) (lds_b3 + (((phase) - grp) % B3P_REGIONS) * B3_KH_F4)   // the wave's block index = its phase - grp
-
-    for (int net = 0; net < 2; net++) {
-        const float *b0 = (net ? bias0_t : bias0_d) + (int64_t)sl * 128;
-        float *ht = tile ? tile + (64 + net * 640) * TILE : nullptr;
-        f32x16 acc[4];
-        Frag bh[8], bm[8], bl[8];
-        // ---- block L0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot.  The encoding is computed per net (18
-        // sincosf, ~1 % of a net's instructions) rather than carried in 24 registers through the first net's layers
-        {
-            float bin0[24];
-            enc_bin(xv, h, n_bands, bin0, nullptr);
-#pragma unroll
-            for (int k = 20; k < 24; k++) bin0[k] = 0.f;
-            if (tile && net == 0) {
-#pragma unroll
-                for (int k = 0; k < 32; k++) tile[(2 * k + h) * TILE + pt] = k < 20 ? bin0[k] : 0.f;  // k-step ordered, rows 40..63 pad
-            }
-#pragma unroll
-            for (int s = 0; s < 3; s++)
-#pragma unroll
-                for (int e2 = 0; e2 < 4; e2++) split2(bin0[8 * s + 2 * e2], bin0[8 * s + 2 * e2 + 1], bh[s].u[e2], bm[s].u[e2], bl[s].u[e2]);
-        }
-        acc_bias<4>(acc, b0, h);
-        b3p_begin(ph, w3_d, w3_t, bias_d, bias_t);
-        b3_layer<3, 4>(REGION(ph), bh, bm, bl, acc, lane);
-        ph++;
-        // ---- hidden layer 1, k-half 0: layer 0's whole epilogue is exposed (it is short: 72 MFMAs gave nothing to hide it under)
-        b3p_begin(ph, w3_d, w3_t, bias_d, bias_t);
-        b3_epilogue(acc, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bm, bl);
-        b3p_acc_bias<4>(acc, (ph - grp) % B3P_REGIONS, h);
-        b3p_quarter<0, 0>(REGION(ph), bh, bm, bl, acc, lane);
-        b3p_quarter<2, 0>(REGION(ph), bh, bm, bl, acc, lane);
-        ph++;
-        for (int l = 1; l <= 4; l++) {
-            // phase "k-half 1" of layer l: tiles 0, 1 finish in its first quarter; their epilogue refills the dead slices 0..3 in
-            // k16-step chunks under the second quarter's MFMAs
-            b3p_begin(ph, w3_d, w3_t, bias_d, bias_t);
-            b3p_quarter<0, 1>(REGION(ph), bh, bm, bl, acc, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            uint32_t mt[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                b3p_step_t23(REGION(ph), bh, bm, bl, acc, lane, c);
-                b3_epilogue_eighth(acc, ht ? ht + l * 128 * TILE : nullptr, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (mk) reinterpret_cast<uint32_t *>(mk + (net * 5 + l) * 64 + lane)[0] = mt[0] | (mt[1] << 16);
-            ph++;
-            // next phase (k-half 0 of layer l+1, or the L5 block): the exposed half of layer l's epilogue comes first -- the SIMD
-            // partner is in its k-half 1 and has MFMAs to run meanwhile
-            b3p_begin(ph, w3_d, w3_t, bias_d, bias_t);
-            b3_epilogue_half<2>(acc, ht ? ht + l * 128 * TILE : nullptr, mt, pt, h, bh, bm, bl);
-            if (mk) reinterpret_cast<uint32_t *>(mk + (net * 5 + l) * 64 + lane)[1] = mt[2] | (mt[3] << 16);
-            if (l < 4) {
-                b3p_acc_bias<4>(acc, (ph - grp) % B3P_REGIONS, h);
-                b3p_quarter<0, 0>(REGION(ph), bh, bm, bl, acc, lane);
-                b3p_quarter<2, 0>(REGION(ph), bh, bm, bl, acc, lane);
-                ph++;
-            }
-        }
-        // ---- block L5: 128 -> 3 | 2 (one padded tile); its phase was opened above
-        f32x16 o[1];
-        b3p_acc_bias<1>(o, (ph - grp) % B3P_REGIONS, h);
-        b3_layer<8, 1>(REGION(ph), bh, bm, bl, o, lane);
-        ph++;
-        if (h == 0 && p < M) {
-            if (net == 0) {
-                out_deform[p * 3 + 0] = o[0][0];
-                out_deform[p * 3 + 1] = o[0][1];
-                out_deform[p * 3 + 2] = o[0][2];
-            } else {
-                out_topo[p * 2 + 0] = o[0][0];
-                out_topo[p * 2 + 1] = o[0][1];
-            }
-        }
-    }
-    if (!grp) b3p_begin(ph, w3_d, w3_t, bias_d, bias_t);          // group A keeps group B's last phase company at the barrier
-#undef REGION
-}
-
 // ---- backward-data -------------------------------------------------------------------------------------------------
 // Same chain, transposed packs (T5, T4..T1, T0), ReLU derivative from the sign masks the forward parked; parks dPre tiles in
 // mlp.hip's layout for mh_mlp_wgrad.
@@ -984,16 +772,15 @@ extern "C" int mh_b3_slice(const float *src, void *dst, int32_t n_layers, const 
 extern "C" int64_t mh_warp_w3_bytes(void) { return (int64_t)B3_NET_F4 * 16; }
 
 static int b3_lds_opt_in() {
-    static int done = 0;
-    if (!done) {
+    static MhOncePerDevice done;
+    const int dev = mh_device();
+    if (done.need(dev)) {
         if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_fwd_b3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B3P_LDS_BYTES) !=
                 hipSuccess)
             return MH_ERR_LAUNCH;
-        done = 1;
+        done.mark(dev);
     }
     return MH_OK;
 }
@@ -1007,11 +794,12 @@ extern "C" int mh_field_fwd_b3(const float *xc, const float *feat_s, const float
     if (M < 0 || !xc || !feat_s || !w3 || !bias || !sdf || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && (!feat_c || !albedo)) return MH_ERR_ARG;
     const int64_t n_tiles = mh_mlp_tiles(M);   // dead tail tiles are processed too: the backward reads every scratch tile
-    static int ok = 0;
-    if (!ok) {
+    static MhOncePerDevice ok;
+    const int dev = mh_device();
+    if (ok.need(dev)) {
         if (hipFuncSetAttribute((const void *)field_fwd_b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FB3_F4 * 16) != hipSuccess)
             return MH_ERR_LAUNCH;
-        ok = 1;
+        ok.mark(dev);
     }
     const int64_t need = (n_tiles + FB3_THREADS / 64 - 1) / (FB3_THREADS / 64);
     const int64_t cus = mh_cu_count();
@@ -1048,18 +836,9 @@ extern "C" int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *
     const int64_t blocks = (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    // "phased" = the two waves of a SIMD half a layer apart (warp_fwd_b3p_kernel): measured SLOWER than the lockstep kernel
-    // (4.20 vs 3.70 ms with parking, 2.99 vs 2.65 without, same box) -- these kernels run against the chip's power budget
-    // (effective clock 1.8 GHz in the phase trace), where overlap buys nothing and every extra barrier / DMA round costs
-    static const char *sched = getenv("MORPHEUS_B3_FWD");
-    if (sched && sched[0] == 'p')
-        hipLaunchKernelGGL(warp_fwd_b3p_kernel, dim3((unsigned)blocks), dim3(B3_THREADS), B3P_LDS_BYTES, mh_stream(stream), x, slot,
-                           bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
-                           bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
-    else
-        hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
-                           slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
-                           bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
+                       slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
+                       bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

@@ -18,10 +18,8 @@
 #define WARP_NET_WPACKT (4096 /*T5*/ + 4 * 16384 + 8192 /*T0: MT=2,KS=64*/)
 #define WARP_NET_BIAS (4 * 128 + 32)
 // field acts: S0 [96: 2kk+h, 80 used] | S1 [64] | S2 [64] | C0 [64: 2kk+h] | C1 [64] | C2 [64] | ReLU masks [4][64 lanes]
-// field dpre: P0 [64] | P1 [64] | P2 [64] | Q0 [64] | Q1 [64] | Q2 [32]
 #define FIELD_HID_ROWS (96 + 64 * 5)
 #define FIELD_ACT_ROWS (FIELD_HID_ROWS + 8)  // + ReLU masks of S1, S2, C1, C2: 4 x 64 lanes x 1 dword = 8 rows of 32
-#define FIELD_DPRE_ROWS (64 * 5 + 32)
 #define FIELD_WPACK (5120 + 4096 * 4 + 2048)
 #define FIELD_WPACKT (2048 /*TC2*/ + 4096 /*TC1*/ + 4096 /*TC0*/ + 4096 /*TS2*/ + 4096 /*TS1*/ + 6144 /*TS0 MT=3*/)
 #define FIELD_BIAS (64 * 5 + 32)

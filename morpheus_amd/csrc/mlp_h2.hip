@@ -837,27 +837,18 @@ extern "C" int mh_h2_slice(const float *src, void *dst, int32_t n_blocks, const 
 extern "C" int64_t mh_warp_w2_bytes(void) { return (int64_t)H2_NET_F4 * 16; }
 extern "C" int64_t mh_warp_w2T_bytes(void) { return (int64_t)H2_NETT_F4 * 16; }
 
-// workgroup shape: 8 = one 8-wave workgroup per CU with two LDS buffers, 4 = two independent 4-wave workgroups per CU with one
-// buffer each.  Measured at 2 M points: forward 2.59 (8) / 2.53 ms (4), backward-data 2.39 (8) / 2.58 ms (4) -> the defaults;
-// MORPHEUS_H2_WAVES=4|8 forces both (A/B switch).
-static int h2_waves(bool fwd) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("MORPHEUS_H2_WAVES");
-        forced = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : 0);
-    }
-    return forced ? forced : (fwd ? 4 : 8);
-}
-
+// workgroup shape: the forward runs two independent 4-wave workgroups per CU with one LDS buffer each, backward-data one 8-wave
+// workgroup per CU with two buffers.  Measured at 2 M points: forward 2.59 (8) / 2.53 ms (4), backward-data 2.39 (8) / 2.58 ms (4).
+#define H2_FWD_WAVES 4
+#define H2_BWD_WAVES 8
 static int h2_lds_opt_in() {
-    static int done = 0;
-    if (!done) {
-        if (hipFuncSetAttribute((const void *)warp_fwd_h2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_bwd_h2_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_fwd_h2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_BUF_F4 * 16) != hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_bwd_h2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_BUF_F4 * 16) != hipSuccess)
+    static MhOncePerDevice done;
+    const int dev = mh_device();
+    if (done.need(dev)) {
+        if (hipFuncSetAttribute((const void *)warp_bwd_h2_kernel<H2_BWD_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_fwd_h2_kernel<H2_FWD_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, H2_BUF_F4 * 16) != hipSuccess)
             return MH_ERR_LAUNCH;
-        done = 1;
+        done.mark(dev);
     }
     return MH_OK;
 }
@@ -869,17 +860,12 @@ extern "C" int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *
     if (M < 0 || !x || !bias0_d || !bias0_t || !w2_d || !w2_t || !bias_d || !bias_t || !out_deform || !out_topo || n_bands < 0 ||
         n_bands > 6)
         return MH_ERR_ARG;
-    const int nw = h2_waves(true);
-    const int64_t blocks = (M + nw * TILE - 1) / (nw * TILE);
+    const int64_t blocks = (M + H2_FWD_WAVES * TILE - 1) / (H2_FWD_WAVES * TILE);
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (h2_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
     const f32x4 *wd = reinterpret_cast<const f32x4 *>(w2_d), *wt = reinterpret_cast<const f32x4 *>(w2_t);
-    if (nw == 8)
-        hipLaunchKernelGGL(warp_fwd_h2_kernel<8>, dim3((unsigned)blocks), dim3(512), H2_LDS_BYTES, mh_stream(stream), x, slot, bias0_d,
-                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, amax, M, mh_mlp_tiles(M));
-    else
-        hipLaunchKernelGGL(warp_fwd_h2_kernel<4>, dim3((unsigned)blocks), dim3(256), H2_BUF_F4 * 16, mh_stream(stream), x, slot, bias0_d,
-                           bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, amax, M, mh_mlp_tiles(M));
+    hipLaunchKernelGGL(warp_fwd_h2_kernel<H2_FWD_WAVES>, dim3((unsigned)blocks), dim3(64 * H2_FWD_WAVES), H2_BUF_F4 * 16, mh_stream(stream),
+                       x, slot, bias0_d, bias0_t, wd, wt, bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, amax, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
@@ -889,17 +875,12 @@ extern "C" int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const 
                                    void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !x || !w2T_d || !w2T_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
-    const int nw = h2_waves(false);
-    const int64_t blocks = (M + nw * TILE - 1) / (nw * TILE);
+    const int64_t blocks = (M + H2_BWD_WAVES * TILE - 1) / (H2_BWD_WAVES * TILE);
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (h2_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
     const f32x4 *wd = reinterpret_cast<const f32x4 *>(w2T_d), *wt = reinterpret_cast<const f32x4 *>(w2T_t);
-    if (nw == 8)
-        hipLaunchKernelGGL(warp_bwd_h2_kernel<8>, dim3((unsigned)blocks), dim3(512), H2_LDS_BYTES, mh_stream(stream), x, g_deform, g_topo,
-                           wd, wt, (int)n_bands, acts, dpre, g_x, amax, M, mh_mlp_tiles(M));
-    else
-        hipLaunchKernelGGL(warp_bwd_h2_kernel<4>, dim3((unsigned)blocks), dim3(256), H2_BUF_F4 * 16, mh_stream(stream), x, g_deform, g_topo,
-                           wd, wt, (int)n_bands, acts, dpre, g_x, amax, M, mh_mlp_tiles(M));
+    hipLaunchKernelGGL(warp_bwd_h2_kernel<H2_BWD_WAVES>, dim3((unsigned)blocks), dim3(64 * H2_BWD_WAVES), H2_LDS_BYTES, mh_stream(stream),
+                       x, g_deform, g_topo, wd, wt, (int)n_bands, acts, dpre, g_x, amax, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
@@ -913,11 +894,12 @@ extern "C" int mh_field_fwd_h2(const float *xc, const float *feat_s, const float
     if (M < 0 || !xc || !feat_s || !w2 || !bias || !sdf || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && (!feat_c || !albedo)) return MH_ERR_ARG;
     const int64_t n_tiles = mh_mlp_tiles(M);   // dead tail tiles are processed too: the backward reads every scratch tile
-    static int ok = 0;
-    if (!ok) {
+    static MhOncePerDevice ok;
+    const int dev = mh_device();
+    if (ok.need(dev)) {
         if (hipFuncSetAttribute((const void *)field_fwd_h2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FH2_F4 * 16) != hipSuccess)
             return MH_ERR_LAUNCH;
-        ok = 1;
+        ok.mark(dev);
     }
     const int64_t need = (n_tiles + FH2_THREADS / 64 - 1) / (FH2_THREADS / 64);
     const int64_t cus = mh_cu_count();

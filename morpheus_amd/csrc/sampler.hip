@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rays_sample_uniform_kernel(float fx, floa
 //   [t_near, t_far] = slab clip to the AABB, t_near >= 0;   t0 = t_near + u * step;
 //   interval k: ts = t0 + k*step, te = min(ts + step, t_far), kept while ts < t_far and only if the grid cell
 //   containing the interval's midpoint is occupied.
-// Two passes (count, fill) around an exclusive scan of the per-ray counts: the packed layout is ragged.
+// The packed layout is ragged: march into per-ray slot rows, scan the counts, pack (march_wave_kernel, march_pack_kernel).
 struct MarchRay {
     float o[3], d[3];
     float t0, tfar;
@@ -191,39 +191,11 @@ __device__ __forceinline__ bool march_occupied(const MarchRay &m, float ts, floa
     return binary[((int64_t)c[0] * R + c[1]) * R + c[2]] != 0;
 }
 
-template <bool FILL>
-__global__ __launch_bounds__(64) void march_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
-                                                   const float *__restrict__ jitter, int N, float step, float bound, int R,
-                                                   const uint8_t *__restrict__ binary, int32_t *__restrict__ ray_cnt,
-                                                   const int32_t *__restrict__ ray_start, int32_t *__restrict__ ray_idx,
-                                                   float *__restrict__ t_starts, float *__restrict__ t_ends) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= N) return;
-    const MarchRay m = march_setup(rays_o, rays_d, jitter, r, step, bound);
-    int n = 0;
-    const int64_t base = FILL ? ray_start[r] : 0;
-    for (int k = 0;; k++) {
-        const float ts = m.t0 + (float)k * step;
-        if (!(ts < m.tfar)) break;
-        const float te = fminf(ts + step, m.tfar);
-        if (march_occupied(m, ts, te, bound, R, binary)) {
-            if (FILL) {
-                ray_idx[base + n] = r;
-                t_starts[base + n] = ts;
-                t_ends[base + n] = te;
-            }
-            n++;
-        }
-    }
-    if (!FILL) ray_cnt[r] = n;
-}
-
 // Wave-per-ray marcher: one wavefront walks one ray, 64 consecutive steps per iteration (a lane = one step: setup once,
 // one occupancy byte per lane in flight instead of a 350-iteration dependent-load loop per thread), ballot + prefix
 // popcount compacts the occupied steps into the ray's slot row [cap]; 2 048 rays fill 2 048 waves (8 per CU) where the
 // thread-per-ray form filled 32 workgroups.  A second launch copies the slot rows to their packed positions once the
-// exclusive scan of the counts is known -- the march itself runs ONCE (the count/fill pair above runs it twice).
-// Per-step arithmetic is the same expression as march_kernel's, so the samples are bit-identical.
+// exclusive scan of the counts is known -- the march itself runs ONCE (a count pass + a fill pass would run it twice).
 __global__ __launch_bounds__(256) void march_wave_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                                                          const float *__restrict__ jitter, int N, float step, float bound,
                                                          int R, const uint8_t *__restrict__ binary, int cap,
@@ -253,7 +225,7 @@ __global__ __launch_bounds__(256) void march_wave_kernel(const float *__restrict
     if (lane == 0) {
         ray_cnt[r] = n < cap ? n : cap;
         // a ray with more steps than the slot row holds (directions much shorter than unit length): tell the host, which
-        // re-runs the batch through the un-capped count/fill pair
+        // re-runs the batch with a longer slot row
         if (n > cap || (m.t0 + (float)k0 * step) < m.tfar) atomicOr(overflow, 1);
     }
 }
@@ -324,30 +296,6 @@ extern "C" int mh_sample_uniform(const float *rays_o, const float *rays_d, const
     if (total > 0x7fffffffLL) return MH_ERR_ARG;
     hipLaunchKernelGGL(sample_uniform_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, mh_stream(stream),
                        rays_o, rays_d, jitter, (int)N, (int)S, bound, ray_idx, t_starts, t_ends, xyz, ray_start, ray_cnt);
-    MH_CHECK_LAUNCH();
-    return MH_OK;
-}
-
-extern "C" int mh_march_count(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step,
-                              float bound, int32_t R, const uint8_t *binary, int32_t *ray_cnt, void *stream) {
-    if (N == 0) return MH_OK;
-    if (!rays_o || !rays_d || !binary || !ray_cnt || N < 0 || R <= 0 || !(step > 0.f) || !(bound > 0.f)) return MH_ERR_ARG;
-    hipLaunchKernelGGL(march_kernel<false>, dim3((N + 63) / 64), dim3(64), 0, mh_stream(stream), rays_o, rays_d, jitter,
-                       (int)N, step, bound, (int)R, binary, ray_cnt, (const int32_t *)nullptr, (int32_t *)nullptr,
-                       (float *)nullptr, (float *)nullptr);
-    MH_CHECK_LAUNCH();
-    return MH_OK;
-}
-
-extern "C" int mh_march_fill(const float *rays_o, const float *rays_d, const float *jitter, int32_t N, float step,
-                             float bound, int32_t R, const uint8_t *binary, const int32_t *ray_start, int32_t *ray_idx,
-                             float *t_starts, float *t_ends, void *stream) {
-    if (N == 0) return MH_OK;
-    if (!rays_o || !rays_d || !binary || !ray_start || !ray_idx || !t_starts || !t_ends || N < 0 || R <= 0 || !(step > 0.f) ||
-        !(bound > 0.f))
-        return MH_ERR_ARG;
-    hipLaunchKernelGGL(march_kernel<true>, dim3((N + 63) / 64), dim3(64), 0, mh_stream(stream), rays_o, rays_d, jitter, (int)N,
-                       step, bound, (int)R, binary, (int32_t *)nullptr, ray_start, ray_idx, t_starts, t_ends);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

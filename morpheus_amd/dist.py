@@ -36,8 +36,24 @@ def init_from_env(backend: str | None = None):
 
 
 class GradBucket:
-    """Flat gradient bucket; `zero()` ... backward ... `allreduce_mean()` (collect + the one exchange step) is a step.
-    After `collect()` / `allreduce_mean()` every `p.grad` is a view of `flat`."""
+    """Flat gradient bucket; `zero()` ... backward ... `allreduce_mean()` (collect + the exchange step) is a step.
+    After `collect()` / `allreduce_mean()` every `p.grad` is a view of `flat`.
+
+    Replicas stay identical by construction, whatever the data does on one rank:
+      * the SEQUENCE of collectives of a step depends only on how the bucket was configured (early range or not), never on
+        which gradients happened to arrive on a rank -- an early range that was not sent from the hooks (a rank whose batch
+        produced no gradient for one table) is sent at `allreduce_mean()`, before the remainder, so every rank issues
+        [early range][remainder] in that order;
+      * one has-gradient flag per parameter rides behind the gradients in the same buffer and is summed by the remainder's
+        all-reduce: a parameter counts as "no gradient" (torch.optim.Adam then skips it: no moment decay, no step
+        increment; optim.FlatAdam reads `missing`) only when it had none on EVERY rank.  The flags are read back (one
+        host sync) only on a rank that itself has a parameter without gradient; the common step never syncs;
+      * the early exchange fires after `backwards_per_step` backward passes (the reference accumulates a virtual-view and
+        a real-view backward before one optimiser step when `freeze_lr` is off, morpheus.py:1396-1424).  A backward pass
+        BEYOND the declared count finds the early range already summed across ranks; its gradients are kept apart, summed
+        by one extra all-reduce at `allreduce_mean()` and added -- the result is still the mean of the accumulated
+        gradients -- and the bucket then stops overlapping (one all-reduce after backward from the next step on; the call
+        pattern is code, identical on every rank, so every rank switches at the same step)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         plist = [p for p in params if p.requires_grad]
@@ -58,29 +74,39 @@ class GradBucket:
     def _init(self, layout, n, device):
         self._layout = layout
         self.params: List[torch.nn.Parameter] = [p for p, _, _ in layout]
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self._index = {id(p): i for i, (p, _, _) in enumerate(layout)}
+        # [gradients: n | has-gradient flags: one per parameter]; `flat` is the gradient part
+        self._buf = torch.zeros(n + len(layout), dtype=torch.float32, device=device)
+        self.flat = self._buf[:n]
+        self._flags = self._buf[n:]
         self._early = {}          # id(param) -> (param, offset, numel): gradients exchanged as soon as they land
         self._early_hooks = []
-        self._early_seen = 0
+        self._early_hits = 0      # post-accumulate hooks fired since zero()
+        self._early_fired = False  # the early range of this step is summed (or in flight)
+        self._early_disabled = False
+        self._backwards = 1
+        self._landed = set()      # layout indices whose gradient a hook already moved into the bucket this step
+        self._late = None         # gradients of backward passes beyond `backwards_per_step` (early range only)
+        self._late_used = False
         self._early_work = []     # outstanding async collectives of this step
         self._side = None         # side stream the early exchange is queued on (GPU only)
-        self.missing = set()      # layout indices whose p.grad was None at the last collect() (optim.FlatAdam skips them)
+        self.missing = set()      # layout indices without gradient at the last collect() (on every rank, once exchanged)
         self.rebind(force=True)
 
     # ---- overlap of the exchange with the tail of backward -----------------------------------------------
-    def overlap_early(self, early_params: Iterable[torch.nn.Parameter]):
+    def overlap_early(self, early_params: Iterable[torch.nn.Parameter], backwards_per_step: int = 1):
         """Exchange the gradients of `early_params` while backward is still running.
 
         On the render path the two hash tables (6.4 of the 7.45 MB) get their gradients from the brick kernels in the
         MIDDLE of backward; everything after that (the warp nets' backward-data and weight gradients, about half of the
-        backward pass) does not touch them.  A post-accumulate hook on each early parameter copies its fresh gradient
-        into the bucket and, once all of them have landed, queues ONE all-reduce of their (contiguous) range on a side
-        stream, so it runs under the rest of backward; `allreduce_mean()` then only has the small remainder left on the
-        critical path.  Contract: one backward per `zero()` (the bench / the reference's real-view steps); call
-        `overlap_early([])` to switch it off for gradient-accumulating callers."""
+        backward pass) does not touch them.  A post-accumulate hook on each early parameter moves its fresh gradient
+        into the bucket and, once all of them have landed `backwards_per_step` times, queues ONE all-reduce of their
+        (contiguous) range on a side stream, so it runs under the rest of backward; `allreduce_mean()` then only has the
+        small remainder left on the critical path.  `overlap_early([])` switches it off."""
         for h in self._early_hooks:
             h.remove()
         self._early_hooks, self._early = [], {}
+        self._early_disabled, self._backwards = False, max(int(backwards_per_step), 1)
         ids = {id(p) for p in early_params}
         for p, o, k in self._layout:
             if id(p) in ids:
@@ -96,44 +122,67 @@ class GradBucket:
         for p, _, _ in self._early.values():
             self._early_hooks.append(p.register_post_accumulate_grad_hook(self._on_early_grad))
 
-    def _on_early_grad(self, p):
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
-            return
-        _, o, k = self._early[id(p)]
-        view = self.flat[o:o + k].view(p.shape)
-        if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
-            view.copy_(p.grad)
-            p.grad = view
-        self._early_seen += 1
-        if self._early_seen != len(self._early):
-            return
+    @staticmethod
+    def _multi_rank() -> bool:
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def _send_early(self, async_op: bool):
         a, b = self._early_span
         seg = self.flat[a:b]
-        try:
-            if seg.is_cuda:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=seg.device)
-                cur = torch.cuda.current_stream(seg.device)      # the autograd thread's stream: the copies above are on it
-                self._side.wait_stream(cur)
-                with torch.cuda.stream(self._side):
-                    self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
-            else:
+        if async_op and seg.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=seg.device)
+            cur = torch.cuda.current_stream(seg.device)      # the autograd thread's stream: the hooks' copies are on it
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
                 self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
-        except Exception as e:      # noqa: BLE001 -- never lose a step to the overlap: fall back to the single exchange
-            import warnings
-            warnings.warn(f"early gradient exchange disabled ({type(e).__name__}: {e}); using one all-reduce after backward")
-            self._early_work = []
-            for h in self._early_hooks:
-                h.remove()
-            self._early_hooks, self._early = [], {}
+        elif async_op:
+            self._early_work.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        self._early_fired = True
+
+    def _on_early_grad(self, p):
+        if not self._multi_rank() or self._early_disabled or p.grad is None:
+            return
+        _, o, k = self._early[id(p)]
+        i = self._index[id(p)]
+        g = p.grad
+        p.grad = None               # the next backward pass hands over a fresh tensor instead of adding into the bucket
+        if self._early_fired:
+            # a backward pass beyond `backwards_per_step`: the range is already summed over the ranks (maybe still in
+            # flight) -- keep this gradient apart; allreduce_mean() sums and adds it
+            a, b = self._early_span
+            if self._late is None:
+                self._late = torch.zeros(b - a, dtype=torch.float32, device=self.flat.device)
+            self._late[o - a:o - a + k].view(p.shape).add_(g)
+            self._late_used = True
+            return
+        view = self.flat[o:o + k].view(p.shape)
+        if i in self._landed:
+            view.add_(g)
+        else:
+            if g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+            self._landed.add(i)
+        self._early_hits += 1
+        if self._early_hits == len(self._early) * self._backwards:
+            self._send_early(async_op=True)     # a failing collective is fatal (the peers are already inside theirs): let it raise
 
     def zero(self):
         """Start a step: clear the bucket and detach `p.grad`, so that autograd hands each parameter its fresh gradient
         tensor (a pointer move) instead of launching one accumulate-add per parameter into a bound view; `collect()`
         gathers them with one multi-tensor copy."""
+        if self._early_work:
+            raise RuntimeError("GradBucket.zero(): the early exchange of the previous step was never completed "
+                               "(call allreduce_mean() once per step)")
         self.flat.zero_()
         self.missing = set()
-        self._early_seen = 0
+        self._landed = set()
+        self._early_hits, self._early_fired = 0, False
+        if self._late_used:
+            self._late.zero_()
+            self._late_used = False
         for p in self.params:
             p.grad = None
 
@@ -142,13 +191,17 @@ class GradBucket:
         dst, src = [], []
         for i, (p, o, k) in enumerate(self._layout):
             g = p.grad
+            view = self.flat[o:o + k].view(p.shape)
             if g is None:
-                self.missing.add(i)
-                p.grad = self.flat[o:o + k].view(p.shape)       # no gradient this step: the zeros of zero()
-            elif g.data_ptr() != self.flat[o:o + k].data_ptr():
-                view = self.flat[o:o + k].view(p.shape)
-                dst.append(view)
-                src.append(g)
+                if i not in self._landed:
+                    self.missing.add(i)                         # no gradient this step: the zeros of zero()
+                p.grad = view
+            elif g.data_ptr() != view.data_ptr():
+                if i in self._landed:                           # landed early, then another (un-hooked) accumulation
+                    view.add_(g)
+                else:
+                    dst.append(view)
+                    src.append(g)
                 p.grad = view
         if dst:
             torch._foreach_copy_(dst, src)
@@ -161,23 +214,44 @@ class GradBucket:
 
     def allreduce_mean(self):
         self.collect()
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not self._multi_rank():
             return
-        if self._early_work:
-            # the early range is already summed (or in flight on the side stream): exchange only what is left
+        world = dist.get_world_size()
+        # has-gradient flags (device-side fills, no host data): 1 everywhere, 0 for this rank's missing parameters
+        self._flags.fill_(1.0)
+        for i in self.missing:
+            self._flags[i] = 0.0
+        n, total = self.flat.numel(), self._buf.numel()
+        if self._early and not self._early_disabled:
+            if not self._early_fired:
+                # not every early gradient arrived on this rank (or fewer backward passes than declared): the peers'
+                # sequence starts with the early range, so does ours
+                self._send_early(async_op=False)
             a, b = self._early_span
-            n = self.flat.numel()
-            for lo, hi in ((0, a), (b, n)):
-                if hi > lo:
-                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+            if a > 0:
+                dist.all_reduce(self.flat[0:a], op=dist.ReduceOp.SUM)
+            dist.all_reduce(self._buf[b:total], op=dist.ReduceOp.SUM)       # remainder + flags
             for w in self._early_work:
                 w.wait()                       # nccl: the current stream waits for the collective; gloo: host wait
             if self._side is not None:
                 torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
             self._early_work = []
+            if self._late_used:
+                import warnings
+                dist.all_reduce(self._late, op=dist.ReduceOp.SUM)
+                self.flat[a:b].add_(self._late)
+                warnings.warn(f"GradBucket: more than backwards_per_step={self._backwards} backward passes before the "
+                              "exchange; the extra gradients were summed by a second all-reduce and the early overlap is "
+                              "switched off from the next step on (declare overlap_early(..., backwards_per_step=k))")
+                self._early_disabled = True
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(dist.get_world_size())
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
+        self.flat.div_(world)
+        if self.missing:
+            # this rank had parameters without gradient: they stay "missing" only if no rank had one (rare path, one sync)
+            idx = sorted(self.missing)
+            had = self._flags[torch.tensor(idx, device=self._flags.device)].tolist()
+            self.missing = {i for i, c in zip(idx, had) if c == 0.0}
 
     @property
     def nbytes(self) -> int:

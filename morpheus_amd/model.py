@@ -245,9 +245,9 @@ class scene_representation(nn.Module):
 
     PER_SAMPLE_SLOTS = 1 << 17   # up to this many samples a non-constant time tensor gets one code slot per sample
 
-    def _slots(self, t: torch.Tensor, frame_slots=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        """-> (slot times [F], per-sample slot ids [M] int32 or None when F == 1), without a device->host sync on any
-        path the training step takes:
+    def _slots(self, t: torch.Tensor, frame_slots=None) -> Tuple[torch.Tensor, Optional[torch.Tensor], bool]:
+        """-> (slot times [F], per-sample slot ids [M] int32 or None when F == 1, slot ids are the identity map), without
+        a device->host sync on any path the training step takes:
           * `frame_slots = (t_rows [F], slot [M])` from the renderer (a batch row is one frame, SURVEY C.11);
           * a time tensor that is an expanded scalar (stride 0: `rays_t[:1].expand(M, 1)`, how the renderer and
             `density(allow_shape=True)` / `density(t=float)` hand over a single frame) is constant by construction;
@@ -255,14 +255,14 @@ class scene_representation(nn.Module):
             M x 128 floats per net) up to PER_SAMPLE_SLOTS samples -- `get_real_view_point_loss` sends N = 2048;
           * beyond that, torch.unique (sort + sync) keeps the bias table small."""
         if frame_slots is not None:
-            return frame_slots
+            return frame_slots[0], frame_slots[1], False
         tf = t.reshape(-1)
         if tf.numel() == 1 or (t.dim() >= 1 and t.shape[0] > 1 and t.stride(0) == 0):
-            return tf[:1], None
+            return tf[:1], None, False
         if tf.numel() <= self.PER_SAMPLE_SLOTS:
-            return tf, torch.arange(tf.numel(), device=t.device, dtype=torch.int32)
+            return tf, torch.arange(tf.numel(), device=t.device, dtype=torch.int32), True
         tu, inv = torch.unique(tf, return_inverse=True)
-        return tu, inv.to(torch.int32)
+        return tu, inv.to(torch.int32), False
 
     def _warp_params(self, net: MLP, w):
         b = net.biases()
@@ -349,10 +349,10 @@ class scene_representation(nn.Module):
 
     def warp(self, x, t, frame_slots=None):
         """-> deform [M,3], topo [M,2], app_code (None)   (model.py:412-437).  `frame_slots`: see `_slots`."""
-        tu, slot = self._slots(t, frame_slots)
+        tu, slot, identity = self._slots(t, frame_slots)
         opnd, code_w = self._warp_operands()
         bias0_d, bias0_t = self._warp_bias0(tu, code_w)                   # per-frame first-layer bias
-        deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), opnd)
+        deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), opnd, slots_are_identity=identity)
         return deform, topo, None
 
     def get_topo(self, x, t, frame_slots=None):

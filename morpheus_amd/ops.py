@@ -95,46 +95,49 @@ def _bin_points(lib, x, bound):
     return perm, bstart
 
 
-GRID_BWD_NAIVE = os.environ.get("MORPHEUS_GRID_BWD", "") == "naive"   # A/B switch: per-point global atomics
-# A/B switch: "two" = both tables of a query in ONE forward launch (mh_grid_encode_fwd2: shared indices and weights).
-# Measured on MI355X (cfg3, same box): 1.05 ms against 2 x 0.43 = 0.86 ms for two launches -- twice the gathers in flight per
-# lane cost more occupancy than the shared index arithmetic saves -- so one launch per table stays the default.
-GRID_FWD_TWO = os.environ.get("MORPHEUS_GRID_FWD", "") == "two"
-# warp nets (MORPHEUS_MLP): fp32 values, parked tiles, accumulation and results in every mode; what differs is how a product
-# reaches the matrix cores.
-#   "h2" (default) = two fp16 slices per operand at per-layer / per-point power-of-two scales (22 significand bits), three
-#          slice products per MAC through v_mfma_f32_32x32x16_f16 (csrc/mlp_h2.hip); weight gradients on the "b3" kernels
-#   "b3" = three bf16 slices per operand (exact split), six slice products per MAC (csrc/mlp_b3.hip)
-#   "f32" = the native fp32 MFMA kernels of csrc/mlp.hip
-# Both sliced forms are held to the fp32 kernels' own error against float64 (test_warp_sliced_arithmetic_is_fp32_grade).
-_MLP_MODE = os.environ.get("MORPHEUS_MLP", "h2")
-if _MLP_MODE not in ("h2", "b3", "f32"):
-    raise ValueError(f"MORPHEUS_MLP={_MLP_MODE!r}: expected h2, b3 or f32")
-MLP_B3 = _MLP_MODE == "b3"
-MLP_H2 = _MLP_MODE == "h2"
+# ---- arithmetic mode of the MLP kernels (MORPHEUS_MLP, or set_mlp_mode() at run time) -------------------------------------
+# Values, parked tiles, accumulation and results are fp32 in every mode; what differs is how a product reaches the matrix cores.
+#   "b3"  (default) bf16 x 3: every fp32 operand is cut EXACTLY into three bf16 slices (all 24 significand bits), the six
+#         significant cross products go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation (csrc/mlp_b3.hip): warp nets
+#         forward / backward-data / weight gradients and the field forward.  fp32-faithful: what is dropped is below 2^-24 of a
+#         product, less than the rounding of an fp32 multiply-add.
+#   "f32" the native fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere (csrc/mlp.hip): the reference's arithmetic instruction for
+#         instruction, and the slowest (the fp32 MFMA runs at the vector-ALU rate on gfx950).
+#   "h2"  fp16 x 2: two fp16 slices per operand at power-of-two scales (22 significand bits, block-scaled: per layer for
+#         weights, per point for activations / gradients, per tensor for the weight-gradient operands), three slice products
+#         per MAC (csrc/mlp_h2.hip).  The fastest and NOT fp32-faithful (operands are narrower than fp32's 24 bits): an
+#         opt-in mode; bench.py reports it beside the headline with its own dtype string.
+# The field nets' backward (mh_field_bwd_fused) runs on the native fp32 MFMA in every mode.
+MLP_MODES = ("b3", "f32", "h2")
+MODE_DTYPE = {"f32": "f32", "b3": "f32 (exact 3 x bf16 operand split, 6 slice products per MAC on the bf16 MFMA pipe, fp32 accumulate)",
+              "h2": "f32-emulated (2 x fp16 slices, 22-bit block-scaled operands, 3 slice products per MAC, fp32 accumulate)"}
+_mode = os.environ.get("MORPHEUS_MLP", "b3")
+if _mode not in MLP_MODES:
+    raise ValueError(f"MORPHEUS_MLP={_mode!r}: expected one of {MLP_MODES}")
+
+
+def mlp_mode() -> str:
+    return _mode
+
+
+def set_mlp_mode(mode: str) -> str:
+    """Select the arithmetic of the MLP kernels for the operands prepared FROM NOW ON (a model.operand_scope() keeps the mode
+    it was opened under: parked tiles are mode-independent, sliced weight packs are not).  -> the previous mode."""
+    global _mode
+    if mode not in MLP_MODES:
+        raise ValueError(f"mlp mode {mode!r}: expected one of {MLP_MODES}")
+    prev, _mode = _mode, mode
+    return prev
 
 
 def _warp_mode() -> str:
-    return "h2" if MLP_H2 else ("b3" if MLP_B3 else "")
-# field nets (sdf / colour): forward on the bf16 pipe too (mh_field_fwd_b3); the fused backward stays on the fp32 MFMA
-_FIELD_MODE = os.environ.get("MORPHEUS_FIELD_FWD", "h2")   # "h2" (default: mh_field_fwd_h2) | "b3" (mh_field_fwd_b3) | "f32"
-if _FIELD_MODE not in ("h2", "b3", "f32"):
-    raise ValueError(f"MORPHEUS_FIELD_FWD={_FIELD_MODE!r}: expected h2, b3 or f32")
-FIELD_B3 = _FIELD_MODE == "b3"
-FIELD_H2 = _FIELD_MODE == "h2"
+    """operand-pack tag of the warp nets: "h2" / "b3" / "" (native fp32 MFMA)."""
+    return "" if _mode == "f32" else _mode
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
     """One forward launch per table at the same points -> list of [M, L*2]."""
     M = x.shape[0]
-    if len(embs) == 2 and int(group) == 1 and GRID_FWD_TWO:
-        out_a = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
-        out_b = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
-        _e = TIMER.start()
-        check(lib.mh_grid_encode_fwd2(ptr(x), ptr(embs[0]), ptr(embs[1]), o_p, r_p, ptr(out_a), ptr(out_b), M, L, n_levels,
-                                      float(bound), stream()), "mh_grid_encode_fwd2")
-        TIMER.stop("mh_grid_encode_fwd2", _e)
-        return [out_a, out_b]
     outs = []
     for emb in embs:
         out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
@@ -159,7 +162,7 @@ def _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gmax_p
         grad = grad.contiguous()
         g_emb = torch.zeros_like(emb)
         g_x = torch.empty_like(x) if need_dx else None
-        if M > 0 and not GRID_BWD_NAIVE and L == 16:
+        if M > 0 and L == 16:      # the brick kernel's level table is sized for the shipped 16-level geometry
             if binned is None:
                 binned = _bin_points(lib, x, bound)
             _e = TIMER.start()
@@ -331,14 +334,11 @@ def rays_sample_uniform(fx, fy, cx, cy, c2w, H: int, W: int, pix, jitter, S: int
     return o, d, ri, ts, te, xyz, rs, rc
 
 
-MARCH_TWO_PASS = os.environ.get("MORPHEUS_MARCH", "") == "two_pass"   # A/B switch: thread-per-ray count + fill
-
-
 def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.Tensor):
     """Occupancy-grid marcher -> (ray_idx int32 [M], t_starts [M], t_ends [M], ray_start [N], ray_cnt [N]).
     One host sync on the path: M = total sample count sizes the packed arrays (nerfacc synchronises at the same point).
     Single pass, one wavefront per ray (mh_march_slots + mh_march_pack); a batch with rays that overflow the per-ray slot
-    row (directions much shorter than unit length) is re-run through the un-capped thread-per-ray count/fill pair."""
+    row (directions much shorter than unit length) is marched again with a slot row twice as long."""
     require_gpu(rays_o, rays_d, jitter, binary)
     lib = _lib.load()
     o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
@@ -349,8 +349,8 @@ def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.
         e = torch.empty(0, device=dev)
         z = torch.empty(0, dtype=torch.int32, device=dev)
         return z, e, e.clone(), z.clone(), z.clone()
-    if not MARCH_TWO_PASS:
-        cap = int(lib.mh_march_cap(float(step), float(bound)))
+    cap = int(lib.mh_march_cap(float(step), float(bound)))
+    while True:
         cnt_ovf = torch.zeros(N + 1, dtype=torch.int32, device=dev)     # [ray_cnt | overflow flag]
         cnt = cnt_ovf[:N]
         slots = torch.empty(2, N, cap, device=dev)
@@ -362,30 +362,18 @@ def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.
         start = (csum[:N] - cnt).contiguous()
         M, tot = csum[N - 1:].tolist()                                  # the one device->host sync
         if tot == M:                                                    # no overflow
-            ri = torch.empty(M, dtype=torch.int32, device=dev)
-            ts, te = torch.empty(M, device=dev), torch.empty(M, device=dev)
-            if M > 0:
-                _e = TIMER.start()
-                check(lib.mh_march_pack(ptr(start), ptr(cnt), ptr(slots[0]), ptr(slots[1]), N, cap, ptr(ri), ptr(ts), ptr(te),
-                                        stream()), "mh_march_pack")
-                TIMER.stop("mh_march_pack", _e)
-            return ri, ts, te, start, cnt.contiguous()
-    cnt = torch.empty(N, dtype=torch.int32, device=dev)
-    _e = TIMER.start()
-    check(lib.mh_march_count(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), ptr(cnt), stream()),
-          "mh_march_count")
-    TIMER.stop("mh_march_count", _e)
-    csum = torch.cumsum(cnt, 0, dtype=torch.int32)
-    start = (csum - cnt).contiguous()
-    M = int(csum[-1].item())
+            break
+        if cap > (1 << 20):
+            raise _lib.MorpheusHipError("march_rays: a ray takes more than 2^20 steps inside the box (step size / direction scale?)")
+        cap *= 2
     ri = torch.empty(M, dtype=torch.int32, device=dev)
     ts, te = torch.empty(M, device=dev), torch.empty(M, device=dev)
     if M > 0:
         _e = TIMER.start()
-        check(lib.mh_march_fill(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), ptr(start), ptr(ri),
-                                ptr(ts), ptr(te), stream()), "mh_march_fill")
-        TIMER.stop("mh_march_fill", _e)
-    return ri, ts, te, start, cnt
+        check(lib.mh_march_pack(ptr(start), ptr(cnt), ptr(slots[0]), ptr(slots[1]), N, cap, ptr(ri), ptr(ts), ptr(te),
+                                stream()), "mh_march_pack")
+        TIMER.stop("mh_march_pack", _e)
+    return ri, ts, te, start, cnt.contiguous()
 
 
 # ------------------------------------------------------------------------------------ field-query glue (csrc/normal.hip)
@@ -571,7 +559,8 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     i_np, i_p = _i32arr(in_pad)
     o_np, o_p = _i32arr(out_pad)
     ws = torch.empty(lib.mh_mlp_wgrad_workspace_floats(n_layers, i_p, o_p, n_tiles), device=dev)
-    raw = torch.empty(dw_len + db_len, device=dev)
+    # an empty query (n_tiles == 0) returns MH_OK without writing: the token gradient must then be zeros, not heap contents
+    raw = torch.empty(dw_len + db_len, device=dev) if n_tiles > 0 else torch.zeros(dw_len + db_len, device=dev)
     dw_raw, db_raw = raw[:dw_len], raw[dw_len:]
     _e = TIMER.start()
     if amax is not None:
@@ -590,7 +579,7 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
 
 
 WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640 + 40, 2 * 672     # csrc/mlp.hip: activations + 40 rows of ReLU masks
-FIELD_ACT_ROWS, FIELD_DPRE_ROWS = 96 + 64 * 5 + 8, 64 * 5 + 32   # activations + 8 rows of ReLU masks
+FIELD_ACT_ROWS = 96 + 64 * 5 + 8   # activations + 8 rows of ReLU masks
 
 
 class _PackOperands(torch.autograd.Function):
@@ -626,6 +615,8 @@ class _PackOperands(torch.autograd.Function):
             w3 = torch.zeros((jp.fwd2_total_f4 + jp.bwd2_total_f4) * 4, device=flat.device)
             for key, blocks, table, base in (("fwd3", jp.h2_blocks, jp.h2_table, 0),
                                              ("bwd3", jp.h2T_blocks, jp.h2T_table, jp.fwd2_total_f4)):
+                if key == "bwd3" and not jp.sliced_bwd:
+                    continue
                 src = flat[m[key]]
                 so, sp = _i32arr([b[0] for b in blocks])
                 no, np_ = _i32arr([b[1] for b in blocks])
@@ -640,6 +631,8 @@ class _PackOperands(torch.autograd.Function):
             lib = _lib.load()
             w3 = torch.zeros((jp.fwd3_total_f4 + jp.bwd3_total_f4) * 4, device=flat.device)
             for key, layers, base in (("fwd3", jp.b3_layers, 0), ("bwd3", jp.b3T_layers, jp.fwd3_total_f4)):
+                if key == "bwd3" and not jp.sliced_bwd:
+                    continue
                 src = flat[m[key]]
                 so, sp = _i32arr([l[0] for l in layers])
                 no, np_ = _i32arr([l[1] for l in layers])
@@ -690,8 +683,7 @@ def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[t
 def prepare_field_operands(params: Sequence[torch.Tensor]) -> MLPOperands:
     """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
     jp = field_joint_packer()
-    # the bf16x3 form of the fused backward (opt-in) needs the transposed bf16x3 slices: it pins the operands to "b3"
-    mode = "b3" if (FIELD_B3 or (FIELD_BWD_B3 and not FIELD_BWD_SPLIT)) else ("h2" if FIELD_H2 else "")
+    mode = _warp_mode()        # the field FORWARD follows the mode; the fused backward reads the fp32 transposed pack in every mode
     return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), *params), mode=mode)
 
 
@@ -703,7 +695,7 @@ class _WarpMLP(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, slot, bias0_d, bias0_t, token, n_bands, opnd):
+    def forward(ctx, x, slot, bias0_d, bias0_t, token, n_bands, opnd, slots_are_identity=False):
         require_gpu(x, bias0_d, bias0_t)
         lib = _lib.load()
         (wd, wt), (bd, bt), (wdT, wtT) = opnd.w, opnd.b, opnd.wT
@@ -718,7 +710,8 @@ class _WarpMLP(torch.autograd.Function):
         amax = None
         if opnd.mode == "h2":
             # the kernels record the largest magnitude of every parked block: per-tensor scales of the weight-gradient kernel
-            amax = torch.zeros(lib.mh_h2_amax_words(), dtype=torch.int32, device=dev) if (need_grad and WGRAD_H2) else None
+            if need_grad and WGRAD_H2:
+                amax = torch.zeros(lib.mh_h2_amax_words(), dtype=torch.int32, device=dev) if AMAX_SEED is None else AMAX_SEED.clone()
             check(lib.mh_warp_fwd_h2(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
                                      n_bands, ptr(deform), ptr(topo), ptr(acts), ptr(amax), M, stream()), "mh_warp_fwd_h2")
         elif opnd.w3 is not None:
@@ -733,6 +726,9 @@ class _WarpMLP(torch.autograd.Function):
             wdT, wtT = opnd.wT3
         ctx.save_for_backward(x, slot_c, wdT, wtT, acts, amax)
         ctx.n_bands, ctx.n_slots, ctx.jp = n_bands, bias0_d.shape[0], opnd.jp
+        # the caller SAYS when slot[i] == i (model._slots' one-slot-per-sample case); n_slots == M alone does not imply it
+        # (B frames == M samples, or torch.unique's sorted inverse)
+        ctx.identity = bool(slots_are_identity) and bias0_d.shape[0] == M
         return deform, topo
 
     @staticmethod
@@ -763,13 +759,13 @@ class _WarpMLP(torch.autograd.Function):
             dp = dpre.view(n_tiles, WARP_DPRE_ROWS, 32)
             per_pt_d = dp[:, 0:128, :].permute(0, 2, 1).reshape(-1, 128)[:M]
             per_pt_t = dp[:, 672:800, :].permute(0, 2, 1).reshape(-1, 128)[:M]
-            if ctx.n_slots == M:          # one slot per sample (model._slots): the per-point rows ARE the answer
+            if ctx.identity:              # one slot per sample, slot[i] == i: the per-point rows ARE the answer
                 g_b0d, g_b0t = per_pt_d, per_pt_t
             else:
                 idx = slot.long()
                 g_b0d = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_d)
                 g_b0t = torch.zeros(ctx.n_slots, 128, device=dev).index_add_(0, idx, per_pt_t)
-        return (g_x, None, g_b0d, g_b0t, raw, None, None)
+        return (g_x, None, g_b0d, g_b0t, raw, None, None, None)
 
 
 def _warp_wg_geometry():
@@ -787,11 +783,19 @@ _WARP_WG = _warp_wg_geometry()
 # amax-table words (csrc/mlp_h2.hip: H2_AMAX_*) of the warp layers' dPre and input activations; the 32-row last layers stay bf16 x 3
 _WARP_WG_SLOTS = ([(16 + 6 * net + l) if l < 5 else -1 for net in range(2) for l in range(6)],
                   [(0 if l == 0 else 1 + 5 * net + (l - 1)) if l < 5 else -1 for net in range(2) for l in range(6)])
-WGRAD_H2 = os.environ.get("MORPHEUS_WGRAD_H2", "1") != "0"    # A/B switch: 0 keeps the h2 mode's weight gradients on bf16 x 3
 
 
-def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, opnd: MLPOperands):
-    return _WarpMLP.apply(x, slot, bias0_d, bias0_t, opnd.token, n_bands, opnd)
+# Test hooks of the h2 mode (tests/test_gpu_ops.py; never set by the product path): WGRAD_H2 = False keeps the h2 mode's weight
+# gradients on the bf16 x 3 kernel (the two are compared on the same parked tensors); AMAX_SEED pre-loads the table of parked
+# maxima (the kernels only ever raise it), so a run can be given ANOTHER run's per-tensor scales.
+WGRAD_H2 = True
+AMAX_SEED = None
+
+
+def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, opnd: MLPOperands, slots_are_identity: bool = False):
+    """slots_are_identity: slot[i] == i for every sample (bias0 rows are per sample): the first-layer bias gradient is then
+    the per-point dPre0 rows themselves; any other slot map goes through index_add_."""
+    return _WarpMLP.apply(x, slot, bias0_d, bias0_t, opnd.token, n_bands, opnd, slots_are_identity)
 
 
 def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad):
@@ -813,24 +817,12 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     return sdf, sigma, albedo, acts
 
 
-FIELD_BWD_SPLIT = os.environ.get("MORPHEUS_FIELD_BWD", "") == "split"   # A/B switch: backward-data + mh_mlp_wgrad
-# "b3" = the fused field backward on the bf16 pipe (mh_field_bwd_fused_b3).  Measured, NOT the default: one wave per SIMD holds
-# the 224 weight-gradient accumulators, so the slicing VALU work is serial with its MFMAs and the kernel gains 3 % on cfg3
-# (2.15 -> 2.08 ms) and loses 3 % on the training step's small calls (1.44 -> 1.48 ms)
-FIELD_BWD_B3 = os.environ.get("MORPHEUS_FIELD_BWD", "") == "b3"
-
-
-def _field_wT(opnd):
-    """-> (transposed weight operand for the field backward, is it the bf16x3 pack?)"""
-    if FIELD_BWD_B3 and not FIELD_BWD_SPLIT and opnd.wT3 is not None and opnd.mode == "b3":
-        return opnd.wT3[0], True
-    return opnd.wT[0], False
-
-
-def _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-                     need_dx, jp, b3=False):
+def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
+               need_dx, jp):
     """mh_field_bwd_fused: backward-data and weight gradients of the field nets in one pass per net (the pre-activation
-    gradients stay on the chip).  Same returns as _field_bwd."""
+    gradients stay on the chip).
+    -> g_xc|None, g_fs, g_fc|None, g_tp|None, g_beta, raw (tile-order weight gradient), gmax (int32[2]: max|g_fs|, max|g_fc|
+    as float bits, reduced on the fly by the kernel for the hash-grid backward's fixed point)."""
     M, dev = xc.shape[0], xc.device
     n_tiles = lib.mh_mlp_tiles(M)
     if not with_color:
@@ -843,72 +835,13 @@ def _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_a
     gmax = torch.zeros(2, dtype=torch.int32, device=dev)
     dgeo = torch.empty(lib.mh_field_dgeo_floats(M), device=dev) if with_color else None
     ws = torch.empty(lib.mh_field_bwd_fused_workspace_floats(M), device=dev)
-    raw = torch.empty(jp.raw_len, device=dev)
+    raw = torch.empty(jp.raw_len, device=dev) if M > 0 else torch.zeros(jp.raw_len, device=dev)   # empty query: see _wgrad
     c = lambda t: None if t is None else t.contiguous()
     _e = TIMER.start()
-    fused = lib.mh_field_bwd_fused_b3 if b3 else lib.mh_field_bwd_fused
-    check(fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT),
-                ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws), ptr(raw), ptr(g_xc), ptr(g_fs), ptr(g_fc),
-                ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()), "mh_field_bwd_fused")
+    check(lib.mh_field_bwd_fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT),
+                                 ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws), ptr(raw), ptr(g_xc),
+                                 ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()), "mh_field_bwd_fused")
     TIMER.stop("mh_field_bwd_fused", _e)
-    return g_xc, g_fs, g_fc, g_tp, g_bp.sum().reshape(()), raw, gmax
-
-
-def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-               need_dx, jp, b3=False):
-    if not FIELD_BWD_SPLIT:
-        return _field_bwd_fused(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo,
-                                has_fc, need_dx, jp, b3)
-    return _field_bwd_split(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-                            need_dx, jp)
-
-
-def _field_bwd_split(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-                     need_dx, jp):
-    """Backward-data + weight gradients of the field nets.
-    -> g_xc|None, g_fs, g_fc|None, g_tp|None, g_beta, raw (tile-order weight gradient), gmax (int32[2]: max|g_fs|, max|g_fc|
-    as float bits, reduced on the fly by the kernel for the hash-grid backward's fixed point)."""
-    M, dev = xc.shape[0], xc.device
-    n_tiles = lib.mh_mlp_tiles(M)
-    dpre = torch.empty(lib.mh_field_dpre_floats(M), device=dev)
-    if not with_color:
-        g_albedo = None   # colour rows of the scratch are neither written nor read on this path
-    g_xc = torch.empty(M, 3, device=dev) if need_dx else None   # NULL: the kernel skips the d/dx stage
-    g_fs = torch.empty(M, 32, device=dev)
-    g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
-    g_tp = torch.empty(M, 2, device=dev) if has_topo else None
-    g_bp = torch.empty(n_tiles, device=dev)
-    gmax = torch.zeros(2, dtype=torch.int32, device=dev)
-    c = lambda t: None if t is None else t.contiguous()
-    _e = TIMER.start()
-    check(lib.mh_field_bwd_data(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)),
-                                ptr(c(g_albedo)), ptr(wT), ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dpre),
-                                ptr(g_xc), ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()),
-          "mh_field_bwd_data")
-    TIMER.stop("mh_field_bwd_data", _e)
-    pk = field_packer()
-    act_rows = [0, 96, 160, 224, 288, 352]
-    dpre_rows = [0, 64, 128, 192, 256, 320]
-    if with_color:
-        raw = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows],
-                     [r * 32 for r in dpre_rows], pk.wg_in, pk.wg_out, n_tiles, dev, "field")
-    else:   # FD-normal taps: the sdf net only; the colour net's gradients are zero
-        # dP2 has one non-zero row (the sdf output, first row of its second 32-row tile): the kernel parked only that
-        # tile, so layer 2's weight gradient is a 32-row launch on it; the geo rows' gradients are zero
-        wg_out = [pk.wg_out[0], pk.wg_out[1], 32]
-        part = _wgrad(lib, acts, dpre, FIELD_ACT_ROWS * 32, FIELD_DPRE_ROWS * 32, [r * 32 for r in act_rows[:3]],
-                      [dpre_rows[0] * 32, dpre_rows[1] * 32, (dpre_rows[2] + 32) * 32], pk.wg_in[:3], wg_out, n_tiles, dev,
-                      "field")
-        n01 = pk.wg_in[0] * pk.wg_out[0] + pk.wg_in[1] * pk.wg_out[1]
-        n2 = pk.wg_in[2] * 32
-        nb01 = pk.wg_out[0] + pk.wg_out[1]
-        # full-length raw gradient: [dW s0 s1 | L2 tile 0 = 0 | L2 tile 1 | colour = 0 || db s0 s1 | 0 | sdf tile | 0]
-        raw = part.new_zeros(jp.raw_len)
-        raw[:n01] = part[:n01]
-        raw[n01 + n2:n01 + 2 * n2] = part[n01:n01 + n2]
-        db = part[n01 + n2:]
-        raw[pk.raw_dw:pk.raw_dw + nb01] = db[:nb01]
-        raw[pk.raw_dw + nb01 + 32:pk.raw_dw + nb01 + 64] = db[nb01:]
     return g_xc, g_fs, g_fc, g_tp, g_bp.sum().reshape(()), raw, gmax
 
 
@@ -930,8 +863,7 @@ class _FieldMLP(torch.autograd.Function):
         tp = None if topo is None else topo.detach().contiguous()
         beta_c = beta.detach().reshape(1).contiguous().float()
         sdf, sigma, albedo, acts = _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, any(ctx.needs_input_grad))
-        wT_sel, ctx.bwd_b3 = _field_wT(opnd)
-        ctx.save_for_backward(xc, wT_sel, beta_c, acts, sdf, albedo)
+        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo)
         ctx.cfg = (n_bands, bool(with_color), topo is not None, feat_c is not None)
         ctx.jp = opnd.jp
         if albedo is None:
@@ -946,7 +878,7 @@ class _FieldMLP(torch.autograd.Function):
         n_bands, with_color, has_topo, has_fc = ctx.cfg
         g_xc, g_fs, g_fc, g_tp, g_beta, raw, _ = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
                                                             n_bands, with_color, has_topo, has_fc, ctx.needs_input_grad[0],
-                                                            ctx.jp, ctx.bwd_b3)
+                                                            ctx.jp)
         return (g_xc, g_fs, g_fc, g_tp, g_beta, raw, None, None, None)
 
 
@@ -976,8 +908,7 @@ class _FieldQuery(torch.autograd.Function):
         beta_c = beta.detach().reshape(1).contiguous().float()
         sdf, sigma, albedo, acts = _field_fwd(lib, xc, feats[0], feats[1] if with_color else None, tp, beta_c, n_bands,
                                               with_color, opnd, any(ctx.needs_input_grad))
-        wT_sel, ctx.bwd_b3 = _field_wT(opnd)
-        ctx.save_for_backward(xc, wT_sel, beta_c, acts, sdf, albedo, *embs)
+        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo, *embs)
         ctx.cfg = (n_bands, with_color, topo is not None, o_np, r_np, n_levels, float(bound), L)
         ctx.jp = opnd.jp
         if albedo is None:
@@ -992,8 +923,7 @@ class _FieldQuery(torch.autograd.Function):
         n_bands, with_color, has_topo, o_np, r_np, n_levels, bound, L = ctx.cfg
         need_dx = ctx.needs_input_grad[0]
         g_xc, g_fs, g_fc, g_tp, g_beta, raw, gmax = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
-                                                               n_bands, with_color, has_topo, with_color, need_dx, ctx.jp,
-                                                               ctx.bwd_b3)
+                                                               n_bands, with_color, has_topo, with_color, need_dx, ctx.jp)
         o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
         grads = [g_fs] + ([g_fc] if with_color else [])
         gptrs = [gmax.data_ptr(), gmax.data_ptr() + 4][:len(grads)]

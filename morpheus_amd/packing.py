@@ -346,8 +346,11 @@ class JointPacker:
       natural   : [dW net 0 | dW net 1 | ... | db net 0 | db net 1 | ...]
     """
 
-    def __init__(self, packers: Sequence[NetPacker], skip_first_bias: bool):
+    def __init__(self, packers: Sequence[NetPacker], skip_first_bias: bool, sliced_bwd: bool = True):
         self.packers = list(packers)
+        # sliced_bwd: do the sliced (bf16 x 3 / fp16 x 2) kernels read TRANSPOSED slices of these nets?  The warp nets'
+        # backward-data does; the field nets' fused backward runs on the fp32 MFMA and reads the fp32 transposed pack only
+        self.sliced_bwd = sliced_bwd
         nW = sum(p.n_weights for p in self.packers)
         nB = sum(p.n_biases for p in self.packers)
         zero = nW + nB
@@ -519,5 +522,5 @@ def warp_joint_packer() -> JointPacker:
 
 def field_joint_packer() -> JointPacker:
     if "field_joint" not in _PACKERS:
-        _PACKERS["field_joint"] = JointPacker([field_packer()], skip_first_bias=False)
+        _PACKERS["field_joint"] = JointPacker([field_packer()], skip_first_bias=False, sliced_bwd=False)
     return _PACKERS["field_joint"]

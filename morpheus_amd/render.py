@@ -74,13 +74,15 @@ class HotPathRenderer:
             phi = torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
         return torch.cos(phi) * u + torch.sin(phi) * v
 
-    def get_normal_smoothness_loss(self, rays_o, rays_d, rays_t, depth, offsets=None, phi=None, ray_slots=None):
+    def get_normal_smoothness_loss(self, rays_o, rays_d, rays_t, depth, offsets=None, phi=None, ray_slots=None,
+                                   single_frame=None):
         """morpheus.py:530-556: normals at npts = trunc*100+1 points around the rendered depth of every ray vs normals at
         points displaced by smoothness_std along a random direction orthogonal to the normal.  The reference drops the
         points outside the 1.1 sphere with a boolean index (a device->host sync and a data-dependent shape); here they
         stay in the batch and leave the mean through a 0/1 weight -- the same value, no sync.
         `offsets` [npts] / `phi` [npts*N, 1] inject the two random draws (parity tests); `ray_slots` = (t_rows, slot per
-        ray) for multi-frame batches."""
+        ray) for multi-frame batches; `single_frame`: every ray carries rays_t[0] (one batch row = one frame).  With neither,
+        the points take their own ray's time, as the reference does (per-ray rays_t)."""
         trunc = self.config["train"]["trunc"]
         npts = int(trunc * 100 + 1)
         if offsets is None:
@@ -91,10 +93,12 @@ class HotPathRenderer:
         pts = (depth + off[:, None].to(depth))[..., None] * rays_d[None] + rays_o[None]
         pts = pts.view(-1, 3)
         n_rays = rays_t.shape[0]
-        if ray_slots is None:      # one frame: the time is an expanded scalar (model._slots sees a single slot)
-            tt, fs = rays_t[:1].expand(npts * n_rays, 1), None
-        else:
+        if ray_slots is not None:
             tt, fs = rays_t[None].repeat(npts, 1, 1).view(-1, 1), (ray_slots[0], ray_slots[1].repeat(npts))
+        elif single_frame:         # one frame: the time is an expanded scalar (model._slots sees a single slot)
+            tt, fs = rays_t[:1].expand(npts * n_rays, 1), None
+        else:                      # rays of several times without a row structure: per-sample times (model._slots)
+            tt, fs = rays_t[None].repeat(npts, 1, 1).view(-1, 1), None
         keep = (torch.linalg.norm(pts, ord=2, dim=-1) < 1.1).float()[:, None]
         n1, _ = self.model.normal(pts, t=tt, frame_slots=fs)
         w = self.get_ortho_normal_dir(n1, phi)
@@ -260,8 +264,10 @@ class HotPathRenderer:
                                               ray_start, ray_cnt)
                 results["normal_image"] = nimg
             if tr["normal_smoothness"] > 0:
+                # the normals are taken at the rays' own times even in a canonical render (morpheus.py:548-553 warps always)
+                one_t = self.frame_batched and len(prefix) == 2 and prefix[0] == 1
                 results["normal_reg"] = self.get_normal_smoothness_loss(rays_o, rays_d, rays_t, depth.reshape(1, -1),
-                                                                        ray_slots=ray_slots)
+                                                                        ray_slots=ray_slots, single_frame=one_t)
             if rays_depth is not None:
                 # get_sdf_loss (utils.py:91-113, morpheus.py:789) on the packed samples: one launch each way
                 fs_loss, sdf_loss = ops.sdf_losses(sdf, t_starts_, t_ends_, ri32(), rays_depth, rays_mask, tr["trunc"])

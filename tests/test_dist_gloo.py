@@ -134,3 +134,117 @@ def test_single_process_equivalence():
     assert torch.equal(b.flat, g1) and lin.weight.grad.data_ptr() == b.flat.data_ptr()
     lo, hi = mdist.shard_rays(10, 3, 4)
     assert (lo, hi) == (9, 10) and mdist.shard_rays(10, 0, 4) == (0, 3)
+
+
+def _pattern_worker(rank, world, port, out, case):
+    """Data- and call-pattern cases the exchange must survive with identical replicas."""
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from morpheus_amd import dist as mdist
+    mdist.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    table_a = torch.nn.Parameter(torch.randn(32, 2))       # two "hash tables" (the early range) ...
+    table_b = torch.nn.Parameter(torch.randn(32, 2))
+    w = torch.nn.Parameter(torch.randn(6, 3))              # ... an MLP weight and a pose-like parameter behind them
+    pose = torch.nn.Parameter(torch.randn(4))
+    params = [table_a, table_b, w, pose]
+    bucket = mdist.GradBucket(params)
+    g = torch.Generator().manual_seed(7 + rank)
+    x = torch.randn(8, 6, generator=g)
+
+    def loss_fn(use_a=True, use_b=True, use_pose=True, scale=1.0):
+        y = (x @ w).sum()
+        if use_a:
+            y = y + (table_a ** 2).sum() * (rank + 1)
+        if use_b:
+            y = y + (table_b * 3.0).sum() * (rank + 2)
+        if use_pose:
+            y = y + (pose * (rank + 1.0)).sum()
+        return y * scale
+
+    def local_grads(**kw):
+        """What this rank's backward produces, computed on clones (no hooks, no bucket)."""
+        ps = [p.detach().clone().requires_grad_(True) for p in params]
+        saved = [p.data for p in params]
+        y = (x @ ps[2]).sum()
+        if kw.get("use_a", True):
+            y = y + (ps[0] ** 2).sum() * (rank + 1)
+        if kw.get("use_b", True):
+            y = y + (ps[1] * 3.0).sum() * (rank + 2)
+        if kw.get("use_pose", True):
+            y = y + (ps[3] * (rank + 1.0)).sum()
+        (y * kw.get("scale", 1.0)).backward()
+        del saved
+        return [torch.zeros_like(p) if p.grad is None else p.grad for p in ps]
+
+    def mean_over_ranks(mine):
+        """Reference exchange: a plain all-reduce per tensor."""
+        outg = []
+        for t in mine:
+            t = t.clone()
+            dist.all_reduce(t)
+            outg.append(t / world)
+        return outg
+
+    res = {}
+    if case == "asymmetric_none":
+        # rank 1's batch gives the pose parameter no gradient at all; rank 0's does -> both ranks must step it
+        bucket.zero()
+        loss_fn(use_pose=(rank == 0)).backward()
+        bucket.allreduce_mean()
+        want = mean_over_ranks(local_grads(use_pose=(rank == 0)))
+        res["missing"] = sorted(bucket.missing)
+        res["err"] = max(float((p.grad - t).abs().max()) for p, t in zip(params, want))
+        # no rank has a gradient for it -> missing everywhere (torch.optim.Adam's skip)
+        bucket.zero()
+        loss_fn(use_pose=False).backward()
+        bucket.allreduce_mean()
+        res["missing_all"] = sorted(bucket.missing)
+    elif case == "early_param_missing_on_one_rank":
+        bucket.overlap_early([table_a, table_b])
+        for it in range(2):
+            bucket.zero()
+            loss_fn(use_b=(rank == 0)).backward()             # rank 1 never touches table_b: its hook does not fire there
+            bucket.allreduce_mean()
+            want = mean_over_ranks(local_grads(use_b=(rank == 0)))
+            res["err%d" % it] = max(float((p.grad - t).abs().max()) for p, t in zip(params, want))
+        res["missing"] = sorted(bucket.missing)
+    elif case in ("two_backwards_undeclared", "two_backwards_declared"):
+        declared = case.endswith("_declared")
+        bucket.overlap_early([table_a, table_b], backwards_per_step=2 if declared else 1)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for it in range(3):
+                bucket.zero()
+                loss_fn(scale=1.0).backward()                 # virtual-view backward ...
+                loss_fn(scale=0.5, use_pose=False).backward()  # ... and real-view backward before ONE optimiser step
+                bucket.allreduce_mean()
+                a, b = local_grads(scale=1.0), local_grads(scale=0.5, use_pose=False)
+                want = mean_over_ranks([u + v for u, v in zip(a, b)])
+                res["err%d" % it] = max(float((p.grad - t).abs().max()) for p, t in zip(params, want))
+        res["warned"] = any("backwards_per_step" in str(c.message) for c in caught)
+        res["disabled"] = bucket._early_disabled
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["asymmetric_none", "early_param_missing_on_one_rank", "two_backwards_undeclared",
+                                  "two_backwards_declared"])
+def test_exchange_patterns_keep_replicas_identical(case):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pattern_worker, args=(2, _free_port(), out, case), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    errs = [v for r in (r0, r1) for k, v in r.items() if k.startswith("err")]
+    assert errs and max(errs) <= 1e-6, (r0, r1)
+    if case == "asymmetric_none":
+        assert r0["missing"] == [] and r1["missing"] == []            # a gradient on ANY rank steps the parameter everywhere
+        assert r0["missing_all"] == [3] and r1["missing_all"] == [3]   # none anywhere: skipped everywhere
+    if case == "early_param_missing_on_one_rank":
+        assert r0["missing"] == [] and r1["missing"] == []
+    if case == "two_backwards_undeclared":
+        assert r0["warned"] and r1["warned"] and r0["disabled"] and r1["disabled"]
+    if case == "two_backwards_declared":
+        assert not r0["warned"] and not r0["disabled"] and not r1["disabled"]

@@ -17,9 +17,10 @@ DEV = "cuda"
 
 
 def _set_mlp(monkeypatch, ops, mode):
-    """warp-net arithmetic: "b3" (bf16 x 3 slices), "h2" (fp16 x 2 slices) or "f32" (native fp32 MFMA)"""
-    monkeypatch.setattr(ops, "MLP_B3", mode == "b3")
-    monkeypatch.setattr(ops, "MLP_H2", mode == "h2")
+    """arithmetic of the MLP kernels for this test: "b3" (bf16 x 3 slices, the fp32-faithful default), "h2" (fp16 x 2 slices)
+    or "f32" (native fp32 MFMA); restored by monkeypatch at teardown"""
+    monkeypatch.setattr(ops, "_mode", ops.mlp_mode())      # registers the restore
+    ops.set_mlp_mode(mode)
 
 
 def _grid_setup(scale=0.1):
@@ -204,11 +205,11 @@ def test_warp_mlp(kind, max_level, mlp, monkeypatch):
 @pytest.mark.parametrize("with_color", [True, False])
 @pytest.mark.parametrize("fwd", ["h2", "b3", "f32"])
 def test_field_mlp(kind, with_color, fwd, monkeypatch):
-    """sdf_net + Laplace density + color_net (fused MFMA kernels; forward with fp16 x 2 slices = the default, bf16 x 3 slices,
-    native fp32 MFMA) vs the oracle, given identical hash features (the hash grid itself is checked above)."""
+    """sdf_net + Laplace density + color_net (fused MFMA kernels; forward with bf16 x 3 slices = the default, fp16 x 2 slices,
+    native fp32 MFMA; backward = the fused fp32-MFMA kernels in every mode) vs the oracle, given identical hash features (the
+    hash grid itself is checked above)."""
     from morpheus_amd import ops
-    monkeypatch.setattr(ops, "FIELD_H2", fwd == "h2")
-    monkeypatch.setattr(ops, "FIELD_B3", fwd == "b3")
+    _set_mlp(monkeypatch, ops, fwd)
     M = 777
     x = synth.hash_tensor((M, 3), 600, 1.0)
     fs, fc = synth.hash_tensor((M, 32), 601, 0.1), synth.hash_tensor((M, 32), 602, 0.1)
@@ -541,26 +542,6 @@ def test_field_query_glue_vs_torch():
     assert float(ob.grad[5].abs().sum()) == 0.0 and float(db.grad[40].abs().sum()) == 0.0
 
 
-def test_two_table_forward_is_bit_identical_to_two_launches():
-    """mh_grid_encode_fwd2 (sdf + colour table at the same points, one launch, shared indices / weights) against two
-    mh_grid_encode_fwd launches, incl. out-of-range points and a reduced level count; gradients unchanged."""
-    from morpheus_amd import ops
-    emb, offs, res = _grid_setup()
-    emb_b = synth.hash_tensor(tuple(emb.shape), 9011, 0.1)
-    x = synth.hash_tensor((5003, 3), 9012, 1.1).to(DEV)
-    old = ops.GRID_FWD_TWO
-    try:
-        for ml in (None, 0.5):
-            ops.GRID_FWD_TWO = True
-            a2, b2 = ops.grid_encode_multi(x, (emb.to(DEV), emb_b.to(DEV)), offs, res, 1.01, ml)
-            ops.GRID_FWD_TWO = False
-            a1, b1 = ops.grid_encode_multi(x, (emb.to(DEV), emb_b.to(DEV)), offs, res, 1.01, ml)
-            assert torch.equal(a2, a1) and torch.equal(b2, b1)
-            assert torch.equal(a1, ops.grid_encode(x, emb.to(DEV), offs, res, 1.01, ml))
-    finally:
-        ops.GRID_FWD_TWO = old
-
-
 def test_multicode_sample_kernel():
     """mh_multicode_fwd/bwd: bit for bit the per-level lerp of deform_code.py:20-38 written in torch on the same device,
     the reference's own output (fixture operators.npz:multicode, generated by the reference's MultiCode.sample), and the
@@ -744,13 +725,11 @@ def test_warp_large_batch_weight_gradients(mlp, monkeypatch):
 
 
 @pytest.mark.parametrize("with_color", [True, False])
-@pytest.mark.parametrize("bwd", ["f32", "b3"])
-def test_field_large_batch_gradients(with_color, bwd, monkeypatch):
+def test_field_large_batch_gradients(with_color):
     """The persistent field kernels loop over many tiles per wave only at large batches (a 777-point test gives every wave
     at most one tile): 400 000 points in one call against the same points in 40 chunks of 10 000 -- outputs and input
     gradients bit for bit, parameter gradients to summation order."""
     from morpheus_amd import ops
-    monkeypatch.setattr(ops, "FIELD_BWD_B3", bwd == "b3")      # the opt-in bf16x3 form of the fused backward is held to it too
     torch.manual_seed(5)
     M, CH = 400_000, 10_000
     pg = _state("b", DEV, grad=False)
@@ -820,30 +799,6 @@ def test_grid_large_batch_gradients():
     assert torch.equal(gx1, gx2)
     scale = float(ge2.abs().max())
     assert float((ge1 - ge2).abs().max()) / scale <= 1e-5, float((ge1 - ge2).abs().max()) / scale
-
-
-@pytest.mark.parametrize("env", [{"MORPHEUS_WGRAD_B3": "share"}, {"MORPHEUS_WGRAD_B3": "ring"}, {"MORPHEUS_B3_FWD": "phased"},
-                                 {"MORPHEUS_WGRAD": "merged"}, {"MORPHEUS_WGRAD": "per_layer"}, {"MORPHEUS_H2_WAVES": "8"},
-                                 {"MORPHEUS_H2_WAVES": "4"}],
-                         ids=lambda e: "-".join(f"{k}={v}" for k, v in e.items()))
-def test_ab_switch_kernels_stay_correct(env):
-    """The opt-in A/B kernels DESIGN.md section 3 quotes (LDS-ring weight-gradient kernels, the phased bf16 x 3 forward, forced
-    merged / per-layer weight-gradient launches, the two workgroup shapes of the fp16 x 2 kernels) are read once per process
-    by the library, so each runs the warp-net parity, accuracy and large-batch tests of its arithmetic mode in a child
-    interpreter with the switch set."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    mode = "h2" if any(k.startswith("MORPHEUS_H2") for k in env) else "b3"
-    pick = (f"test_warp_mlp and {mode}-None-a or test_warp_sliced_arithmetic_is_fp32_grade and {mode} or "
-            f"test_warp_large_batch_weight_gradients and {mode}")
-    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-x", "-m", "gpu",
-                          "-k", pick, "-p", "no:cacheprovider"], cwd=root, env={**os.environ, **env}, capture_output=True,
-                         text=True, timeout=600)
-    tail = (run.stdout + run.stderr)[-3000:]
-    assert run.returncode == 0, tail
-    assert "3 passed" in run.stdout, tail
 
 
 def test_warp_weight_gradient_kernel_on_fp16_slices(monkeypatch):

@@ -36,7 +36,6 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.mh_mlp_tiles(1) == 4 and lib.mh_mlp_tiles(129) == 8
     assert lib.mh_warp_acts_floats(128) == 4 * (64 + 2 * 640 + 40) * 32      # activations + 40 rows of ReLU masks
     assert lib.mh_field_acts_floats(128) == 4 * (96 + 64 * 5 + 8) * 32
-    assert lib.mh_field_dpre_floats(128) == 4 * (64 * 5 + 32) * 32
     assert lib.mh_grid_bin_bricks() == 4096 and lib.mh_grid_bin_index_ints() == 2 * 4096 + 8
 
 
