@@ -20,8 +20,12 @@ ragged samples, albedo_normal, shipped regularisers, point loss, pose optimisati
 density128 (forward-only model.density on a 128^3 grid: export_mesh / update_occ_grid's query, morpheus.py:367-408).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel: algorithmic FLOPs per launch / HIP-event launch time vs the fp32 MFMA peak
+  roofline     -- the step's LARGEST time item (the weight-gradient group included), SURVEY 8(d): algorithmic FLOPs / HIP-event
+                  time vs the peak of the matrix pipe the kernels issue on, next to the HBM view (parked bytes, algorithmic
+                  bytes, PMC traffic)
   cpu_baseline -- the CPU oracle ("port") timed on a bounded sample of the same workload
+  modes        -- N=1: the three arithmetic modes (b3 / f32 / h2), each timed in its own process; the top-level numbers are
+                  the faster fp32-faithful one's
 plus roofline_hashgrid (HBM-bound hash-grid stage, as north_star asks) and a per-kernel time table.
 """
 from __future__ import annotations
@@ -65,6 +69,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one all-reduce after backward instead of the early "
                                                               "side-stream exchange of the hash-table gradients")
+    ap.add_argument("--mode", default="auto", choices=["auto", "b3", "f32", "h2"],
+                    help="arithmetic of the MLP kernels (morpheus_amd.ops).  auto at N=1 on a headline workload: every mode is "
+                         "timed in its own process and reported in `modes`, the top-level line is the faster fp32-faithful one "
+                         "(b3 / f32); auto elsewhere = MORPHEUS_MLP or the library default (b3)")
+    ap.add_argument("--modes", default="b3,f32,h2", help="the modes `--mode auto` times, in this order")
     ap.add_argument("--graph", action="store_true",
                     help="capture one whole step (render fwd+bwd, all-reduce excluded, Adam) in a HIP graph and replay it; "
                          "disables the per-kernel event timers")
@@ -272,19 +281,159 @@ def build_density128(args, rank, world, dev):
                 desc=f"forward-only model.density (warp + both hash grids + sdf/colour nets) on {R}^3 grid points, no_grad")
 
 
-# ------------------------------------------------------------------------------------------------ main
-def main(argv=None):
-    argv = sys.argv[1:] if argv is None else argv
-    args = parse_args(argv)
-    if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(launch_ranks(args, argv))
+# ------------------------------------------------------------------------------------------------ roofline
+PRODUCTS = {"f32": 1.0, "b3": 6.0, "h2": 3.0}     # matrix-pipe slice products issued per fp32 MAC
+PIPE = {"f32": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS),
+        "b3": ("bf16 MFMA (v_mfma_f32_32x32x16_bf16)", BF16_MFMA_PEAK_TFLOPS),
+        "h2": ("fp16 MFMA (v_mfma_f32_32x32x16_f16)", BF16_MFMA_PEAK_TFLOPS)}
+# kernel symbols (rocprofv3 names, profiles/*_pmc_summary.csv) behind each timed C-ABI entry, per arithmetic mode
+SYMBOLS = {
+    "mh_warp_fwd": {"f32": ["warp_fwd_kernel"], "b3": ["warp_fwd_b3_kernel<8>"], "h2": ["warp_fwd_h2_kernel<4>"]},
+    "mh_warp_bwd_data": {"f32": ["warp_bwd_kernel"], "b3": ["warp_bwd_b3_kernel<8>"], "h2": ["warp_bwd_h2_kernel<8>"]},
+    "mh_mlp_wgrad[warp]": {"f32": ["wgrad_kernel<4, false>", "wgrad_kernel<2, false>", "wgrad_reduce_kernel"],
+                           "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"],
+                           "h2": ["wgrad_regs_h2_kernel<4>", "wgrad_regs_h2_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"]},
+    "mh_field_fwd": {"f32": ["field_fwd_kernel"], "b3": ["field_fwd_b3_kernel"], "h2": ["field_fwd_h2_kernel"]},
+    "mh_field_bwd_fused": {m: ["field_fused_color_kernel", "field_fused_sdf_kernel<true>"] for m in ("f32", "b3", "h2")},
+}
+# bytes per sample point.  "algorithmic" = what the operator must move if everything recomputable stayed on the chip (SURVEY 8d:
+# inputs in, results out); "parked" = what THIS design moves by construction (activations / pre-activation gradients parked
+# in HBM between the forward, backward-data and weight-gradient kernels, csrc/mlp_dev.h)
+IO_BYTES = {
+    "mh_warp_fwd": dict(algorithmic=12 + 20, parked=4 * (64 + 2 * 640) + 4 * 40 + 12 + 20),
+    "mh_warp_bwd_data": dict(algorithmic=12 + 20, parked=4 * 2 * 672 + 4 * 40 + 12 + 20),
+    "mh_mlp_wgrad[warp]": dict(algorithmic=12 + 20, parked=4 * (2 * 64 + 2 * 5 * 128 + 2 * (5 * 128 + 32))),
+    "mh_field_fwd": dict(algorithmic=12 + 2 * 128 + 8 + 4 + 4 + 12, parked=4 * (96 + 64 * 5) + 4 * 8 + 12 + 2 * 128 + 8 + 20),
+    "mh_field_bwd_fused": dict(algorithmic=12 + 20 + 2 * 128 + 8 + 12, parked=4 * (96 + 64 * 5) + 4 * 8 + 64 + 20 + 2 * 128 + 8 + 12),
+}
 
+
+def pmc_step_bytes(symbols, mode):
+    """HBM bytes per STEP of the given kernel symbols, from the committed rocprofv3 --pmc passes of `python bench.py` in the
+    same arithmetic mode (profiles/r0N_pmc_summary[_mode].csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB
+    units, separate passes).  None when no matching profile is committed."""
+    import csv
+    for rnd in ("r03", "r02"):
+        for name in (f"{rnd}_pmc_summary_{mode}.csv", f"{rnd}_pmc_summary.csv"):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                continue
+            try:
+                rows = {r["k"]: r for r in csv.DictReader(open(path))}
+            except Exception:      # noqa: BLE001
+                continue
+            tot, hit = 0.0, 0
+            for sym in symbols:
+                r = rows.get(sym)
+                if r is None:
+                    continue
+                per = float(r["hbm_read_MB_per_launch"]) + float(r["hbm_write_MB_per_launch"])
+                tot += per * float(r.get("launches_per_step", 1) or 1)
+                hit += 1
+            if hit:
+                return round(tot * 1024 * 1024), name, hit == len(symbols)
+    return None, None, False
+
+
+def build_roofline(ktab, mode, M, workload, full_size):
+    """SURVEY 8(d) roofline of the step's LARGEST time item (weight-gradient group included):
+    mfma view  -- algorithmic FLOPs (2 per MAC of the reference's dense layers) / time vs the peak of the pipe the kernels
+                  issue on, divided by the slice products they issue per MAC (stated in peak_note);
+    hbm view   -- the bytes the design moves by construction ("parked") / time vs 8 TB/s, next to the algorithmic bytes of
+                  8(d) and the PMC-measured traffic, so that the waste ratio is visible."""
+    warp_f = 2.0 * (MACS["deform"] + MACS["topo"]) * M
+    field_f = 2.0 * (MACS["sdf"] + MACS["color"]) * M
+    flops = {"mh_warp_fwd": warp_f, "mh_warp_bwd_data": warp_f, "mh_mlp_wgrad[warp]": warp_f, "mh_field_fwd": field_f,
+             "mh_field_bwd_fused": 2.0 * field_f}
+    if workload == "cfg3b":
+        flops = {k: v for k, v in flops.items() if k.startswith(("mh_warp", "mh_mlp"))}   # field entries mix 1-point and 6-tap calls
+    cands = [(v["ms_per_step"], k) for k, v in ktab.items() if k in flops and v.get("calls_per_step", 0) > 0]
+    if not cands:
+        return None
+    _, name = max(cands)
+    e = ktab[name]
+    secs = e["ms_per_step"] * 1e-3
+    per_step_flops = flops[name] * e["calls_per_step"]      # flops[] is per call on the step's M points
+    fused_fp32 = name == "mh_field_bwd_fused"
+    kmode = "f32" if fused_fp32 else mode
+    prod = PRODUCTS[kmode]
+    pipe, unit_peak = PIPE[kmode]
+    alg_tflops = per_step_flops / secs / 1e12
+    peak = unit_peak / prod
+    io = IO_BYTES[name]
+    parked = io["parked"] * M
+    algb = io["algorithmic"] * M
+    hbm_gbs = parked / secs / 1e9
+    traffic, src, complete = pmc_step_bytes(SYMBOLS[name][kmode if not fused_fp32 else mode], mode) if (full_size and workload == "cfg3") else (None, None, False)
+    mfma = dict(bound="mfma", achieved=round(alg_tflops, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(alg_tflops / peak, 4),
+                peak_note=f"{pipe} dense peak {unit_peak} TFLOP/s (MI355X_MICROARCH.md) / {prod:g} slice product(s) issued per fp32 "
+                          f"MAC = {peak:.1f} TFLOP/s of ALGORITHMIC fp32 work",
+                issued_tflops=round(alg_tflops * prod, 1), unit_peak=unit_peak, flops_per_step=per_step_flops)
+    hbm = dict(bound="hbm", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_gbs / HBM_PEAK_GBS, 4),
+               bytes_per_step=round(parked),
+               note="bytes this design moves by construction (parked activation / pre-activation-gradient tiles, each row written or "
+                    "read once); a streaming read reaches 5.6-6.6 TB/s and a streaming write 6.8 TB/s on this box "
+                    "(profiles/r02_micro_hbm_read.txt, r02_micro_hbm_rates.txt)")
+    near = mfma if mfma["frac"] >= hbm["frac"] else hbm
+    out = dict(kernel=name, launches_per_step=e["calls_per_step"], ms_per_step=e["ms_per_step"], mode=kmode,
+               largest_item_of_step=True)
+    out.update({k: near[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
+    out.update(traffic=traffic, algorithmic_bytes=round(algb), parked_bytes=round(parked),
+               waste_ratio_traffic_over_algorithmic=None if not traffic else round(traffic / algb, 1),
+               traffic_note=("HBM bytes per step of this item's kernels from the committed rocprofv3 --pmc passes (profiles/" +
+                             str(src) + (")" if complete else "; some kernels of the group missing in that file)")) if traffic else
+               "null: no committed PMC profile matches this workload / mode (traffic is collected by tools/gpu/r3_prof.sh)",
+               algorithmic_bytes_note="SURVEY 8(d): inputs in + results out per point (everything else is recomputable on the chip); "
+                                      "traffic far above it is the design's activation parking (DESIGN.md section 3)",
+               mfma=mfma, hbm=hbm)
+    return out
+
+
+def build_hash_roofline(ktab, M, workload, full_size, mode):
+    if "mh_grid_encode_fwd" not in ktab:
+        return None
+    # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b)
+    enc_points = (2 * M + (6 * M if workload == "cfg3b" else 0))
+    fwd_key = "mh_grid_encode_fwd"
+    pts_per_launch = enc_points / ktab[fwd_key]["calls_per_step"]
+    secs = ktab[fwd_key]["avg_ms"] * 1e-3
+    gb = GRID_FWD_BYTES * pts_per_launch / secs / 1e9
+    l2 = GRID_GATHERS_PER_POINT * 64 * pts_per_launch / secs / 1e9
+    traffic = None
+    if full_size and workload != "cfg3b":
+        t, _, _ = pmc_step_bytes(["grid_fwd_kernel"], mode)
+        traffic = None if t is None else round(t / ktab[fwd_key]["calls_per_step"])
+    roof = dict(kernel="grid_fwd_kernel", bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic, bytes_per_launch=round(GRID_FWD_BYTES * pts_per_launch),
+                launch=fwd_key, hbm_measured_gbs=None if traffic is None else round(traffic / secs / 1e9, 1),
+                gathers_per_s=round(GRID_GATHERS_PER_POINT * pts_per_launch / secs / 1e9, 1),
+                l2_sector_gbs_if_every_gather_missed_l1=round(l2, 1), l2_peak_gbs=L2_PEAK_GBS,
+                note="achieved = ALGORITHMIC bytes (SURVEY 8d: 1164 B/point) / time -- the yardstick north_star asks for, NOT an "
+                     "HBM utilisation: both 3.2 MB tables are L2/MALL resident, so the gathers are cache-served "
+                     "(hbm_measured_gbs = PMC traffic / time).  What bounds the kernel is the gather rate (gathers_per_s, in G "
+                     "8-byte gathers/s); see DESIGN.md section 3")
+    bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
+    if bwd_name in ktab:
+        gbb = GRID_BWD_BYTES * (enc_points / ktab[bwd_name]["calls_per_step"]) / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9
+        roof.update(bwd_kernel=bwd_name, bwd_achieved=round(gbb, 1), bwd_frac=round(gbb / HBM_PEAK_GBS, 4),
+                    bwd_note="algorithmic bytes of the reference's formulation (2188 B per point incl. the atomics' "
+                             "read-modify-write); the brick kernel accumulates on-chip, so this is a throughput in the "
+                             "reference's units, not an HBM utilisation")
+    return roof
+
+
+# ------------------------------------------------------------------------------------------------ one timed run
+def run_one(args):
+    """W warm-up steps, K timed steps between barrier + synchronize, MAX over ranks -> the result dict (rank 0) or None."""
     import torch
     import torch.distributed as dist
     from morpheus_amd import dist as mdist
     from morpheus_amd import ops
 
     stub = bool(os.environ.get("MORPHEUS_BENCH_STUB"))
+    if args.mode != "auto":
+        ops.set_mlp_mode(args.mode)
+    mode = ops.mlp_mode()
     rank, local, world = mdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -340,164 +489,49 @@ def main(argv=None):
     timers = ops.TIMER.summary() if rank == 0 else {}
     ops.TIMER.reset(False)
 
+    # who ran where: rank 0 prints it so that a multi-GPU run can be checked for "N ranks, N devices, backend nccl"
+    n_dev = 0 if stub else torch.cuda.device_count()
+    me = dict(rank=rank, device=str(dev), name=(torch.cuda.get_device_name(dev) if not stub else "cpu"), host_pid=os.getpid())
+    ranks = [me]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks = gathered
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        return None
     N, S = wl["rays_per_step"], args.samples
     M = float(wl["samples"]())                     # sample points per step per GPU (ragged workloads: mean over the timed steps)
     ms_step = elapsed / args.steps * 1e3
     total_rays = N * world * args.steps
     render_wl = args.workload in ("cfg3", "cfg2", "cfg3b")
-    # algorithmic FLOPs per launch of each timed C-ABI call (2 FLOPs per MAC; bwd-data = wgrad = fwd)
-    warp_f = 2.0 * (MACS["deform"] + MACS["topo"]) * M
-    field_f = 2.0 * (MACS["sdf"] + MACS["color"]) * M
-    flops = {"mh_warp_fwd": warp_f, "mh_warp_bwd_data": warp_f, "mh_mlp_wgrad[warp]": warp_f,
-             "mh_field_fwd": field_f, "mh_field_bwd_data": field_f, "mh_mlp_wgrad[field]": field_f} if render_wl and \
-        args.workload != "cfg3b" else ({"mh_warp_fwd": warp_f, "mh_warp_bwd_data": warp_f, "mh_mlp_wgrad[warp]": warp_f}
-                                       if args.workload == "cfg3b" else {})
-    ktab, dominant = {}, None
+    ktab = {}
     for name, (calls, total_ms) in sorted(timers.items(), key=lambda kv: -kv[1][1]):
         avg_ms = total_ms / max(calls, 1)
         ktab[name] = dict(calls_per_step=round(calls / args.steps, 3), avg_ms=round(avg_ms, 4),
                           ms_per_step=round(total_ms / args.steps, 4))
-        if name in flops:
-            ktab[name]["tflops"] = round(flops[name] / (avg_ms * 1e-3) / 1e12, 2)
-            # the roofline entry is the largest SINGLE kernel launch; "mh_mlp_wgrad[...]" is a group of 6-12 per-layer
-            # launches plus a reduction (each <= 0.65 ms) and is listed in "kernels" with its own TFLOP/s
-            if dominant is None and not name.startswith("mh_mlp_wgrad"):
-                dominant = name
-
-    def pmc_traffic(kernel_symbol):
-        """HBM bytes per launch measured by the committed rocprofv3 --pmc passes of this same command
-        (profiles/r0N_pmc_summary.csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB units)."""
-        import csv
-        for rnd in ("r02", "r01"):
-            try:
-                with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.csv")) as f:
-                    for row in csv.DictReader(f):
-                        if row["k"] == kernel_symbol:
-                            return round((float(row["hbm_read_MB_per_launch"]) + float(row["hbm_write_MB_per_launch"])) * 1024 * 1024)
-            except Exception:      # noqa: BLE001
-                continue
-        return None
-
-    mode = ops._warp_mode()                     # "h2" / "b3" / "" (native fp32 MFMA)
-    b3 = mode != ""                             # the warp nets run on the 16-bit matrix pipe with sliced operands
-    fsym = {"h2": "warp_fwd_h2_kernel<4>", "b3": "warp_fwd_b3_kernel<8>", "": "warp_fwd_kernel"}[mode]
-    bsym = {"h2": "warp_bwd_h2_kernel<8>", "b3": "warp_bwd_b3_kernel<8>", "": "warp_bwd_kernel"}[mode]
-    symbol = {"mh_warp_fwd": fsym, "mh_warp_bwd_data": bsym, "mh_field_fwd": "field_fwd_kernel", "mh_field_bwd_data": "field_bwd_kernel"}
     full = render_wl and N * S == 128 * 128 * 128
-    roofline = None
-    if dominant is not None:
-        ach = flops[dominant] / (ktab[dominant]["avg_ms"] * 1e-3) / 1e12
-        on_b3 = b3 and dominant.startswith("mh_warp")
-        # sliced kernels issue `prod` 16-bit slice products per fp32 MAC on the 2.5 PFLOP/s dense bf16 / fp16 matrix pipe: the
-        # yardstick for ALGORITHMIC fp32 FLOP/s on that unit is 2500 / prod (the native fp32 MFMA peak, 157.3, is no longer
-        # the ceiling).  b3: three bf16 slices, six products; h2: two fp16 slices, three products.
-        prod = {"h2": 3.0, "b3": 6.0}.get(mode, 1.0) if on_b3 else 1.0
-        peak = BF16_MFMA_PEAK_TFLOPS / prod if on_b3 else FP32_MFMA_PEAK_TFLOPS
-        notes = {"b3": "algorithmic fp32 FLOP/s against the dense bf16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 "
-                       "slice products per MAC: every fp32 operand is cut exactly into three bf16 slices, the six "
-                       "significant cross products go through v_mfma_f32_32x32x16_bf16 with fp32 accumulation",
-                 "h2": "algorithmic fp32 FLOP/s against the dense fp16 MFMA peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 3 "
-                       "slice products per MAC: every fp32 operand is cut into two fp16 slices at a power-of-two scale (22 "
-                       "significand bits), the three significant cross products go through v_mfma_f32_32x32x16_f16 with "
-                       "fp32 accumulation; fp32-grade by test_warp_sliced_arithmetic_is_fp32_grade"}
-        roofline = dict(kernel=dominant, bound="mfma", achieved=round(ach, 2), peak=round(peak, 1),
-                        unit="TFLOP/s", frac=round(ach / peak, 4),
-                        peak_note=(notes[mode] if on_b3 else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), MI355X_MICROARCH.md"),
-                        issued_tflops=round(prod * ach, 1) if on_b3 else round(ach, 2),
-                        issued_frac_of_unit_peak=round(prod * ach / BF16_MFMA_PEAK_TFLOPS, 4) if on_b3 else round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        vs_fp32_mfma_peak=round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                        traffic=pmc_traffic(symbol.get(dominant, "")) if (full and args.workload == "cfg3") else None,
-                        traffic_note="HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), not a live "
-                                     "measurement; null when the workload differs from the profiled one",
-                        flops_per_launch=flops[dominant], avg_launch_ms=ktab[dominant]["avg_ms"])
-        if dominant == "mh_warp_fwd" and ktab[dominant].get("calls_per_step", 1.0) == 1.0:
-            # the training forward parks every layer's activations for the weight gradients: 1344 fp32 rows + 40 rows of ReLU sign
-            # masks per 32-point tile (csrc/mlp_dev.h: WARP_ACT_ROWS), x in, 5 floats out -- 5568 B per point, written once.
-            # With the fp16 x 2 slices the kernel sits closer to THAT roof than to the matrix pipe's; report the nearer one as
-            # the bound and keep the other view beside it.
-            park_bytes = M * (4.0 * (64 + 2 * 640) + 4.0 * 40 + 12.0 + 20.0)
-            gbs = park_bytes / (ktab[dominant]["avg_ms"] * 1e-3) / 1e9
-            if gbs / HBM_PEAK_GBS > roofline["frac"]:
-                mfma_view = {k: roofline[k] for k in ("bound", "achieved", "peak", "unit", "frac", "peak_note", "issued_tflops",
-                                                      "issued_frac_of_unit_peak", "vs_fp32_mfma_peak", "flops_per_launch")}
-                roofline = dict(kernel=dominant, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=roofline["traffic"], traffic_note=roofline["traffic_note"],
-                                bytes_per_launch=round(park_bytes), avg_launch_ms=ktab[dominant]["avg_ms"],
-                                note="algorithmic bytes = the parked activation tile (5568 B per point, written once; reads are "
-                                     "the 12 B of x and the L2-resident weight slices); a pure streaming WRITE reaches 6.8 TB/s on "
-                                     "this box (profiles/r02_micro_hbm_rates.txt), and the kernel's clock sits at 1.6 GHz while it "
-                                     "parks against 1.9 GHz when it does not (profiles/r02_phase_trace_warp_fwd.txt)",
-                                mfma=mfma_view)
-        step_flops = 3.0 * (warp_f * (0 if args.workload == "cfg2" else 1) + field_f)
-        if args.workload != "cfg3b":
-            roofline["whole_step"] = dict(flops=step_flops, tflops=round(step_flops / (ms_step * 1e-3) / 1e12, 2),
-                                          frac=round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                                          frac_note="algorithmic FLOP/s of the whole step over the native fp32 MFMA peak (157.3): "
-                                                    "a speed-of-light figure for an all-fp32-MFMA step, kept for continuity with "
-                                                    "round 1" + ("; the warp nets now run on the 16-bit matrix pipe" if b3 else ""))
-    # the warp weight-gradient group is the step's largest item and a streaming kernel: every parked activation and dPre row is
-    # read exactly once (2 x 5.4 KB per point: SURVEY 8d's tile geometry, profiles/r02_pmc_summary.csv confirms the bytes)
-    roof_wgrad = None
-    if render_wl and args.workload != "cfg2" and "mh_mlp_wgrad[warp]" in ktab:
-        wg_bytes = M * 4.0 * (2 * 64 + 2 * 5 * 128 + 2 * (5 * 128 + 32))      # H0 per net + hidden activations + dPre rows
-        wg_gbs = wg_bytes / (ktab["mh_mlp_wgrad[warp]"]["avg_ms"] * 1e-3) / 1e9
-        roof_wgrad = dict(kernel="mh_mlp_wgrad[warp] (12 launches + reduction)", bound="hbm", achieved=round(wg_gbs, 1),
-                          peak=HBM_PEAK_GBS, unit="GB/s", frac=round(wg_gbs / HBM_PEAK_GBS, 4), bytes_per_step=round(wg_bytes),
-                          note="algorithmic = measured bytes (each operand row read once); this box's torch kernels sustain 4.0 "
-                               "(sum) - 5.3 (copy) - 6.8 (fill) TB/s, profiles/r02_micro_hbm_rates.txt")
-    roof_hash = None
-    if render_wl and ("mh_grid_encode_fwd" in ktab or "mh_grid_encode_fwd2" in ktab):
-        # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b).  The two-table launch
-        # (mh_grid_encode_fwd2: sdf + colour encoder at the same points) does two table-passes per point, reading x once.
-        enc_points = (2 * M + (6 * M if args.workload == "cfg3b" else 0))
-        if "mh_grid_encode_fwd2" in ktab:
-            fwd_key = "mh_grid_encode_fwd2"
-            pts_per_launch = 2 * M                      # table-passes in that launch
-            fwd_bytes = (2 * GRID_FWD_BYTES - 12) / 2.0  # algorithmic bytes per table-pass (x is read once for both)
-        else:
-            fwd_key = "mh_grid_encode_fwd"
-            pts_per_launch = enc_points / ktab[fwd_key]["calls_per_step"]
-            fwd_bytes = GRID_FWD_BYTES
-        secs = ktab[fwd_key]["avg_ms"] * 1e-3
-        gb = fwd_bytes * pts_per_launch / secs / 1e9
-        l2 = GRID_GATHERS_PER_POINT * 64 * pts_per_launch / secs / 1e9
-        traffic = pmc_traffic("grid_fwd_kernel<true>" if fwd_key.endswith("2") else "grid_fwd_kernel") if (full and args.workload != "cfg3b") else None
-        roof_hash = dict(kernel="grid_fwd_kernel", bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                         frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic,
-                         bytes_per_launch=round(fwd_bytes * pts_per_launch), launch=fwd_key,
-                         hbm_measured_gbs=None if traffic is None else round(traffic / secs / 1e9, 1),
-                         gathers_per_s=round(GRID_GATHERS_PER_POINT * pts_per_launch / secs / 1e9, 1),
-                         l2_sector_gbs_if_every_gather_missed_l1=round(l2, 1), l2_peak_gbs=L2_PEAK_GBS,
-                         note="achieved = ALGORITHMIC bytes (SURVEY 8d: 1164 B/point) / time -- the yardstick north_star asks "
-                              "for, NOT an HBM utilisation: both 3.2 MB tables are L2/MALL resident, so the gathers are "
-                              "cache-served (hbm_measured_gbs = PMC traffic / time).  What bounds the kernel is the gather rate "
-                              "(gathers_per_s, in G 8-byte gathers/s): at one 64-byte L2 sector per gather it would need more "
-                              "than the 34.5 TB/s aggregate L2 bandwidth, i.e. part of the gathers is served by the per-CU L1 "
-                              "(ray-ordered points share cells); see DESIGN.md section 3")
-        bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
-        if bwd_name in ktab:
-            gbb = GRID_BWD_BYTES * (enc_points / ktab[bwd_name]["calls_per_step"]) / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9
-            roof_hash["bwd_kernel"] = bwd_name
-            roof_hash["bwd_achieved"] = round(gbb, 1)
-            roof_hash["bwd_frac"] = round(gbb / HBM_PEAK_GBS, 4)
-            roof_hash["bwd_note"] = ("algorithmic bytes of the reference's formulation (2188 B per point incl. the atomics' "
-                                     "read-modify-write); the brick kernel accumulates on-chip, so this rate can exceed the HBM "
-                                     "peak -- it is a throughput in the reference's units, not an HBM utilisation")
+    roofline = build_roofline(ktab, mode, M, args.workload, full) if render_wl else None
+    if roofline is not None and args.workload != "cfg3b":
+        step_flops = 3.0 * (2.0 * (MACS["deform"] + MACS["topo"]) * M * (0 if args.workload == "cfg2" else 1) +
+                            2.0 * (MACS["sdf"] + MACS["color"]) * M)
+        roofline["whole_step"] = dict(flops=step_flops, tflops=round(step_flops / (ms_step * 1e-3) / 1e12, 2),
+                                      frac_of_fp32_mfma_peak=round(step_flops / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                                      note="algorithmic FLOP/s of the whole step (SURVEY 8d: 6 FLOPs per MAC fwd+bwd) over the native "
+                                           "fp32 MFMA peak, 157.3 TFLOP/s: the speed of light of an all-fp32-MFMA step, a continuity figure")
+    roof_hash = build_hash_roofline(ktab, M, args.workload, full, mode) if render_wl else None
     bucket = wl["bucket"]
     backend = dist.get_backend() if world > 1 else None
-    n_dev = 0 if stub else torch.cuda.device_count()
     headline = args.workload in ("cfg3", "cfg2", "cfg3b")
+    kernel_sum = round(sum(v["ms_per_step"] for v in ktab.values()), 4)
     out = {
         "metric": "rays/sec (fwd+bwd, 128 samples/ray)" if headline else
                   {"train_real": "rays/sec (real-view training step, ragged occupancy samples)",
                    "density128": "points/sec (forward-only field query)"}[args.workload],
         "value": round(total_rays / elapsed, 1), "unit": "rays/s" if args.workload != "density128" else "points/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ops.MODE_DTYPE[mode], "data": "synthetic",
         "config": {"workload": wl["desc"], "rays_per_gpu": N, "samples_per_ray": S if headline else round(M / max(N, 1), 1),
                    "sample_points_per_step_per_gpu": round(M),
                    "parallelism": f"dp{world}" + ("" if bucket is None else
@@ -505,33 +539,90 @@ def main(argv=None):
                                                   f"per step" + (", hash-table range early on a side stream" if world > 1 and
                                                                  not args.no_overlap else "") + ")"),
                    "world_size": world, "backend": backend, "devices_visible": n_dev,
-                   "ranks_share_devices": bool(world > 1 and n_dev < world),
-                   "mlp_arithmetic": {"b3": "warp nets: fp32 values, exact three-way bf16 split of both operands, six slice "
-                                            "products per MAC on the bf16 matrix pipe, fp32 accumulate (fp32-grade: <= 3 * 2^-24 of a "
-                                            "product dropped); field forward: fp16 x 2 slices unless MORPHEUS_FIELD_FWD says otherwise, "
-                                            "field backward native fp32 MFMA (MORPHEUS_MLP=b3)",
-                                      "h2": "warp nets (forward, backward-data, large-batch weight gradients) and the field forward: fp32 "
-                                            "values, two fp16 slices per operand at power-of-two scales (per layer for weights, per point "
-                                            "for activations / gradients, per tensor for the weight-gradient operands; 22 significand "
-                                            "bits), three slice products per MAC on the fp16 matrix pipe, fp32 accumulate -- fp32-grade: "
-                                            "measured error against float64 equal to the fp32-MFMA kernels'; 32-row layers' and small "
-                                            "batches' weight gradients: bf16 x 3 slices; field backward: native fp32 MFMA (the default, "
-                                            "MORPHEUS_MLP=h2)",
-                                      "": "native fp32 MFMA (MORPHEUS_MLP=f32)"}[mode],
+                   "ranks_share_devices": bool(world > 1 and n_dev < world), "ranks": ranks,
+                   "mlp_mode": mode,
+                   "mlp_arithmetic": {"b3": "fp32 values everywhere; warp nets (forward, backward-data, weight gradients) and the field "
+                                            "forward: EXACT three-way bf16 split of both operands (all 24 significand bits), six slice "
+                                            "products per MAC on the bf16 matrix pipe, fp32 accumulate; field backward: native fp32 MFMA",
+                                      "h2": "NOT fp32-faithful: warp nets and field forward on two fp16 slices per operand at power-of-two "
+                                            "scales (22 significand bits, block-scaled per layer / per point / per tensor), three slice "
+                                            "products per MAC on the fp16 matrix pipe, fp32 accumulate; 32-row layers' and small batches' "
+                                            "weight gradients bf16 x 3; field backward native fp32 MFMA",
+                                      "f32": "native fp32 MFMA (v_mfma_f32_32x32x2_f32) in every MLP kernel"}[mode],
                    "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
-        "roofline": roofline, "roofline_hashgrid": roof_hash, "roofline_weight_gradients": roof_wgrad, "kernels": ktab,
+        "roofline": roofline, "roofline_hashgrid": roof_hash, "kernels": ktab,
+        "kernel_sum_ms_per_step": kernel_sum, "timed_launches_per_step": round(sum(v["calls_per_step"] for v in ktab.values()), 1),
     }
     if "occupied" in wl:
         out["config"]["occupied_fraction"] = round(wl["occupied"], 4)
-    if world == 1 and not args.no_cpu_baseline and not stub and headline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_rays, S)
-        if out["cpu_baseline"]["value"]:
-            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-    else:
-        out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    out["cpu_baseline"] = None
     if world > 1:
         dist.destroy_process_group()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ all three arithmetic modes
+FAITHFUL = ("b3", "f32")      # modes whose operands keep all 24 significand bits of the reference's fp32 (models/decoders.py:59-64)
+
+
+def run_modes(args, argv):
+    """N = 1, headline workloads, --mode auto: time every arithmetic mode in its OWN process (fresh allocator, timers and
+    operand caches; the same isolation the CPU baseline gets) and report them side by side.  The top-level line is the
+    faster of the fp32-faithful modes; h2 rides beside it under its own dtype string."""
+    base = [a for a in argv]
+    results, errors = {}, {}
+    for m in args.modes.split(","):
+        cmd = [sys.executable, os.path.abspath(__file__)] + base + ["--mode", m, "--no-cpu-baseline"]
+        try:
+            run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                                 env={**os.environ, "MORPHEUS_MLP": m})
+            lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+            if run.returncode != 0 or not lines:
+                errors[m] = (run.stderr or run.stdout)[-400:]
+                continue
+            results[m] = json.loads(lines[-1])
+        except Exception as e:      # noqa: BLE001
+            errors[m] = f"{type(e).__name__}: {e}"[:400]
+    faithful = [m for m in FAITHFUL if m in results]
+    if not faithful:
+        raise SystemExit("bench.py: no fp32-faithful mode produced a result: " + json.dumps(errors))
+    best = min(faithful, key=lambda m: results[m]["ms_per_step"])
+    out = dict(results[best])
+    out["headline_mode"] = best
+    out["headline_rule"] = ("value / ms_per_step / dtype / roofline / kernels are those of the faster fp32-faithful mode (b3: exact "
+                            "3 x bf16 operand split; f32: native fp32 MFMA); h2 (22-bit block-scaled operands) is reported in "
+                            "`modes` only")
+    out["modes"] = {m: {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "kernels",
+                                          "kernel_sum_ms_per_step")} | {"loss": r["config"]["loss"],
+                                                                        "fp32_faithful": m in FAITHFUL}
+                    for m, r in results.items()}
+    if errors:
+        out["mode_errors"] = errors
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_rays, args.samples)
+        if out["cpu_baseline"]["value"]:
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args, argv))
+    stub = bool(os.environ.get("MORPHEUS_BENCH_STUB"))
+    headline = args.workload in ("cfg3", "cfg2", "cfg3b")
+    if args.gpus == 1 and args.mode == "auto" and headline and not stub and not args.graph:
+        out = run_modes(args, argv)
+    else:
+        out = run_one(args)
+        if out is not None and args.gpus == 1 and headline and not args.no_cpu_baseline and not stub:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_rays, args.samples)
+            if out["cpu_baseline"]["value"]:
+                out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

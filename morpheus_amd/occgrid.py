@@ -81,14 +81,21 @@ class OccupancyGrid(torch.nn.Module):
         if step < warmup_steps:
             idx = torch.arange(R3, device=dev)
         else:
+            # a quarter of the cells uniformly at random plus up to a quarter drawn among the occupied ones -- without the
+            # device->host sync of a nonzero(): every cell gets a random key, unoccupied cells key 0, and the k largest keys
+            # are k occupied cells drawn without replacement (fewer occupied cells than k: the zero-key remainder re-evaluates
+            # unoccupied cells, which only refreshes them).  Fixed shapes: k + k points every refresh.
             k = R3 // 4
             uni = torch.randint(R3, (k,), device=dev)
-            occ_idx = torch.nonzero(self.binaries.reshape(-1)).squeeze(-1)
-            if occ_idx.numel() > k:
-                occ_idx = occ_idx[torch.randint(occ_idx.numel(), (k,), device=dev)]
+            keys = torch.rand(R3, device=dev) * self.binaries.reshape(-1)
+            occ_idx = torch.topk(keys, k, sorted=False).indices
             idx = torch.cat([uni, occ_idx])
         occ = occ_eval_fn(self._cell_points(idx)).reshape(-1).float()
-        self.occs[idx] = torch.maximum(self.occs[idx] * ema_decay, occ)
+        # EMA-max update.  `idx` may name a cell more than once (two uniform draws, or a uniform and an occupied draw): the
+        # cell then takes the LARGEST of its evaluations -- a scatter-max, deterministic -- where an indexed assignment
+        # would keep whichever duplicate the hardware wrote last.
+        new = torch.maximum(self.occs[idx] * ema_decay, occ)
+        self.occs.scatter_reduce_(0, idx, new, reduce="amax", include_self=False)
         thre = torch.clamp(self.occs.mean(), max=occ_thre)
         self.binaries.copy_((self.occs > thre).view_as(self.binaries))
 

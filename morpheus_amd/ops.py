@@ -751,6 +751,8 @@ class _WarpMLP(torch.autograd.Function):
         TIMER.stop("mh_warp_bwd_data", _e)
         raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
                      _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3, amax=amax, slots=_WARP_WG_SLOTS)
+        if AMAX_CAPTURE is not None and amax is not None:
+            AMAX_CAPTURE.append(amax.clone())
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
             (od, ot) = ctx.jp.bias0_raw
@@ -790,6 +792,7 @@ _WARP_WG_SLOTS = ([(16 + 6 * net + l) if l < 5 else -1 for net in range(2) for l
 # maxima (the kernels only ever raise it), so a run can be given ANOTHER run's per-tensor scales.
 WGRAD_H2 = True
 AMAX_SEED = None
+AMAX_CAPTURE = None      # a list: every h2 backward appends its table of parked maxima (after the weight gradients ran)
 
 
 def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, opnd: MLPOperands, slots_are_identity: bool = False):

@@ -1,9 +1,12 @@
 """GPU parity: the whole render_rays path (HIP) against (i) the committed goldens generated from the
 reference's own Python and (ii) the CPU oracle on the same seeded rays / samples / weights.
 
-Bar (BASELINE.json north_star): rendered RGB / depth and SDF within 1e-4 relative,
-rel = |a-b| / max(|b|, floor), floor = 1e-2 for RGB and SDF (1% of their O(1) range; an absolute
-1e-6, i.e. fp32 round-off, near the SDF's zero crossing) and 5e-2 for depth (2% of its [0,2.6] range).
+Bar (BASELINE.json north_star): rendered RGB / depth and SDF within 1e-4 relative, checked twice:
+  * at SURVEY 8(d)'s floor, rel = |a-b| / max(|b|, 1e-3), as a COUNTED gate (tests/util.py: assert_close_counted): every
+    element within 5e-4 and at most 32 per 65 536 SDF samples (2 % of the rays for depth / opacity) above 1e-4 -- the
+    exceedances are |reference| < ~1e-3 values carrying one or two fp32 ulps of the O(1) quantities that cancel to them;
+  * strictly (no exceedance) at the relaxed floors 1e-2 for RGB / SDF / opacity (1 % of their O(1) range) and 5e-2 for
+    depth (2 % of its [0, 2.6] range).
 The reference's Laplace density 0.5 + 0.5*sign(s)*expm1(-|s|/beta) cancels catastrophically far from
 the surface, so sigma itself (and anything dominated by far-field density, e.g. the depth of rays that
 only graze the box) carries ~1e-4 relative libm noise between ANY two fp32 implementations.
@@ -13,7 +16,7 @@ import torch
 
 from morpheus_amd import synth
 from oracle import field as of
-from tests.util import assert_close, grad_digest_check, load_golden, max_rel
+from tests.util import assert_close, assert_close_counted, grad_digest_check, load_golden, max_rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -67,6 +70,12 @@ def test_render_rays_vs_reference_goldens(kind, case):
         assert_close(res["depth"], g[key + "|depth"], TOL, key + " depth", floor=DEPTH_FLOOR)
         assert_close(res["weights_sum"], g[key + "|weights_sum"], TOL, key + " opacity", floor=FLOOR)
         assert_close(res["sdf"][::16], g[key + "|sdf_s16"], TOL, key + " sdf", floor=FLOOR)
+        if not lam:
+            # the contract floor (1e-3), counted: SDF per sample, image / depth / opacity per ray
+            assert_close_counted(res["sdf"][::16], g[key + "|sdf_s16"], key + " sdf @1e-3")
+            assert_close_counted(res["image"], g[key + "|image"], key + " image @1e-3")
+            assert_close_counted(res["depth"], g[key + "|depth"], key + " depth @1e-3", max_frac=0.02)
+            assert_close_counted(res["weights_sum"], g[key + "|weights_sum"], key + " opacity @1e-3", max_frac=0.02)
         assert_close(res["weights"][::16], g[key + "|weights_s16"], 5e-4, key + " weights", floor=1e-3)
         if res["deform"] is not None:
             assert_close(res["deform"][::16], g[key + "|deform_s16"], TOL, key + " deform", floor=1e-3)
@@ -161,6 +170,60 @@ def test_full_size_properties():
     c1, c2 = torch.rand(M, 3, device=DEV), torch.rand(M, 3, device=DEV)
     f = lambda c: ops.composite(sig, ts, te, c, rs, rc)[3]
     assert_close(f(0.3 * c1 + 0.7 * c2), 0.3 * f(c1) + 0.7 * f(c2), 1e-5, "linearity", floor=1e-3)
+
+
+def test_full_size_forward_backward_equals_chunked_renders():
+    """BASELINE full size WITH gradients (16 384 rays x 128 samples, deform on, the bench's loss): the one-call render and its
+    backward -- the large-batch kernels: per-layer weight-gradient launches, persistent field kernels looping over hundreds
+    of tiles, brick-binned hash backward with hot bricks in many chunks -- against the SAME rays rendered as 64 calls of 256
+    rays whose gradients accumulate (the small-batch forms the oracle / golden tests pin), and the first chunk against the
+    committed reference golden (b_cfg3head).  Same terms, different kernels and summation orders."""
+    from morpheus_amd import harness
+    g = load_golden("render.npz")
+    o, d, t, rid = [v.to(DEV) for v in synth.frame_rays(25, 128, 128)]
+    N, S, CH = o.shape[1], 128, 256
+    jit = synth.ray_jitter(N).to(DEV)
+    timg, tdep = [v.to(DEV) for v in synth.targets(N)]
+    light = of.safe_normalize(o[0].cpu() + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
+
+    def loss_of(res, a, b):            # the bench's MSE(image) + MSE(depth), normalised by the FULL ray count so that chunks add up
+        return (((res["image"][0] - timg[a:b]) ** 2).sum() / (3 * N)) + (((res["depth"][0] - tdep[a:b]) ** 2).sum() / N)
+
+    def run(chunk):
+        model = harness.build_model("b", DEV).train()
+        for k in ("normal_smoothness", "normal_smooth_3d", "code_reg", "ori_weight"):
+            model.config["train"][k] = 0.0
+        total, first = 0.0, None
+        for a in range(0, N, chunk):
+            b = min(a + chunk, N)
+            rend = harness.make_renderer(model, S, jitter=jit[a:b])
+            res = rend.render_rays(o[:, a:b], d[:, a:b], t[:, a:b], rid[:, a:b], 128, 128, ambient_ratio=1.0, light_d=light[a:b],
+                                   shading="albedo")
+            l = loss_of(res, a, b)
+            l.backward()
+            total += float(l)
+            if first is None:
+                first = dict(image=res["image"].detach()[:, :CH], depth=res["depth"].detach()[:, :CH], sdf=res["sdf"].detach()[:CH * S])
+        return total, first, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    loss_full, first_full, g_full = run(N)
+    loss_chunk, first_chunk, g_chunk = run(CH)
+    key = "b_cfg3head_eval_albedo_deform"
+    for first, tag in ((first_full, "one call"), (first_chunk, "first chunk")):
+        assert_close(first["image"], g[key + "|image"], TOL, tag + " image vs golden", floor=FLOOR)
+        assert_close(first["depth"], g[key + "|depth"], TOL, tag + " depth vs golden", floor=DEPTH_FLOOR)
+        assert_close(first["sdf"][::16], g[key + "|sdf_s16"], TOL, tag + " sdf vs golden", floor=FLOOR)
+    assert torch.equal(first_full["sdf"], first_chunk["sdf"])          # forward values do not depend on the batch size
+    assert abs(loss_full - loss_chunk) <= 1e-5 * abs(loss_chunk), (loss_full, loss_chunk)
+    assert set(g_full) == set(g_chunk) and len(g_full) >= 60
+    worst = {}
+    for k, gc in g_chunk.items():
+        gf = g_full[k]
+        rel = float((gf.double() - gc.double()).norm() / gc.double().norm().clamp_min(1e-30))
+        worst[k] = rel
+        # embedding gradients: fixed-point bricks vs atomics-free small batches; MLP gradients: fp32 sums of 2 M terms in two orders
+        assert rel <= 2e-4, (k, rel)
+    assert max(worst.values()) > 0.0      # the two runs really took different kernels / orders
 
 
 def test_render_with_occupancy_marcher_ragged():

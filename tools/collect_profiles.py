@@ -44,18 +44,21 @@ def short(name):
     return name.split("(")[0]
 
 
-def pmc_summary(tag):
+def pmc_summary(tag, suffix="", steps_in_run=3):
+    """suffix: "" for the default (b3) passes in gpurun_out/pmc_{sq,fetch,write}, "_h2" / "_f32" for the per-mode passes in
+    gpurun_out/pmc_{sq,fetch,write}_<mode>.  steps_in_run: warm-up + timed steps of the profiled bench command (its
+    launches / steps_in_run = launches per step)."""
     per = defaultdict(lambda: defaultdict(list))
     for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
-        f = latest(f"{d}/runc/*_counter_collection.csv")
+        f = latest(f"{d}{suffix}/runc/*_counter_collection.csv")
         if not f:
             return False
         for row in csv.DictReader(open(f)):
             per[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     mean = lambda v: sum(v) / len(v) if v else 0.0
     cols = ["k", "hbm_read_MB_per_launch", "hbm_write_MB_per_launch", "mfma_busy_frac", "l2_hit_rate", "SQ_WAVE_CYCLES",
-            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"]
-    with open(os.path.join(PROF, f"{tag}_pmc_summary.csv"), "w", newline="") as fo:
+            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "launches_per_step"]
+    with open(os.path.join(PROF, f"{tag}_pmc_summary{suffix}.csv"), "w", newline="") as fo:
         w = csv.writer(fo)
         w.writerow(cols)
         for k in sorted(per):
@@ -68,12 +71,13 @@ def pmc_summary(tag):
             w.writerow([k, round(2.0 * mean(c["FETCH_SIZE"]) / 1024.0, 4), round(mean(c["WRITE_SIZE"]) / 1024.0, 4),
                         round(busy / gui, 4) if gui else 0.0, round(hit / (hit + miss), 4) if hit + miss else 0.0,
                         round(mean(c["SQ_WAVE_CYCLES"]), 4), round(mean(c["SQ_WAIT_ANY"]), 4),
-                        round(mean(c["SQ_WAIT_INST_ANY"]), 4), round(mean(c["GRBM_GUI_ACTIVE"]), 4)])
+                        round(mean(c["SQ_WAIT_INST_ANY"]), 4), round(mean(c["GRBM_GUI_ACTIVE"]), 4),
+                        round(len(c["FETCH_SIZE"]) / float(steps_in_run), 3)])
     return True
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(PROF, exist_ok=True)
     for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b"),
                     ("bench_train_real.log", "train_real"), ("bench_density128.log", "density128"), ("bench_n2.log", "n2_one_gpu_gloo"),
@@ -101,7 +105,7 @@ def main():
         if os.path.exists(src):
             shutil.copy(src, os.path.join(PROF, f"{tag}_{name}"))
             print("copied", name)
-    print("pmc summary", pmc_summary(tag))
+    print("pmc summary", pmc_summary(tag), [pmc_summary(tag, "_" + m) for m in ("h2", "f32")])
 
 
 if __name__ == "__main__":
