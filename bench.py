@@ -241,21 +241,34 @@ def build_train_real(args, rank, world, dev):
     occ = float(grid.binaries.float().mean())
     sample_log = []
 
-    def step():
-        bucket.zero()
-        loss = ts()
-        loss.backward()
-        bucket.allreduce_mean()
-        opt.step()
-        sample_log.append(ts.last_samples)
-        return loss
+    graphed = None
+    if args.graph:
+        assert world == 1, "--graph captures the single-GPU step (the gradient exchange stays outside a graph)"
+        graphed = trainstep.GraphedRealViewStep(ts, bucket)
+        graphed.prepare()                    # capture the capacity buckets of the frames' batches up front (not in the timed region)
+
+        def step():
+            loss = graphed()                 # render + losses + backward + gradient gather: one graph replay
+            opt.step()
+            sample_log.append(ts.last_samples)
+            return loss
+    else:
+        def step():
+            bucket.zero()
+            loss = ts()
+            loss.backward()
+            bucket.allreduce_mean()
+            opt.step()
+            sample_log.append(ts.last_samples)
+            return loss
 
     desc = (f"snoopy.yaml real-view training step (morpheus.py:1147-1236): {args.rays} random rays of one frame per GPU, "
             f"occupancy-marched ragged samples (step 0.01, {occ * 100:.1f}% of 128^3 cells occupied), albedo_normal, "
             "normal_smooth_3d + normal_smoothness + code_reg, depth/mask/sdf/surface-point losses, pose optimisation, "
             "occupancy refresh every 16 steps, Adam")
-    return dict(step=step, rays_per_step=args.rays, bucket=bucket, desc=desc,
-                samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ)
+    return dict(step=step, rays_per_step=args.rays, bucket=bucket, desc=desc + (", captured in a HIP graph" if graphed else ""),
+                samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ,
+                graphed=graphed)
 
 
 def build_density128(args, rank, world, dev):
@@ -455,7 +468,7 @@ def run_one(args):
     for _ in range(args.warmup):
         step()
     graph = None
-    if args.graph:
+    if args.graph and args.workload != "train_real":     # train_real brings its own graphed step (trainstep.GraphedRealViewStep)
         assert world == 1 and args.workload in ("cfg3", "cfg2", "cfg3b"), "--graph captures the single-GPU fixed-shape step"
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
@@ -476,8 +489,11 @@ def run_one(args):
         dist.barrier()
     sync()
     t0 = time.perf_counter()
+    loss_acc = None
     for _ in range(args.steps):
         loss = step()
+        if hasattr(loss, "detach"):          # mean loss of the timed steps, accumulated on the device (no sync)
+            loss_acc = loss.detach().clone() if loss_acc is None else loss_acc + loss.detach()
     sync()
     if world > 1:
         dist.barrier()
@@ -549,12 +565,22 @@ def run_one(args):
                                             "products per MAC on the fp16 matrix pipe, fp32 accumulate; 32-row layers' and small batches' "
                                             "weight gradients bf16 x 3; field backward native fp32 MFMA",
                                       "f32": "native fp32 MFMA (v_mfma_f32_32x32x2_f32) in every MLP kernel"}[mode],
-                   "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss)},
+                   "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss),
+                   "loss_mean_of_timed_steps": None if loss_acc is None else float(loss_acc.item()) / args.steps},
         "roofline": roofline, "roofline_hashgrid": roof_hash, "kernels": ktab,
         "kernel_sum_ms_per_step": kernel_sum, "timed_launches_per_step": round(sum(v["calls_per_step"] for v in ktab.values()), 1),
     }
     if "occupied" in wl:
         out["config"]["occupied_fraction"] = round(wl["occupied"], 4)
+    if wl.get("graphed") is not None:
+        g = wl["graphed"]
+        out["config"]["hip_graph"] = dict(capacity_buckets=sorted(c for c, _ in g.graphs), bucket_step=g.bucket_step,
+                                          capacity_of_last_step=g.last_capacity, samples_of_last_step=g.last_samples,
+                                          overflowed_batches=int(g.check_overflow()) + g.overflows, margin=g.margin,
+                                          note="sample_points_per_step_per_gpu is the mean CAPACITY the kernels ran on (padding "
+                                               "included); each batch is drawn and counted one step ahead on a side stream to pick its bucket")
+    elif args.graph:
+        out["config"]["hip_graph"] = dict(note="render + loss + backward + Adam captured once, replayed per step")
     out["cpu_baseline"] = None
     if world > 1:
         dist.destroy_process_group()

@@ -44,7 +44,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 2
+#define MH_ABI_VERSION 3   /* 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -166,12 +166,15 @@ int mh_multicode_bwd(const float *t, const float *g_out, float *g0, float *g1, f
                      int32_t C, int32_t F, void *stream);
 /* get_sdf_loss (utils.py:91-113) on packed samples: per-ray depth [N] / mask [N] (NULL: none) are read through ray_idx, the
  * sample depth is (t_starts + t_ends)/2.  sums [3] (device) = free-space sum, near-surface sum, count of samples whose target
- * depth is non-zero; the caller divides the two sums by the count.  Backward: g_fs / g_sl are device scalars (NULL = 0). */
+ * depth is non-zero; the caller divides the two sums by the count.  Backward: g_fs / g_sl are device scalars (NULL = 0).
+ * n_valid: NULL, or a DEVICE int: only the first *n_valid of the M packed entries are samples (fixed-capacity sampling pads
+ * the packed arrays so that a captured HIP graph sees constant shapes); the padding adds nothing and gets zero gradient. */
 int mh_sdf_losses_fwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
-                      const float *rays_depth, const float *rays_mask, float trunc, int64_t M, float *sums, void *stream);
+                      const float *rays_depth, const float *rays_mask, float trunc, int64_t M, const int32_t *n_valid,
+                      float *sums, void *stream);
 int mh_sdf_losses_bwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
-                      const float *rays_depth, const float *rays_mask, float trunc, int64_t M, const float *sums,
-                      const float *g_fs, const float *g_sl, float *g_pred, void *stream);
+                      const float *rays_depth, const float *rays_mask, float trunc, int64_t M, const int32_t *n_valid,
+                      const float *sums, const float *g_fs, const float *g_sl, float *g_pred, void *stream);
 int mh_sample_positions_bwd(const float *g_xyz, const float *t_starts, const float *t_ends, const int32_t *ray_start,
                             const int32_t *ray_cnt, int32_t N, float *g_o, float *g_d, void *stream);
 

@@ -43,8 +43,8 @@ _SIGS = {
     "mh_fd_normal_bwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
     "mh_multicode_fwd": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "mh_multicode_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
-    "mh_sdf_losses_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _P, _P]),
-    "mh_sdf_losses_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P, _P]),
+    "mh_sdf_losses_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _P, _P, _P]),
+    "mh_sdf_losses_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _F, _I64, _P, _P, _P, _P, _P, _P]),
     "mh_sample_positions": (ctypes.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "mh_sample_positions_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "mh_mlp_tiles": (_I64, [_I64]),
@@ -105,7 +105,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mh_abi_version() != 2:
+        if lib.mh_abi_version() != 3:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
         _lib = lib
     return _lib

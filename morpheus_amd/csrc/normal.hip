@@ -248,10 +248,11 @@ __device__ __forceinline__ SdfLossTerm sdf_loss_term(float z, float target, floa
 __global__ __launch_bounds__(256) void sdf_losses_kernel(const float *__restrict__ pred, const float *__restrict__ ts,
                                                          const float *__restrict__ te, const int32_t *__restrict__ ray_idx,
                                                          const float *__restrict__ rays_depth, const float *__restrict__ rays_mask,
-                                                         float trunc, int64_t M, float *__restrict__ sums /*[3]: fs, sl, nd*/) {
+                                                         float trunc, int64_t M, const int32_t *__restrict__ n_valid,
+                                                         float *__restrict__ sums /*[3]: fs, sl, nd*/) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float fs = 0.f, sl = 0.f, nd = 0.f;
-    if (m < M) {
+    if (m < M && (!n_valid || m < (int64_t)*n_valid)) {
         const int r = ray_idx[m];
         const SdfLossTerm o = sdf_loss_term((ts[m] + te[m]) / 2.0f, rays_depth[r], pred[m], trunc, rays_mask ? rays_mask[r] > 0.5f : true);
         fs = o.fs;
@@ -276,10 +277,15 @@ __global__ __launch_bounds__(256) void sdf_losses_bwd_kernel(const float *__rest
                                                              const float *__restrict__ te, const int32_t *__restrict__ ray_idx,
                                                              const float *__restrict__ rays_depth,
                                                              const float *__restrict__ rays_mask, float trunc, int64_t M,
+                                                             const int32_t *__restrict__ n_valid,
                                                              const float *__restrict__ sums, const float *__restrict__ g_fs,
                                                              const float *__restrict__ g_sl, float *__restrict__ g_pred) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
+    if (n_valid && m >= (int64_t)*n_valid) {      // padding behind the packed samples (fixed-capacity sampling): no loss, no gradient
+        g_pred[m] = 0.0f;
+        return;
+    }
     const int r = ray_idx[m];
     const SdfLossTerm o = sdf_loss_term((ts[m] + te[m]) / 2.0f, rays_depth[r], pred[m], trunc, rays_mask ? rays_mask[r] > 0.5f : true);
     const float nd = sums[2];
@@ -372,25 +378,26 @@ extern "C" int mh_multicode_bwd(const float *t, const float *g_out, float *g0, f
 }
 
 extern "C" int mh_sdf_losses_fwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
-                                 const float *rays_depth, const float *rays_mask, float trunc, int64_t M, float *sums,
-                                 void *stream) {
+                                 const float *rays_depth, const float *rays_mask, float trunc, int64_t M,
+                                 const int32_t *n_valid, float *sums, void *stream) {
     if (!sums) return MH_ERR_ARG;
     if (hipMemsetAsync(sums, 0, 3 * sizeof(float), mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
     if (M == 0) return MH_OK;
     if (M < 0 || !pred_sdf || !t_starts || !t_ends || !ray_idx || !rays_depth) return MH_ERR_ARG;
     hipLaunchKernelGGL(sdf_losses_kernel, dim3(blocks_for(M)), dim3(256), 0, mh_stream(stream), pred_sdf, t_starts, t_ends, ray_idx,
-                       rays_depth, rays_mask, trunc, M, sums);
+                       rays_depth, rays_mask, trunc, M, n_valid, sums);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
 
 extern "C" int mh_sdf_losses_bwd(const float *pred_sdf, const float *t_starts, const float *t_ends, const int32_t *ray_idx,
-                                 const float *rays_depth, const float *rays_mask, float trunc, int64_t M, const float *sums,
-                                 const float *g_fs, const float *g_sl, float *g_pred, void *stream) {
+                                 const float *rays_depth, const float *rays_mask, float trunc, int64_t M,
+                                 const int32_t *n_valid, const float *sums, const float *g_fs, const float *g_sl, float *g_pred,
+                                 void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !pred_sdf || !t_starts || !t_ends || !ray_idx || !rays_depth || !sums || !g_pred) return MH_ERR_ARG;
     hipLaunchKernelGGL(sdf_losses_bwd_kernel, dim3(blocks_for(M)), dim3(256), 0, mh_stream(stream), pred_sdf, t_starts, t_ends,
-                       ray_idx, rays_depth, rays_mask, trunc, M, sums, g_fs, g_sl, g_pred);
+                       ray_idx, rays_depth, rays_mask, trunc, M, n_valid, sums, g_fs, g_sl, g_pred);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

@@ -42,6 +42,14 @@ class OccupancyGrid(torch.nn.Module):
         self._R = R
         self.packed = None       # (ray_start, ray_cnt) of the last sampling() call, consumed by the compositor
         self.fixed_jitter: Optional[torch.Tensor] = None   # parity runs pin the per-ray jitter
+        # Fixed-capacity sampling (None = off: ragged packed samples sized by one device->host sync, as nerfacc does).
+        # With a capacity the packed arrays always have that length, the first `n_valid` (a device int) entries are the
+        # samples and the rest is padding no ray owns: constant shapes and no sync, so a whole training step can be captured
+        # in a HIP graph (trainstep.GraphedRealViewStep).  `overflow` (device int, sticky) is set when a batch had more
+        # samples than the capacity -- its tail rays were truncated -- and is the caller's cue to raise the capacity.
+        self.sample_capacity: Optional[int] = None
+        self.n_valid: Optional[torch.Tensor] = None
+        self.overflow: Optional[torch.Tensor] = None
 
     # -- sampling --------------------------------------------------------------------------------
     @torch.no_grad()
@@ -60,8 +68,16 @@ class OccupancyGrid(torch.nn.Module):
         else:
             u = None
         # a bool tensor is one byte per cell holding 0/1: the marcher reads it as uint8 without a copy
-        ri, ts, te, rs, rc = ops.march_rays(rays_o, rays_d, u, float(render_step_size), self.bound,
-                                            self.binaries[0].view(torch.uint8))
+        binary = self.binaries[0].view(torch.uint8)
+        if self.sample_capacity is not None:
+            ri, ts, te, rs, rc, self.n_valid, ovf = ops.march_rays_capped(rays_o, rays_d, u, float(render_step_size), self.bound,
+                                                                          binary, int(self.sample_capacity))
+            if self.overflow is None:
+                self.overflow = torch.zeros((), dtype=torch.int32, device=rays_o.device)
+            self.overflow.copy_(torch.maximum(self.overflow, ovf))
+        else:
+            ri, ts, te, rs, rc = ops.march_rays(rays_o, rays_d, u, float(render_step_size), self.bound, binary)
+            self.n_valid = None
         self.packed = (rs, rc)
         return ri, ts, te
 

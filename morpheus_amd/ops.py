@@ -229,14 +229,17 @@ def grid_encode_multi(x, embs, offsets_np, res_np, bound, max_level=None):
 # ------------------------------------------------------------------------------------ compositor
 class _Composite(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sigma, t_starts, t_ends, rgb, ray_start, ray_cnt):
+    def forward(ctx, sigma, t_starts, t_ends, rgb, ray_start, ray_cnt, padded=False):
         require_gpu(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt)
         lib = _lib.load()
         sigma, t_starts, t_ends = sigma.detach().contiguous(), t_starts.contiguous(), t_ends.contiguous()
         rgbc = rgb.detach().contiguous()
         N, M = ray_start.shape[0], sigma.shape[0]
         dev = sigma.device
-        weights = torch.empty(M, device=dev)
+        # padded: the packed arrays are longer than the rays' samples (fixed-capacity sampling); entries no ray owns are
+        # never visited by the kernels (one wavefront per ray) and must read as weight 0 / gradient 0
+        ctx.padded = bool(padded)
+        weights = torch.zeros(M, device=dev) if padded else torch.empty(M, device=dev)
         opacity, depth = torch.empty(N, device=dev), torch.empty(N, device=dev)
         color = torch.empty(N, 3, device=dev)
         _e = TIMER.start()
@@ -252,19 +255,19 @@ class _Composite(torch.autograd.Function):
         sigma, ts, te, rgb, ray_start, ray_cnt, weights = ctx.saved_tensors
         N = ray_start.shape[0]
         c = lambda t: None if t is None else t.contiguous()
-        d_sigma = torch.empty_like(sigma)
-        d_rgb = torch.empty_like(rgb)
+        d_sigma = torch.zeros_like(sigma) if ctx.padded else torch.empty_like(sigma)
+        d_rgb = torch.zeros_like(rgb) if ctx.padded else torch.empty_like(rgb)
         _e = TIMER.start()
         check(lib.mh_composite_bwd(ptr(sigma), ptr(ts), ptr(te), ptr(rgb), ptr(ray_start), ptr(ray_cnt), ptr(weights),
                                    ptr(c(g_w)), ptr(c(g_o)), ptr(c(g_d)), ptr(c(g_c)), ptr(d_sigma), ptr(d_rgb), N,
                                    stream()), "mh_composite_bwd")
         TIMER.stop("mh_composite_bwd", _e)
-        return d_sigma, None, None, d_rgb, None, None
+        return d_sigma, None, None, d_rgb, None, None, None
 
 
-def composite(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt):
-    """-> weights [M], opacity [N], depth [N], color [N,3]  (morpheus.py:675-685)."""
-    return _Composite.apply(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt)
+def composite(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt, padded: bool = False):
+    """-> weights [M], opacity [N], depth [N], color [N,3]  (morpheus.py:675-685).  padded: see _Composite.forward."""
+    return _Composite.apply(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt, padded)
 
 
 def packed_info(ray_indices: torch.Tensor, n_rays: int):
@@ -374,6 +377,59 @@ def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.
                                 stream()), "mh_march_pack")
         TIMER.stop("mh_march_pack", _e)
     return ri, ts, te, start, cnt.contiguous()
+
+
+def march_count(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.Tensor) -> torch.Tensor:
+    """Total number of samples the marcher would emit for these rays, as a 0-dim int32 DEVICE tensor (no host sync): lets a
+    caller size / pick a fixed-capacity buffer ahead of the step (trainstep.GraphedRealViewStep)."""
+    require_gpu(rays_o, rays_d, jitter, binary)
+    lib = _lib.load()
+    o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+    j = None if jitter is None else jitter.contiguous()
+    N, R, dev = o.shape[0], binary.shape[0], o.device
+    cap = int(lib.mh_march_cap(float(step), float(bound)))
+    cnt_ovf = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+    slots = torch.empty(2, N, cap, device=dev)
+    check(lib.mh_march_slots(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), cap, ptr(cnt_ovf),
+                             ptr(slots[0]), ptr(slots[1]), cnt_ovf.data_ptr() + 4 * N, stream()), "mh_march_slots")
+    return cnt_ovf[:N].sum(dtype=torch.int32)
+
+
+def march_rays_capped(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.Tensor, capacity: int):
+    """The same marcher with a FIXED packed length and no device->host sync, so that a training step has constant shapes and
+    can be captured in a HIP graph: -> (ray_idx int32 [capacity], t_starts, t_ends [capacity], ray_start [N], ray_cnt [N],
+    n_valid int32 0-dim, overflow int32 0-dim).  The first n_valid entries are the packed samples (identical to march_rays');
+    the rest is padding (ray 0, t = 0) that no ray owns: ray_cnt is clamped so that start + cnt never passes `capacity`.
+    overflow != 0: the batch had more samples than `capacity` (the tail rays were truncated) or a ray overflowed its slot
+    row -- the caller re-captures with a larger capacity."""
+    require_gpu(rays_o, rays_d, jitter, binary)
+    lib = _lib.load()
+    o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+    j = None if jitter is None else jitter.contiguous()
+    assert binary.dtype == torch.uint8 and binary.is_contiguous() and binary.dim() == 3
+    N, R, dev = o.shape[0], binary.shape[0], o.device
+    assert N > 0 and capacity > 0
+    cap = int(lib.mh_march_cap(float(step), float(bound)))
+    cnt_ovf = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+    cnt = cnt_ovf[:N]
+    slots = torch.empty(2, N, cap, device=dev)
+    _e = TIMER.start()
+    check(lib.mh_march_slots(ptr(o), ptr(d), ptr(j), N, float(step), float(bound), R, ptr(binary), cap, ptr(cnt),
+                             ptr(slots[0]), ptr(slots[1]), cnt_ovf.data_ptr() + 4 * N, stream()), "mh_march_slots")
+    TIMER.stop("mh_march_slots", _e)
+    csum = torch.cumsum(cnt, 0, dtype=torch.int32)
+    start = (csum - cnt).contiguous()
+    total = csum[N - 1]
+    cnt_c = torch.minimum(cnt, (capacity - start).clamp(min=0)).contiguous()
+    n_valid = total.clamp(max=capacity)
+    overflow = ((total > capacity) | (cnt_ovf[N] != 0)).to(torch.int32)
+    ri = torch.zeros(capacity, dtype=torch.int32, device=dev)
+    ts, te = torch.zeros(capacity, device=dev), torch.zeros(capacity, device=dev)
+    _e = TIMER.start()
+    check(lib.mh_march_pack(ptr(start), ptr(cnt_c), ptr(slots[0]), ptr(slots[1]), N, cap, ptr(ri), ptr(ts), ptr(te), stream()),
+          "mh_march_pack")
+    TIMER.stop("mh_march_pack", _e)
+    return ri, ts, te, start, cnt_c, n_valid, overflow
 
 
 # ------------------------------------------------------------------------------------ field-query glue (csrc/normal.hip)
@@ -487,35 +543,37 @@ def multicode_sample(t, volumes):
 
 class _SdfLosses(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred_sdf, ts, te, ray_idx, rays_depth, rays_mask, trunc):
-        require_gpu(pred_sdf, ts, te, ray_idx, rays_depth, rays_mask)
+    def forward(ctx, pred_sdf, ts, te, ray_idx, rays_depth, rays_mask, trunc, n_valid=None):
+        require_gpu(pred_sdf, ts, te, ray_idx, rays_depth, rays_mask, n_valid)
         lib = _lib.load()
         p = pred_sdf.detach().contiguous().float()
         dep = rays_depth.detach().reshape(-1).contiguous().float()
         msk = None if rays_mask is None else rays_mask.detach().reshape(-1).contiguous().float()
         sums = torch.empty(3, device=p.device)
-        check(lib.mh_sdf_losses_fwd(ptr(p), ptr(ts), ptr(te), ptr(ray_idx), ptr(dep), ptr(msk), float(trunc), p.shape[0], ptr(sums),
-                                    stream()), "mh_sdf_losses_fwd")
-        ctx.save_for_backward(p, ts, te, ray_idx, dep, msk, sums)
+        nv = None if n_valid is None else n_valid.detach().reshape(1).to(torch.int32).contiguous()
+        check(lib.mh_sdf_losses_fwd(ptr(p), ptr(ts), ptr(te), ptr(ray_idx), ptr(dep), ptr(msk), float(trunc), p.shape[0], ptr(nv),
+                                    ptr(sums), stream()), "mh_sdf_losses_fwd")
+        ctx.save_for_backward(p, ts, te, ray_idx, dep, msk, sums, nv)
         ctx.trunc = float(trunc)
         return sums[0] / sums[2], sums[1] / sums[2]
 
     @staticmethod
     def backward(ctx, g_fs, g_sl):
         lib = _lib.load()
-        p, ts, te, ray_idx, dep, msk, sums = ctx.saved_tensors
+        p, ts, te, ray_idx, dep, msk, sums, nv = ctx.saved_tensors
         g = torch.empty_like(p)
         c = lambda t: None if t is None else t.reshape(1).contiguous().float()
-        check(lib.mh_sdf_losses_bwd(ptr(p), ptr(ts), ptr(te), ptr(ray_idx), ptr(dep), ptr(msk), ctx.trunc, p.shape[0], ptr(sums),
-                                    ptr(c(g_fs)), ptr(c(g_sl)), ptr(g), stream()), "mh_sdf_losses_bwd")
-        return g, None, None, None, None, None, None
+        check(lib.mh_sdf_losses_bwd(ptr(p), ptr(ts), ptr(te), ptr(ray_idx), ptr(dep), ptr(msk), ctx.trunc, p.shape[0], ptr(nv),
+                                    ptr(sums), ptr(c(g_fs)), ptr(c(g_sl)), ptr(g), stream()), "mh_sdf_losses_bwd")
+        return g, None, None, None, None, None, None, None
 
 
-def sdf_losses(pred_sdf, t_starts, t_ends, ray_idx, rays_depth, rays_mask, trunc: float):
+def sdf_losses(pred_sdf, t_starts, t_ends, ray_idx, rays_depth, rays_mask, trunc: float, n_valid=None):
     """-> (fs_loss, sdf_loss) of utils.py:91-113 on packed samples; rays_depth / rays_mask are PER RAY ([N] or [N,1], mask may
-    be None) and read through ray_idx (int32 [M]); the sample depth is (t_starts + t_ends) / 2."""
+    be None) and read through ray_idx (int32 [M]); the sample depth is (t_starts + t_ends) / 2.  n_valid: 0-dim device int
+    tensor -- only the first n_valid packed entries are samples (march_rays_capped) -- or None."""
     return _SdfLosses.apply(pred_sdf, t_starts.contiguous(), t_ends.contiguous(), ray_idx.contiguous(), rays_depth, rays_mask,
-                            trunc)
+                            trunc, n_valid)
 
 
 class _SamplePositions(torch.autograd.Function):

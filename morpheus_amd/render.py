@@ -65,10 +65,21 @@ class HotPathRenderer:
         self.frame_batched = frame_batched
 
     # -- helpers of morpheus.py:518-556
+    def _const(self, key, build, device):
+        """small device constants built once per device (a torch.tensor(list, device=...) is a host->device copy: a sync
+        point of the eager step and illegal inside a captured HIP graph)"""
+        c = self.__dict__.setdefault("_consts", {})
+        k = (key, str(device))
+        if k not in c:
+            c[k] = build().to(device)
+        return c[k]
+
     def get_ortho_normal_dir(self, normals, phi=None):
         """morpheus.py:518-528; `phi` injects the random angle (parity tests)."""
         n = torch.nn.functional.normalize(normals, dim=-1)
-        u = torch.nn.functional.normalize(n[..., [1, 0, 2]] * torch.tensor([1.0, -1.0, 0.0], device=n.device), dim=-1)
+        # n[..., [1, 0, 2]] * (1, -1, 0) without host-built index / constant tensors (each is a host->device copy: a sync in the
+        # eager step, illegal inside a captured HIP graph); the same three values
+        u = torch.nn.functional.normalize(torch.stack([n[..., 1], -n[..., 0], n[..., 2] * 0.0], -1), dim=-1)
         v = torch.cross(n, u, dim=-1)
         if phi is None:
             phi = torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
@@ -86,7 +97,7 @@ class HotPathRenderer:
         trunc = self.config["train"]["trunc"]
         npts = int(trunc * 100 + 1)
         if offsets is None:
-            off = torch.linspace(-0.5 * trunc, 0.5 * trunc, npts)
+            off = self._const(("smooth_offsets", trunc, npts), lambda: torch.linspace(-0.5 * trunc, 0.5 * trunc, npts), depth.device)
             off = off + 0.01 * torch.rand_like(off)
         else:
             off = offsets
@@ -162,6 +173,17 @@ class HotPathRenderer:
         if light_d is None and lit:
             light_d = safe_normalize(rays_o + torch.randn(3, device=rays_o.device))      # morpheus.py:641
         M_samples = ray_indices.shape[0]
+        # fixed-capacity sampling (occgrid.OccupancyGrid.sample_capacity): only the first n_valid packed entries are samples
+        n_valid = getattr(self.occupancy_grid, "n_valid", None)
+        valid = None if n_valid is None else (torch.arange(M_samples, device=rays_o.device) < n_valid)
+
+        def smean(v):
+            """mean over the SAMPLES of a per-sample tensor [M, ...] (the reference's `.mean()`); padding entries excluded"""
+            if valid is None:
+                return v.mean()
+            w = valid.view(-1, *([1] * (v.dim() - 1))).to(v.dtype)
+            return (v * w).sum() / (n_valid.clamp(min=1).to(v.dtype) * (v.numel() // max(v.shape[0], 1)))
+
         single_frame = (not cano) and self.frame_batched and len(prefix) == 2 and prefix[0] == 1
         ray_idx32 = ray_indices
         _long = []
@@ -209,7 +231,7 @@ class HotPathRenderer:
                                                                shading=shading, cano=cano, frame_slots=frame_slots)
 
         weights, opacity, depth, rgb_acc = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), rgbs,
-                                                         ray_start, ray_cnt)
+                                                         ray_start, ray_cnt, padded=valid is not None)
         opacity, depth = opacity[:, None], depth[:, None]
         if bg_color is None:
             if cfg["model"]["bg_radius"] > 0 and cano and (not real_view):
@@ -220,6 +242,8 @@ class HotPathRenderer:
         depth = depth.view(*prefix)
         results.update(image=image, depth=depth, sdf=sdf, weights=weights, weights_sum=opacity, normal=normals,
                        deform=deform, normal_raw=normal_raw)
+        if valid is not None:
+            results.update(valid=valid, n_valid=n_valid)      # for the caller's own per-sample means (trainstep.sample_mean)
 
         if model.training:
             tr = cfg["train"]
@@ -237,20 +261,20 @@ class HotPathRenderer:
                 else:
                     normals_p, _ = model.normal(xyzs_p, topo=model.get_topo(xyzs_p, t=time_step, frame_slots=frame_slots),
                                                 cano=cano)
-                results["loss_normal_perturb"] = (normals - normals_p).abs().mean()
+                results["loss_normal_perturb"] = smean((normals - normals_p).abs())
                 if tr["normal_smooth_3d_t"] > 0:
                     tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
                     normals_pt, _ = model.normal(xyzs, topo=model.get_topo(xyzs, t=tt), cano=cano)
-                    results["loss_normal_perturb_t"] = (normals - normals_pt).abs().mean()
+                    results["loss_normal_perturb_t"] = smean((normals - normals_pt).abs())
                 if tr["deform_smooth"] > 0 and not cano:
                     deform_p, _, _ = model.warp(xyzs_p, t=time_step, frame_slots=frame_slots)
-                    results["loss_deform_perturb"] = (deform - deform_p).abs().mean()
+                    results["loss_deform_perturb"] = smean((deform - deform_p).abs())
             if (tr["deform_smooth_t"] > 0 or tr["topo_smooth_t"] > 0) and not cano:
                 tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
                 deform_pt, topo_pt, _ = model.warp(xyzs, t=tt)
                 topo_now = model.get_topo(xyzs, t=time_step, frame_slots=frame_slots)   # the reference reads an undefined `topo` here
-                results["loss_deform_perturb_t"] = (deform - deform_pt).abs().mean()
-                results["loss_topo_perturb_t"] = (topo_now - topo_pt).abs().mean()
+                results["loss_deform_perturb_t"] = smean((deform - deform_pt).abs())
+                results["loss_topo_perturb_t"] = smean((topo_now - topo_pt).abs())
             if tr["code_reg"] > 0 and not cano:
                 t0 = time_step[:1]
                 code = model.get_deform_code(t0)
@@ -261,7 +285,7 @@ class HotPathRenderer:
                 # accumulate_along_rays(weights, (normals+1)/2) with the LIVE weights (morpheus.py:775): the density
                 # gradient of the normal image is part of the normal_smooth_2d loss
                 _, _, _, nimg = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), (normals + 1) / 2,
-                                              ray_start, ray_cnt)
+                                              ray_start, ray_cnt, padded=valid is not None)
                 results["normal_image"] = nimg
             if tr["normal_smoothness"] > 0:
                 # the normals are taken at the rays' own times even in a canonical render (morpheus.py:548-553 warps always)
@@ -270,6 +294,6 @@ class HotPathRenderer:
                                                                         ray_slots=ray_slots, single_frame=one_t)
             if rays_depth is not None:
                 # get_sdf_loss (utils.py:91-113, morpheus.py:789) on the packed samples: one launch each way
-                fs_loss, sdf_loss = ops.sdf_losses(sdf, t_starts_, t_ends_, ri32(), rays_depth, rays_mask, tr["trunc"])
+                fs_loss, sdf_loss = ops.sdf_losses(sdf, t_starts_, t_ends_, ri32(), rays_depth, rays_mask, tr["trunc"], n_valid)
                 results["sdf_loss"], results["fs_loss"] = sdf_loss, fs_loss
         return results

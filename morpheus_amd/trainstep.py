@@ -65,6 +65,16 @@ def sample_real_view_rays(frame: Dict[str, torch.Tensor], ray_num: int, index: O
 
 
 # ------------------------------------------------------------------------------------------ the losses
+def sample_mean(v, outputs):
+    """`v.mean()` over the samples of a per-sample tensor [M, ...]; with fixed-capacity sampling (render_rays then returns
+    `valid` / `n_valid`) the padding entries are left out -- the same value the ragged layout gives."""
+    valid = outputs.get("valid")
+    if valid is None:
+        return v.mean()
+    w = valid.view(-1, *([1] * (v.dim() - 1))).to(v.dtype)
+    return (v * w).sum() / (outputs["n_valid"].clamp(min=1).to(v.dtype) * (v.numel() // max(v.shape[0], 1)))
+
+
 def get_gt_from_data(data, bg_color, B, H, W):
     """morpheus.py:930-945."""
     gt_rgb, gt_depth, gt_mask = data["image"], data["depth"], data["mask"]
@@ -101,7 +111,7 @@ def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_
     if tr["sdf_weight"] > 0:
         loss = loss + tr["sdf_weight"] * outputs["sdf_loss"]
     if tr["sdf_reg"] > 0:
-        loss = loss + tr["sdf_reg"] * torch.mean(outputs["sdf"] ** 2)
+        loss = loss + tr["sdf_reg"] * sample_mean(outputs["sdf"] ** 2, outputs)
     if tr["fs_weight"] > 0:
         loss = loss + tr["fs_weight"] * outputs["fs_loss"]
     if tr["surf_sdf_weight"] > 0:
@@ -121,8 +131,9 @@ def get_regularization_loss(tr, model, outputs, pred_normal, global_step: int, e
     loss = 0
     if tr["entropy_weight"] > 0:
         alphas = outputs["weights"].clamp(1e-5, 1 - 1e-5)
-        ent = (-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas)).mean()
-        loss = loss + tr["entropy_weight"] * min(1, 2 * global_step / end_iter) * ent
+        ent = sample_mean(-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas), outputs)
+        ramp = min(1, 2 * global_step / end_iter) if not torch.is_tensor(global_step) else (2 * global_step / end_iter).clamp(max=1.0)
+        loss = loss + tr["entropy_weight"] * ramp * ent
     if tr["normal_smooth_2d"] > 0 and pred_normal is not None:
         sm = (pred_normal[:, 1:, :, :] - pred_normal[:, :-1, :, :]).square().mean() + \
              (pred_normal[:, :, 1:, :] - pred_normal[:, :, :-1, :]).square().mean()
@@ -135,13 +146,13 @@ def get_regularization_loss(tr, model, outputs, pred_normal, global_step: int, e
         loss = loss + tr["normal_smooth_3d_t"] * outputs["loss_normal_perturb_t"]
     if outputs["normal_raw"] is not None and tr["eik_weight"] > 0:
         ge = (torch.linalg.norm(outputs["normal_raw"], ord=2, dim=-1) - 1.0) ** 2
-        loss = loss + tr["eik_weight"] * torch.mean(ge)
+        loss = loss + tr["eik_weight"] * sample_mean(ge, outputs)
     if tr["beta_weight"] > 0:
         loss = loss + tr["beta_weight"] * torch.mean(model.sdf2density.get_beta())
     if tr["normal_smoothness"] > 0:
         loss = loss + tr["normal_smoothness"] * outputs["normal_reg"]
     if tr["deform_weight"] > 0:
-        loss = loss + tr["deform_weight"] * outputs["deform"].abs().mean()
+        loss = loss + tr["deform_weight"] * sample_mean(outputs["deform"].abs(), outputs)
     for w, k in (("deform_smooth", "loss_deform_perturb"), ("deform_smooth_t", "loss_deform_perturb_t"),
                  ("topo_smooth_t", "loss_topo_perturb_t")):
         if tr[w] > 0 and k in outputs:
@@ -173,23 +184,34 @@ class RealViewTrainStep:
         self.r.occupancy_grid.update_every_n_steps(step=self.global_step - 1, occ_eval_fn=occ_eval_fn)
 
     def __call__(self, frame_index: Optional[int] = None, pixel_index: Optional[torch.Tensor] = None):
+        self.begin_step()
+        fi = self.frame_of_step() if frame_index is None else frame_index
+        self.update_occ_grid(self.frames[fi]["rays_t"][None, :1], cano=False)
         with self.model.operand_scope():      # render_rays and the point loss share one set of prepared weight operands
-            return self._step(frame_index, pixel_index)
+            return self._step(sample_real_view_rays(self.frames[fi], self.ray_num, pixel_index), self.global_step)
 
-    def _step(self, frame_index, pixel_index):
-        tr = self.cfg["train"]
+    def begin_step(self):
+        """host-side bookkeeping of one iteration (morpheus.py:808-813, 1377-1399)"""
         self.global_step += 1
-        if tr["progressive_level"]:                                   # morpheus.py:808-813
+        self.apply_level()
+
+    def apply_level(self):
+        if self.cfg["train"]["progressive_level"]:                    # morpheus.py:808-813
             self.model.max_level = min(1.0, 0.5 + 0.5 * self.epoch / self.n_epochs)
-        fi = (self.global_step * 7) % len(self.frames) if frame_index is None else frame_index
-        data = sample_real_view_rays(self.frames[fi], self.ray_num, pixel_index)
+
+    def frame_of_step(self) -> int:
+        return (self.global_step * 7) % len(self.frames)
+
+    def _step(self, data, global_step):
+        """render + the three loss groups on one batch of real-view rays.  `global_step`: int, or a 0-dim device tensor when
+        the step is captured in a HIP graph (it only feeds the entropy ramp)."""
+        tr = self.cfg["train"]
         rays_o, rays_d, rays_t, rays_id = data["rays_o"], data["rays_d"], data["rays_t"], data["rays_id"]
         B, N = rays_o.shape[:2]
         H, W = data["H"], data["W"]
         rays_depth, rays_mask = data["depth"].view(B, -1, 1), data["mask"].view(B, -1, 1)
         ambient_ratio, shading = 1.0, "albedo_normal"                  # get_shading, real view (:869-871)
         bg_color = torch.rand((B * N, 3), device=rays_o.device)        # get_bg_color, real view (:893-894)
-        self.update_occ_grid(rays_t, cano=False)
         outputs = self.r.render_rays(rays_o, rays_d, rays_t, rays_id, H, W, perturb=True, bg_color=bg_color,
                                      ambient_ratio=ambient_ratio, shading=shading, real_view=True, cano=False,
                                      rays_depth=rays_depth, rays_mask=rays_mask, optimize_pose=True)
@@ -201,8 +223,175 @@ class RealViewTrainStep:
         gt_rgb, gt_depth, gt_mask = get_gt_from_data(data, bg_color, B, H, W)
         loss = get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask, rays_o, rays_d)
         loss = loss + get_real_view_point_loss(tr, self.model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs)
-        loss = loss + get_regularization_loss(tr, self.model, outputs, pred_normal, self.global_step, self.end_iter)
+        loss = loss + get_regularization_loss(tr, self.model, outputs, pred_normal, global_step, self.end_iter)
         return loss
+
+
+class GraphedRealViewStep:
+    """The real-view step -- render_rays, the three loss groups, backward, the gather of the gradients into the flat bucket --
+    captured in HIP graphs and replayed: ~700 launches per step issued by the GPU's own scheduler instead of the Python
+    interpreter (the eager step is half host-bound: bench.py --workload train_real).
+
+    What makes the step capturable
+      * fixed-capacity sampling (OccupancyGrid.sample_capacity): the packed sample arrays have a constant length, the real
+        sample count is a device scalar, the marcher does not synchronise;
+      * the batch is DRAWN outside the graph, one step ahead and on a side stream while the previous step's graph runs: pixel
+        indices and the per-ray stratified jitter go into staging buffers, and the batch's rays (before pose correction) are
+        marched once to learn its sample count M, which reaches the host through pinned memory.  The step replays the graph
+        captured for the smallest capacity bucket >= 1.02 M + 512 (buckets of `bucket_step` samples): the padding the kernels
+        chew through stays around 5 % instead of the spread between frames, and no per-step synchronisation stalls the
+        pipeline.  The margin covers what the learned pose correction moves between the count and the replay; a batch that
+        still overflowed its capacity (its tail rays truncated) raises the sticky OccupancyGrid.overflow flag, which
+        `check_overflow()` turns into a larger margin -- it is read once per occupancy refresh, not per step;
+      * the frame is addressed on the device (one table of all frames' pixels), the step counter is a device scalar, small
+        constants are built once (render.HotPathRenderer._const).
+    What stays outside the graphs: the occupancy refresh every 16 steps (morpheus.py:905-913; the batch of a refresh step is
+    counted after it, synchronously), the optimiser step (its per-parameter step counts are host integers) and the
+    learning-rate schedule.  Graphs are keyed by (capacity bucket, progressive level), each with its own memory pool.
+
+    Usage:  gs = GraphedRealViewStep(ts, opt.bucket);  loss = gs();  opt.step()        (loss: a 0-dim device tensor)"""
+
+    def __init__(self, step: RealViewTrainStep, bucket, bucket_step: int = 8192, margin: float = 0.02):
+        self.ts, self.bucket = step, bucket
+        self.grid = step.r.occupancy_grid
+        dev = step.frames[0]["rays_o"].device
+        n = step.ray_num
+        # all frames' per-pixel data as ONE table per key, [F * H*W, ...]: a batch is a gather at frame * H*W + pixel
+        self.n_pix = step.frames[0]["rays_o"].shape[0]
+        self.table = {k: torch.cat([f[k] for f in step.frames]) for k in step.frames[0]}
+        self.index = torch.zeros(n, dtype=torch.long, device=dev)       # static (read by the graphs): the batch's table rows
+        self.jitter = torch.zeros(n, device=dev)                        # static: per-ray near-plane jitter
+        self.gs = torch.zeros((), dtype=torch.float32, device=dev)      # static: global step (entropy ramp)
+        self.idx_stage, self.jit_stage = torch.zeros_like(self.index), torch.zeros_like(self.jitter)   # the NEXT batch
+        self.cnt_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.side = torch.cuda.Stream(device=dev)
+        self.ev_staged, self.ev_taken = torch.cuda.Event(), torch.cuda.Event()
+        self.staged_for = None      # (frame, global step) the staging buffers hold a batch for
+        self.bucket_step, self.margin = int(bucket_step), float(margin)
+        self.graphs = {}            # (capacity, max_level) -> dict(graph, loss, n_valid, missing)
+        self.last_capacity, self.last_samples, self.overflows = None, None, 0
+
+    # ---- the batch: drawn one step ahead on a side stream, handed to the graphs through static buffers ---------------------
+    def _stage(self, fi: int, for_step: int, after_main: bool):
+        """draw the batch (frame fi) into the staging buffers and count its samples, on the side stream.  after_main: the side
+        stream first waits for everything queued on the main stream (an occupancy refresh the count must see)."""
+        ts, main = self.ts, torch.cuda.current_stream()
+        if after_main:
+            self.side.wait_stream(main)
+        self.side.wait_event(self.ev_taken)          # the previous batch has been copied out of the staging buffers
+        with torch.cuda.stream(self.side), torch.no_grad():
+            self.idx_stage.copy_(torch.randint(0, self.n_pix, (ts.ray_num,), device=self.index.device) + fi * self.n_pix)
+            self.jit_stage.copy_(torch.rand(ts.ray_num, device=self.jitter.device))
+            o, d = self.table["rays_o"][self.idx_stage], self.table["rays_d"][self.idx_stage]
+            from . import ops
+            cnt = ops.march_count(o, d, self.jit_stage, float(ts.cfg["render"]["step_size"]), self.grid.bound,
+                                  self.grid.binaries[0].view(torch.uint8))
+            self.cnt_host.copy_(cnt.reshape(1), non_blocking=True)
+            self.ev_staged.record(self.side)
+        self.staged_for = (fi, for_step)
+
+    def _take(self) -> int:
+        """the staged batch -> the static buffers the graphs read (main stream); -> its sample count (un-posed rays)"""
+        self.ev_staged.synchronize()                 # host: the count has landed (normally long ago)
+        m = int(self.cnt_host[0])
+        main = torch.cuda.current_stream()
+        main.wait_event(self.ev_staged)
+        self.index.copy_(self.idx_stage)
+        self.jitter.copy_(self.jit_stage)
+        self.ev_taken.record(main)
+        return m
+
+    def _capacity_for(self, m: int) -> int:
+        need = int(m * (1.0 + self.margin)) + 512
+        return max(self.bucket_step, -(-need // self.bucket_step) * self.bucket_step)
+
+    def _body(self, capacity: int):
+        self.grid.sample_capacity, self.grid.fixed_jitter = capacity, self.jitter
+        self.bucket.zero()
+        with self.ts.model.operand_scope():
+            loss = self.ts._step(sample_real_view_rays(self.table, self.ts.ray_num, self.index), self.gs)
+        loss.backward()
+        self.bucket.collect()
+        return loss
+
+    def capture(self, capacity: int):
+        """capture the step for one capacity bucket (two eager passes on the capture stream first: allocator warm-up and every
+        lazy one-time setup -- kernel attributes, cached constants, index maps -- must not happen inside the capture)"""
+        if self.grid.overflow is None:
+            self.grid.overflow = torch.zeros((), dtype=torch.int32, device=self.index.device)
+        torch.cuda.synchronize()
+        keep = self.grid.overflow.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._body(capacity)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):          # its own memory pool (~35 KB per sample point: a few GB of the 288 per bucket)
+            loss = self._body(capacity)
+        self.grid.overflow.copy_(keep)         # the warm-up passes ran on whatever batch the static buffers held
+        entry = dict(graph=graph, loss=loss, n_valid=self.grid.n_valid, missing=set(self.bucket.missing))
+        self.graphs[(capacity, self.ts.model.max_level)] = entry
+        return entry
+
+    def prepare(self, probes_per_frame: int = 2):
+        """capture ahead of time the buckets the frames' batches fall into (each +- one bucket), so that a timed run or the first
+        epochs do not pay the captures one by one"""
+        self.ts.apply_level()
+        caps = set()
+        for fi in range(len(self.ts.frames)):
+            for _ in range(probes_per_frame):
+                self._stage(fi, -1, after_main=True)
+                c = self._capacity_for(self._take())
+                caps.update((max(self.bucket_step, c - self.bucket_step), c, c + self.bucket_step))
+        for c in sorted(caps):
+            if (c, self.ts.model.max_level) not in self.graphs:
+                self.capture(c)
+        self.staged_for = None
+        return sorted(caps)
+
+    def check_overflow(self) -> bool:
+        """did a replayed batch need more samples than its capacity (tail rays truncated)?  One device->host read; on overflow
+        the margin doubles and the flag is cleared.  Called once per occupancy refresh."""
+        if self.grid.overflow is None or not bool(self.grid.overflow.item()):
+            return False
+        import warnings
+        self.overflows += 1
+        self.margin = max(2 * self.margin, 0.04)
+        self.grid.overflow.zero_()
+        warnings.warn(f"GraphedRealViewStep: a batch overflowed its sample capacity (tail rays truncated in that step); "
+                      f"margin raised to {self.margin:.2f}")
+        return True
+
+    def release(self):
+        """drop every captured graph (after a device synchronisation: a graph must not be destroyed while a replay is in flight)"""
+        torch.cuda.synchronize()
+        self.graphs.clear()
+
+    def __call__(self):
+        ts = self.ts
+        ts.begin_step()
+        fi = ts.frame_of_step()
+        refresh = (ts.global_step - 1) % 16 == 0
+        ts.update_occ_grid(ts.frames[fi]["rays_t"][None, :1], cano=False)         # eager, every 16th step
+        if refresh:
+            self.check_overflow()
+        if refresh or self.staged_for != (fi, ts.global_step):
+            self._stage(fi, ts.global_step, after_main=True)      # first step / refreshed grid: count now, against the new grid
+        m = self._take()
+        cap = self._capacity_for(m)
+        entry = self.graphs.get((cap, ts.model.max_level)) or self.capture(cap)
+        self.gs.fill_(float(ts.global_step))
+        entry["graph"].replay()
+        self.bucket.missing = set(entry["missing"])
+        self.last_capacity, self.last_samples = cap, m
+        ts.last_samples = cap
+        # the next batch is drawn and counted on the side stream while this replay runs (not across an occupancy refresh)
+        if ts.global_step % 16 != 0:
+            self._stage(((ts.global_step + 1) * 7) % len(ts.frames), ts.global_step + 1, after_main=False)
+        return entry["loss"]
 
 
 def warm_up_occupancy(step: RealViewTrainStep, frame_index: int = 0, n_updates: int = 4):

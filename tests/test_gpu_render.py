@@ -646,3 +646,155 @@ def test_two_frames_vs_reference_golden():
     loss.backward()
     n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, "two", 5e-4)
     assert n_ok >= 40, n_ok
+
+
+def _real_view_setup(capacity=None, seed_jitter=True):
+    """2 048-ray real-view training render on a marched occupancy ball (the reference's call shape), jitter pinned."""
+    from morpheus_amd import harness
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.render import HotPathRenderer
+    hw = 32
+    o, d, t, rid = [v.to(DEV) for v in synth.frame_rays(25, hw, hw)]
+    N = o.shape[1]
+    c = (torch.arange(128).float() + 0.5) / 128 * 2.02 - 1.01
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    ball = ((X ** 2 + Y ** 2 + Z ** 2).sqrt() < 0.6).to(torch.uint8).contiguous()
+    model = harness.build_model("b", DEV, 0.75).train()
+    grid = OccupancyGrid([-1.01] * 3 + [1.01] * 3, 128).to(DEV)
+    grid.set_binary(ball.to(DEV))
+    grid.fixed_jitter = synth.ray_jitter(N).to(DEV)
+    grid.sample_capacity = capacity
+    rend = HotPathRenderer(model, model.config, grid, 200)
+    depth = synth.hash_tensor((1, N, 1), 400, 0.3, 1.5).to(DEV)
+    mask = (synth.hash_tensor((1, N, 1), 401, 0.5, 0.5) > 0.3).float().to(DEV)
+    return model, grid, rend, (o, d, t, rid), depth, mask, N
+
+
+def test_fixed_capacity_sampling_equals_ragged_sampling(monkeypatch):
+    """OccupancyGrid.sample_capacity (constant-shape packed samples + a device-side count: what lets a training step be captured
+    in a HIP graph) against the ragged layout on the same rays: the rendered outputs, the per-sample outputs of the real
+    samples, every in-render loss (incl. the per-sample means, which must leave the padding out) and every parameter gradient."""
+    # the random regularisers draw per SAMPLE (shape [M] vs [capacity]): pin the draws to a function of nothing
+    monkeypatch.setattr(torch, "randn_like", lambda t, **kw: torch.full_like(t, 0.37))
+    monkeypatch.setattr(torch, "rand_like", lambda t, **kw: torch.full_like(t, 0.61))
+    monkeypatch.setattr(torch, "rand", lambda *s, **kw: torch.full(s[0] if len(s) == 1 and isinstance(s[0], (list, tuple, torch.Size)) else s, 0.43,
+                                                                   device=kw.get("device")))
+    outs = {}
+    for tag in ("ragged", "capped"):
+        model, grid, rend, (o, d, t, rid), depth, mask, N = _real_view_setup()
+        if tag == "capped":
+            grid.sample_capacity = outs["ragged"][3] + 9000          # not a multiple of anything: 9 000 padding entries
+        res = rend.render_rays(o, d, t, rid, N, 1, ambient_ratio=1.0, shading="albedo_normal", real_view=True, cano=False,
+                               rays_depth=depth, rays_mask=mask, optimize_pose=True)
+        M = int(grid.n_valid) if tag == "capped" else res["sdf"].shape[0]
+        loss = (res["image"] ** 2).mean() + (res["depth"] ** 2).mean() + res["loss_normal_perturb"] + res["normal_reg"] + \
+            res["sdf_loss"] + 0.1 * res["fs_loss"] + res["loss_code"]
+        model.zero_grad()
+        loss.backward()
+        outs[tag] = (res, float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, M)
+    (ra, la, ga, Ma), (rb, lb, gb, Mb) = outs["ragged"], outs["capped"]
+    assert Ma == Mb and rb["sdf"].shape[0] == Ma + 9000 and int(rb["valid"].sum()) == Ma
+    for k in ("image", "depth", "weights_sum"):
+        assert torch.equal(ra[k], rb[k]), k
+    for k in ("sdf", "weights", "normal", "deform"):
+        assert torch.equal(ra[k], rb[k][:Ma]), k
+    assert float(rb["weights"][Ma:].abs().max()) == 0.0
+    for k in ("loss_normal_perturb", "normal_reg", "sdf_loss", "fs_loss", "loss_code"):
+        assert_close(rb[k], ra[k], 1e-6, k, floor=1e-6)
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    assert set(ga) == set(gb)
+    for k in ga:
+        rel = float((ga[k] - gb[k]).norm() / ga[k].norm().clamp_min(1e-30))
+        assert rel <= 1e-4, (k, rel)        # same terms; atomics / partial sums in another order
+    # too small a capacity: the tail rays are truncated and the sticky overflow flag says so
+    model, grid, rend, (o, d, t, rid), depth, mask, N = _real_view_setup(capacity=4096)
+    with torch.no_grad():
+        res = rend.render_rays(o, d, t, rid, N, 1, ambient_ratio=1.0, shading="albedo")
+    assert int(grid.overflow) == 1 and int(grid.n_valid) == 4096 and res["sdf"].shape[0] == 4096
+
+
+def test_graphed_real_view_step_replays_the_eager_step():
+    """trainstep.GraphedRealViewStep: the real-view step captured in a HIP graph.  Draw-for-draw equality with the eager step is
+    not available (the graph owns its Philox offsets), so: (i) with every random draw pinned the replayed graph's loss and
+    gradient bucket equal the eager step's on the same frame; (ii) un-pinned, three replays give finite, different losses,
+    the optimiser moves the parameters, the sample count stays under the capacity (the next batch is drawn and counted on a
+    side stream while a replay runs); (iii) a progressive-level change captures a graph of its own."""
+    from morpheus_amd import harness, trainstep
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.optim import FlatAdam
+    from morpheus_amd.render import HotPathRenderer
+
+    def build():
+        model = harness.build_model("b", DEV).train()
+        grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(DEV)
+        rend = HotPathRenderer(model, model.config, grid, 200)
+        frames = trainstep.make_frames([25, 33], 64, 64, DEV)
+        ts = trainstep.RealViewTrainStep(rend, frames, ray_num=512)
+        ts.epoch = 1000
+        opt = FlatAdam(model.get_params_all(model.config["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
+        with torch.no_grad():
+            trainstep.warm_up_occupancy(ts)
+        ts.global_step = 4096 + 3                       # no occupancy refresh in the next steps
+        return model, grid, ts, opt
+
+    # (i) pinned draws: six optimiser steps eager vs six replays of the captured step, from the same weights
+    saved = (torch.rand, torch.rand_like, torch.randn_like, torch.randint)
+    try:
+        torch.rand = lambda *s, **kw: torch.full(s[0] if len(s) == 1 and isinstance(s[0], (list, tuple, torch.Size)) else s, 0.43, device=kw.get("device"))
+        torch.rand_like = lambda t, **kw: torch.full_like(t, 0.61)
+        torch.randn_like = lambda t, **kw: torch.full_like(t, 0.37)
+        torch.randint = lambda lo, hi, size, **kw: (torch.arange(size[0], device=kw.get("device")) * 7) % hi
+        model, grid, ts, opt = build()              # (the marcher's per-ray jitter is a torch.rand draw: pinned with the rest)
+        p_init = opt.flat_p.clone()
+        eager_losses, flat_first = [], None
+        for k in range(6):
+            opt.bucket.zero()
+            ts.begin_step()
+            fi = ts.frame_of_step()
+            with model.operand_scope():
+                le = ts._step(trainstep.sample_real_view_rays(ts.frames[fi], ts.ray_num), ts.global_step)
+            le.backward()
+            opt.bucket.collect()
+            if k == 0:
+                flat_first = opt.bucket.flat.clone()
+            opt.step()
+            eager_losses.append(float(le))
+            del le                                       # no eager autograd graph (AccumulateGrad nodes of the default stream) survives
+        p_eager = opt.flat_p.clone()
+        model, grid, ts, opt = build()
+        gs = trainstep.GraphedRealViewStep(ts, opt.bucket)
+        graph_losses = []
+        for k in range(6):
+            lg = gs()
+            if k == 0:
+                rel = float((opt.bucket.flat - flat_first).norm() / flat_first.norm())
+                assert rel <= 1e-4, rel                  # the first replay's gradient bucket == the eager step's
+            opt.step()
+            graph_losses.append(float(lg))
+        assert not gs.check_overflow() and gs.last_samples <= gs.last_capacity < 1.02 * gs.last_samples + 512 + gs.bucket_step
+        for k, (a, b) in enumerate(zip(graph_losses, eager_losses)):
+            # the first steps agree to round-off; Adam with eps = 1e-15 then lets the two trajectories drift apart slowly
+            assert abs(a - b) <= (1e-5 if k < 2 else 2e-2) * abs(b), (graph_losses, eager_losses)
+        # six Adam steps (eps = 1e-15: every touched entry moves by ~lr per step whatever its gradient's size, so an entry whose
+        # gradient cancels to round-off may step the other way): the two trajectories are compared in L2 against the distance moved
+        moved = float((p_eager - p_init).norm())
+        apart = float((opt.flat_p - p_eager).norm())
+        assert apart <= 0.1 * moved, (apart, moved)
+    finally:
+        torch.rand, torch.rand_like, torch.randn_like, torch.randint = saved
+    # (ii) un-pinned replays drive the optimiser
+    model, grid, ts, opt = build()
+    gs = trainstep.GraphedRealViewStep(ts, opt.bucket)
+    p0 = opt.flat_p.clone()
+    losses = []
+    for _ in range(3):
+        losses.append(float(gs()))
+        opt.step()
+    assert all(l == l and abs(l) < 1e6 for l in losses) and len(set(losses)) == 3, losses
+    assert float((opt.flat_p - p0).abs().max()) > 0 and not gs.check_overflow()
+    # (iii) a new progressive level changes the kernels' band / level counts: the step captures a graph for it by itself
+    n0 = len(gs.graphs)
+    ts.epoch = 0
+    losses.append(float(gs()))
+    assert len(gs.graphs) == n0 + 1 and {lv for _, lv in gs.graphs} == {0.75, 0.5} and losses[-1] == losses[-1]
+    gs.release()
