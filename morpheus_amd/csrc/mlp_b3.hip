@@ -7,9 +7,11 @@
 // and a product W.x is the six cross terms whose weight is >= 2^-16 of the leading one,
 //      Wh.xh + Wh.xm + Wm.xh + Wh.xl + Wm.xm + Wl.xh,
 // each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  What is dropped (Wm.xl, Wl.xm, Wl.xl)
-// is below 2^-24 of the product, less than one fp32 rounding: the result is fp32-grade (tests/test_gpu_ops.py:
-// test_warp_sliced_arithmetic_is_fp32_grade holds values and every gradient to the fp32 kernels' own error against float64), for 6/16 of the
-// matrix cycles.
+// is below 2^-24 of the product, less than one fp32 rounding: every operand keeps all 24 significand bits (the fp32-faithful
+// default mode "b3"), for 6/16 of the matrix cycles.  tests/test_gpu_ops.py::test_warp_sliced_arithmetic_against_float64 measures
+// it against float64 on six operand distributions: forward values and d/dx at the native fp32 kernels' own error; weight
+// gradients -- 10^3..10^6-term sums through the bf16 pipe's internal adder, which does not round to nearest -- 3-8x theirs
+// (2e-6..8e-6 rel-L2), two orders below the 1e-4 contract.
 //
 // Range: the split needs |x| below the bf16 maximum (3.39e38; fp32 reaches 3.40e38) -- above it hi rounds to infinity and the
 // residual is NaN -- and operands below ~1e-33 lose their low slices to the bf16 subnormal range; neither occurs in a network

@@ -1,12 +1,15 @@
-// The warp networks (deform_net + topo_net, models/model.py:412-437) with fp32-grade products from TWO fp16 slices per operand.
+// The warp networks (deform_net + topo_net, models/model.py:412-437) with products from TWO fp16 slices per operand: the
+// OPT-IN arithmetic mode "h2" (ops.set_mlp_mode / MORPHEUS_MLP=h2).  Its operands carry 22 of fp32's 24 significand bits at
+// block scales, so it is NOT fp32-faithful and bench.py reports it beside the headline only; the default is mlp_b3.hip.
 //
 // Same idea as mlp_b3.hip -- fp32 operands cut into narrow slices, slice products exact on the 16-bit matrix pipe, fp32
 // accumulation -- at half the matrix work: fp16 carries 11 significand bits, so
 //      x . 2^k = h + l + r,   h = fp16(x . 2^k),  l = fp16(x . 2^k - h),  |r| <= 2^-22 |x . 2^k|
 // and a product W.x is THREE slice products, Wh.xh + Wh.xl + Wl.xh, through v_mfma_f32_32x32x16_f16 (what is dropped, Wl.xl
 // and the residuals r, is <= ~2^-22 of a product and unbiased; measured on layer-shaped data the representation error is
-// 7e-8 relative, a third of the accumulation error a plain fp32 GEMM has: tools/h2_error_model.py, and
-// tests/test_gpu_ops.py::test_warp_sliced_arithmetic_is_fp32_grade holds the kernels to the fp32 kernels' own error).
+// 7e-8 relative, a third of the accumulation error a plain fp32 GEMM has: tools/h2_error_model.py;
+// tests/test_gpu_ops.py::test_warp_sliced_arithmetic_against_float64 measures it against float64 on six operand distributions:
+// forward values and d/dx at the fp32 kernels' own error, weight gradients 3-8x theirs -- DESIGN.md section 4).
 //
 // fp16 has five exponent bits, so the slices only work at the right scale; every operand carries a power-of-two scale that
 // puts its largest magnitude in [2^14, 2^15) -- an exact operation in both directions:
