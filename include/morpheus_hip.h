@@ -346,6 +346,14 @@ int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, c
 int mh_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
                  const int64_t *seg_end_host, const float *seg_lr_host, const int64_t *seg_step_host, float beta1,
                  float beta2, float eps, void *stream);
+/* The same step with the per-segment bookkeeping ON THE DEVICE, for data-parallel runs: seg_flag_dev [n_segs] > 0 = the
+ * segment's parameter has a gradient this step ON SOME RANK (the all-reduced has-gradient flags of the gradient bucket, which
+ * only the device knows without a synchronisation); seg_step_dev [n_segs] int64 in/out = the per-segment step counts,
+ * incremented where the flag is set; seg_scratch_dev [2 * n_segs] floats of workspace.  A segment whose flag is 0 is left
+ * untouched (value, moments, count).  Two launches (one thread per segment, then the update). */
+int mh_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
+                     const int64_t *seg_end_host, const float *seg_lr_host, const float *seg_flag_dev, int64_t *seg_step_dev,
+                     float *seg_scratch_dev, float beta1, float beta2, float eps, void *stream);
 
 #ifdef __cplusplus
 }

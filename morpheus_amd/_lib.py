@@ -83,6 +83,7 @@ _SIGS = {
     "mh_weight_norm_fwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
     "mh_weight_norm_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _P]),
+    "mh_adam_step_dev": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _F, _F, _F, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -21,11 +21,15 @@ struct AdamSegs {
 // parameter and leaves a parameter whose gradient is None untouched -- no moment decay, no move, no step increment
 // (the reference steps the pose group only on real-view iterations, morpheus.py:1399-1424 with freeze_lr) -- so the
 // bias corrections and the skip flag travel per segment.
+// dyn: NULL (step sizes / bias corrections travel by value in `segs`), or [2 * n_segs] DEVICE floats
+// (step_size | bc2_sqrt) written by adam_steps_kernel from device-side flags and counters (mh_adam_step_dev).
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, AdamSegs segs, float beta1, float beta2, float eps,
-                                                   int64_t n) {
+                                                   int64_t n, const float *__restrict__ dyn) {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= n) return;
+#define SEG_STEP(s) (dyn ? dyn[(s)] : segs.step_size[(s)])
+#define SEG_BC2(s) (dyn ? dyn[segs.n + (s)] : segs.bc2_sqrt[(s)])
     const int cnt = (n - i0) < 4 ? (int)(n - i0) : 4;
     // first segment whose end is beyond i0 (binary search over <= 160 ends)
     int lo = 0, hi = segs.n - 1;
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
     int seg = lo;
     const bool one_seg = (i0 + cnt) <= segs.end[seg];
-    if (one_seg && segs.step_size[seg] < 0.f) return;       // skipped parameter: nothing is read or written
+    if (one_seg && SEG_STEP(seg) < 0.f) return;             // skipped parameter: nothing is read or written
     float pv[4], gv[4], mv[4], vv[4];
     if (cnt == 4) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(p + i0), b = *reinterpret_cast<const f32x4 *>(g + i0);
@@ -49,11 +53,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     for (int k = 0; k < 4; k++) {
         if (k < cnt) {
             while (seg < segs.n - 1 && i0 + k >= segs.end[seg]) seg++;
-            if (segs.step_size[seg] >= 0.f) {
+            const float ss = SEG_STEP(seg);
+            if (ss >= 0.f) {
                 mv[k] = mv[k] + (gv[k] - mv[k]) * (1.0f - beta1);
                 vv[k] = beta2 * vv[k] + (1.0f - beta2) * gv[k] * gv[k];
-                const float denom = sqrtf(vv[k]) / segs.bc2_sqrt[seg] + eps;
-                pv[k] -= segs.step_size[seg] * mv[k] / denom;
+                const float denom = sqrtf(vv[k]) / SEG_BC2(seg) + eps;
+                pv[k] -= ss * mv[k] / denom;
             }
         }
     }
@@ -66,6 +71,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         *reinterpret_cast<f32x4 *>(v + i0) = d;
     } else {
         for (int k = 0; k < cnt; k++) p[i0 + k] = pv[k], m[i0 + k] = mv[k], v[i0 + k] = vv[k];
+    }
+#undef SEG_STEP
+#undef SEG_BC2
+}
+
+// Device-side bookkeeping of a data-parallel step: whether a parameter "has a gradient" is then a property of ALL ranks (the
+// all-reduced has-gradient flags of dist.GradBucket), known on the device only -- reading it back would cost the host a
+// synchronisation per step.  One thread per segment: flag > 0 -> the segment's step count goes up and its step size /
+// second-moment correction are written for adam_kernel; otherwise step size -1 (skipped: value, moments, count untouched).
+struct AdamLrs {
+    float lr[ADAM_MAX_SEGS];
+};
+__global__ void adam_steps_kernel(const float *__restrict__ flag, int64_t *__restrict__ step, float *__restrict__ dyn, AdamLrs lrs,
+                                  int n_segs, float beta1, float beta2) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    if (flag[s] > 0.0f) {
+        const int64_t t = step[s] + 1;
+        step[s] = t;
+        dyn[s] = (float)((double)lrs.lr[s] / (1.0 - pow((double)beta1, (double)t)));
+        dyn[n_segs + s] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    } else {
+        dyn[s] = -1.0f;
+        dyn[n_segs + s] = 1.0f;
     }
 }
 
@@ -96,7 +125,38 @@ extern "C" int mh_adam_step(float *params, const float *grads, float *exp_avg, f
     if (prev != n) return MH_ERR_ARG;
     const int64_t threads = (n + 3) / 4;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, mh_stream(stream), params, grads,
-                       exp_avg, exp_avg_sq, segs, beta1, beta2, eps, n);
+                       exp_avg, exp_avg_sq, segs, beta1, beta2, eps, n, (const float *)nullptr);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
+                                const int64_t *seg_end_host, const float *seg_lr_host, const float *seg_flag_dev,
+                                int64_t *seg_step_dev, float *seg_scratch_dev, float beta1, float beta2, float eps, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || n_segs <= 0 || n_segs > ADAM_MAX_SEGS || !seg_end_host ||
+        !seg_lr_host || !seg_flag_dev || !seg_step_dev || !seg_scratch_dev || !(beta1 >= 0.f && beta1 < 1.f) ||
+        !(beta2 >= 0.f && beta2 < 1.f))
+        return MH_ERR_ARG;
+    if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return MH_ERR_ARG;
+    AdamSegs segs;
+    AdamLrs lrs;
+    segs.n = n_segs;
+    int64_t prev = 0;
+    for (int s = 0; s < n_segs; s++) {
+        if (seg_end_host[s] < prev || seg_end_host[s] > n) return MH_ERR_ARG;
+        prev = segs.end[s] = seg_end_host[s];
+        segs.step_size[s] = -1.0f;      // unused: the kernel reads the device values
+        segs.bc2_sqrt[s] = 1.0f;
+        lrs.lr[s] = seg_lr_host[s];
+    }
+    if (prev != n) return MH_ERR_ARG;
+    hipLaunchKernelGGL(adam_steps_kernel, dim3(1), dim3(ADAM_MAX_SEGS), 0, mh_stream(stream), seg_flag_dev, seg_step_dev,
+                       seg_scratch_dev, lrs, (int)n_segs, beta1, beta2);
+    MH_CHECK_LAUNCH();
+    const int64_t threads = (n + 3) / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, mh_stream(stream), params, grads,
+                       exp_avg, exp_avg_sq, segs, beta1, beta2, eps, n, (const float *)seg_scratch_dev);
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

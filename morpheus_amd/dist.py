@@ -46,8 +46,9 @@ class GradBucket:
         [early range][remainder] in that order;
       * one has-gradient flag per parameter rides behind the gradients in the same buffer and is summed by the remainder's
         all-reduce: a parameter counts as "no gradient" (torch.optim.Adam then skips it: no moment decay, no step
-        increment; optim.FlatAdam reads `missing`) only when it had none on EVERY rank.  The flags are read back (one
-        host sync) only on a rank that itself has a parameter without gradient; the common step never syncs;
+        increment) only when it had none on EVERY rank.  The summed flags stay on the DEVICE (`grad_counts`):
+        optim.FlatAdam hands them to mh_adam_step_dev, which skips and counts per parameter without a host
+        synchronisation; `resolve_missing()` reads them back for callers that need the answer on the host;
       * the early exchange fires after `backwards_per_step` backward passes (the reference accumulates a virtual-view and
         a real-view backward before one optimiser step when `freeze_lr` is off, morpheus.py:1396-1424).  A backward pass
         BEYOND the declared count finds the early range already summed across ranks; its gradients are kept apart, summed
@@ -75,10 +76,11 @@ class GradBucket:
         self._layout = layout
         self.params: List[torch.nn.Parameter] = [p for p, _, _ in layout]
         self._index = {id(p): i for i, (p, _, _) in enumerate(layout)}
-        # [gradients: n | has-gradient flags: one per parameter]; `flat` is the gradient part
-        self._buf = torch.zeros(n + len(layout), dtype=torch.float32, device=device)
+        # [gradients: n | has-gradient flags: one per parameter | one spare that stays 0]; `flat` is the gradient part
+        self._buf = torch.zeros(n + len(layout) + 1, dtype=torch.float32, device=device)
         self.flat = self._buf[:n]
-        self._flags = self._buf[n:]
+        self._flags = self._buf[n:n + len(layout)]
+        self.exchanged = False    # allreduce_mean() ran on several ranks since zero(): `grad_counts` is this step's
         self._early = {}          # id(param) -> (param, offset, numel): gradients exchanged as soon as they land
         self._early_hooks = []
         self._early_hits = 0      # post-accumulate hooks fired since zero()
@@ -178,6 +180,7 @@ class GradBucket:
                                "(call allreduce_mean() once per step)")
         self.flat.zero_()
         self.missing = set()
+        self.exchanged = False
         self._landed = set()
         self._early_hits, self._early_fired = 0, False
         if self._late_used:
@@ -247,11 +250,21 @@ class GradBucket:
         else:
             dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
         self.flat.div_(world)
-        if self.missing:
-            # this rank had parameters without gradient: they stay "missing" only if no rank had one (rare path, one sync)
+        self.exchanged = True
+
+    @property
+    def grad_counts(self) -> torch.Tensor:
+        """[n_params + 1] device floats, valid after a multi-rank allreduce_mean(): how many ranks had a gradient for each
+        parameter of the layout this step; the extra last element is always 0 (a slot for segments that are no parameter)."""
+        return self._buf[self.flat.numel():]
+
+    def resolve_missing(self) -> set:
+        """`missing` as a property of ALL ranks (one device->host read): the parameters that had no gradient anywhere."""
+        if self.exchanged and self.missing:
             idx = sorted(self.missing)
             had = self._flags[torch.tensor(idx, device=self._flags.device)].tolist()
             self.missing = {i for i, c in zip(idx, had) if c == 0.0}
+        return self.missing
 
     @property
     def nbytes(self) -> int:

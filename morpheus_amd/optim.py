@@ -78,6 +78,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.bucket = GradBucket.from_layout(self._views, self.n, dev)
         self._steps = [0] * len(self._views)      # per-parameter step counts (torch.optim.Adam's state['step'])
         self._kseg_end_c = (ctypes.c_int64 * len(self._kseg_end))(*self._kseg_end)
+        # data-parallel runs keep the counts on the device (mh_adam_step_dev: the skip decision is the all-reduced has-gradient
+        # flag, which only the device knows without a sync); created at the first multi-rank step
+        self._steps_dev = None
         self._bind_state()
 
     # ---- torch.optim.Adam-format state -----------------------------------------------------------------------------
@@ -87,7 +90,16 @@ class FlatAdam(torch.optim.Optimizer):
                              "exp_avg": self.exp_avg[o:o + k].view(p.shape),
                              "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape)}
 
+    def _pull_steps(self):
+        """device-side step counts (data-parallel runs) -> the host list; one sync, at checkpoint time only"""
+        if self._steps_dev is not None:
+            per_seg = self._steps_dev.tolist()
+            for s, pi in enumerate(self._kseg_param):
+                if pi >= 0:
+                    self._steps[pi] = int(per_seg[s])
+
     def state_dict(self):
+        self._pull_steps()
         for i, (p, _, _) in enumerate(self._views):
             self.state[p]["step"] = torch.tensor(float(self._steps[i]))
         return super().state_dict()
@@ -105,6 +117,7 @@ class FlatAdam(torch.optim.Optimizer):
                     self.exp_avg[o:o + k].zero_()
                     self.exp_avg_sq[o:o + k].zero_()
                     self._steps[i] = 0
+        self._steps_dev = None        # rebuilt from the host counts at the next multi-rank step
         self._bind_state()
 
     # ---- stepping ---------------------------------------------------------------------------------------------------
@@ -119,6 +132,30 @@ class FlatAdam(torch.optim.Optimizer):
             raise MorpheusHipError("FlatAdam steps on an MI355X only; there is no CPU path")
         lib = _lib.load()
         self.bucket.collect()       # no-op when allreduce_mean() already gathered the gradients
+        g0 = self.param_groups[0]
+        ns = len(self._kseg_end)
+        lrs = (ctypes.c_float * ns)(*[float(self.param_groups[gi]["lr"]) for gi in self._kseg_group])
+        import torch.distributed as tdist
+        if tdist.is_initialized() and tdist.get_world_size() > 1:
+            # data-parallel: "has a gradient" is a property of all ranks -- the all-reduced flags of the bucket, on the device
+            if not self.bucket.exchanged:
+                raise RuntimeError("FlatAdam.step() on several ranks needs bucket.allreduce_mean() after backward (its "
+                                   "has-gradient flags decide, identically on every rank, which parameters are stepped)")
+            dev = self.flat_p.device
+            if self._steps_dev is None:
+                self._steps_dev = torch.tensor([0 if pi < 0 else self._steps[pi] for pi in self._kseg_param], dtype=torch.int64,
+                                               device=dev)
+                n_par = len(self._views)
+                self._seg_flag_index = torch.tensor([n_par if pi < 0 else pi for pi in self._kseg_param], dtype=torch.long,
+                                                    device=dev)           # pads read the spare slot that is always 0
+                self._seg_scratch = torch.empty(2 * ns, dtype=torch.float32, device=dev)
+            seg_flags = self.bucket.grad_counts[self._seg_flag_index]
+            self.bucket.missing = set()
+            check(lib.mh_adam_step_dev(ptr(self.flat_p), ptr(self.bucket.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n, ns,
+                                       self._kseg_end_c, lrs, ptr(seg_flags), ptr(self._steps_dev), ptr(self._seg_scratch),
+                                       float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), stream()),
+                  "mh_adam_step_dev")
+            return
         # torch.optim.Adam skips a parameter whose gradient is None: no moment decay, no move, no step increment
         no_grad = self.bucket.missing
         steps = []
@@ -129,9 +166,6 @@ class FlatAdam(torch.optim.Optimizer):
                 self._steps[pi] += 1
                 steps.append(self._steps[pi])
         self.bucket.missing = set()
-        g0 = self.param_groups[0]
-        ns = len(self._kseg_end)
-        lrs = (ctypes.c_float * ns)(*[float(self.param_groups[gi]["lr"]) for gi in self._kseg_group])
         check(lib.mh_adam_step(ptr(self.flat_p), ptr(self.bucket.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n, ns,
                                self._kseg_end_c, lrs, (ctypes.c_int64 * ns)(*steps), float(g0["betas"][0]),
                                float(g0["betas"][1]), float(g0["eps"]), stream()), "mh_adam_step")

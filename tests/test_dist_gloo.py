@@ -194,13 +194,15 @@ def _pattern_worker(rank, world, port, out, case):
         loss_fn(use_pose=(rank == 0)).backward()
         bucket.allreduce_mean()
         want = mean_over_ranks(local_grads(use_pose=(rank == 0)))
-        res["missing"] = sorted(bucket.missing)
+        res["counts"] = bucket.grad_counts.tolist()              # what mh_adam_step_dev reads: ranks with a gradient, per parameter
+        res["missing"] = sorted(bucket.resolve_missing())
         res["err"] = max(float((p.grad - t).abs().max()) for p, t in zip(params, want))
         # no rank has a gradient for it -> missing everywhere (torch.optim.Adam's skip)
         bucket.zero()
         loss_fn(use_pose=False).backward()
         bucket.allreduce_mean()
-        res["missing_all"] = sorted(bucket.missing)
+        res["missing_all"] = sorted(bucket.resolve_missing())
+        res["counts_all"] = bucket.grad_counts.tolist()
     elif case == "early_param_missing_on_one_rank":
         bucket.overlap_early([table_a, table_b])
         for it in range(2):
@@ -209,7 +211,7 @@ def _pattern_worker(rank, world, port, out, case):
             bucket.allreduce_mean()
             want = mean_over_ranks(local_grads(use_b=(rank == 0)))
             res["err%d" % it] = max(float((p.grad - t).abs().max()) for p, t in zip(params, want))
-        res["missing"] = sorted(bucket.missing)
+        res["missing"] = sorted(bucket.resolve_missing())
     elif case in ("two_backwards_undeclared", "two_backwards_declared"):
         declared = case.endswith("_declared")
         bucket.overlap_early([table_a, table_b], backwards_per_step=2 if declared else 1)
@@ -242,6 +244,8 @@ def test_exchange_patterns_keep_replicas_identical(case):
     if case == "asymmetric_none":
         assert r0["missing"] == [] and r1["missing"] == []            # a gradient on ANY rank steps the parameter everywhere
         assert r0["missing_all"] == [3] and r1["missing_all"] == [3]   # none anywhere: skipped everywhere
+        assert r0["counts"] == r1["counts"] == [2.0, 2.0, 2.0, 1.0, 0.0]          # [per parameter | the spare zero slot]
+        assert r0["counts_all"] == r1["counts_all"] == [2.0, 2.0, 2.0, 0.0, 0.0]
     if case == "early_param_missing_on_one_rank":
         assert r0["missing"] == [] and r1["missing"] == []
     if case == "two_backwards_undeclared":

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _frame_grads(frame, bucket_factory=None):
+def _frame_grads(frame, bucket_factory=None, optimize_pose=False):
     from morpheus_amd import harness, synth
     dev = torch.device("cuda", 0)
     model = harness.build_model("b", dev).train()
@@ -36,7 +36,7 @@ def _frame_grads(frame, bucket_factory=None):
     if bucket is not None:
         bucket.zero()
     res = rend.render_rays(o, d, t, rid, HW, HW, ambient_ratio=1.0, shading="albedo",
-                           light_d=torch.nn.functional.normalize(o[0] + 0.3, dim=-1))
+                           light_d=torch.nn.functional.normalize(o[0] + 0.3, dim=-1), optimize_pose=optimize_pose)
     harness.bench_loss(res, timg, tdep).backward()
     return model, bucket
 
@@ -48,16 +48,32 @@ def _worker(rank, world, port, out):
     from morpheus_amd.optim import FlatAdam
     mdist.init_from_env(backend="gloo")
 
+    opts = []
+
     def factory(model):
         opt = FlatAdam(model.get_params_all(5e-4), betas=(0.9, 0.99), eps=1e-15)
         opt.bucket.overlap_early([model.encoder.embeddings, model.encoder_c.embeddings])
+        opts.append(opt)
         return opt.bucket
 
-    model, bucket = _frame_grads(25 * rank, factory)
+    # rank 0 optimises the pose (its pose_array gets a gradient), rank 1 does not: "has a gradient" must be decided across ranks
+    model, bucket = _frame_grads(25 * rank, factory, optimize_pose=(rank == 0))
     assert len(bucket._early_work) == 1, "the hash-table range should have left from the autograd hook"
     bucket.allreduce_mean()
     torch.cuda.synchronize()
-    out[rank] = {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+    before = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+    opts[0].step()                                           # the device-side path: no host read of the flags
+    torch.cuda.synchronize()
+    sd = opts[0].state_dict()
+    names = [k for k, _ in model.named_parameters()]
+    order = {id(p): k for k, p in model.named_parameters()}
+    steps = {}
+    for gi, g in enumerate(opts[0].param_groups):
+        for p in g["params"]:
+            steps[order[id(p)]] = int(float(opts[0].state[p]["step"]))
+    out[rank] = dict(grads=grads, before=before, after={k: p.detach().cpu().clone() for k, p in model.named_parameters()},
+                     steps=steps, names=names)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,17 +83,28 @@ def test_two_ranks_render_and_average_gradients():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     ref = []
-    for frame in (0, 25):
-        model, _ = _frame_grads(frame)
-        ref.append({k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
+    for frame, pose in ((0, True), (25, False)):
+        model, _ = _frame_grads(frame, optimize_pose=pose)
+        ref.append({k: (torch.zeros_like(p) if p.grad is None else p.grad.detach()).cpu() for k, p in model.named_parameters()})
     checked = 0
     for k in ref[0]:
         want = 0.5 * (ref[0][k].double() + ref[1][k].double())
         if float(want.norm()) == 0:
             continue
         for r in (0, 1):
-            err = float((out[r][k].double() - want).norm() / want.norm())
+            err = float((out[r]["grads"][k].double() - want).norm() / want.norm())
             assert err < 1e-5, (k, r, err)
-        assert torch.equal(out[0][k], out[1][k]), k       # both ranks hold the same bucket after the exchange
+        assert torch.equal(out[0]["grads"][k], out[1]["grads"][k]), k       # both ranks hold the same bucket after the exchange
         checked += 1
     assert checked >= 40, checked
+    # the optimiser step: identical replicas; a parameter with a gradient on ONE rank (the pose, rank 0 only) is stepped on BOTH
+    # with the mean gradient and counts one step; parameters without gradient anywhere (the background net) are untouched, count 0
+    for k in out[0]["names"]:
+        assert torch.equal(out[0]["after"][k], out[1]["after"][k]), k
+        assert out[0]["steps"][k] == out[1]["steps"][k], k
+    assert out[0]["steps"]["pose_array.data"] == 1 and not torch.equal(out[0]["after"]["pose_array.data"], out[0]["before"]["pose_array.data"])
+    for k in out[0]["names"]:
+        if k.startswith("bg_net"):
+            assert out[0]["steps"][k] == 0 and torch.equal(out[0]["after"][k], out[0]["before"][k]), k
+        elif float(ref[0][k].norm()) + float(ref[1][k].norm()) > 0:
+            assert out[0]["steps"][k] == 1, k
