@@ -209,9 +209,15 @@ class scene_representation(nn.Module):
                  num_frames=None, use_app=False, use_t=False, color_grid=True, use_joint=False, encode_topo=False,
                  encode_deform=True):
         super().__init__()
-        if use_app or use_t or encode_topo or not color_grid or not use_joint or not encode_deform:
-            raise NotImplementedError("fused HIP path covers the shipped configuration only: use_t=False, "
-                                      "use_app=False, use_joint=True, color_grid=True, encode_topo=False")
+        if use_app or encode_topo or not color_grid:
+            # these change what the kernels read PER POINT (an appearance code per sample in the colour net, an encoded topology
+            # vector, a frequency-encoded colour input); use_t / use_joint are covered: they only change per-frame constants or
+            # zero out first-layer columns (see _warp_bias0 / _field_operands)
+            raise NotImplementedError("fused HIP path: use_app=True, encode_topo=True and color_grid=False are not supported "
+                                      "(no shipped config uses them); use_t and use_joint (either value) are")
+        if not encode_deform:
+            raise NotImplementedError("encode_deform=False: the reference itself cannot run it (models/model.py:253,422 call the "
+                                      "encoder that get_encodings returned as None)")
         if (num_layers, num_layers_t, hidden_dim, hidden_dim_t, hidden_dim_tpo, geo_dim, deform_dim, amb_dim) != \
                 (3, 6, 64, 128, 128, 32, 16, 2):
             raise NotImplementedError("kernel geometry is fixed to the reference defaults (model.py:36-44)")
@@ -219,14 +225,15 @@ class scene_representation(nn.Module):
         self.num_layers, self.hidden_dim, self.geo_dim, self.num_frames = num_layers, hidden_dim, geo_dim, num_frames
         self.use_t, self.use_app, self.use_joint = use_t, use_app, use_joint
         self.encode_topo, self.encode_deform = encode_topo, encode_deform
-        self.in_dim_t, self.in_dim_amb, self.in_dim_deform, self.in_dim_xyz = 0, amb_dim, 39, 39
+        self.in_dim_t, self.in_dim_amb = (13 if use_t else 0), amb_dim                   # model.py:98-103
+        self.in_dim_deform, self.in_dim_xyz = 39, (39 if use_joint else 3)               # :114-119, :162-167
         self.deform_dim, self.app_dim = 3 * deform_dim, 0
         self.encoder_t = self.encoder_topo = self.app_code = None
 
         self.pose_array = PoseArray(num_frames)
         self.deform_code = MultiCode([num_frames // 8, num_frames // 4, num_frames], deform_dim)
-        self.deform_net = MLP(self.in_dim_deform + self.deform_dim, 3, hidden_dim_t, num_layers_t)
-        self.topo_net = MLP(self.in_dim_deform + self.deform_dim, amb_dim, hidden_dim_tpo, num_layers_t)
+        self.deform_net = MLP(self.in_dim_t + self.in_dim_deform + self.deform_dim, 3, hidden_dim_t, num_layers_t)
+        self.topo_net = MLP(self.in_dim_t + self.in_dim_deform + self.deform_dim, amb_dim, hidden_dim_tpo, num_layers_t)
         self.encoder = GridEncoder()
         self.encoder_c = GridEncoder()
         self.in_dim = self.in_dim_c = self.encoder.output_dim
@@ -265,6 +272,9 @@ class scene_representation(nn.Module):
         return tu, inv.to(torch.int32), False
 
     def _warp_params(self, net: MLP, w):
+        """-> (kernel parameters, per-frame columns of W0, b0).  The kernels' first layer reads the 39-column frequency
+        encoding of x; its per-frame inputs -- the deform code and, with use_t, the 13-column encoding of t that the reference
+        puts between them (model.py:427-432) -- are folded into a per-frame bias (_warp_bias0)."""
         b = net.biases()
         return [w[0][:, :39]] + w[1:] + b, w[0][:, 39:], b[0]
 
@@ -309,6 +319,8 @@ class scene_representation(nn.Module):
 
         def build():
             code = self.deform_code.sample(tu[:, None])                       # [F,48], F = distinct frames / slots
+            if self.use_t:                                                    # [t_enc(13), code(48)], model.py:427-432
+                code = torch.cat([_freq_encode_torch(tu[:, None], 6, self.max_level), code], -1)
             return torch.addmm(b0_d, code, wcode_d.t()), torch.addmm(b0_t, code, wcode_t.t()), tu
         if tu.numel() != 1:
             return build()[:2]
@@ -316,7 +328,13 @@ class scene_representation(nn.Module):
 
     def _field_operands(self):
         def build():
-            params = self.sdf_net.weights() + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
+            ws = self.sdf_net.weights()
+            if not self.use_joint:
+                # sdf input [x(3), hash(32), topo(2)] (model.py:285-289): the kernel reads [enc(x)(39), hash, topo] and the
+                # encoding's first three entries are x -- the 36 sin / cos columns get zero weights
+                w0 = ws[0]
+                ws = [torch.cat([w0[:, :3], w0.new_zeros(w0.shape[0], 36), w0[:, 3:]], 1)] + ws[1:]
+            params = ws + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
                 self.color_net.biases()
             return ops.prepare_field_operands(params), self.sdf2density.get_beta()
         return self._cached("field", build)

@@ -133,6 +133,35 @@ def make_state(kind: str = "b", num_frames: int = 200, bg: bool = True) -> Dict[
     return sd
 
 
+def variant_state(kind: str = "b", num_frames: int = 200, use_t: bool = False, use_joint: bool = True) -> Dict[str, torch.Tensor]:
+    """make_state() for the model switches that change first-layer shapes (models/model.py:36-53, :195-227):
+    use_t (13 time-encoding columns between the position encoding and the deform code of deform_net / topo_net) and
+    use_joint=False (raw x instead of its 39-column encoding in front of sdf_net).  Only the affected first layers get new
+    closed-form tensors."""
+    sd = make_state(kind, num_frames)
+    st = [7300 if kind == "a" else 7600]
+
+    def nxt():
+        st[0] += 1
+        return st[0]
+
+    din = 39 + (13 if use_t else 0) + 48
+    if din != 39 + 48:
+        for prefix in ("deform_net", "topo_net"):
+            bound = 1.0 / math.sqrt(din)
+            v = hash_tensor((128, din), nxt(), bound)
+            sd[f"{prefix}.net.0.weight_v"] = v
+            sd[f"{prefix}.net.0.weight_g"] = (v.norm(dim=1, keepdim=True) * (1.0 + hash_tensor((128, 1), nxt(), 0.2))).contiguous()
+    if not use_joint:
+        w0 = hash_tensor((64, 3 + 32 + 2), nxt(), math.sqrt(2) / math.sqrt(64) * 1.7)
+        if kind == "a":
+            w0[:, 3:] = 0.0
+        else:
+            w0[:, 3:] *= 0.6
+        sd["sdf_net.net.0.weight"] = w0
+    return sd
+
+
 # ----------------------------------------------------------------------------
 # rays and samples (SURVEY.md section 8(d) "Synthetic inputs")
 # ----------------------------------------------------------------------------

@@ -116,13 +116,14 @@ def ref_config():
         return yaml.safe_load(f)
 
 
-def build_ref_model(state, max_level=None):
+def build_ref_model(state, max_level=None, **switches):
+    """switches: overrides of the YAML's model switches (use_t, use_joint: gen_variants)"""
     from models.model import scene_representation
     cfg = ref_config()
-    m = scene_representation(cfg, 1.01, num_frames=200, deform_dim=cfg["model"]["deform_dim"],
-                             use_app=cfg["model"]["use_app"], use_t=cfg["model"]["use_t"],
-                             amb_dim=cfg["model"]["amb_dim"], color_grid=cfg["model"]["color_grid"],
-                             use_joint=cfg["model"]["use_joint"], encode_topo=cfg["model"]["encode_topo"])
+    sw = {k: cfg["model"][k] for k in ("use_app", "use_t", "color_grid", "use_joint", "encode_topo")}
+    sw.update(switches)
+    m = scene_representation(cfg, 1.01, num_frames=200, deform_dim=cfg["model"]["deform_dim"], amb_dim=cfg["model"]["amb_dim"],
+                             **sw)
     missing, unexpected = m.load_state_dict(state, strict=False)
     assert not unexpected, unexpected
     assert all("res_tab" in k for k in missing), missing
@@ -309,6 +310,38 @@ def gen_render():
     print("render.npz", len(g), "arrays")
 
 
+# ----------------------------------------------------------------------------- round-3 fixtures (variants.npz)
+VARIANTS = {"use_t": dict(use_t=True, use_joint=True), "no_joint": dict(use_t=False, use_joint=False),
+            "use_t_no_joint": dict(use_t=True, use_joint=False)}
+
+
+def gen_variants():
+    """The model switches no shipped YAML sets but the reference's constructor takes (models/model.py:36-53): use_t=True
+    (time encoding next to the deform code) and use_joint=False (raw x in front of sdf_net), through the reference's own
+    forward() / density() / warp() on 1024 probe points at two frame times, with gradient digests."""
+    g = {}
+    n = 1024
+    x = probe_points(n, 360)
+    t = torch.where(torch.arange(n)[:, None] % 2 == 0, torch.tensor(37 / 200), torch.tensor(0.615))
+    for tag, sw in VARIANTS.items():
+        for kind in ("a", "b"):
+            for ml_tag, ml in (("full", None), ("half", 0.5)):
+                m, _ = build_ref_model(synth.variant_state(kind, 200, **sw), ml, **sw)
+                m.eval()
+                m.zero_grad()
+                sdf, sig, col, _, dfm, _ = m(x, t, None, ratio=1.0, shading="albedo", cano=False)
+                key = f"{tag}_{kind}_{ml_tag}"
+                g[key + "|sdf"], g[key + "|sigma"], g[key + "|color"], g[key + "|deform"] = npf(sdf), npf(sig), npf(col), npf(dfm)
+                g[key + "|topo"] = npf(m.warp(x, t)[1])
+                if ml is None:
+                    probe = (col ** 2).sum() + 0.01 * (sig ** 2).mean() + (sdf ** 2).sum() + (dfm ** 2).sum()
+                    probe.backward()
+                    for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
+                        g[key + "|grad|" + kk] = v
+    np.savez_compressed(os.path.join(OUT, "variants.npz"), **g)
+    print("variants.npz", len(g), "arrays")
+
+
 # ----------------------------------------------------------------------------- round-2 fixtures (extras.npz)
 class DrawInjector:
     """Closed-form stand-ins for torch.rand / rand_like / randn_like while a reference (or HIP) function runs: the k-th
@@ -489,11 +522,15 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     torch.set_num_threads(8)
+    if "--variants-only" in sys.argv:      # round 3: only the model-switch fixtures (the others are unchanged)
+        gen_variants()
+        return
     if "--extras-only" not in sys.argv:
         gen_operators()
         gen_model()
         gen_render()
     gen_extras()
+    gen_variants()
 
 
 if __name__ == "__main__":

@@ -89,7 +89,7 @@ def test_state_dict_and_param_groups_match_reference_layout():
     # unsupported switches fail loudly instead of silently taking another path
     from morpheus_amd.model import scene_representation
     with pytest.raises(NotImplementedError):
-        scene_representation(model.config, 1.01, num_frames=200, use_t=True, use_joint=True)
+        scene_representation(model.config, 1.01, num_frames=200, use_app=True, use_joint=True)
 
 
 def _mfma_emulate(wpack, KS, MT, bin_lanes):
@@ -346,3 +346,25 @@ def test_fp16_slice_arithmetic_model():
     rel = lambda a: float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
     e_h2, e_f32 = rel(sliced), rel((W @ X).astype(np.float64))
     assert e_h2 < 1.5e-7 and e_h2 < e_f32, (e_h2, e_f32)
+
+
+def test_model_switches_shapes_and_refusals():
+    """scene_representation's constructor switches (models/model.py:36-53): use_t and use_joint (either value) build the
+    reference's state_dict shapes (the fixtures' states load strictly); the switches whose per-point inputs the kernels do not
+    read, and the one the reference itself cannot run, are refused loudly."""
+    import pytest
+    from morpheus_amd import harness, synth
+    from morpheus_amd.model import scene_representation
+    cfg = harness.load_config()
+    base = dict(num_frames=200, deform_dim=16, amb_dim=2, color_grid=True, encode_topo=False, use_app=False)
+    for sw, d0, s0 in ((dict(use_t=True, use_joint=True), 100, 73), (dict(use_t=False, use_joint=False), 87, 37),
+                       (dict(use_t=True, use_joint=False), 100, 37)):
+        m = scene_representation(cfg, 1.01, **base, **sw)
+        m.load_state_dict(synth.variant_state("b", 200, **sw), strict=True)
+        assert tuple(m.deform_net.net[0].weight_v.shape) == (128, d0) and tuple(m.topo_net.net[0].weight_v.shape) == (128, d0)
+        assert tuple(m.sdf_net.net[0].weight.shape) == (64, s0)
+    for bad in (dict(use_app=True), dict(encode_topo=True), dict(color_grid=False), dict(encode_deform=False)):
+        kw = dict(base, use_t=False, use_joint=True)
+        kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            scene_representation(cfg, 1.01, **kw)
