@@ -1677,6 +1677,13 @@ static inline int wg_chunks(int out_pad, int64_t n_tiles) {
     // 4 waves per CU per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
     // large batches (the per-layer launches, from 16 384 tiles on): WG_REG_WAVES workgroups per CU (wgrad_regs_b3_kernel)
     int64_t c = (int64_t)(4 * ((n_tiles >= WG_PER_LAYER_TILES && out_pad == 128) ? WG_REG_WAVES : 1) * mh_cu_count()) / (out_pad / 32);
+    if (n_tiles < WG_PER_LAYER_TILES) {
+        // small batches (one merged launch for all layers: 12 x chunks workgroups): every chunk writes a full partial dW that the
+        // reduction reads back -- at 700 tiles (the 22 000-point calls of a training step) 256 chunks per layer are 164 MB of
+        // partials against 250 MB of operands.  At least 8 tiles per chunk, but never fewer than 32 chunks per layer.
+        const int64_t cap = n_tiles / 8 > 32 ? n_tiles / 8 : 32;
+        if (c > cap) c = cap;
+    }
     if (c > n_tiles) c = n_tiles;
     return (int)(c < 1 ? 1 : c);
 }

@@ -780,6 +780,10 @@ static int b3_lds_opt_in() {
         if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess)
             return MH_ERR_LAUNCH;
         done.mark(dev);
@@ -814,16 +818,29 @@ extern "C" int mh_field_fwd_b3(const float *xc, const float *feat_s, const float
 
 extern "C" int64_t mh_warp_w3T_bytes(void) { return (int64_t)B3_NETT_F4 * 16; }
 
+// Workgroup shape by batch size.  Large batches: one 8-wave workgroup per 256 points (two waves per SIMD share one LDS copy of a
+// layer's slices and fill each other's epilogues).  Small batches are latency-bound -- a call on 2 048 points (the surface-point
+// query of a training step) is 8 such workgroups on 256 CUs and takes as long as one on 22 000 points: every SIMD walks two
+// tiles through 12 layer steps -- so up to one 128-point workgroup per CU (32 768 points on MI355X) the 4-wave shape runs one
+// tile per SIMD and twice the CUs.
+static inline bool b3_small_batch(int64_t M) { return M <= (int64_t)BLOCK_PTS * mh_cu_count(); }
+
 extern "C" int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const float *g_topo, const void *w3T_d, const void *w3T_t,
                                    int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !x || !w3T_d || !w3T_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
-    const int64_t blocks = (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
+    const bool small = b3_small_batch(M);
+    const int64_t blocks = small ? (M + BLOCK_PTS - 1) / BLOCK_PTS : (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    hipLaunchKernelGGL(warp_bwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x, g_deform,
-                       g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t), (int)n_bands, acts,
-                       dpre, g_x, M, mh_mlp_tiles(M));
+    if (small)
+        hipLaunchKernelGGL(warp_bwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LDS_BYTES, mh_stream(stream), x, g_deform,
+                           g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t), (int)n_bands,
+                           acts, dpre, g_x, M, mh_mlp_tiles(M));
+    else
+        hipLaunchKernelGGL(warp_bwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
+                           g_deform, g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t),
+                           (int)n_bands, acts, dpre, g_x, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
@@ -835,12 +852,18 @@ extern "C" int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *
     if (M < 0 || !x || !bias0_d || !bias0_t || !w3_d || !w3_t || !bias_d || !bias_t || !out_deform || !out_topo || n_bands < 0 ||
         n_bands > 6)
         return MH_ERR_ARG;
-    const int64_t blocks = (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
+    const bool small = b3_small_batch(M);
+    const int64_t blocks = small ? (M + BLOCK_PTS - 1) / BLOCK_PTS : (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
-                       slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
-                       bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    if (small)
+        hipLaunchKernelGGL(warp_fwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LDS_BYTES, mh_stream(stream), x, slot,
+                           bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
+                           bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+    else
+        hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
+                           slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
+                           bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
