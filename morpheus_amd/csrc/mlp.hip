@@ -1922,37 +1922,27 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
     }
 #undef FUSED_LAUNCH_SDF
     MH_CHECK_LAUNCH();
-    // reduce the per-wave partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format)
+    // reduce the per-wave partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format).  On the sdf-only pass the
+    // colour net's segments are reduced over ZERO chunks, i.e. written as 0 by the same launch (no separate memsets)
     const int n_l = with_color ? 6 : 3;
     WgReduce rd;
-    rd.n = 2 * n_l;
+    rd.n = 12;
     int64_t dw_out = 0, db_out = 0;
     rd.first[0] = 0;
     for (int l = 0; l < 6; l++) {
-        if (l < n_l) {
-            rd.chunks[l] = (int32_t)chunks;
-            rd.len[l] = FUSED_IN[l] * FUSED_OUT[l];
-            rd.part_off[l] = dw_off[l];
-            rd.out_off[l] = dw_out;
-            rd.chunks[n_l + l] = (int32_t)chunks;
-            rd.len[n_l + l] = FUSED_OUT[l];
-            rd.part_off[n_l + l] = db_off[l];
-            rd.out_off[n_l + l] = dw_total + db_out;
-        }
+        const int32_t ch = l < n_l ? (int32_t)chunks : 0;
+        rd.chunks[l] = ch;
+        rd.len[l] = FUSED_IN[l] * FUSED_OUT[l];
+        rd.part_off[l] = dw_off[l];
+        rd.out_off[l] = dw_out;
+        rd.chunks[6 + l] = ch;
+        rd.len[6 + l] = FUSED_OUT[l];
+        rd.part_off[6 + l] = db_off[l];
+        rd.out_off[6 + l] = dw_total + db_out;
         dw_out += (int64_t)FUSED_IN[l] * FUSED_OUT[l];
         db_out += FUSED_OUT[l];
     }
     for (int sgm = 0; sgm < rd.n; sgm++) rd.first[sgm + 1] = rd.first[sgm] + rd.len[sgm];
-    if (!with_color) {   // the colour net's gradients are zero on the sdf-only pass
-        int64_t dw3 = 0, db3 = 0;
-        for (int l = 0; l < 3; l++) {
-            dw3 += (int64_t)FUSED_IN[l] * FUSED_OUT[l];
-            db3 += FUSED_OUT[l];
-        }
-        if (hipMemsetAsync(raw + dw3, 0, sizeof(float) * (size_t)(dw_total - dw3), st) != hipSuccess ||
-            hipMemsetAsync(raw + dw_total + db3, 0, sizeof(float) * (size_t)(db_total - db3), st) != hipSuccess)
-            return MH_ERR_LAUNCH;
-    }
     const int64_t total = rd.first[rd.n];
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace, raw, rd);
     MH_CHECK_LAUNCH();

@@ -189,6 +189,7 @@ class _GridEncode(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, offsets_np, res_np, n_levels, bound, group, *embs):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(x, *embs)
         lib = _lib.load()
         x = x.detach().contiguous().float()
@@ -230,6 +231,7 @@ def grid_encode_multi(x, embs, offsets_np, res_np, bound, max_level=None):
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sigma, t_starts, t_ends, rgb, ray_start, ray_cnt, padded=False):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(sigma, t_starts, t_ends, rgb, ray_start, ray_cnt)
         lib = _lib.load()
         sigma, t_starts, t_ends = sigma.detach().contiguous(), t_starts.contiguous(), t_ends.contiguous()
@@ -436,6 +438,7 @@ def march_rays_capped(rays_o, rays_d, jitter, step: float, bound: float, binary:
 class _FdTaps(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, topo, eps, bound):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(x, topo)
         lib = _lib.load()
         xc = x.detach().contiguous().float()
@@ -480,6 +483,7 @@ def fd_taps(x, topo, eps: float, bound: float):
 class _FdNormal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf6, eps):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(sdf6)
         lib = _lib.load()
         s = sdf6.detach().contiguous().float()
@@ -508,6 +512,7 @@ def fd_normal(sdf6, eps: float):
 class _MultiCode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, v0, v1, v2):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(t, v0, v1, v2)
         lib = _lib.load()
         tc = t.detach().reshape(-1).contiguous().float()
@@ -544,6 +549,7 @@ def multicode_sample(t, volumes):
 class _SdfLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred_sdf, ts, te, ray_idx, rays_depth, rays_mask, trunc, n_valid=None):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(pred_sdf, ts, te, ray_idx, rays_depth, rays_mask, n_valid)
         lib = _lib.load()
         p = pred_sdf.detach().contiguous().float()
@@ -579,6 +585,7 @@ def sdf_losses(pred_sdf, t_starts, t_ends, ray_idx, rays_depth, rays_mask, trunc
 class _SamplePositions(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, ray_idx, ts, te, ray_start, ray_cnt):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(rays_o, rays_d, ray_idx, ts, te)
         lib = _lib.load()
         o, d = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
@@ -655,6 +662,7 @@ class _PackOperands(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, jp, zero_bias0, b3, n_w, *params):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(*params)
         weights, biases, o = [], [], 0
         for pk in jp.packers:
@@ -754,6 +762,7 @@ class _WarpMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, slot, bias0_d, bias0_t, token, n_bands, opnd, slots_are_identity=False):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(x, bias0_d, bias0_t)
         lib = _lib.load()
         (wd, wt), (bd, bt), (wdT, wtT) = opnd.w, opnd.b, opnd.wT
@@ -916,6 +925,7 @@ class _FieldMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xc, feat_s, feat_c, topo, beta, token, n_bands, with_color, opnd):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         require_gpu(xc, feat_s, feat_c, topo, beta)
         lib = _lib.load()
         xc = xc.detach().contiguous().float()
@@ -956,6 +966,7 @@ class _FieldQuery(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xc, topo, beta, token, emb_s, emb_c, offsets_np, res_np, n_levels, bound, group, n_bands, opnd):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         with_color = emb_c is not None
         require_gpu(xc, topo, beta, emb_s, emb_c)
         lib = _lib.load()
@@ -1006,6 +1017,7 @@ class _WeightNormAll(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, n, *vg):
+        ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
         vs, gs = vg[:n], vg[n:]
         require_gpu(*vg)
         lib = _lib.load()

@@ -773,9 +773,9 @@ def test_graphed_real_view_step_replays_the_eager_step():
             graph_losses.append(float(lg))
         assert not gs.check_overflow() and gs.last_samples <= gs.last_capacity < 1.02 * gs.last_samples + 512 + gs.bucket_step
         for k, (a, b) in enumerate(zip(graph_losses, eager_losses)):
-            # the first three steps agree to round-off (measured: 7 digits); Adam with eps = 1e-15 then amplifies the round-off of
-            # noise-sized gradients and the two trajectories drift apart (measured 0.1 % / 1.3 % / 2.7 % at steps 4..6)
-            assert abs(a - b) <= (1e-5 if k < 3 else 6e-2) * abs(b), (graph_losses, eager_losses)
+            # the first two steps agree to round-off (7 digits); Adam with eps = 1e-15 then amplifies the round-off of noise-sized
+            # gradients and the two trajectories drift apart (measured 0-3e-5 at step 3, then 0.1 % / 1.3 % / 2.7 % at steps 4..6)
+            assert abs(a - b) <= (1e-5 if k < 2 else (2e-4 if k == 2 else 6e-2)) * abs(b), (graph_losses, eager_losses)
         # six Adam steps with eps = 1e-15: every touched entry moves by ~lr per step whatever its gradient's size, so the ~1 % of
         # entries whose gradient is round-off noise step in a run-dependent direction (measured distance between the two runs:
         # 0.16-0.25 of the distance moved).  The two displacement vectors must point the same way
