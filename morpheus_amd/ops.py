@@ -64,7 +64,26 @@ class KernelTimer:
 TIMER = KernelTimer()
 
 
+_I32_CACHE = {}
+
+
 def _i32arr(a):
+    """host int32 array + its ctypes pointer for the C ABI's *_host arguments.  The arrays the hot path passes are static
+    geometry (level tables, tile offsets, layer lists): lists / tuples and read-only numpy arrays are converted once and cached
+    by value -- a training step makes ~150 of these calls."""
+    if isinstance(a, (list, tuple)):
+        key = tuple(a)
+    elif isinstance(a, np.ndarray) and a.dtype == np.int32 and a.ndim == 1 and a.size <= 64:
+        key = (a.size,) + tuple(a.tolist())
+    else:
+        key = None
+    if key is not None:
+        hit = _I32_CACHE.get(key)
+        if hit is None:
+            arr = np.ascontiguousarray(a, dtype=np.int32)
+            arr.setflags(write=False)
+            hit = _I32_CACHE[key] = (arr, arr.ctypes.data_as(ctypes.c_void_p))
+        return hit
     a = np.ascontiguousarray(a, dtype=np.int32)
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
