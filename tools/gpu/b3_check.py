@@ -22,7 +22,7 @@ def params(scale):
 
 def run(M, n_slots, with_acts, scale=0.15):
     pd, pt_ = params(scale)
-    ops.MLP_B3, ops.MLP_H2 = True, False
+    ops.set_mlp_mode("b3")
     op = ops.prepare_warp_operands(pd, pt_)
     assert op.w3 is not None
     x = (torch.rand(M, 3, device=dev) * 2 - 1) * (0.0 if scale == 0.0 else 1.0)

@@ -14,7 +14,7 @@ slot = (torch.arange(M, device=DEV) % 3).int()
 b0 = [torch.randn(3, 128, device=DEV) * 0.3 for _ in range(2)]
 wd_, wt_ = torch.randn(M, 3, device=DEV), torch.randn(M, 2, device=DEV)
 def run(b3):
-    ops.MLP_B3, ops.MLP_H2 = b3, False
+    ops.set_mlp_mode("b3" if b3 else "f32")
     ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
     xg = x.clone().requires_grad_(True)
     bb = [t.clone().requires_grad_(True) for t in b0]

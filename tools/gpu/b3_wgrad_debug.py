@@ -22,7 +22,7 @@ def both(lib, acts, dpre, *a, **kw):
     cap["r32"], cap["r3"], cap["acts"], cap["dpre"] = r32, r3, acts, dpre
     return r3
 ops._wgrad = both
-ops.MLP_B3, ops.MLP_H2 = True, False
+ops.set_mlp_mode("b3")
 ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
 d, t = ops.warp_mlp(x, None, b0[0], b0[1], 6, ops.prepare_warp_operands(ps[0], ps[1]))
 ((d * wd_).sum() + (t * wt_).sum()).backward()

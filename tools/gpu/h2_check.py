@@ -18,7 +18,7 @@ wd_, wt_ = torch.randn(M, 3, device=DEV), torch.randn(M, 2, device=DEV)
 
 
 def set_mode(m):
-    ops.MLP_B3, ops.MLP_H2 = m == "b3", m == "h2"
+    ops.set_mlp_mode(m)
 
 
 # ---- 1. slices -----------------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ beta = torch.tensor([0.05], device=DEV)
 
 
 def run(mode, M, x, fs, fc, tp, with_color=True, reps=1):
-    ops.FIELD_H2, ops.FIELD_B3 = mode == "h2", mode == "b3"
+    ops.set_mlp_mode(mode)
     opnd = ops.prepare_field_operands(Ws + Wc + bs + bc)
     best = 1e9
     for _ in range(reps):

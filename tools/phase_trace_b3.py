@@ -21,7 +21,7 @@ for nout in (3, 2):
     W = [torch.randn(128, 39, device=dev) * 0.15] + [torch.randn(128, 128, device=dev) * 0.1 for _ in range(4)] + [torch.randn(nout, 128, device=dev) * 0.15]
     b = [torch.randn(128, device=dev) * 0.1 for _ in range(5)] + [torch.randn(nout, device=dev) * 0.1]
     ps.append(W + b)
-ops.MLP_B3, ops.MLP_H2 = True, False
+ops.set_mlp_mode("b3")
 op = ops.prepare_warp_operands(ps[0], ps[1])
 x = torch.rand(M, 3, device=dev) * 2 - 1
 b0d, b0t = torch.randn(1, 128, device=dev) * 0.3, torch.randn(1, 128, device=dev) * 0.3

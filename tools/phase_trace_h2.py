@@ -22,7 +22,7 @@ for nout in (3, 2):
     W = [torch.randn(128, 39, device=dev) * 0.15] + [torch.randn(128, 128, device=dev) * 0.1 for _ in range(4)] + [torch.randn(nout, 128, device=dev) * 0.15]
     b = [torch.randn(128, device=dev) * 0.1 for _ in range(5)] + [torch.randn(nout, device=dev) * 0.1]
     ps.append(W + b)
-ops.MLP_B3, ops.MLP_H2 = False, True
+ops.set_mlp_mode("h2")
 op = ops.prepare_warp_operands(ps[0], ps[1])
 x = torch.rand(M, 3, device=dev) * 2 - 1
 b0d, b0t = torch.randn(1, 128, device=dev) * 0.3, torch.randn(1, 128, device=dev) * 0.3
@@ -36,7 +36,7 @@ for it in range(int(os.environ.get("MH_TRACE_ITERS", "4"))):
                             op.b[0].data_ptr(), op.b[1].data_ptr(), 6, deform.data_ptr(), topo.data_ptr(),
                             None if acts is None else acts.data_ptr(), None, M, st)
     e1.record(); torch.cuda.synchronize(); assert rc == 0
-print("kernel ms", e0.elapsed_time(e1), "(stamped build, MORPHEUS_H2_WAVES=%s, parking %s)" % (os.environ.get("MORPHEUS_H2_WAVES", "default"), acts is not None))
+print("kernel ms", e0.elapsed_time(e1), "(stamped build, parking %s)" % (acts is not None,))
 buf = (ctypes.c_longlong * (256 * 64))()
 assert lib.mh_h2_trace_read(buf) == 0
 t = np.frombuffer(buf, dtype=np.int64).reshape(256, 64).astype(np.float64)
