@@ -485,6 +485,7 @@ def run_one(args):
             graph.replay()
             return loss_g
     ops.TIMER.reset(enabled=timers_on)
+    captures0 = wl["graphed"].n_captures if wl.get("graphed") is not None else 0
     if world > 1:
         dist.barrier()
     sync()
@@ -577,6 +578,7 @@ def run_one(args):
         out["config"]["hip_graph"] = dict(capacity_buckets=sorted(c for c, _ in g.graphs), bucket_step=g.bucket_step,
                                           capacity_of_last_step=g.last_capacity, samples_of_last_step=g.last_samples,
                                           overflowed_batches=int(g.check_overflow()) + g.overflows, margin=g.margin,
+                                          graphs_captured=g.n_captures, captures_inside_the_timed_region=g.n_captures - captures0,
                                           note="sample_points_per_step_per_gpu is the mean CAPACITY the kernels ran on (padding "
                                                "included); each batch is drawn and counted one step ahead on a side stream to pick its bucket")
     elif args.graph:

@@ -46,3 +46,19 @@ static inline int mh_cu_count() {
     }
     return cus[dev];
 }
+
+// Zero-fill as an ordinary KERNEL.  hipMemsetAsync becomes a memset NODE when the stream is being captured into a HIP graph,
+// and on ROCm 7.2 such nodes were observed not to hold their place in the replayed order (the d/dx buffer of the binned
+// hash-grid backward was accumulated into before it was cleared, from the second replay on -- the first one found fresh,
+// zeroed pool memory; tests/test_gpu_render.py::test_graphed_real_view_step_replays_the_eager_step).  A kernel node does.
+static __global__ __launch_bounds__(256) void mh_zero_kernel(uint32_t *__restrict__ p, int64_t n_words) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline bool mh_zero_async(void *p, size_t bytes, hipStream_t stream) {      // bytes: a multiple of 4, p 4-byte aligned
+    if (bytes == 0) return true;
+    const int64_t n = (int64_t)(bytes / 4);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mh_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(p), n);
+    return hipGetLastError() == hipSuccess;
+}

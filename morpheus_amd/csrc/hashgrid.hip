@@ -627,13 +627,13 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
     const uint32_t *gmax = gmax_bits;
     if (!gmax) {
         uint32_t *own = reinterpret_cast<uint32_t *>(const_cast<int32_t *>(brick_start)) + (2 * NBRK + 4);
-        if (hipMemsetAsync(own, 0, sizeof(uint32_t), mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
+        if (!mh_zero_async(own, sizeof(uint32_t), mh_stream(stream))) return MH_ERR_LAUNCH;
         hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, mh_stream(stream), grad, M * (int64_t)L * 2, own);
         gmax = own;
     }
     if (grad_x) {
         // points outside the box are never visited by a brick: their d/dx is zero
-        if (hipMemsetAsync(grad_x, 0, sizeof(float) * 3 * (size_t)M, mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
+        if (!mh_zero_async(grad_x, sizeof(float) * 3 * (size_t)M, mh_stream(stream))) return MH_ERR_LAUNCH;
         hipLaunchKernelGGL(grid_bwd_brick_kernel<true>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
                            reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
                            brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);

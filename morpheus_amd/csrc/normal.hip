@@ -381,7 +381,7 @@ extern "C" int mh_sdf_losses_fwd(const float *pred_sdf, const float *t_starts, c
                                  const float *rays_depth, const float *rays_mask, float trunc, int64_t M,
                                  const int32_t *n_valid, float *sums, void *stream) {
     if (!sums) return MH_ERR_ARG;
-    if (hipMemsetAsync(sums, 0, 3 * sizeof(float), mh_stream(stream)) != hipSuccess) return MH_ERR_LAUNCH;
+    if (!mh_zero_async(sums, 3 * sizeof(float), mh_stream(stream))) return MH_ERR_LAUNCH;
     if (M == 0) return MH_OK;
     if (M < 0 || !pred_sdf || !t_starts || !t_ends || !ray_idx || !rays_depth) return MH_ERR_ARG;
     hipLaunchKernelGGL(sdf_losses_kernel, dim3(blocks_for(M)), dim3(256), 0, mh_stream(stream), pred_sdf, t_starts, t_ends, ray_idx,

@@ -251,7 +251,7 @@ class GraphedRealViewStep:
 
     Usage:  gs = GraphedRealViewStep(ts, opt.bucket);  loss = gs();  opt.step()        (loss: a 0-dim device tensor)"""
 
-    def __init__(self, step: RealViewTrainStep, bucket, bucket_step: int = 8192, margin: float = 0.02):
+    def __init__(self, step: RealViewTrainStep, bucket, bucket_step: int = 8192, margin: float = 0.02, lookahead: bool = True):
         self.ts, self.bucket = step, bucket
         self.grid = step.r.occupancy_grid
         dev = step.frames[0]["rays_o"].device
@@ -267,9 +267,9 @@ class GraphedRealViewStep:
         self.side = torch.cuda.Stream(device=dev)
         self.ev_staged, self.ev_taken = torch.cuda.Event(), torch.cuda.Event()
         self.staged_for = None      # (frame, global step) the staging buffers hold a batch for
-        self.bucket_step, self.margin = int(bucket_step), float(margin)
+        self.bucket_step, self.margin, self.lookahead = int(bucket_step), float(margin), bool(lookahead)
         self.graphs = {}            # (capacity, max_level) -> dict(graph, loss, n_valid, missing)
-        self.last_capacity, self.last_samples, self.overflows = None, None, 0
+        self.last_capacity, self.last_samples, self.overflows, self.n_captures = None, None, 0, 0
 
     # ---- the batch: drawn one step ahead on a side stream, handed to the graphs through static buffers ---------------------
     def _stage(self, fi: int, for_step: int, after_main: bool):
@@ -332,12 +332,17 @@ class GraphedRealViewStep:
         with torch.cuda.graph(graph):          # its own memory pool (~35 KB per sample point: a few GB of the 288 per bucket)
             loss = self._body(capacity)
         self.grid.overflow.copy_(keep)         # the warm-up passes ran on whatever batch the static buffers held
-        entry = dict(graph=graph, loss=loss, n_valid=self.grid.n_valid, missing=set(self.bucket.missing))
+        # keep the loss VALUE (same storage), not its autograd graph: a live graph keeps its AccumulateGrad nodes -- and the
+        # stream they were created on -- alive, and the next capture's backward would then accumulate on that other, non-capturing
+        # stream (gradients of a later-captured bucket silently stale)
+        entry = dict(graph=graph, loss=loss.detach(), n_valid=self.grid.n_valid, missing=set(self.bucket.missing))
+        del loss
         self.graphs[(capacity, self.ts.model.max_level)] = entry
+        self.n_captures += 1
         return entry
 
-    def prepare(self, probes_per_frame: int = 2):
-        """capture ahead of time the buckets the frames' batches fall into (each +- one bucket), so that a timed run or the first
+    def prepare(self, probes_per_frame: int = 3):
+        """capture ahead of time the buckets the frames' batches fall into (each +- two buckets), so that a timed run or the first
         epochs do not pay the captures one by one"""
         self.ts.apply_level()
         caps = set()
@@ -345,7 +350,7 @@ class GraphedRealViewStep:
             for _ in range(probes_per_frame):
                 self._stage(fi, -1, after_main=True)
                 c = self._capacity_for(self._take())
-                caps.update((max(self.bucket_step, c - self.bucket_step), c, c + self.bucket_step))
+                caps.update(max(self.bucket_step, c + k * self.bucket_step) for k in (-2, -1, 0, 1, 2))
         for c in sorted(caps):
             if (c, self.ts.model.max_level) not in self.graphs:
                 self.capture(c)
@@ -389,7 +394,7 @@ class GraphedRealViewStep:
         self.last_capacity, self.last_samples = cap, m
         ts.last_samples = cap
         # the next batch is drawn and counted on the side stream while this replay runs (not across an occupancy refresh)
-        if ts.global_step % 16 != 0:
+        if self.lookahead and ts.global_step % 16 != 0:
             self._stage(((ts.global_step + 1) * 7) % len(ts.frames), ts.global_step + 1, after_main=False)
         return entry["loss"]
 

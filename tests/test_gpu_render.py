@@ -763,6 +763,8 @@ def test_graphed_real_view_step_replays_the_eager_step():
         p_eager = opt.flat_p.clone()
         model, grid, ts, opt = build()
         gs = trainstep.GraphedRealViewStep(ts, opt.bucket)
+        caps = gs.prepare()                              # several capacity buckets captured one after the other: the replays below
+        assert len(caps) >= 3 and gs.n_captures == len(caps)       # use graphs that were NOT the first capture of the process
         graph_losses = []
         for k in range(6):
             lg = gs()
@@ -771,6 +773,7 @@ def test_graphed_real_view_step_replays_the_eager_step():
                 assert rel <= 1e-4, rel                  # the first replay's gradient bucket == the eager step's
             opt.step()
             graph_losses.append(float(lg))
+        assert gs.n_captures == len(caps)               # every batch found its bucket among the prepared ones
         assert not gs.check_overflow() and gs.last_samples <= gs.last_capacity < 1.02 * gs.last_samples + 512 + gs.bucket_step
         for k, (a, b) in enumerate(zip(graph_losses, eager_losses)):
             # the first two steps agree to round-off (7 digits); Adam with eps = 1e-15 then amplifies the round-off of noise-sized

@@ -80,7 +80,8 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(PROF, exist_ok=True)
     for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b"),
-                    ("bench_train_real.log", "train_real"), ("bench_density128.log", "density128"), ("bench_n2.log", "n2_one_gpu_gloo"),
+                    ("bench_train_real.log", "train_real"), ("bench_train_real_graph.log", "train_real_hip_graph"),
+                    ("bench_density128.log", "density128"), ("bench_n2.log", "n2_one_gpu_gloo"),
                     ("bench_cfg3_f32.log", "cfg3_fp32_mfma_kernels"), ("bench_cfg3_b3.log", "cfg3_bf16x3_kernels")):
         line = json_line(os.path.join(OUT, log))
         if line:
@@ -100,7 +101,8 @@ def main():
     for log, name in (("phase_trace.log", "phase_trace_warp_fwd_fp32_mfma.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd_bf16x3.txt"),
                       ("phase_trace_h2.log", "phase_trace_warp_fwd.txt"),
                       ("hbm_rates.log", "micro_hbm_rates.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
-                      ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt")):
+                      ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt"),
+                      ("precision_report.jsonl", "precision_report.jsonl")):
         src = os.path.join(OUT, log)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(PROF, f"{tag}_{name}"))

@@ -7,11 +7,11 @@ tail -30 gpurun_out/graph_tests.log
 
 timeout 300 python bench.py --workload train_real --no-kernel-timers > gpurun_out/bench_train_real_eager.log 2>&1
 timeout 300 python bench.py --workload train_real --graph > gpurun_out/bench_train_real_graph.log 2>&1
-timeout 300 python bench.py --workload train_real --graph --mode h2 > gpurun_out/bench_train_real_graph_h2.log 2>&1
+
 
 python - <<'PY'
 import json
-for f in ["bench_train_real_eager", "bench_train_real_graph", "bench_train_real_graph_h2"]:
+for f in ["bench_train_real_eager", "bench_train_real_graph"]:
     try:
         d = json.loads([l for l in open(f"gpurun_out/{f}.log") if l.startswith("{")][-1])
         print(f, d["value"], d["ms_per_step"], d["config"].get("hip_graph"), d["config"]["sample_points_per_step_per_gpu"], d["config"]["loss"], d["config"].get("loss_mean_of_timed_steps"))

@@ -13,6 +13,7 @@ for wl in cfg2 train_real cfg3b density128; do
 done
 ( time timeout 900 python bench.py ) > gpurun_out/bench.log 2>&1
 timeout 300 python bench.py --gpus 2 --steps 6 --warmup 2 --no-kernel-timers > gpurun_out/bench_n2.log 2>&1
+timeout 300 python bench.py --workload train_real --graph > gpurun_out/bench_train_real_graph.log 2>&1
 cd /tmp
 for m in b3 h2 f32; do
   sfx=$([ $m = b3 ] && echo "" || echo "_$m")
