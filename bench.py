@@ -476,10 +476,12 @@ def run_one(args):
         with torch.cuda.stream(side):
             step()                                   # warm the allocator on the capture stream
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph(keep_graph=True)
         eager_step = step
         with torch.cuda.graph(graph):
-            loss_g = eager_step()
+            loss_g = eager_step().detach()
+        ops.graph_replace_memset_nodes(graph)        # csrc/graph.hip: small memset nodes replay wrongly on ROCm 7.2
+        graph.instantiate()
 
         def step():                                  # noqa: F811 -- replay the captured step
             graph.replay()
@@ -579,6 +581,7 @@ def run_one(args):
                                           capacity_of_last_step=g.last_capacity, samples_of_last_step=g.last_samples,
                                           overflowed_batches=int(g.check_overflow()) + g.overflows, margin=g.margin,
                                           graphs_captured=g.n_captures, captures_inside_the_timed_region=g.n_captures - captures0,
+                                          memset_nodes_replaced_by_fill_kernels=g.memset_nodes_replaced,
                                           note="sample_points_per_step_per_gpu is the mean CAPACITY the kernels ran on (padding "
                                                "included); each batch is drawn and counted one step ahead on a side stream to pick its bucket")
     elif args.graph:

@@ -44,7 +44,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 3   /* 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
+#define MH_ABI_VERSION 4   /* 4: mh_graph_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -354,6 +354,15 @@ int mh_adam_step(float *params, const float *grads, float *exp_avg, float *exp_a
 int mh_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
                      const int64_t *seg_end_host, const float *seg_lr_host, const float *seg_flag_dev, int64_t *seg_step_dev,
                      float *seg_scratch_dev, float beta1, float beta2, float eps, void *stream);
+
+/* ---- HIP-graph hygiene (no reference counterpart: the reference runs its step eagerly; morpheus.py:1147-1236 is the step
+ * trainstep.GraphedRealViewStep captures).  graph = a hipGraph_t obtained by stream capture, not yet instantiated.
+ * On ROCm 7.2 a small memset node replays wrongly from the second launch on (csrc/graph.hip); the library itself never
+ * memsets, PyTorch's multi-block reductions do.  mh_graph_count_memset_nodes reports what a captured graph holds;
+ * mh_graph_replace_memset_nodes turns every memset node into a fill-kernel node with the same edges (1-, 2- or 4-byte
+ * patterns, 1-D or pitched 2-D; anything else -> MH_ERR_ARG and the graph is left as far as it got: discard it). */
+int mh_graph_count_memset_nodes(void *graph, int64_t *n_nodes, int64_t *n_memset, int64_t *smallest_bytes);
+int mh_graph_replace_memset_nodes(void *graph, int64_t *n_replaced);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,8 @@ _SIGS = {
     "mh_weight_norm_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _P]),
     "mh_adam_step_dev": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _F, _F, _F, _P]),
+    "mh_graph_count_memset_nodes": (ctypes.c_int, [_P, _P, _P, _P]),
+    "mh_graph_replace_memset_nodes": (ctypes.c_int, [_P, _P]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -106,7 +108,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mh_abi_version() != 3:
+        if lib.mh_abi_version() != 4:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1072,3 +1072,23 @@ def weight_norm_all(vs: Sequence[torch.Tensor], gs: Sequence[torch.Tensor]):
     """Effective weights of weight-normed layers: vs[l] [out,in], gs[l] [out,1] -> list of [out,in]."""
     assert len(vs) == len(gs) and all(v.dim() == 2 for v in vs)
     return list(_WeightNormAll.apply(len(vs), *vs, *gs))
+
+
+# ------------------------------------------------------------------------------------------ HIP-graph hygiene
+def graph_memset_nodes(graph: "torch.cuda.CUDAGraph"):
+    """(nodes, memset nodes, smallest memset in bytes) of a captured, not yet instantiated graph (`CUDAGraph(keep_graph=True)`)."""
+    lib = _lib.load()
+    n, m, b = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    check(lib.mh_graph_count_memset_nodes(ctypes.c_void_p(graph.raw_cuda_graph()), ctypes.byref(n), ctypes.byref(m), ctypes.byref(b)),
+          "mh_graph_count_memset_nodes")
+    return n.value, m.value, b.value
+
+
+def graph_replace_memset_nodes(graph: "torch.cuda.CUDAGraph") -> int:
+    """Every memset node of the captured graph becomes a fill-kernel node with the same edges (csrc/graph.hip: small memset
+    nodes replay wrongly on ROCm 7.2, and PyTorch's multi-block reductions memset their semaphores).  Call between the end of
+    the capture and the first replay, on a graph made with `torch.cuda.CUDAGraph(keep_graph=True)`.  -> nodes replaced."""
+    lib = _lib.load()
+    n = ctypes.c_int64()
+    check(lib.mh_graph_replace_memset_nodes(ctypes.c_void_p(graph.raw_cuda_graph()), ctypes.byref(n)), "mh_graph_replace_memset_nodes")
+    return n.value

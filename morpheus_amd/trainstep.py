@@ -27,7 +27,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
-from . import synth
+from . import ops, synth
 
 
 # ------------------------------------------------------------------------------------------ synthetic real-view frames
@@ -270,6 +270,7 @@ class GraphedRealViewStep:
         self.bucket_step, self.margin, self.lookahead = int(bucket_step), float(margin), bool(lookahead)
         self.graphs = {}            # (capacity, max_level) -> dict(graph, loss, n_valid, missing)
         self.last_capacity, self.last_samples, self.overflows, self.n_captures = None, None, 0, 0
+        self.memset_nodes_replaced = 0
 
     # ---- the batch: drawn one step ahead on a side stream, handed to the graphs through static buffers ---------------------
     def _stage(self, fi: int, for_step: int, after_main: bool):
@@ -283,7 +284,6 @@ class GraphedRealViewStep:
             self.idx_stage.copy_(torch.randint(0, self.n_pix, (ts.ray_num,), device=self.index.device) + fi * self.n_pix)
             self.jit_stage.copy_(torch.rand(ts.ray_num, device=self.jitter.device))
             o, d = self.table["rays_o"][self.idx_stage], self.table["rays_d"][self.idx_stage]
-            from . import ops
             cnt = ops.march_count(o, d, self.jit_stage, float(ts.cfg["render"]["step_size"]), self.grid.bound,
                                   self.grid.binaries[0].view(torch.uint8))
             self.cnt_host.copy_(cnt.reshape(1), non_blocking=True)
@@ -328,9 +328,13 @@ class GraphedRealViewStep:
                 self._body(capacity)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graph = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(graph):          # its own memory pool (~35 KB per sample point: a few GB of the 288 per bucket)
             loss = self._body(capacity)
+        # small memset nodes replay wrongly on ROCm 7.2 (csrc/graph.hip); the library has none, PyTorch's multi-block
+        # reductions (every .sum() over the sample points, and autograd's broadcast gradients) zero their semaphores with one
+        self.memset_nodes_replaced += ops.graph_replace_memset_nodes(graph)
+        graph.instantiate()
         self.grid.overflow.copy_(keep)         # the warm-up passes ran on whatever batch the static buffers held
         # keep the loss VALUE (same storage), not its autograd graph: a live graph keeps its AccumulateGrad nodes -- and the
         # stream they were created on -- alive, and the next capture's backward would then accumulate on that other, non-capturing

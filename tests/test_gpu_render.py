@@ -744,23 +744,27 @@ def test_graphed_real_view_step_replays_the_eager_step():
         torch.rand_like = lambda t, **kw: torch.full_like(t, 0.61)
         torch.randn_like = lambda t, **kw: torch.full_like(t, 0.37)
         torch.randint = lambda lo, hi, size, **kw: (torch.arange(size[0], device=kw.get("device")) * 7) % hi
-        model, grid, ts, opt = build()              # (the marcher's per-ray jitter is a torch.rand draw: pinned with the rest)
-        p_init = opt.flat_p.clone()
-        eager_losses, flat_first = [], None
-        for k in range(6):
-            opt.bucket.zero()
-            ts.begin_step()
-            fi = ts.frame_of_step()
-            with model.operand_scope():
-                le = ts._step(trainstep.sample_real_view_rays(ts.frames[fi], ts.ray_num), ts.global_step)
-            le.backward()
-            opt.bucket.collect()
-            if k == 0:
-                flat_first = opt.bucket.flat.clone()
-            opt.step()
-            eager_losses.append(float(le))
-            del le                                       # no eager autograd graph (AccumulateGrad nodes of the default stream) survives
-        p_eager = opt.flat_p.clone()
+        def eager_run():                            # (the marcher's per-ray jitter is a torch.rand draw: pinned with the rest)
+            model, grid, ts, opt = build()
+            p0 = opt.flat_p.clone()
+            losses, first = [], None
+            for k in range(6):
+                opt.bucket.zero()
+                ts.begin_step()
+                fi = ts.frame_of_step()
+                with model.operand_scope():
+                    le = ts._step(trainstep.sample_real_view_rays(ts.frames[fi], ts.ray_num), ts.global_step)
+                le.backward()
+                opt.bucket.collect()
+                if k == 0:
+                    first = opt.bucket.flat.clone()
+                opt.step()
+                losses.append(float(le))
+                del le                                   # no eager autograd graph (AccumulateGrad nodes of the default stream) survives
+            return losses, first, p0, opt.flat_p.clone()
+
+        eager_losses, flat_first, p_init, p_eager = eager_run()
+        eager_again, _, _, p_again = eager_run()        # the run-to-run spread of the eager step itself (atomics in the scatters)
         model, grid, ts, opt = build()
         gs = trainstep.GraphedRealViewStep(ts, opt.bucket)
         caps = gs.prepare()                              # several capacity buckets captured one after the other: the replays below
@@ -775,15 +779,22 @@ def test_graphed_real_view_step_replays_the_eager_step():
             graph_losses.append(float(lg))
         assert gs.n_captures == len(caps)               # every batch found its bucket among the prepared ones
         assert not gs.check_overflow() and gs.last_samples <= gs.last_capacity < 1.02 * gs.last_samples + 512 + gs.bucket_step
+        print("graphed vs eager loss, relative:", ["%.2e" % (abs(a - b) / abs(b)) for a, b in zip(graph_losses, eager_losses)])
+        print("eager vs eager loss, relative:  ", ["%.2e" % (abs(a - b) / abs(b)) for a, b in zip(eager_again, eager_losses)])
+        dc = (p_again - p_init).double()
+        print("eager vs eager: distance / moved %.4f" % float((dc - (p_eager - p_init).double()).norm() / dc.norm()))
         for k, (a, b) in enumerate(zip(graph_losses, eager_losses)):
             # the first two steps agree to round-off (7 digits); Adam with eps = 1e-15 then amplifies the round-off of noise-sized
-            # gradients and the two trajectories drift apart (measured 0-3e-5 at step 3, then 0.1 % / 1.3 % / 2.7 % at steps 4..6)
-            assert abs(a - b) <= (1e-5 if k < 2 else (2e-4 if k == 2 else 6e-2)) * abs(b), (graph_losses, eager_losses)
+            # gradients (the padded layout sums the weight gradients in a different order: 5e-9 of the bucket) and the trajectories
+            # drift apart -- measured 3e-5 / 2-5e-4 / 5e-3 / 1e-2 at steps 3..6, next to 1e-7 / 3e-4 / 3-9e-4 / 3-5e-3 between two
+            # EAGER runs of the same six steps (printed above: atomics in the scatters make the eager step itself run-dependent)
+            assert abs(a - b) <= (1e-5 if k < 2 else (2e-4 if k == 2 else 4e-2)) * abs(b), (graph_losses, eager_losses)
         # six Adam steps with eps = 1e-15: every touched entry moves by ~lr per step whatever its gradient's size, so the ~1 % of
         # entries whose gradient is round-off noise step in a run-dependent direction (measured distance between the two runs:
-        # 0.16-0.25 of the distance moved).  The two displacement vectors must point the same way
+        # 0.18-0.20 of the distance moved; 0.13-0.14 between two eager runs).  The two displacement vectors must point the same way
         da, db = (opt.flat_p - p_init).double(), (p_eager - p_init).double()
         cos = float((da * db).sum() / (da.norm() * db.norm()))
+        print("cosine of the two six-step displacements: %.5f, distance / moved: %.4f" % (cos, float((da - db).norm() / db.norm())))
         assert cos >= 0.95, cos
     finally:
         torch.rand, torch.rand_like, torch.randn_like, torch.randint = saved
