@@ -44,7 +44,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 4   /* 4: mh_graph_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
+#define MH_ABI_VERSION 4   /* 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -354,6 +354,26 @@ int mh_adam_step(float *params, const float *grads, float *exp_avg, float *exp_a
 int mh_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int32_t n_segs,
                      const int64_t *seg_end_host, const float *seg_lr_host, const float *seg_flag_dev, int64_t *seg_step_dev,
                      float *seg_scratch_dev, float beta1, float beta2, float eps, void *stream);
+
+/* ---- caller-side glue as single launches (csrc/losses.hip) -------------------------------------------------------------
+ * Per-sample means of the training losses.  kind: 0 a, 1 a^2, 2 |a|, 3 binary entropy in bits of clamp(a, 1e-5, 1 - 1e-5)
+ * (morpheus.py:1093-1096), 4 eikonal (|row| - 1)^2 of [M,3] rows (morpheus.py:1117-1119), 5 |a - b|, 6 (a - b)^2
+ * (morpheus.py:764-777, :556).  a, b: [M, C] contiguous fp32 (b only for kinds 5, 6).  n_valid: device int32 or NULL -- only
+ * the first n_valid rows count (fixed-capacity sampling); w_row [M] or NULL -- per-row weights.  out[0] = sum / den, out[1] =
+ * den, with den = per_row * max(rows, 1) without weights (the reference's `.mean()`; per_row = C, 1 for kind 4) and
+ * max(per_row * sum(w_row), 1) with them (morpheus.py:556).  ws: mh_masked_mean_workspace_floats() floats.  Two launches
+ * forward (block partials, then one block adding them in a fixed order: deterministic, nothing to zero), one backward:
+ * g_a = g * f'(a) * w_row / den inside the valid rows and 0 behind them, g_b = -g_a (either may be NULL); g: device scalar. */
+int64_t mh_masked_mean_workspace_floats(void);
+int mh_masked_mean_fwd(int32_t kind, const float *a, const float *b, const float *w_row, int64_t M, int32_t C,
+                       const int32_t *n_valid, float *ws, float *out, void *stream);
+int mh_masked_mean_bwd(int32_t kind, const float *a, const float *b, const float *w_row, int64_t M, int32_t C,
+                       const int32_t *n_valid, const float *out, const float *g, float *g_a, float *g_b, void *stream);
+/* out = x + scale * (cos(phi) u + sin(phi) v), u = normalize((n^_y, -n^_x, 0)), v = n^ x u, n^ = normalize(n): the random
+ * direction orthogonal to the normal of morpheus.py:518-528 (get_ortho_normal_dir) applied to the points (:549, :766).
+ * x, n, out [M,3], phi [M] (the caller's uniform draw times 2 pi).  Backward: g_x = g_out (no launch), g_n from *_bwd. */
+int mh_ortho_perturb_fwd(const float *x, const float *n, const float *phi, float scale, int64_t M, float *out, void *stream);
+int mh_ortho_perturb_bwd(const float *n, const float *phi, const float *g_out, float scale, int64_t M, float *g_n, void *stream);
 
 /* ---- HIP-graph hygiene (no reference counterpart: the reference runs its step eagerly; morpheus.py:1147-1236 is the step
  * trainstep.GraphedRealViewStep captures).  graph = a hipGraph_t obtained by stream capture, not yet instantiated.

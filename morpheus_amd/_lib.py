@@ -84,6 +84,11 @@ _SIGS = {
     "mh_weight_norm_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _P]),
     "mh_adam_step_dev": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _F, _F, _F, _P]),
+    "mh_masked_mean_workspace_floats": (_I64, []),
+    "mh_masked_mean_fwd": (ctypes.c_int, [_I32, _P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "mh_masked_mean_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "mh_ortho_perturb_fwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
+    "mh_ortho_perturb_bwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
     "mh_graph_count_memset_nodes": (ctypes.c_int, [_P, _P, _P, _P]),
     "mh_graph_replace_memset_nodes": (ctypes.c_int, [_P, _P]),
 }

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 SO = os.path.join(OUT_DIR, "libmorpheus_hip.so")
-SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_b3.hip", "mlp_h2.hip", "optim.hip", "wnorm.hip", "normal.hip", "graph.hip"]
+SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_b3.hip", "mlp_h2.hip", "optim.hip", "wnorm.hip", "normal.hip", "graph.hip", "losses.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "morpheus_hip.h")]
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar fp32 adds / muls of the epilogues into v_pk_* instructions, which
 # cost more than two plain ones beside MFMAs (MI355X_MICROARCH.md); measured on one box, whole library, cfg3: 15.61 -> 15.38

@@ -1074,6 +1074,131 @@ def weight_norm_all(vs: Sequence[torch.Tensor], gs: Sequence[torch.Tensor]):
     return list(_WeightNormAll.apply(len(vs), *vs, *gs))
 
 
+# ------------------------------------------------------------------------------------------ caller-side glue, one launch each
+MEAN_KINDS = {"identity": 0, "square": 1, "abs": 2, "entropy": 3, "eikonal": 4, "absdiff": 5, "sqdiff": 6}
+
+
+class _MaskedMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, a, b, w_row, n_valid):
+        ctx.set_materialize_grads(False)
+        require_gpu(a, b, w_row, n_valid)
+        lib = _lib.load()
+        a_c = a.detach().contiguous().float()
+        b_c = None if b is None else b.detach().contiguous().float()
+        assert a_c.dim() >= 1 and (b_c is None or b_c.shape == a_c.shape)
+        M = a_c.shape[0]
+        C = max(a_c.numel() // max(M, 1), 1)
+        w_c = None if w_row is None else w_row.detach().reshape(-1).contiguous().float()
+        assert w_c is None or w_c.numel() == M
+        nv = None if n_valid is None else n_valid.detach().reshape(1).to(torch.int32).contiguous()
+        ws = torch.empty(lib.mh_masked_mean_workspace_floats(), device=a_c.device)
+        out = torch.empty(2, device=a_c.device)
+        check(lib.mh_masked_mean_fwd(kind, ptr(a_c), ptr(b_c), ptr(w_c), M, C, ptr(nv), ptr(ws), ptr(out), stream()), "mh_masked_mean_fwd")
+        ctx.save_for_backward(a_c, b_c, w_c, nv, out)
+        ctx.kind, ctx.shape = kind, a.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None
+        lib = _lib.load()
+        a_c, b_c, w_c, nv, out = ctx.saved_tensors
+        M = a_c.shape[0]
+        C = max(a_c.numel() // max(M, 1), 1)
+        want_a, want_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2] and b_c is not None
+        g_a = torch.empty_like(a_c) if want_a else None
+        g_b = torch.empty_like(b_c) if want_b else None
+        if want_a or want_b:
+            check(lib.mh_masked_mean_bwd(ctx.kind, ptr(a_c), ptr(b_c), ptr(w_c), M, C, ptr(nv), ptr(out), ptr(g.reshape(1).contiguous().float()),
+                                         ptr(g_a), ptr(g_b), stream()), "mh_masked_mean_bwd")
+        return None, g_a, g_b, None, None
+
+
+def masked_mean(kind: str, a, b=None, *, n_valid=None, row_weight=None):
+    """Mean over the samples of f(a[, b]) for a per-sample tensor [M, ...] (include/morpheus_hip.h: mh_masked_mean_*): the
+    reference's `f(a).mean()` when every row counts; with n_valid (0-dim device int tensor, fixed-capacity sampling) the rows behind
+    it are left out; with row_weight [M] the value is sum(f * w) / max(per_row * sum(w), 1) (morpheus.py:556).  kind: see
+    MEAN_KINDS ("eikonal": a is [M,3], f = (|row| - 1)^2; "absdiff" / "sqdiff": f(a - b))."""
+    return _MaskedMean.apply(MEAN_KINDS[kind], a, b, row_weight, n_valid)
+
+
+class _OrthoPerturb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, normals, phi, scale):
+        ctx.set_materialize_grads(False)
+        require_gpu(x, normals, phi)
+        lib = _lib.load()
+        x_c, n_c = x.detach().contiguous().float(), normals.detach().contiguous().float()
+        p_c = phi.detach().reshape(-1).contiguous().float()
+        M = x_c.shape[0]
+        assert x_c.shape == (M, 3) and n_c.shape == (M, 3) and p_c.numel() == M
+        out = torch.empty_like(x_c)
+        check(lib.mh_ortho_perturb_fwd(ptr(x_c), ptr(n_c), ptr(p_c), float(scale), M, ptr(out), stream()), "mh_ortho_perturb_fwd")
+        ctx.save_for_backward(n_c, p_c)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        n_c, p_c = ctx.saved_tensors
+        g_n = None
+        if ctx.needs_input_grad[1]:
+            lib = _lib.load()
+            g_c = g.contiguous().float()
+            g_n = torch.empty_like(n_c)
+            check(lib.mh_ortho_perturb_bwd(ptr(n_c), ptr(p_c), ptr(g_c), ctx.scale, n_c.shape[0], ptr(g_n), stream()), "mh_ortho_perturb_bwd")
+        return (g if ctx.needs_input_grad[0] else None), g_n, None, None
+
+
+def ortho_perturb(x, normals, phi, scale: float):
+    """x + scale * get_ortho_normal_dir(normals)  (morpheus.py:518-528 applied at :549 / :766) in one launch; phi [M] or [M,1] is the
+    caller's uniform draw times 2 pi.  Gradients reach x (identity) and the normals."""
+    return _OrthoPerturb.apply(x, normals, phi, scale)
+
+
+class _WeightedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.set_materialize_grads(False)
+        stacked = torch.stack([t.detach().reshape(()) for t in terms])
+        ctx.save_for_backward(weights)
+        ctx.n = len(terms)
+        return (stacked * weights).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * (ctx.n + 1)
+        (weights,) = ctx.saved_tensors
+        gs = (weights * g).unbind(0)
+        return (None, *[gs[k] if ctx.needs_input_grad[k + 1] else None for k in range(ctx.n)])
+
+
+_WEIGHT_CACHE: dict = {}
+
+
+def weighted_sum(pairs):
+    """sum_k w_k * term_k for 0-dim device tensors term_k and host floats w_k: three launches forward (stack, multiply, add) and
+    one backward, whatever the number of terms -- the reference's `loss = loss + w * term` chains (morpheus.py:946-1145) cost two
+    launches per term each way.  The weight vector is built once per distinct tuple of weights (no host->device copy per step:
+    that would be a sync in the eager step and illegal inside a captured graph)."""
+    pairs = [(float(w), t) for w, t in pairs]
+    if not pairs:
+        return 0
+    dev = pairs[0][1].device
+    key = (tuple(w for w, _ in pairs), str(dev))
+    wt = _WEIGHT_CACHE.get(key)
+    if wt is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("weighted_sum: a new set of loss weights inside a captured graph (run the step once eagerly first)")
+        wt = _WEIGHT_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
+    return _WeightedSum.apply(wt, *[t for _, t in pairs])
+
+
 # ------------------------------------------------------------------------------------------ HIP-graph hygiene
 def graph_memset_nodes(graph: "torch.cuda.CUDAGraph"):
     """(nodes, memset nodes, smallest memset in bytes) of a captured, not yet instantiated graph (`CUDAGraph(keep_graph=True)`)."""

@@ -82,8 +82,13 @@ class HotPathRenderer:
         u = torch.nn.functional.normalize(torch.stack([n[..., 1], -n[..., 0], n[..., 2] * 0.0], -1), dim=-1)
         v = torch.cross(n, u, dim=-1)
         if phi is None:
-            phi = torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
+            phi = self._ortho_angle(normals)
         return torch.cos(phi) * u + torch.sin(phi) * v
+
+    @staticmethod
+    def _ortho_angle(normals):
+        """the random angle of get_ortho_normal_dir (morpheus.py:525): one uniform draw per normal, times 2 pi"""
+        return torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
 
     def get_normal_smoothness_loss(self, rays_o, rays_d, rays_t, depth, offsets=None, phi=None, ray_slots=None,
                                    single_frame=None):
@@ -110,11 +115,12 @@ class HotPathRenderer:
             tt, fs = rays_t[:1].expand(npts * n_rays, 1), None
         else:                      # rays of several times without a row structure: per-sample times (model._slots)
             tt, fs = rays_t[None].repeat(npts, 1, 1).view(-1, 1), None
-        keep = (torch.linalg.norm(pts, ord=2, dim=-1) < 1.1).float()[:, None]
+        keep = (torch.linalg.norm(pts, ord=2, dim=-1) < 1.1).float()
         n1, _ = self.model.normal(pts, t=tt, frame_slots=fs)
-        w = self.get_ortho_normal_dir(n1, phi)
-        n2, _ = self.model.normal(pts + w * self.config["train"]["smoothness_std"], t=tt, frame_slots=fs)
-        return (torch.square(n1 - n2) * keep).sum() / (3.0 * keep.sum()).clamp(min=1.0)
+        # pts + get_ortho_normal_dir(n1) * smoothness_std, then sum(square(n1 - n2) * keep) / max(3 sum(keep), 1): one launch each
+        pts_p = ops.ortho_perturb(pts, n1, self._ortho_angle(n1) if phi is None else phi, self.config["train"]["smoothness_std"])
+        n2, _ = self.model.normal(pts_p, t=tt, frame_slots=fs)
+        return ops.masked_mean("sqdiff", n1, n2, row_weight=keep)
 
     # -- forward-only consumer (f-4)
     def eval_step(self, data, cano=False, optimize_pose=False, max_chunk=300 * 300):
@@ -177,12 +183,10 @@ class HotPathRenderer:
         n_valid = getattr(self.occupancy_grid, "n_valid", None)
         valid = None if n_valid is None else (torch.arange(M_samples, device=rays_o.device) < n_valid)
 
-        def smean(v):
-            """mean over the SAMPLES of a per-sample tensor [M, ...] (the reference's `.mean()`); padding entries excluded"""
-            if valid is None:
-                return v.mean()
-            w = valid.view(-1, *([1] * (v.dim() - 1))).to(v.dtype)
-            return (v * w).sum() / (n_valid.clamp(min=1).to(v.dtype) * (v.numel() // max(v.shape[0], 1)))
+        def l1_mean(a, b):
+            """mean |a - b| over the SAMPLES of two per-sample tensors [M, ...] (the reference's `(a - b).abs().mean()`), padding
+            entries excluded: one launch each way"""
+            return ops.masked_mean("absdiff", a, b, n_valid=n_valid)
 
         single_frame = (not cano) and self.frame_batched and len(prefix) == 2 and prefix[0] == 1
         ray_idx32 = ray_indices
@@ -253,7 +257,7 @@ class HotPathRenderer:
                 results["loss_orient"] = lo.sum(-1).mean()
             if tr["normal_smooth_3d"] > 0 and normals is not None:
                 if tr["normal_dir"]:
-                    xyzs_p = xyzs + self.get_ortho_normal_dir(normals) * tr["smoothness_std"]
+                    xyzs_p = ops.ortho_perturb(xyzs, normals, self._ortho_angle(normals), tr["smoothness_std"])
                 else:
                     xyzs_p = xyzs + torch.randn_like(xyzs) * tr["smoothness_std"]
                 if tr["topo_none"]:
@@ -261,20 +265,20 @@ class HotPathRenderer:
                 else:
                     normals_p, _ = model.normal(xyzs_p, topo=model.get_topo(xyzs_p, t=time_step, frame_slots=frame_slots),
                                                 cano=cano)
-                results["loss_normal_perturb"] = smean((normals - normals_p).abs())
+                results["loss_normal_perturb"] = l1_mean(normals, normals_p)
                 if tr["normal_smooth_3d_t"] > 0:
                     tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
                     normals_pt, _ = model.normal(xyzs, topo=model.get_topo(xyzs, t=tt), cano=cano)
-                    results["loss_normal_perturb_t"] = smean((normals - normals_pt).abs())
+                    results["loss_normal_perturb_t"] = l1_mean(normals, normals_pt)
                 if tr["deform_smooth"] > 0 and not cano:
                     deform_p, _, _ = model.warp(xyzs_p, t=time_step, frame_slots=frame_slots)
-                    results["loss_deform_perturb"] = smean((deform - deform_p).abs())
+                    results["loss_deform_perturb"] = l1_mean(deform, deform_p)
             if (tr["deform_smooth_t"] > 0 or tr["topo_smooth_t"] > 0) and not cano:
                 tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames
                 deform_pt, topo_pt, _ = model.warp(xyzs, t=tt)
                 topo_now = model.get_topo(xyzs, t=time_step, frame_slots=frame_slots)   # the reference reads an undefined `topo` here
-                results["loss_deform_perturb_t"] = smean((deform - deform_pt).abs())
-                results["loss_topo_perturb_t"] = smean((topo_now - topo_pt).abs())
+                results["loss_deform_perturb_t"] = l1_mean(deform, deform_pt)
+                results["loss_topo_perturb_t"] = l1_mean(topo_now, topo_pt)
             if tr["code_reg"] > 0 and not cano:
                 t0 = time_step[:1]
                 code = model.get_deform_code(t0)

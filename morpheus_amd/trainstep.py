@@ -65,14 +65,11 @@ def sample_real_view_rays(frame: Dict[str, torch.Tensor], ray_num: int, index: O
 
 
 # ------------------------------------------------------------------------------------------ the losses
-def sample_mean(v, outputs):
-    """`v.mean()` over the samples of a per-sample tensor [M, ...]; with fixed-capacity sampling (render_rays then returns
-    `valid` / `n_valid`) the padding entries are left out -- the same value the ragged layout gives."""
-    valid = outputs.get("valid")
-    if valid is None:
-        return v.mean()
-    w = valid.view(-1, *([1] * (v.dim() - 1))).to(v.dtype)
-    return (v * w).sum() / (outputs["n_valid"].clamp(min=1).to(v.dtype) * (v.numel() // max(v.shape[0], 1)))
+def sample_mean(kind, a, outputs, b=None):
+    """`f(a).mean()` over the samples of a per-sample tensor [M, ...] in one launch (ops.masked_mean; kind: ops.MEAN_KINDS); with
+    fixed-capacity sampling (render_rays then returns `n_valid`) the padding entries are left out -- the same value the ragged
+    layout gives."""
+    return ops.masked_mean(kind, a, b, n_valid=outputs.get("n_valid"))
 
 
 def get_gt_from_data(data, bg_color, B, H, W):
@@ -93,73 +90,71 @@ def _valid_depth_mask(gt_depth, gt_mask, rays_o, rays_d):
 
 def get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask, rays_o, rays_d):
     """morpheus.py:946-983."""
-    loss = 0
+    terms = []
     if tr["rgb_weight"] > 0:
-        loss = loss + tr["rgb_weight"] * F.mse_loss(pred_rgb, gt_rgb)
+        terms.append((tr["rgb_weight"], F.mse_loss(pred_rgb, gt_rgb)))
     if tr["mask_weight"] > 0:
-        loss = loss + tr["mask_weight"] * F.binary_cross_entropy(pred_mask[:, 0].clip(1e-5, 1.0 - 1e-5), gt_mask.float())
+        terms.append((tr["mask_weight"], F.binary_cross_entropy(pred_mask[:, 0].clip(1e-5, 1.0 - 1e-5), gt_mask.float())))
     if tr["depth_weight"] > 0:
         depth_mask, _ = _valid_depth_mask(gt_depth, gt_mask, rays_o, rays_d)
-        loss = loss + tr["depth_weight"] * F.mse_loss(pred_depth[:, 0] * depth_mask, gt_depth * depth_mask)
-    return loss
+        terms.append((tr["depth_weight"], F.mse_loss(pred_depth[:, 0] * depth_mask, gt_depth * depth_mask)))
+    return ops.weighted_sum(terms)
 
 
 def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs):
     """morpheus.py:985-1029: SDF / free-space losses from the renderer plus one `model.density` query at the N
     back-projected surface points (x and t of equal length, gradients into both hash tables, the warp and the codes)."""
-    loss = 0
+    terms = []
     if tr["sdf_weight"] > 0:
-        loss = loss + tr["sdf_weight"] * outputs["sdf_loss"]
+        terms.append((tr["sdf_weight"], outputs["sdf_loss"]))
     if tr["sdf_reg"] > 0:
-        loss = loss + tr["sdf_reg"] * sample_mean(outputs["sdf"] ** 2, outputs)
+        terms.append((tr["sdf_reg"], sample_mean("square", outputs["sdf"], outputs)))
     if tr["fs_weight"] > 0:
-        loss = loss + tr["fs_weight"] * outputs["fs_loss"]
+        terms.append((tr["fs_weight"], outputs["fs_loss"]))
     if tr["surf_sdf_weight"] > 0:
         depth_mask, xyzs = _valid_depth_mask(gt_depth, gt_mask, rays_o, rays_d)
         results = model.density(xyzs.reshape(-1, 3), t=rays_t.reshape(-1, 1))
         sdf, albedo = results["sdf"], results["albedo"]
         masked_color = albedo.view(*depth_mask.shape, 3).permute(0, 3, 1, 2).contiguous()
-        surf_color_loss = tr["surf_color_weight"] * F.mse_loss(masked_color * depth_mask[None, ...], gt_rgb * depth_mask[None, ...])
+        surf_color_loss = F.mse_loss(masked_color * depth_mask[None, ...], gt_rgb * depth_mask[None, ...])
         # mean of sdf^2 over the valid points == F.mse_loss(sdf[mask], 0) of :1018-1026, without the boolean index
-        sq = (sdf.view(*depth_mask.shape) ** 2 * depth_mask).sum() / depth_mask.sum().clamp(min=1.0)
-        loss = loss + tr["surf_sdf_weight"] * sq + surf_color_loss
-    return loss
+        sq = ops.masked_mean("square", sdf.reshape(-1), row_weight=depth_mask.reshape(-1))
+        terms += [(tr["surf_sdf_weight"], sq), (tr["surf_color_weight"], surf_color_loss)]
+    return ops.weighted_sum(terms)
 
 
 def get_regularization_loss(tr, model, outputs, pred_normal, global_step: int, end_iter: int, cano=False):
     """morpheus.py:1090-1145."""
-    loss = 0
+    terms = []
     if tr["entropy_weight"] > 0:
-        alphas = outputs["weights"].clamp(1e-5, 1 - 1e-5)
-        ent = sample_mean(-alphas * torch.log2(alphas) - (1 - alphas) * torch.log2(1 - alphas), outputs)
+        ent = sample_mean("entropy", outputs["weights"], outputs)
         ramp = min(1, 2 * global_step / end_iter) if not torch.is_tensor(global_step) else (2 * global_step / end_iter).clamp(max=1.0)
-        loss = loss + tr["entropy_weight"] * ramp * ent
+        terms.append((tr["entropy_weight"], ent * ramp))      # the ramp changes per step: it multiplies the term, not the cached weights
     if tr["normal_smooth_2d"] > 0 and pred_normal is not None:
         sm = (pred_normal[:, 1:, :, :] - pred_normal[:, :-1, :, :]).square().mean() + \
              (pred_normal[:, :, 1:, :] - pred_normal[:, :, :-1, :]).square().mean()
-        loss = loss + tr["normal_smooth_2d"] * sm
+        terms.append((tr["normal_smooth_2d"], sm))
     if tr["ori_weight"] > 0 and "loss_orient" in outputs:
-        loss = loss + tr["ori_weight"] * outputs["loss_orient"]
+        terms.append((tr["ori_weight"], outputs["loss_orient"]))
     if tr["normal_smooth_3d"] > 0 and "loss_normal_perturb" in outputs:
-        loss = loss + tr["normal_smooth_3d"] * outputs["loss_normal_perturb"]
+        terms.append((tr["normal_smooth_3d"], outputs["loss_normal_perturb"]))
     if tr["normal_smooth_3d_t"] > 0 and "loss_normal_perturb_t" in outputs:
-        loss = loss + tr["normal_smooth_3d_t"] * outputs["loss_normal_perturb_t"]
+        terms.append((tr["normal_smooth_3d_t"], outputs["loss_normal_perturb_t"]))
     if outputs["normal_raw"] is not None and tr["eik_weight"] > 0:
-        ge = (torch.linalg.norm(outputs["normal_raw"], ord=2, dim=-1) - 1.0) ** 2
-        loss = loss + tr["eik_weight"] * sample_mean(ge, outputs)
+        terms.append((tr["eik_weight"], sample_mean("eikonal", outputs["normal_raw"], outputs)))
     if tr["beta_weight"] > 0:
-        loss = loss + tr["beta_weight"] * torch.mean(model.sdf2density.get_beta())
+        terms.append((tr["beta_weight"], torch.mean(model.sdf2density.get_beta())))
     if tr["normal_smoothness"] > 0:
-        loss = loss + tr["normal_smoothness"] * outputs["normal_reg"]
+        terms.append((tr["normal_smoothness"], outputs["normal_reg"]))
     if tr["deform_weight"] > 0:
-        loss = loss + tr["deform_weight"] * sample_mean(outputs["deform"].abs(), outputs)
+        terms.append((tr["deform_weight"], sample_mean("abs", outputs["deform"], outputs)))
     for w, k in (("deform_smooth", "loss_deform_perturb"), ("deform_smooth_t", "loss_deform_perturb_t"),
                  ("topo_smooth_t", "loss_topo_perturb_t")):
         if tr[w] > 0 and k in outputs:
-            loss = loss + tr[w] * outputs[k]
+            terms.append((tr[w], outputs[k]))
     if tr["code_reg"] > 0 and not cano and "loss_code" in outputs:
-        loss = loss + tr["code_reg"] * outputs["loss_code"]
-    return loss
+        terms.append((tr["code_reg"], outputs["loss_code"]))
+    return ops.weighted_sum(terms)
 
 
 # ------------------------------------------------------------------------------------------ the step

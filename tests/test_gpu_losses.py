@@ -1,0 +1,137 @@
+"""GPU: the caller-side glue kernels (csrc/losses.hip) against the torch operator chains they replace -- the expressions of the
+reference's loss code (morpheus.py:518-528, :556, :764-777, :1090-1145) written with torch operators, values and gradients."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def _torch_mean(kind, a, b, valid, n_valid, w_row):
+    if kind == "identity":
+        f = a
+    elif kind == "square":
+        f = a ** 2
+    elif kind == "abs":
+        f = a.abs()
+    elif kind == "entropy":
+        x = a.clamp(1e-5, 1 - 1e-5)
+        f = -x * torch.log2(x) - (1 - x) * torch.log2(1 - x)
+    elif kind == "eikonal":
+        f = (torch.linalg.norm(a, ord=2, dim=-1) - 1.0) ** 2
+    elif kind == "absdiff":
+        f = (a - b).abs()
+    else:
+        f = torch.square(a - b)
+    per_row = f.numel() // f.shape[0]
+    if w_row is not None:
+        w = w_row.view(-1, *([1] * (f.dim() - 1)))
+        return (f * w).sum() / (per_row * w_row.sum()).clamp(min=1.0)
+    if valid is None:
+        return f.mean()
+    w = valid.view(-1, *([1] * (f.dim() - 1))).to(f.dtype)
+    return (f * w).sum() / (n_valid.clamp(min=1).to(f.dtype) * per_row)
+
+
+@pytest.mark.parametrize("kind,C", [("identity", 1), ("square", 1), ("abs", 3), ("entropy", 1), ("eikonal", 3), ("absdiff", 3),
+                                    ("absdiff", 2), ("sqdiff", 3)])
+@pytest.mark.parametrize("mode", ["all_rows", "n_valid", "row_weight"])
+def test_masked_mean_equals_the_torch_chain(kind, C, mode):
+    from morpheus_amd import ops
+    torch.manual_seed(3)
+    M = 70001
+    shape = (M,) if C == 1 and kind != "eikonal" else (M, C)
+    a = torch.randn(shape, device=DEV) * (0.6 if kind != "entropy" else 0.4) + (0.5 if kind == "entropy" else 0.0)
+    if kind == "entropy":
+        a[:50] = 0.0                     # clamped entries: value at the clamp, no gradient
+        a[50:100] = 1.5
+    if kind == "eikonal":
+        a[7] = 0.0                       # |row| = 0: the norm's gradient is 0 there
+    b = torch.randn(shape, device=DEV) if kind in ("absdiff", "sqdiff") else None
+    if b is not None:
+        b[:100] = a[:100]                # a == b: sign(0) = 0
+    n_valid = valid = w_row = None
+    if mode == "n_valid":
+        n_valid = torch.tensor(51234, dtype=torch.int32, device=DEV)
+        valid = torch.arange(M, device=DEV) < n_valid
+        a[51234:] = float("nan") if kind not in ("absdiff", "sqdiff") else a[51234:]     # padding is never read into the sum
+    if mode == "row_weight":
+        w_row = (torch.rand(M, device=DEV) < 0.7).float()
+    a1, a2 = a.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    b1 = b2 = None
+    if b is not None:
+        b1, b2 = b.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    got = ops.masked_mean(kind, a1, b1, n_valid=n_valid, row_weight=w_row)
+    a2m = a2 if mode != "n_valid" else torch.where(valid.view(-1, *([1] * (a2.dim() - 1))), a2, torch.zeros_like(a2))
+    want = _torch_mean(kind, a2m, b2, valid, n_valid, w_row)
+    assert _rel(got, want) <= 3e-6, (float(got), float(want))
+    (got * 1.7).backward()
+    (want * 1.7).backward()
+    ga, wa = a1.grad, a2.grad
+    if mode == "n_valid":
+        assert float(ga[51234:].abs().max()) == 0.0
+    assert _rel(ga, wa) <= 3e-6, _rel(ga, wa)
+    if b is not None:
+        assert _rel(b1.grad, b2.grad) <= 3e-6
+
+
+def test_masked_mean_of_an_empty_selection_is_zero():
+    from morpheus_amd import ops
+    a = torch.randn(100, 3, device=DEV, requires_grad=True)
+    got = ops.masked_mean("abs", a, n_valid=torch.tensor(0, dtype=torch.int32, device=DEV))
+    got.backward()
+    assert float(got) == 0.0 and float(a.grad.abs().max()) == 0.0
+
+
+def _torch_ortho(x, normals, phi, scale):
+    n = torch.nn.functional.normalize(normals, dim=-1)
+    u = torch.nn.functional.normalize(torch.stack([n[..., 1], -n[..., 0], n[..., 2] * 0.0], -1), dim=-1)
+    v = torch.cross(n, u, dim=-1)
+    return x + (torch.cos(phi) * u + torch.sin(phi) * v) * scale
+
+
+def test_ortho_perturb_equals_the_torch_chain():
+    from morpheus_amd import ops
+    torch.manual_seed(5)
+    M = 40000
+    x = torch.randn(M, 3, device=DEV)
+    nrm = torch.randn(M, 3, device=DEV) * torch.rand(M, 1, device=DEV) * 3
+    nrm[0] = torch.tensor([0.0, 0.0, 1.0])          # u_raw = 0: u = 0 / eps = 0, the point does not move
+    nrm[1] = 0.0                                     # zero normal
+    phi = torch.rand(M, 1, device=DEV) * 2 * math.pi
+    gout = torch.randn(M, 3, device=DEV)
+    for scale in (0.004, 1.0):
+        x1, n1 = x.clone().requires_grad_(True), nrm.clone().requires_grad_(True)
+        x2, n2 = x.double().clone().requires_grad_(True), nrm.double().clone().requires_grad_(True)
+        got = ops.ortho_perturb(x1, n1, phi, scale)
+        want = _torch_ortho(x2, n2, phi.double(), scale)
+        assert float((got.double() - want).abs().max()) <= 2e-6 * max(scale, 1.0) + 1e-6 * float(x.abs().max())
+        # the displacement itself (the point minus x) to fp32 round-off of the unit vectors
+        assert float(((got.double() - x.double()) - (want - x2)).abs().max()) <= 4e-7 * float(x.abs().max()) + 2e-6 * scale
+        got.backward(gout)
+        want.backward(gout.double())
+        assert torch.equal(x1.grad, gout)
+        sel = torch.ones(M, dtype=torch.bool, device=DEV)
+        sel[:2] = False                              # degenerate rows: compared separately below
+        err = (n1.grad.double() - n2.grad)[sel].abs().max() / n2.grad[sel].abs().max()
+        assert float(err) <= 2e-5, float(err)
+        assert torch.isfinite(n1.grad).all()
+
+
+def test_weighted_sum_equals_the_chain_of_adds():
+    from morpheus_amd import ops
+    ts = [torch.tensor(v, device=DEV, requires_grad=True) for v in (0.3, -1.2, 4.0, 0.07)]
+    ws = (1.0, 0.5, 0.01, 30.0)
+    got = ops.weighted_sum(list(zip(ws, ts)))
+    want = sum(w * t.detach().double() for w, t in zip(ws, ts))
+    assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+    (got * 2.0).backward()
+    for w, t in zip(ws, ts):
+        assert abs(float(t.grad) - 2.0 * w) <= 1e-6 * abs(2.0 * w)

@@ -700,8 +700,8 @@ def test_fixed_capacity_sampling_equals_ragged_sampling(monkeypatch):
         assert torch.equal(ra[k], rb[k][:Ma]), k
     assert float(rb["weights"][Ma:].abs().max()) == 0.0
     for k in ("loss_normal_perturb", "normal_reg", "sdf_loss", "fs_loss", "loss_code"):
-        assert_close(rb[k], ra[k], 1e-6, k, floor=1e-6)
-    assert abs(la - lb) <= 1e-6 * abs(la)
+        assert_close(rb[k], ra[k], 5e-6, k, floor=1e-6)     # sums of ~10^5 floats by atomics / a different block partition
+    assert abs(la - lb) <= 5e-6 * abs(la)
     assert set(ga) == set(gb)
     for k in ga:
         rel = float((ga[k] - gb[k]).norm() / ga[k].norm().clamp_min(1e-30))
