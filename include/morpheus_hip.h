@@ -44,7 +44,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 4   /* 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
+#define MH_ABI_VERSION 4   /* 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -374,6 +374,16 @@ int mh_masked_mean_bwd(int32_t kind, const float *a, const float *b, const float
  * x, n, out [M,3], phi [M] (the caller's uniform draw times 2 pi).  Backward: g_x = g_out (no launch), g_n from *_bwd. */
 int mh_ortho_perturb_fwd(const float *x, const float *n, const float *phi, float scale, int64_t M, float *out, void *stream);
 int mh_ortho_perturb_bwd(const float *n, const float *phi, const float *g_out, float scale, int64_t M, float *g_n, void *stream);
+
+/* Per-frame pose correction of a ray batch made of B rows of n_per_row rays, ONE frame per row (models/pose.py:4-64 PoseArray,
+ * models/model.py:335-346 pose_optimisation): o' = o + t_f, d' = R(a, b, g)_f d with pose [n_frames, 6] = (a, b, g, t) per frame
+ * and frame_of_row [B] (int64).  Backward: g_pose [n_frames, 6] = the full gradient (zeroed inside; rows of one frame add up
+ * in row order); g_o / g_d may be NULL; ws: mh_pose_bwd_workspace_floats(B, n_per_row) floats.  One launch forward, two back. */
+int64_t mh_pose_bwd_workspace_floats(int64_t B, int64_t n_per_row);
+int mh_pose_apply_fwd(const float *rays_o, const float *rays_d, const float *pose, const int64_t *frame_of_row, int64_t B,
+                      int64_t n_per_row, float *o_out, float *d_out, void *stream);
+int mh_pose_apply_bwd(const float *rays_d, const float *pose, const int64_t *frame_of_row, int64_t B, int64_t n_per_row,
+                      int64_t n_frames, const float *g_o, const float *g_d, float *ws, float *g_pose, void *stream);
 
 /* ---- HIP-graph hygiene (no reference counterpart: the reference runs its step eagerly; morpheus.py:1147-1236 is the step
  * trainstep.GraphedRealViewStep captures).  graph = a hipGraph_t obtained by stream capture, not yet instantiated.

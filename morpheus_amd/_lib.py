@@ -89,6 +89,9 @@ _SIGS = {
     "mh_masked_mean_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "mh_ortho_perturb_fwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
     "mh_ortho_perturb_bwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
+    "mh_pose_bwd_workspace_floats": (_I64, [_I64, _I64]),
+    "mh_pose_apply_fwd": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "mh_pose_apply_bwd": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
     "mh_graph_count_memset_nodes": (ctypes.c_int, [_P, _P, _P, _P]),
     "mh_graph_replace_memset_nodes": (ctypes.c_int, [_P, _P]),
 }

@@ -273,3 +273,146 @@ extern "C" int mh_ortho_perturb_bwd(const float *n, const float *phi, const floa
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
+
+// ---- per-frame pose correction of a batch of rays: o' = o + t_f, d' = R(a, b, g)_f d  (models/pose.py:4-64, model.py:335-346) ------
+// The batch is B rows of n rays, one frame per row.  As torch operators this is ~60 launches forward (six
+// sin/cos, twenty products, four stacks, two gathers) and ~100 backward for 3 x 3 numbers per frame; here: one launch forward,
+// two backward (per-block partial sums of dL/dR = sum_rays g_d' d^T and dL/dt = sum_rays g_o', then one block that adds them in a
+// fixed order, applies dR/d(angles) and adds the rows' results into the zeroed [F,6] gradient: deterministic, no atomics).
+#define POSE_RAYS_PER_BLOCK 1024
+
+struct PoseR {
+    float r[3][3];
+};
+
+__device__ __forceinline__ PoseR pose_matrix(float a, float b, float g) {
+    const float ca = cosf(a), cb = cosf(b), cg = cosf(g), sa = sinf(a), sb = sinf(b), sg = sinf(g);
+    // every product and sum rounded on its own, left to right (this file is compiled with -ffp-contract=off, morpheus_amd/build.py:
+    // HIP's __fmul_rn / __fadd_rn are plain operators the compiler would otherwise fuse): the values the reference's operator chain
+    // (models/pose.py:44-53) produces -- a one-ulp difference in R moves sample positions enough to show in SDF values next to 0
+    PoseR m;
+    const float casb = __fmul_rn(ca, sb), sasb = __fmul_rn(sa, sb);
+    m.r[0][0] = __fmul_rn(ca, cb);  m.r[1][0] = __fmul_rn(sa, cb);  m.r[2][0] = -sb;
+    m.r[0][1] = __fsub_rn(__fmul_rn(casb, sg), __fmul_rn(sa, cg));
+    m.r[1][1] = __fadd_rn(__fmul_rn(sasb, sg), __fmul_rn(ca, cg));
+    m.r[2][1] = __fmul_rn(cb, sg);
+    m.r[0][2] = __fadd_rn(__fmul_rn(casb, cg), __fmul_rn(sa, sg));
+    m.r[1][2] = __fsub_rn(__fmul_rn(sasb, cg), __fmul_rn(ca, sg));
+    m.r[2][2] = __fmul_rn(cb, cg);
+    return m;
+}
+
+__global__ __launch_bounds__(256) void pose_apply_kernel(const float *__restrict__ o, const float *__restrict__ d,
+                                                         const float *__restrict__ pose, const int64_t *__restrict__ frame_of_row,
+                                                         int64_t n_per_row, int64_t N, float *__restrict__ o_out,
+                                                         float *__restrict__ d_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float *p = pose + 6 * frame_of_row[i / n_per_row];
+    const PoseR m = pose_matrix(p[0], p[1], p[2]);
+    const float x = d[3 * i], y = d[3 * i + 1], z = d[3 * i + 2];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        o_out[3 * i + r] = o[3 * i + r] + p[3 + r];
+        // (rays_d[..., None, :] * R).sum(-1) (model.py:346): three rounded products, added in the order PyTorch's reduction over a
+        // length-3 axis adds them on this device ((p0 + p2) + p1; tools/gpu/pose_probe.py) -- bit for bit the operator chain
+        d_out[3 * i + r] = __fadd_rn(__fadd_rn(__fmul_rn(x, m.r[r][0]), __fmul_rn(z, m.r[r][2])), __fmul_rn(y, m.r[r][1]));
+    }
+}
+
+// ws[(row * blocks_per_row + blk) * 12 + k]: k < 9 -> sum g_d'[r] * d[c] (k = 3 r + c), k >= 9 -> sum g_o'[k - 9]
+__global__ __launch_bounds__(256) void pose_bwd_partial_kernel(const float *__restrict__ d, const float *__restrict__ g_o,
+                                                               const float *__restrict__ g_d, int64_t n_per_row,
+                                                               int blocks_per_row, float *__restrict__ ws) {
+    const int row = blockIdx.y, blk = blockIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] = 0.f;
+    const int64_t lo = (int64_t)blk * POSE_RAYS_PER_BLOCK, hi = min(lo + POSE_RAYS_PER_BLOCK, n_per_row);
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+        const int64_t i = (int64_t)row * n_per_row + j;
+        const float x = d[3 * i], y = d[3 * i + 1], z = d[3 * i + 2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float gd = g_d ? g_d[3 * i + r] : 0.f;
+            acc[3 * r] += gd * x;
+            acc[3 * r + 1] += gd * y;
+            acc[3 * r + 2] += gd * z;
+            acc[9 + r] += g_o ? g_o[3 * i + r] : 0.f;
+        }
+    }
+    __shared__ float red[4][12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) acc[k] += __shfl_xor(acc[k], s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12)
+        ws[((int64_t)row * blocks_per_row + blk) * 12 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void pose_bwd_final_kernel(const float *__restrict__ ws, const float *__restrict__ pose,
+                                                             const int64_t *__restrict__ frame_of_row, int B, int blocks_per_row,
+                                                             int64_t n_frames, float *__restrict__ g_pose) {
+    for (int64_t i = threadIdx.x; i < n_frames * 6; i += 256) g_pose[i] = 0.f;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int row = 0; row < B; row++) {                     // rows of the same frame add up in row order
+        float s[12];
+        for (int k = 0; k < 12; k++) {
+            float t = 0.f;
+            for (int blk = 0; blk < blocks_per_row; blk++) t += ws[((int64_t)row * blocks_per_row + blk) * 12 + k];
+            s[k] = t;
+        }
+        const int64_t f = frame_of_row[row];
+        const float *p = pose + 6 * f;
+        const float ca = cosf(p[0]), cb = cosf(p[1]), cg = cosf(p[2]), sa = sinf(p[0]), sb = sinf(p[1]), sg = sinf(p[2]);
+        // dR/da, dR/db, dR/dg of pose_matrix, contracted with G = s[3 r + c]
+        const float Ga = s[0] * (-sa * cb) + s[3] * (ca * cb) + s[1] * (-sa * sb * sg - ca * cg) + s[4] * (ca * sb * sg - sa * cg) +
+                         s[2] * (-sa * sb * cg + ca * sg) + s[5] * (ca * sb * cg + sa * sg);
+        const float Gb = s[0] * (-ca * sb) + s[3] * (-sa * sb) + s[6] * (-cb) + s[1] * (ca * cb * sg) + s[4] * (sa * cb * sg) +
+                         s[7] * (-sb * sg) + s[2] * (ca * cb * cg) + s[5] * (sa * cb * cg) + s[8] * (-sb * cg);
+        const float Gg = s[1] * (ca * sb * cg + sa * sg) + s[4] * (sa * sb * cg - ca * sg) + s[7] * (cb * cg) +
+                         s[2] * (-ca * sb * sg + sa * cg) + s[5] * (-sa * sb * sg - ca * cg) + s[8] * (-cb * sg);
+        g_pose[6 * f + 0] += Ga;
+        g_pose[6 * f + 1] += Gb;
+        g_pose[6 * f + 2] += Gg;
+        g_pose[6 * f + 3] += s[9];
+        g_pose[6 * f + 4] += s[10];
+        g_pose[6 * f + 5] += s[11];
+    }
+}
+
+static inline int pose_blocks_per_row(int64_t n_per_row) { return (int)((n_per_row + POSE_RAYS_PER_BLOCK - 1) / POSE_RAYS_PER_BLOCK); }
+
+extern "C" int64_t mh_pose_bwd_workspace_floats(int64_t B, int64_t n_per_row) { return B * pose_blocks_per_row(n_per_row) * 12; }
+
+extern "C" int mh_pose_apply_fwd(const float *rays_o, const float *rays_d, const float *pose, const int64_t *frame_of_row, int64_t B,
+                                 int64_t n_per_row, float *o_out, float *d_out, void *stream) {
+    const int64_t N = B * n_per_row;
+    if (N == 0) return MH_OK;
+    if (B < 0 || n_per_row < 0 || !rays_o || !rays_d || !pose || !frame_of_row || !o_out || !d_out) return MH_ERR_ARG;
+    hipLaunchKernelGGL(pose_apply_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, mh_stream(stream), rays_o, rays_d, pose,
+                       frame_of_row, n_per_row, N, o_out, d_out);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_pose_apply_bwd(const float *rays_d, const float *pose, const int64_t *frame_of_row, int64_t B, int64_t n_per_row,
+                                 int64_t n_frames, const float *g_o, const float *g_d, float *ws, float *g_pose, void *stream) {
+    if (B < 0 || n_per_row < 0 || n_frames <= 0 || B > 65535 || !pose || !frame_of_row || !ws || !g_pose || (B * n_per_row > 0 && !rays_d))
+        return MH_ERR_ARG;
+    const int bpr = pose_blocks_per_row(n_per_row);
+    if (B * n_per_row > 0) {
+        hipLaunchKernelGGL(pose_bwd_partial_kernel, dim3(bpr, (unsigned)B), dim3(256), 0, mh_stream(stream), rays_d, g_o, g_d, n_per_row,
+                           bpr, ws);
+        MH_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(pose_bwd_final_kernel, dim3(1), dim3(256), 0, mh_stream(stream), (const float *)ws, pose, frame_of_row,
+                       (int)(B * n_per_row > 0 ? B : 0), bpr, n_frames, g_pose);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}

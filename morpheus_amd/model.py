@@ -357,10 +357,13 @@ class scene_representation(nn.Module):
         if rows is not None:
             B, n = rows
             ids = frame_ids.reshape(B, n)[:, 0]
-            R, t = self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)   # [B,3,3], [B,3]
-            o = (rays_o.view(B, n, 3) + t[:, None]).view(-1, 3)
-            d = (rays_d.view(B, n, 1, 3) * R[:, None]).sum(-1).view(-1, 3)
-            return o, d
+            if rays_o.requires_grad or rays_d.requires_grad:       # rays with a gradient of their own: the operator chain
+                R, t = self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)   # [B,3,3], [B,3]
+                o = (rays_o.view(B, n, 3) + t[:, None]).view(-1, 3)
+                d = (rays_d.view(B, n, 1, 3) * R[:, None]).sum(-1).view(-1, 3)
+                return o, d
+            # Euler angles -> R, the translation and both products in one launch (three with the backward) instead of ~160
+            return ops.pose_apply(rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), self.pose_array.data, ids, n)
         ids = frame_ids.squeeze()
         R, t = self.pose_array.get_rotation_matrices(ids), self.pose_array.get_translations(ids)
         return rays_o + t, (rays_d[..., None, :] * R).sum(-1)

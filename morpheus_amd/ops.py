@@ -1160,6 +1160,46 @@ def ortho_perturb(x, normals, phi, scale: float):
     return _OrthoPerturb.apply(x, normals, phi, scale)
 
 
+class _PoseApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, pose, frame_of_row, n_per_row):
+        ctx.set_materialize_grads(False)
+        require_gpu(rays_o, rays_d, pose, frame_of_row)
+        lib = _lib.load()
+        o_c, d_c = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+        p_c = pose.detach().contiguous().float()
+        f_c = frame_of_row.detach().reshape(-1).long().contiguous()
+        B = f_c.numel()
+        assert o_c.shape == (B * n_per_row, 3) and d_c.shape == o_c.shape and p_c.dim() == 2 and p_c.shape[1] == 6
+        o_out, d_out = torch.empty_like(o_c), torch.empty_like(d_c)
+        check(lib.mh_pose_apply_fwd(ptr(o_c), ptr(d_c), ptr(p_c), ptr(f_c), B, n_per_row, ptr(o_out), ptr(d_out), stream()), "mh_pose_apply_fwd")
+        ctx.save_for_backward(d_c, p_c, f_c)
+        ctx.n_per_row = n_per_row
+        return o_out, d_out
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        d_c, p_c, f_c = ctx.saved_tensors
+        if (g_o is None and g_d is None) or not ctx.needs_input_grad[2]:
+            return None, None, None, None, None
+        lib = _lib.load()
+        B = f_c.numel()
+        g_o = None if g_o is None else g_o.contiguous().float()
+        g_d = None if g_d is None else g_d.contiguous().float()
+        ws = torch.empty(max(lib.mh_pose_bwd_workspace_floats(B, ctx.n_per_row), 1), device=d_c.device)
+        g_pose = torch.empty_like(p_c)
+        check(lib.mh_pose_apply_bwd(ptr(d_c), ptr(p_c), ptr(f_c), B, ctx.n_per_row, p_c.shape[0], ptr(g_o), ptr(g_d), ptr(ws), ptr(g_pose),
+                                    stream()), "mh_pose_apply_bwd")
+        return None, None, g_pose, None, None
+
+
+def pose_apply(rays_o, rays_d, pose, frame_of_row, n_per_row: int):
+    """(rays_o + t_f, R_f rays_d) for a batch of B rows of n_per_row rays, one frame per row (include/morpheus_hip.h:
+    mh_pose_apply_*; models/pose.py:4-64 + model.py:335-346): pose [n_frames, 6], frame_of_row [B] frame ids.  The rays are data
+    (no gradient); the gradient reaches `pose`."""
+    return _PoseApply.apply(rays_o, rays_d, pose, frame_of_row, int(n_per_row))
+
+
 class _WeightedSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *terms):

@@ -135,3 +135,38 @@ def test_weighted_sum_equals_the_chain_of_adds():
     (got * 2.0).backward()
     for w, t in zip(ws, ts):
         assert abs(float(t.grad) - 2.0 * w) <= 1e-6 * abs(2.0 * w)
+
+
+@pytest.mark.parametrize("B,n", [(1, 2048), (3, 700), (2, 2500)])
+def test_pose_apply_equals_the_operator_chain(B, n):
+    """models/pose.py + model.py:335-346 as torch operators (PoseArray.get_rotation_matrices / get_translations, float64) against the
+    single launch; rows 0 and B-1 share a frame, so the per-frame gradient has to add rows up."""
+    from morpheus_amd import ops
+    from morpheus_amd.model import PoseArray
+    torch.manual_seed(11)
+    F = 9
+    pa = PoseArray(F).to(DEV)
+    with torch.no_grad():
+        pa.data.copy_(torch.randn(F, 6, device=DEV) * 0.3)
+    ids = torch.tensor([4, 7, 4][:B] if B > 1 else [4], device=DEV)
+    o, d = torch.randn(B * n, 3, device=DEV), torch.nn.functional.normalize(torch.randn(B * n, 3, device=DEV), dim=-1)
+    go, gd = torch.randn(B * n, 3, device=DEV), torch.randn(B * n, 3, device=DEV)
+    o1, d1 = ops.pose_apply(o, d, pa.data, ids, n)
+    (o1 * go).sum().backward(retain_graph=True)
+    (d1 * gd).sum().backward()
+    got = pa.data.grad.clone()
+    pa64 = PoseArray(F).to(DEV).double()
+    with torch.no_grad():
+        pa64.data.copy_(pa.data.double())
+    R, t = pa64.get_rotation_matrices(ids), pa64.get_translations(ids)
+    o2 = (o.double().view(B, n, 3) + t[:, None]).view(-1, 3)
+    d2 = (d.double().view(B, n, 1, 3) * R[:, None]).sum(-1).view(-1, 3)
+    ((o2 * go.double()).sum() + (d2 * gd.double()).sum()).backward()
+    assert float((o1.double() - o2).abs().max()) <= 1e-6 and float((d1.double() - d2).abs().max()) <= 1e-6
+    # bit for bit what the fp32 operator chain gives (same roundings in the same order): sample positions do not move by an ulp
+    R32, t32 = pa.get_rotation_matrices(ids), pa.get_translations(ids)
+    assert torch.equal(o1, (o.view(B, n, 3) + t32[:, None]).view(-1, 3).detach())
+    assert torch.equal(d1, (d.view(B, n, 1, 3) * R32[:, None]).sum(-1).view(-1, 3).detach())
+    want = pa64.data.grad
+    assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()), (got, want)
+    assert float(got[[0, 1, 2, 3, 5, 6, 8]].abs().max()) == 0.0           # frames outside the batch: zero rows
