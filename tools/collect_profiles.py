@@ -102,7 +102,9 @@ def main():
                       ("phase_trace_h2.log", "phase_trace_warp_fwd.txt"),
                       ("hbm_rates.log", "micro_hbm_rates.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
                       ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt"),
-                      ("precision_report.jsonl", "precision_report.jsonl")):
+                      ("precision_report.jsonl", "precision_report.jsonl"),
+                      ("timeline_train_real_graph.txt", "timeline_train_real_hip_graph.txt"),
+                      ("graph_memset_probe.txt", "graph_memset_probe.txt")):
         src = os.path.join(OUT, log)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(PROF, f"{tag}_{name}"))

@@ -24,7 +24,10 @@ for m in b3 h2 f32; do
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/pmc_sq$sfx -- $CMD > $REPO/gpurun_out/pmc_sq$sfx.log 2>&1
 done
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_train_real" -- python "$REPO/bench.py" --workload train_real --steps 16 --warmup 3 --no-kernel-timers > "$REPO/gpurun_out/prof_train_real.log" 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_train_real_graph" -- python "$REPO/bench.py" --workload train_real --graph --steps 8 --warmup 2 --no-kernel-timers > "$REPO/gpurun_out/prof_train_real_graph.log" 2>&1
 cd "$REPO"
+python tools/step_timeline_real.py gpurun_out/prof_train_real_graph > gpurun_out/timeline_train_real_graph.txt 2>&1
+timeout 200 python tools/gpu/graph_memset_probe.py 2>&1 | grep -v "amdgpu\|Warn\|warn" > gpurun_out/graph_memset_probe.txt
 tail -14 gpurun_out/gpu_tests.log; tail -2 gpurun_out/smoke.log | cut -c1-300
 python - <<'PY'
 import json
