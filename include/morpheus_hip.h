@@ -44,7 +44,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 4   /* 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
+#define MH_ABI_VERSION 4   /* 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*, mh_render_loss_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -384,6 +384,19 @@ int mh_pose_apply_fwd(const float *rays_o, const float *rays_d, const float *pos
                       int64_t n_per_row, float *o_out, float *d_out, void *stream);
 int mh_pose_apply_bwd(const float *rays_d, const float *pose, const int64_t *frame_of_row, int64_t B, int64_t n_per_row,
                       int64_t n_frames, const float *g_o, const float *g_d, float *ws, float *g_pose, void *stream);
+
+/* The real-view render loss of a ray batch (morpheus.py:930-945 get_gt_from_data + :946-983 get_real_view_render_loss): per ray
+ * m = mask > 0.5, gt_rgb = image m + bg (1 - m), valid = depth > 0 and |o + depth d| <= 1.1 and m;  rgb = mean (pred_rgb -
+ * gt_rgb)^2, mask = BCE(clip(opacity, 1e-5, 1 - 1e-5), m), depth = mean (valid (pred_depth - depth))^2.  pred_rgb, bg, rays_o,
+ * rays_d [N,3]; image [3,N] (channel-major, the dataset's layout); the others [N].  out[0] = w_rgb rgb + w_mask mask + w_depth
+ * depth, out[1..3] = the terms; gt_rgb [3,N] and valid [N] are returned for the surface-point loss (:1001-1026).  One launch
+ * (one workgroup walks the rays: deterministic) and one backward (g: device scalar; any of g_rgb / g_depth / g_opacity NULL). */
+int mh_render_loss_fwd(const float *pred_rgb, const float *pred_depth, const float *opacity, const float *image,
+                       const float *depth, const float *mask, const float *bg, const float *rays_o, const float *rays_d,
+                       int64_t N, float w_rgb, float w_mask, float w_depth, float *gt_rgb, float *valid, float *out, void *stream);
+int mh_render_loss_bwd(const float *pred_rgb, const float *pred_depth, const float *opacity, const float *gt_rgb,
+                       const float *depth, const float *mask, const float *valid, int64_t N, float w_rgb, float w_mask,
+                       float w_depth, const float *g, float *g_rgb, float *g_depth, float *g_opacity, void *stream);
 
 /* ---- HIP-graph hygiene (no reference counterpart: the reference runs its step eagerly; morpheus.py:1147-1236 is the step
  * trainstep.GraphedRealViewStep captures).  graph = a hipGraph_t obtained by stream capture, not yet instantiated.

@@ -92,6 +92,8 @@ _SIGS = {
     "mh_pose_bwd_workspace_floats": (_I64, [_I64, _I64]),
     "mh_pose_apply_fwd": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "mh_pose_apply_bwd": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
+    "mh_render_loss_fwd": (ctypes.c_int, [_P] * 9 + [_I64, _F, _F, _F, _P, _P, _P, _P]),
+    "mh_render_loss_bwd": (ctypes.c_int, [_P] * 7 + [_I64, _F, _F, _F, _P, _P, _P, _P, _P]),
     "mh_graph_count_memset_nodes": (ctypes.c_int, [_P, _P, _P, _P]),
     "mh_graph_replace_memset_nodes": (ctypes.c_int, [_P, _P]),
 }

@@ -416,3 +416,123 @@ extern "C" int mh_pose_apply_bwd(const float *rays_d, const float *pose, const i
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
+
+// ---- the real-view render loss (morpheus.py:930-983: get_gt_from_data + get_real_view_render_loss) as one launch each way ---------
+// Per ray: m = mask > 0.5; gt_rgb = image * m + bg * (1 - m); valid = depth > 0 and |o + depth d| <= 1.1 and m;
+//   rgb   = mean over rays and channels of (pred_rgb - gt_rgb)^2
+//   mask  = mean of -(m log p + (1 - m) log (1 - p)),  p = clip(opacity, 1e-5, 1 - 1e-5)
+//   depth = mean of (valid (pred_depth - depth))^2
+// out[0] = w_rgb rgb + w_mask mask + w_depth depth, out[1..3] = the three terms; gt_rgb [3,N] (channel-major, the layout the
+// caller's [B,3,H,W] view has) and valid [N] go back to the caller for the surface-point loss (:1001-1026).
+// ONE workgroup of 1024 threads walks the rays (a training batch is a few thousand rays): deterministic, nothing to zero.
+struct RenderLossW {
+    float rgb, mask, depth;
+};
+
+__global__ __launch_bounds__(1024) void render_loss_kernel(const float *__restrict__ pred_rgb /*[N,3]*/,
+                                                           const float *__restrict__ pred_depth, const float *__restrict__ opacity,
+                                                           const float *__restrict__ image /*[3,N]*/, const float *__restrict__ depth,
+                                                           const float *__restrict__ mask, const float *__restrict__ bg /*[N,3]*/,
+                                                           const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                           int64_t N, RenderLossW w, float *__restrict__ gt_rgb /*[3,N]*/,
+                                                           float *__restrict__ valid, float *__restrict__ out /*[4]*/) {
+    float s_rgb = 0.f, s_mask = 0.f, s_depth = 0.f;
+    for (int64_t i = threadIdx.x; i < N; i += 1024) {
+        const float m = mask[i] > 0.5f ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float g = image[c * N + i] * m + bg[3 * i + c] * (1.0f - m);
+            gt_rgb[c * N + i] = g;
+            const float d = pred_rgb[3 * i + c] - g;
+            s_rgb += d * d;
+        }
+        const float p = fminf(fmaxf(opacity[i], 1e-5f), 1.0f - 1e-5f);
+        s_mask -= m * logf(p) + (1.0f - m) * logf(1.0f - p);
+        const float gd = depth[i];
+        const float x = rays_o[3 * i] + gd * rays_d[3 * i], y = rays_o[3 * i + 1] + gd * rays_d[3 * i + 1],
+                    z = rays_o[3 * i + 2] + gd * rays_d[3 * i + 2];
+        const float v = (gd > 0.f && sqrtf(x * x + y * y + z * z) <= 1.1f && m > 0.5f) ? 1.0f : 0.0f;
+        valid[i] = v;
+        const float dd = pred_depth[i] * v - gd * v;
+        s_depth += dd * dd;
+    }
+    __shared__ float red[3][16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s_rgb += __shfl_xor(s_rgb, o);
+        s_mask += __shfl_xor(s_mask, o);
+        s_depth += __shfl_xor(s_depth, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s_rgb;
+        red[1][threadIdx.x >> 6] = s_mask;
+        red[2][threadIdx.x >> 6] = s_depth;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int k = 0; k < 16; k++) {
+            a += red[0][k];
+            b += red[1][k];
+            c += red[2][k];
+        }
+        const float n = (float)(N > 0 ? N : 1);
+        a /= 3.0f * n;
+        b /= n;
+        c /= n;
+        out[0] = w.rgb * a + w.mask * b + w.depth * c;
+        out[1] = a;
+        out[2] = b;
+        out[3] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void render_loss_bwd_kernel(const float *__restrict__ pred_rgb, const float *__restrict__ pred_depth,
+                                                              const float *__restrict__ opacity, const float *__restrict__ gt_rgb,
+                                                              const float *__restrict__ depth, const float *__restrict__ mask,
+                                                              const float *__restrict__ valid, int64_t N, RenderLossW w,
+                                                              const float *__restrict__ g, float *__restrict__ g_rgb,
+                                                              float *__restrict__ g_depth, float *__restrict__ g_opacity) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float gg = *g, n = (float)N;
+    if (g_rgb) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) g_rgb[3 * i + c] = gg * w.rgb * 2.0f * (pred_rgb[3 * i + c] - gt_rgb[c * N + i]) / (3.0f * n);
+    }
+    if (g_depth) {
+        const float v = valid[i];
+        g_depth[i] = gg * w.depth * 2.0f * (pred_depth[i] * v - depth[i] * v) * v / n;
+    }
+    if (g_opacity) {
+        const float o = opacity[i], m = mask[i] > 0.5f ? 1.0f : 0.0f;
+        const float p = fminf(fmaxf(o, 1e-5f), 1.0f - 1e-5f);
+        g_opacity[i] = (o >= 1e-5f && o <= 1.0f - 1e-5f) ? gg * w.mask * (-(m / p) + (1.0f - m) / (1.0f - p)) / n : 0.f;
+    }
+}
+
+extern "C" int mh_render_loss_fwd(const float *pred_rgb, const float *pred_depth, const float *opacity, const float *image,
+                                  const float *depth, const float *mask, const float *bg, const float *rays_o, const float *rays_d,
+                                  int64_t N, float w_rgb, float w_mask, float w_depth, float *gt_rgb, float *valid, float *out,
+                                  void *stream) {
+    if (N < 0 || !out || (N > 0 && (!pred_rgb || !pred_depth || !opacity || !image || !depth || !mask || !bg || !rays_o || !rays_d ||
+                                    !gt_rgb || !valid)))
+        return MH_ERR_ARG;
+    RenderLossW w = {w_rgb, w_mask, w_depth};
+    hipLaunchKernelGGL(render_loss_kernel, dim3(1), dim3(1024), 0, mh_stream(stream), pred_rgb, pred_depth, opacity, image, depth, mask,
+                       bg, rays_o, rays_d, N, w, gt_rgb, valid, out);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
+extern "C" int mh_render_loss_bwd(const float *pred_rgb, const float *pred_depth, const float *opacity, const float *gt_rgb,
+                                  const float *depth, const float *mask, const float *valid, int64_t N, float w_rgb, float w_mask,
+                                  float w_depth, const float *g, float *g_rgb, float *g_depth, float *g_opacity, void *stream) {
+    if (N == 0) return MH_OK;
+    if (N < 0 || !pred_rgb || !pred_depth || !opacity || !gt_rgb || !depth || !mask || !valid || !g) return MH_ERR_ARG;
+    RenderLossW w = {w_rgb, w_mask, w_depth};
+    hipLaunchKernelGGL(render_loss_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, mh_stream(stream), pred_rgb, pred_depth,
+                       opacity, gt_rgb, depth, mask, valid, N, w, g, g_rgb, g_depth, g_opacity);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}

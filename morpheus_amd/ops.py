@@ -1200,6 +1200,55 @@ def pose_apply(rays_o, rays_d, pose, frame_of_row, n_per_row: int):
     return _PoseApply.apply(rays_o, rays_d, pose, frame_of_row, int(n_per_row))
 
 
+class _RenderLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_rgb, pred_depth, opacity, image, depth, mask, bg, rays_o, rays_d, w_rgb, w_mask, w_depth):
+        ctx.set_materialize_grads(False)
+        require_gpu(pred_rgb, pred_depth, opacity, image, depth, mask, bg, rays_o, rays_d)
+        lib = _lib.load()
+        c = lambda t, *shape: t.detach().reshape(*shape).contiguous().float()
+        N = pred_depth.numel()
+        pr, pd, op = c(pred_rgb, N, 3), c(pred_depth, N), c(opacity, N)
+        im, dp, mk, bgc = c(image, 3, N), c(depth, N), c(mask, N), c(bg, N, 3)
+        ro, rd = c(rays_o, N, 3), c(rays_d, N, 3)
+        gt_rgb, valid, out = torch.empty(3, N, device=pr.device), torch.empty(N, device=pr.device), torch.empty(4, device=pr.device)
+        check(lib.mh_render_loss_fwd(ptr(pr), ptr(pd), ptr(op), ptr(im), ptr(dp), ptr(mk), ptr(bgc), ptr(ro), ptr(rd), N, w_rgb, w_mask,
+                                     w_depth, ptr(gt_rgb), ptr(valid), ptr(out), stream()), "mh_render_loss_fwd")
+        ctx.save_for_backward(pr, pd, op, gt_rgb, dp, mk, valid)
+        ctx.w = (float(w_rgb), float(w_mask), float(w_depth))
+        ctx.shapes = (pred_rgb.shape, pred_depth.shape, opacity.shape)
+        ctx.mark_non_differentiable(gt_rgb, valid)
+        return out[0], out[1:], gt_rgb, valid
+
+    @staticmethod
+    def backward(ctx, g, _g_terms, _g_gt, _g_valid):
+        if g is None:
+            return (None,) * 12
+        lib = _lib.load()
+        pr, pd, op, gt_rgb, dp, mk, valid = ctx.saved_tensors
+        N = pd.numel()
+        need = ctx.needs_input_grad
+        g_rgb = torch.empty_like(pr) if need[0] else None
+        g_dep = torch.empty_like(pd) if need[1] else None
+        g_op = torch.empty_like(op) if need[2] else None
+        if need[0] or need[1] or need[2]:
+            check(lib.mh_render_loss_bwd(ptr(pr), ptr(pd), ptr(op), ptr(gt_rgb), ptr(dp), ptr(mk), ptr(valid), N, *ctx.w,
+                                         ptr(g.reshape(1).contiguous().float()), ptr(g_rgb), ptr(g_dep), ptr(g_op), stream()),
+                  "mh_render_loss_bwd")
+        s = ctx.shapes
+        return (None if g_rgb is None else g_rgb.view(s[0]), None if g_dep is None else g_dep.view(s[1]),
+                None if g_op is None else g_op.view(s[2]), None, None, None, None, None, None, None, None, None)
+
+
+def real_view_render_loss(pred_rgb, pred_depth, opacity, image, depth, mask, bg, rays_o, rays_d, w_rgb, w_mask, w_depth):
+    """get_gt_from_data + get_real_view_render_loss (morpheus.py:930-983) in one launch each way (include/morpheus_hip.h:
+    mh_render_loss_*).  pred_rgb [..., 3] per ray (the renderer's `image`), pred_depth / opacity per ray; image: the dataset's
+    [B,3,H,W] batch (B = 1: channel-major [3,N]); bg [N,3].  -> (weighted loss, the three terms [rgb, mask, depth] (detached
+    values), gt_rgb [3,N], valid-depth mask [N])."""
+    return _RenderLoss.apply(pred_rgb, pred_depth, opacity, image, depth, mask, bg, rays_o, rays_d, float(w_rgb), float(w_mask),
+                             float(w_depth))
+
+
 class _WeightedSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *terms):

@@ -101,7 +101,7 @@ def get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_de
     return ops.weighted_sum(terms)
 
 
-def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs):
+def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs, depth_mask=None):
     """morpheus.py:985-1029: SDF / free-space losses from the renderer plus one `model.density` query at the N
     back-projected surface points (x and t of equal length, gradients into both hash tables, the warp and the codes)."""
     terms = []
@@ -112,7 +112,10 @@ def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_
     if tr["fs_weight"] > 0:
         terms.append((tr["fs_weight"], outputs["fs_loss"]))
     if tr["surf_sdf_weight"] > 0:
-        depth_mask, xyzs = _valid_depth_mask(gt_depth, gt_mask, rays_o, rays_d)
+        if depth_mask is None:
+            depth_mask, xyzs = _valid_depth_mask(gt_depth, gt_mask, rays_o, rays_d)
+        else:                   # the mask the fused render loss already built (ops.real_view_render_loss)
+            xyzs = rays_o + gt_depth.reshape(1, -1, 1) * rays_d
         results = model.density(xyzs.reshape(-1, 3), t=rays_t.reshape(-1, 1))
         sdf, albedo = results["sdf"], results["albedo"]
         masked_color = albedo.view(*depth_mask.shape, 3).permute(0, 3, 1, 2).contiguous()
@@ -214,10 +217,22 @@ class RealViewTrainStep:
         pred_depth = outputs["depth"].reshape(B, 1, H, W)
         pred_mask = outputs["weights_sum"].reshape(B, 1, H, W)
         pred_normal = outputs["normal_image"].reshape(B, H, W, 3) if "normal_image" in outputs else None
-        pred_rgb = outputs["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
-        gt_rgb, gt_depth, gt_mask = get_gt_from_data(data, bg_color, B, H, W)
-        loss = get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask, rays_o, rays_d)
-        loss = loss + get_real_view_point_loss(tr, self.model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs)
+        if B == 1:
+            # get_gt_from_data + get_real_view_render_loss in one launch each way (~70 as torch operators); the composited target
+            # and the valid-depth mask come back for the surface-point loss.  (A batch of several rows keeps the operator chain:
+            # the kernel reads the image channel-major over ONE row's rays.)
+            loss, _, gt_flat, valid = ops.real_view_render_loss(
+                outputs["image"], outputs["depth"], outputs["weights_sum"], data["image"], data["depth"], data["mask"], bg_color,
+                rays_o, rays_d, max(tr["rgb_weight"], 0.0), max(tr["mask_weight"], 0.0), max(tr["depth_weight"], 0.0))
+            gt_rgb, gt_depth = gt_flat.view(B, 3, H, W), data["depth"]
+            gt_mask, depth_mask = data["mask"], valid.view(B, H, W)      # (the point loss reads the mask only through depth_mask)
+        else:
+            pred_rgb = outputs["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+            gt_rgb, gt_depth, gt_mask = get_gt_from_data(data, bg_color, B, H, W)
+            loss = get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask, rays_o, rays_d)
+            depth_mask = None
+        loss = loss + get_real_view_point_loss(tr, self.model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs,
+                                               depth_mask=depth_mask)
         loss = loss + get_regularization_loss(tr, self.model, outputs, pred_normal, global_step, self.end_iter)
         return loss
 

@@ -170,3 +170,43 @@ def test_pose_apply_equals_the_operator_chain(B, n):
     want = pa64.data.grad
     assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()), (got, want)
     assert float(got[[0, 1, 2, 3, 5, 6, 8]].abs().max()) == 0.0           # frames outside the batch: zero rows
+
+
+def test_fused_render_loss_equals_the_reference_chain():
+    """trainstep.get_gt_from_data + get_real_view_render_loss (the reference's morpheus.py:930-983 as torch operators) against
+    ops.real_view_render_loss: the weighted loss, its three terms, the composited target, the valid-depth mask and the gradients."""
+    from morpheus_amd import harness, ops, trainstep
+    torch.manual_seed(2)
+    N = 3000
+    tr = harness.load_config()["train"]
+    data = dict(image=torch.rand(1, 3, N, 1, device=DEV), depth=(torch.rand(1, N, 1, device=DEV) * 2.0 - 0.3).clamp(min=0.0),
+                mask=(torch.rand(1, N, 1, device=DEV) < 0.7).float())
+    rays_o = torch.randn(1, N, 3, device=DEV) * 0.2 + torch.tensor([0.0, 0.0, -1.2], device=DEV)
+    rays_d = torch.nn.functional.normalize(torch.randn(1, N, 3, device=DEV) * 0.3 + torch.tensor([0.0, 0.0, 1.0], device=DEV), dim=-1)
+    bg = torch.rand(N, 3, device=DEV)
+    image = torch.rand(1, N, 3, device=DEV)
+    depth = torch.rand(1, N, device=DEV) * 2
+    opac = torch.rand(1, N, 1, device=DEV)
+    opac[0, :20] = 0.0                      # outside the clip: no gradient
+    opac[0, 20:40] = 1.0
+    leaves = lambda: [t.clone().requires_grad_(True) for t in (image, depth, opac)]
+    # reference chain
+    i1, d1, o1 = leaves()
+    B, H, W = 1, N, 1
+    gt_rgb, gt_depth, gt_mask = trainstep.get_gt_from_data(data, bg, B, H, W)
+    pred_rgb = i1.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+    want = trainstep.get_real_view_render_loss(tr, pred_rgb, d1.reshape(B, 1, H, W), o1.reshape(B, 1, H, W), gt_rgb, gt_depth, gt_mask,
+                                               rays_o, rays_d)
+    want_mask, _ = trainstep._valid_depth_mask(gt_depth, gt_mask, rays_o, rays_d)
+    want.backward()
+    # fused
+    i2, d2, o2 = leaves()
+    got, terms, gt_flat, valid = ops.real_view_render_loss(i2, d2, o2, data["image"], data["depth"], data["mask"], bg, rays_o, rays_d,
+                                                           tr["rgb_weight"], tr["mask_weight"], tr["depth_weight"])
+    got.backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want)), (float(got), float(want))
+    assert torch.equal(gt_flat.view(1, 3, N, 1), gt_rgb) and torch.equal(valid.view(1, N, 1), want_mask)
+    assert 0 < float(valid.sum()) < N
+    for a, b, name in ((i2.grad, i1.grad, "image"), (d2.grad, d1.grad, "depth"), (o2.grad, o1.grad, "opacity")):
+        assert _rel(a, b) <= 3e-6, (name, _rel(a, b))
+    assert float(o2.grad[0, :40].abs().max()) == 0.0
