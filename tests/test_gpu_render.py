@@ -700,8 +700,8 @@ def test_fixed_capacity_sampling_equals_ragged_sampling(monkeypatch):
         assert torch.equal(ra[k], rb[k][:Ma]), k
     assert float(rb["weights"][Ma:].abs().max()) == 0.0
     for k in ("loss_normal_perturb", "normal_reg", "sdf_loss", "fs_loss", "loss_code"):
-        assert_close(rb[k], ra[k], 5e-6, k, floor=1e-6)     # sums of ~10^5 floats by atomics / a different block partition
-    assert abs(la - lb) <= 5e-6 * abs(la)
+        assert_close(rb[k], ra[k], 2e-5, k, floor=1e-6)     # sums of ~10^5 floats by atomics / a different block partition (measured 1.3e-6)
+    assert abs(la - lb) <= 2e-5 * abs(la)
     assert set(ga) == set(gb)
     for k in ga:
         rel = float((ga[k] - gb[k]).norm() / ga[k].norm().clamp_min(1e-30))
@@ -737,7 +737,7 @@ def test_graphed_real_view_step_replays_the_eager_step():
         ts.global_step = 4096 + 3                       # no occupancy refresh in the next steps
         return model, grid, ts, opt
 
-    # (i) pinned draws: six optimiser steps eager vs six replays of the captured step, from the same weights
+    # (i) pinned draws: four optimiser steps eager vs four replays of the captured step, from the same weights
     saved = (torch.rand, torch.rand_like, torch.randn_like, torch.randint)
     try:
         torch.rand = lambda *s, **kw: torch.full(s[0] if len(s) == 1 and isinstance(s[0], (list, tuple, torch.Size)) else s, 0.43, device=kw.get("device"))
@@ -748,7 +748,7 @@ def test_graphed_real_view_step_replays_the_eager_step():
             model, grid, ts, opt = build()
             p0 = opt.flat_p.clone()
             losses, first = [], None
-            for k in range(6):
+            for k in range(4):
                 opt.bucket.zero()
                 ts.begin_step()
                 fi = ts.frame_of_step()
@@ -770,7 +770,7 @@ def test_graphed_real_view_step_replays_the_eager_step():
         caps = gs.prepare()                              # several capacity buckets captured one after the other: the replays below
         assert len(caps) >= 3 and gs.n_captures == len(caps)       # use graphs that were NOT the first capture of the process
         graph_losses = []
-        for k in range(6):
+        for k in range(4):
             lg = gs()
             if k == 0:
                 rel = float((opt.bucket.flat - flat_first).norm() / flat_first.norm())
@@ -786,16 +786,17 @@ def test_graphed_real_view_step_replays_the_eager_step():
         for k, (a, b) in enumerate(zip(graph_losses, eager_losses)):
             # the first two steps agree to round-off (7 digits); Adam with eps = 1e-15 then amplifies the round-off of noise-sized
             # gradients (the padded layout sums the weight gradients in a different order: 5e-9 of the bucket) and the trajectories
-            # drift apart -- measured 3e-5 / 2-5e-4 / 5e-3 / 1e-2 at steps 3..6, next to 1e-7 / 3e-4 / 3-9e-4 / 3-5e-3 between two
-            # EAGER runs of the same six steps (printed above: atomics in the scatters make the eager step itself run-dependent)
-            assert abs(a - b) <= (1e-5 if k < 2 else (2e-4 if k == 2 else 4e-2)) * abs(b), (graph_losses, eager_losses)
-        # six Adam steps with eps = 1e-15: every touched entry moves by ~lr per step whatever its gradient's size, so the ~1 % of
-        # entries whose gradient is round-off noise step in a run-dependent direction (measured distance between the two runs:
-        # 0.18-0.20 of the distance moved; 0.13-0.14 between two eager runs).  The two displacement vectors must point the same way
+            # drift apart -- measured 2e-6 / 6-10e-5 at steps 3 and 4, next to 0-2e-7 / 1e-6-3e-5 between two EAGER runs of the same
+            # steps (printed above: atomics in the scatters make the eager step itself run-dependent); the growth is ~30x per step,
+            # which is why the comparison stops after four
+            assert abs(a - b) <= (1e-5 if k < 2 else (3e-5 if k == 2 else 2e-3)) * abs(b), (graph_losses, eager_losses)
+        # Adam steps with eps = 1e-15: every touched entry moves by ~lr per step whatever its gradient's size, so the ~1 % of
+        # entries whose gradient is round-off noise step in a run-dependent direction (measured after four steps: distance between
+        # the two runs 0.075-0.078 of the distance moved, cosine 0.997).  The displacements must point the same way
         da, db = (opt.flat_p - p_init).double(), (p_eager - p_init).double()
         cos = float((da * db).sum() / (da.norm() * db.norm()))
-        print("cosine of the two six-step displacements: %.5f, distance / moved: %.4f" % (cos, float((da - db).norm() / db.norm())))
-        assert cos >= 0.95, cos
+        print("cosine of the two four-step displacements: %.5f, distance / moved: %.4f" % (cos, float((da - db).norm() / db.norm())))
+        assert cos >= 0.99, cos
     finally:
         torch.rand, torch.rand_like, torch.randn_like, torch.randint = saved
     # (ii) un-pinned replays drive the optimiser
