@@ -1284,6 +1284,8 @@ def weighted_sum(pairs):
     if wt is None:
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("weighted_sum: a new set of loss weights inside a captured graph (run the step once eagerly first)")
+        if len(_WEIGHT_CACHE) >= 64:        # weights that change every step do not belong here (multiply the term instead)
+            _WEIGHT_CACHE.clear()
         wt = _WEIGHT_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=dev)
     return _WeightedSum.apply(wt, *[t for _, t in pairs])
 
