@@ -101,9 +101,12 @@ def get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_de
     return ops.weighted_sum(terms)
 
 
-def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs, depth_mask=None):
+def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs, depth_mask=None,
+                             single_frame=False):
     """morpheus.py:985-1029: SDF / free-space losses from the renderer plus one `model.density` query at the N
-    back-projected surface points (x and t of equal length, gradients into both hash tables, the warp and the codes)."""
+    back-projected surface points (x and t of equal length, gradients into both hash tables, the warp and the codes).
+    single_frame: every ray carries rays_t[0] (one batch row = one frame) -- the time goes in as an expanded scalar
+    and the query shares the render's per-frame code bias instead of building a per-sample one (same values)."""
     terms = []
     if tr["sdf_weight"] > 0:
         terms.append((tr["sdf_weight"], outputs["sdf_loss"]))
@@ -116,7 +119,10 @@ def get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_
             depth_mask, xyzs = _valid_depth_mask(gt_depth, gt_mask, rays_o, rays_d)
         else:                   # the mask the fused render loss already built (ops.real_view_render_loss)
             xyzs = rays_o + gt_depth.reshape(1, -1, 1) * rays_d
-        results = model.density(xyzs.reshape(-1, 3), t=rays_t.reshape(-1, 1))
+        tt = rays_t.reshape(-1, 1)
+        if single_frame:
+            tt = tt[:1].expand(tt.shape[0], 1)
+        results = model.density(xyzs.reshape(-1, 3), t=tt)
         sdf, albedo = results["sdf"], results["albedo"]
         masked_color = albedo.view(*depth_mask.shape, 3).permute(0, 3, 1, 2).contiguous()
         surf_color_loss = F.mse_loss(masked_color * depth_mask[None, ...], gt_rgb * depth_mask[None, ...])
@@ -232,7 +238,7 @@ class RealViewTrainStep:
             loss = get_real_view_render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask, rays_o, rays_d)
             depth_mask = None
         loss = loss + get_real_view_point_loss(tr, self.model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs,
-                                               depth_mask=depth_mask)
+                                               depth_mask=depth_mask, single_frame=(B == 1 and self.r.frame_batched))
         loss = loss + get_regularization_loss(tr, self.model, outputs, pred_normal, global_step, self.end_iter)
         return loss
 

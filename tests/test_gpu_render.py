@@ -453,6 +453,12 @@ def test_real_view_step_vs_reference_golden():
     l_point = trainstep.get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, data["rays_o"], data["rays_d"],
                                                  data["rays_t"], res)
     l_reg = trainstep.get_regularization_loss(tr, model, res, None, 1000, 220000)
+    # the same query with the time as an expanded scalar (what RealViewTrainStep passes for a one-row batch): one per-frame code
+    # bias instead of N per-sample ones, the same value
+    with model.operand_scope():
+        l_point_sf = trainstep.get_real_view_point_loss(tr, model, gt_rgb, gt_depth, gt_mask, data["rays_o"], data["rays_d"],
+                                                        data["rays_t"], res, single_frame=True)
+    assert_close(l_point_sf, l_point, 2e-6, "point loss, single-frame time")
     assert_close(l_render, g["realview|loss_render"], TOL, "render loss")
     assert_close(l_point, g["realview|loss_point"], 2e-4, "point loss")
     assert_close(l_reg, g["realview|loss_reg"], 1e-2, "regularisation loss")
