@@ -280,10 +280,11 @@ class HotPathRenderer:
                 results["loss_deform_perturb_t"] = l1_mean(deform, deform_pt)
                 results["loss_topo_perturb_t"] = l1_mean(topo_now, topo_pt)
             if tr["code_reg"] > 0 and not cano:
-                t0 = time_step[:1]
-                code = model.get_deform_code(t0)
-                cp = model.get_deform_code(t0 - 1 / self.num_frames)
-                cn = model.get_deform_code(t0 + 1 / self.num_frames)
+                # the three code samples (t0, t0 - 1/F, t0 + 1/F: morpheus.py:783-787) from ONE launch each way: the offsets are a
+                # cached device constant (t0 + (-d) is t0 - d bit for bit), the rows come apart with unbind (one stack backward)
+                d = 1.0 / self.num_frames
+                offs = self._const(("code_reg_offsets", d), lambda: torch.tensor([[0.0], [-d], [d]]), time_step.device)
+                code, cp, cn = model.get_deform_code(time_step[:1] + offs).unbind(0)
                 results["loss_code"] = torch.square(2 * code - cp - cn).mean()
             if tr["normal_smooth_2d"] > 0 and normals is not None and (not real_view):
                 # accumulate_along_rays(weights, (normals+1)/2) with the LIVE weights (morpheus.py:775): the density
