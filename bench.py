@@ -581,7 +581,7 @@ def run_one(args):
                                           capacity_of_last_step=g.last_capacity, samples_of_last_step=g.last_samples,
                                           overflowed_batches=int(g.check_overflow()) + g.overflows, margin=g.margin,
                                           graphs_captured=g.n_captures, captures_inside_the_timed_region=g.n_captures - captures0,
-                                          memset_nodes_replaced_by_fill_kernels=g.memset_nodes_replaced,
+                                          memset_nodes_replaced_by_fill_kernels=g.memset_nodes_replaced, nodes_per_replayed_step=g.last_graph_nodes,
                                           note="sample_points_per_step_per_gpu is the mean CAPACITY the kernels ran on (padding "
                                                "included); each batch is drawn and counted one step ahead on a side stream to pick its bucket")
     elif args.graph:

@@ -286,7 +286,7 @@ class GraphedRealViewStep:
         self.bucket_step, self.margin, self.lookahead = int(bucket_step), float(margin), bool(lookahead)
         self.graphs = {}            # (capacity, max_level) -> dict(graph, loss, n_valid, missing)
         self.last_capacity, self.last_samples, self.overflows, self.n_captures = None, None, 0, 0
-        self.memset_nodes_replaced = 0
+        self.memset_nodes_replaced, self.last_graph_nodes = 0, 0
 
     # ---- the batch: drawn one step ahead on a side stream, handed to the graphs through static buffers ---------------------
     def _stage(self, fi: int, for_step: int, after_main: bool):
@@ -350,6 +350,7 @@ class GraphedRealViewStep:
         # small memset nodes replay wrongly on ROCm 7.2 (csrc/graph.hip); the library has none, PyTorch's multi-block
         # reductions (every .sum() over the sample points, and autograd's broadcast gradients) zero their semaphores with one
         self.memset_nodes_replaced += ops.graph_replace_memset_nodes(graph)
+        self.last_graph_nodes = ops.graph_memset_nodes(graph)[0]      # launches one replay issues (kernel + copy nodes)
         graph.instantiate()
         self.grid.overflow.copy_(keep)         # the warm-up passes ran on whatever batch the static buffers held
         # keep the loss VALUE (same storage), not its autograd graph: a live graph keeps its AccumulateGrad nodes -- and the
