@@ -3,7 +3,7 @@
 
   python tools/collect_profiles.py [round-tag, default r01]
 
-Inputs (written by tools/gpu/round.sh and tools/gpu/pmc.sh on the GPU box):
+Inputs (written by tools/gpu/r3_round.sh on the GPU box):
   gpurun_out/bench.log, bench_cfg2.log, bench_cfg3b.log   -> profiles/<tag>_bench_<workload>.json (the JSON line)
   gpurun_out/prof/runc/*_kernel_stats.csv                  -> profiles/<tag>_bench_cfg3_kernel_stats.csv
   gpurun_out/prof_cfg3b/runc/*_kernel_stats.csv            -> profiles/<tag>_bench_cfg3b_kernel_stats.csv
