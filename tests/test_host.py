@@ -368,3 +368,21 @@ def test_model_switches_shapes_and_refusals():
         kw.update(bad)
         with pytest.raises(NotImplementedError):
             scene_representation(cfg, 1.01, **kw)
+
+
+def test_weighted_sum_is_the_chain_of_adds_on_any_device():
+    """ops.weighted_sum is plain torch (stack, multiply, add): the reference's `loss = loss + w * term` chains in three launches.
+    Value, gradients, and the weight-vector cache stays bounded when a caller feeds it changing weights."""
+    from morpheus_amd import ops
+    ts = [torch.tensor(v, requires_grad=True) for v in (0.3, -1.2, 4.0, 0.07)]
+    ws = (1.0, 0.5, 0.01, 30.0)
+    got = ops.weighted_sum(list(zip(ws, ts)))
+    want = sum(w * float(t) for w, t in zip(ws, ts))
+    assert abs(float(got) - want) <= 1e-6 * abs(want)
+    (got * 2.0).backward()
+    for w, t in zip(ws, ts):
+        assert abs(float(t.grad) - 2.0 * w) <= 1e-6 * abs(2.0 * w)
+    assert ops.weighted_sum([]) == 0
+    for k in range(200):
+        ops.weighted_sum([(1.0 + k, ts[0].detach())])
+    assert len(ops._WEIGHT_CACHE) <= 64
