@@ -587,14 +587,19 @@ extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_
                                   int32_t *brick_start, void *stream) {
     if (M == 0) return MH_OK;
     if (!x || !workspace || !perm || !brick_start || M < 0 || M > 0x7fffffffLL || !(bound > 0.f)) return MH_ERR_ARG;
-    const int64_t chunk = (M + BIN_BLOCKS - 1) / BIN_BLOCKS;
+    // histogram blocks: one per 1024 points, 8 .. BIN_BLOCKS.  The column scan walks the blocks' histograms serially (one dependent
+    // L2 round trip per 8 rows: 14 us at 256 blocks whatever M is), the histogram / scatter kernels want many blocks: measured per
+    // call at 22 000 / 140 000 points, 256 blocks 30 / 30 us, one per 4096 points 20 / 37 us
+    int64_t G = (M + 1023) / 1024;
+    G = G < 8 ? 8 : (G > BIN_BLOCKS ? BIN_BLOCKS : G);
+    const int64_t chunk = (M + G - 1) / G;
     int32_t *block_hist = workspace, *brick_cnt = workspace + (int64_t)BIN_BLOCKS * (NBRK + 1);
-    hipLaunchKernelGGL(bin_hist_kernel, dim3(BIN_BLOCKS), dim3(256), 0, mh_stream(stream), x, M, chunk, bound, 2.0f * bound,
+    hipLaunchKernelGGL(bin_hist_kernel, dim3((unsigned)G), dim3(256), 0, mh_stream(stream), x, M, chunk, bound, 2.0f * bound,
                        block_hist);
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((NBRK + 1 + 255) / 256), dim3(256), 0, mh_stream(stream), block_hist,
-                       BIN_BLOCKS, brick_cnt);
+                       (int)G, brick_cnt);
     hipLaunchKernelGGL(bin_rowscan_kernel, dim3(1), dim3(1024), 0, mh_stream(stream), brick_cnt, brick_start);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(BIN_BLOCKS), dim3(256), 0, mh_stream(stream), x, M, chunk, bound,
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)G), dim3(256), 0, mh_stream(stream), x, M, chunk, bound,
                        2.0f * bound, block_hist, brick_start, perm);
     MH_CHECK_LAUNCH();
     return MH_OK;

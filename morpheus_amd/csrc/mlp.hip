@@ -514,7 +514,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
 // operand; row stride 36 floats keeps ds_read_b128 conflict-free and 16-byte aligned) and accumulates dW_l.
 // One wave per SIMD (up to 512 registers), persistent 4-wave blocks, transposed weight packs resident in LDS; the two
 // nets are two launches (color first: it hands d(geo) to the sdf launch through a 4 KB-per-tile scratch) so that either
-// accumulator set fits.  Per-wave partial sums go to the workspace in wgrad_kernel's [chunk][out x in] format and
+// accumulator set fits.  Per-WORKGROUP partial sums (the four waves add up through LDS) go to the workspace in wgrad_kernel's [chunk][out x in] format and
 // wgrad_reduce_kernel finishes as before.
 // =====================================================================================
 #define FUSED_THREADS 256
@@ -587,6 +587,26 @@ __device__ __forceinline__ void dw_store(float *__restrict__ dw, const f32x16 (&
     for (int n = 0; n < NI; n++)
 #pragma unroll
         for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, h)) * in_pad + 32 * n + i] = acc[n][r];
+}
+
+// Block-level sum of the four waves' weight-gradient accumulators, through the LDS the transposed weights no longer need once the
+// tile loop is over: ONE partial per workgroup goes to the workspace instead of four (the partial sums of a 140 000-point call were
+// 57 MB written and read back by wgrad_reduce_kernel, 23-38 us of reduction per call; waves add in the fixed order 1, 2, 3).
+template <int N>
+__device__ __forceinline__ float *acc_to_lds(const f32x16 (&a)[N], float *__restrict__ p, int lane) {
+#pragma unroll
+    for (int n = 0; n < N; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) p[(n * 16 + r) * 64 + lane] = a[n][r];
+    return p + N * 1024;
+}
+template <int N>
+__device__ __forceinline__ const float *acc_add_lds(f32x16 (&a)[N], const float *__restrict__ p, int lane) {
+#pragma unroll
+    for (int n = 0; n < N; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[n][r] += p[(n * 16 + r) * 64 + lane];
+    return p + N * 1024;
 }
 
 #define FUSED_LAYER(KS, MT, w, bin, acc) mfma_layer_z<KS, MT>(w, bin, acc, lane)
@@ -714,12 +734,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // partial sums of this wave: layers in the launch's order c0, c1, c2 = part.dw[0..2]
-    dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 32 * 64, w2, 0, 64, i, h);
+    if (gmax) {
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-        dw_store<2>(ws + part.dw[1] + (int64_t)chunk * 64 * 64, w1[mt], mt, 64, i, h);
-        dw_store<2>(ws + part.dw[0] + (int64_t)chunk * 64 * 64, w0[mt], mt, 64, i, h);
+        for (int o = 32; o > 0; o >>= 1) max_c = max(max_c, (uint32_t)__shfl_xor((int)max_c, o));
+        if (lane == 0 && max_c) atomicMax(gmax + 1, max_c);
     }
     b2 += __shfl_xor(b2, 32);
 #pragma unroll
@@ -727,18 +745,52 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         b1[mt] += __shfl_xor(b1[mt], 32);
         b0[mt] += __shfl_xor(b0[mt], 32);
     }
-    if (h == 0) {
-        ws[part.db[2] + (int64_t)chunk * 32 + i] = b2;
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            ws[part.db[1] + (int64_t)chunk * 64 + 32 * mt + i] = b1[mt];
-            ws[part.db[0] + (int64_t)chunk * 64 + 32 * mt + i] = b0[mt];
+    // the workgroup's partial = the sum of its four waves' (acc_to_lds above): 10 accumulator tiles + 5 bias rows = 41 KB of LDS
+    float *red = reinterpret_cast<float *>(lds_fused);
+    for (int src = 1; src < FUSED_THREADS / 64; src++) {
+        __syncthreads();
+        if (wave == src) {
+            float *q = acc_to_lds<2>(w2, red, lane);
+            q = acc_to_lds<2>(w1[0], q, lane);
+            q = acc_to_lds<2>(w1[1], q, lane);
+            q = acc_to_lds<2>(w0[0], q, lane);
+            q = acc_to_lds<2>(w0[1], q, lane);
+            q[0 * 64 + lane] = b2;
+            q[1 * 64 + lane] = b1[0];
+            q[2 * 64 + lane] = b1[1];
+            q[3 * 64 + lane] = b0[0];
+            q[4 * 64 + lane] = b0[1];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float *q = acc_add_lds<2>(w2, red, lane);
+            q = acc_add_lds<2>(w1[0], q, lane);
+            q = acc_add_lds<2>(w1[1], q, lane);
+            q = acc_add_lds<2>(w0[0], q, lane);
+            q = acc_add_lds<2>(w0[1], q, lane);
+            b2 += q[0 * 64 + lane];
+            b1[0] += q[1 * 64 + lane];
+            b1[1] += q[2 * 64 + lane];
+            b0[0] += q[3 * 64 + lane];
+            b0[1] += q[4 * 64 + lane];
         }
     }
-    if (gmax) {
+    if (wave != 0) return;
+    // partial sums of this workgroup: layers in the launch's order c0, c1, c2 = part.dw[0..2]
+    const int64_t pchunk = blockIdx.x;
+    dw_store<2>(ws + part.dw[2] + pchunk * 32 * 64, w2, 0, 64, i, h);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) max_c = max(max_c, (uint32_t)__shfl_xor((int)max_c, o));
-        if (lane == 0 && max_c) atomicMax(gmax + 1, max_c);
+    for (int mt = 0; mt < 2; mt++) {
+        dw_store<2>(ws + part.dw[1] + pchunk * 64 * 64, w1[mt], mt, 64, i, h);
+        dw_store<2>(ws + part.dw[0] + pchunk * 64 * 64, w0[mt], mt, 64, i, h);
+    }
+    if (h == 0) {
+        ws[part.db[2] + pchunk * 32 + i] = b2;
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            ws[part.db[1] + pchunk * 64 + 32 * mt + i] = b1[mt];
+            ws[part.db[0] + pchunk * 64 + 32 * mt + i] = b0[mt];
+        }
     }
 }
 
@@ -932,20 +984,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             }
         }
     }
-    // partial sums: layers s0, s1, s2 = part.dw[0..2]; the sdf-only pass fills tile 1 of s2 only (tile 0 = zeros)
+    if (gmax) {
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-        dw_store<3>(ws + part.dw[0] + (int64_t)chunk * 64 * 96, w0[mt], mt, 96, i, h);
-        dw_store<2>(ws + part.dw[1] + (int64_t)chunk * 64 * 64, w1[mt], mt, 64, i, h);
-    }
-    if (WITH_COLOR) {
-#pragma unroll
-        for (int mt = 0; mt < MT2; mt++) dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 64 * 64, w2[mt], mt, 64, i, h);
-    } else {
-        f32x16 z[2];
-        acc_zero<2>(z);
-        dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 64 * 64, z, 0, 64, i, h);
-        dw_store<2>(ws + part.dw[2] + (int64_t)chunk * 64 * 64, w2[0], 1, 64, i, h);
+        for (int o = 32; o > 0; o >>= 1) max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
+        if (lane == 0 && max_s) atomicMax(gmax + 0, max_s);
     }
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
@@ -953,18 +995,66 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         b1[mt] += __shfl_xor(b1[mt], 32);
         b0[mt] += __shfl_xor(b0[mt], 32);
     }
+    // the workgroup's partial = the sum of its four waves' (acc_to_lds above): up to 14 accumulator tiles + 6 bias rows = 57.5 KB
+    float *red = reinterpret_cast<float *>(lds_fused);
+    for (int src = 1; src < FUSED_THREADS / 64; src++) {
+        __syncthreads();
+        if (wave == src) {
+            float *q = red;
+#pragma unroll
+            for (int mt = 0; mt < MT2; mt++) q = acc_to_lds<2>(w2[mt], q, lane);
+            q = acc_to_lds<2>(w1[0], q, lane);
+            q = acc_to_lds<2>(w1[1], q, lane);
+            q = acc_to_lds<3>(w0[0], q, lane);
+            q = acc_to_lds<3>(w0[1], q, lane);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                q[(0 + mt) * 64 + lane] = b2[mt];
+                q[(2 + mt) * 64 + lane] = b1[mt];
+                q[(4 + mt) * 64 + lane] = b0[mt];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float *q = red;
+#pragma unroll
+            for (int mt = 0; mt < MT2; mt++) q = acc_add_lds<2>(w2[mt], q, lane);
+            q = acc_add_lds<2>(w1[0], q, lane);
+            q = acc_add_lds<2>(w1[1], q, lane);
+            q = acc_add_lds<3>(w0[0], q, lane);
+            q = acc_add_lds<3>(w0[1], q, lane);
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                b2[mt] += q[(0 + mt) * 64 + lane];
+                b1[mt] += q[(2 + mt) * 64 + lane];
+                b0[mt] += q[(4 + mt) * 64 + lane];
+            }
+        }
+    }
+    if (wave != 0) return;
+    // partial sums of this workgroup: layers s0, s1, s2 = part.dw[0..2]; the sdf-only pass fills tile 1 of s2 only (tile 0 = zeros)
+    const int64_t pchunk = blockIdx.x;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        dw_store<3>(ws + part.dw[0] + pchunk * 64 * 96, w0[mt], mt, 96, i, h);
+        dw_store<2>(ws + part.dw[1] + pchunk * 64 * 64, w1[mt], mt, 64, i, h);
+    }
+    if (WITH_COLOR) {
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++) dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, w2[mt], mt, 64, i, h);
+    } else {
+        f32x16 z[2];
+        acc_zero<2>(z);
+        dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, z, 0, 64, i, h);
+        dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, w2[0], 1, 64, i, h);
+    }
     if (h == 0) {
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
-            ws[part.db[2] + (int64_t)chunk * 64 + 32 * mt + i] = b2[mt];
-            ws[part.db[1] + (int64_t)chunk * 64 + 32 * mt + i] = b1[mt];
-            ws[part.db[0] + (int64_t)chunk * 64 + 32 * mt + i] = b0[mt];
+            ws[part.db[2] + pchunk * 64 + 32 * mt + i] = b2[mt];
+            ws[part.db[1] + pchunk * 64 + 32 * mt + i] = b1[mt];
+            ws[part.db[0] + pchunk * 64 + 32 * mt + i] = b0[mt];
         }
-    }
-    if (gmax) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
-        if (lane == 0 && max_s) atomicMax(gmax + 0, max_s);
     }
 }
 
@@ -1915,7 +2005,7 @@ static inline int fused_blocks(int64_t n_tiles) {
 }
 
 extern "C" int64_t mh_field_bwd_fused_workspace_floats(int64_t M) {
-    const int64_t chunks = (int64_t)fused_blocks(n_tiles_for(M)) * (FUSED_THREADS / 64);
+    const int64_t chunks = (int64_t)fused_blocks(n_tiles_for(M));     // one partial per workgroup
     int64_t per = 0;
     for (int l = 0; l < 6; l++) per += (int64_t)FUSED_IN[l] * FUSED_OUT[l] + FUSED_OUT[l];
     return chunks * per;
@@ -1943,7 +2033,7 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
     }
     const int64_t n_tiles = n_tiles_for(M);
     const int blocks = fused_blocks(n_tiles);
-    const int64_t chunks = (int64_t)blocks * (FUSED_THREADS / 64);
+    const int64_t chunks = blocks;                  // one partial per workgroup (its four waves add up through LDS)
     // workspace: [dW partials s0 | s1 | s2 | c0 | c1 | c2][db partials s0 | ... | c2], each [chunks][...]
     int64_t dw_off[6], db_off[6], off = 0, dw_total = 0, db_total = 0;
     for (int l = 0; l < 6; l++) {
@@ -1978,7 +2068,7 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
     }
 #undef FUSED_LAUNCH_SDF
     MH_CHECK_LAUNCH();
-    // reduce the per-wave partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format).  On the sdf-only pass the
+    // reduce the per-workgroup partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format).  On the sdf-only pass the
     // colour net's segments are reduced over ZERO chunks, i.e. written as 0 by the same launch (no separate memsets)
     const int n_l = with_color ? 6 : 3;
     WgReduce rd;
