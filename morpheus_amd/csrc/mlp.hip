@@ -1792,7 +1792,7 @@ extern "C" int mh_field_fwd(const float *xc, const float *feat_s, const float *f
 #ifndef WG_MERGED_REGS_TILES
 #define WG_MERGED_REGS_TILES 256      // from this many tiles on (below the line above): the merged launch uses the slice-once body
 #endif
-static inline int wg_chunks(int out_pad, int64_t n_tiles) {
+static inline int wg_chunks(int out_pad, int64_t n_tiles, int n_layers) {
     // 4 waves per CU per launch = exactly one per SIMD (see wgrad_kernel) whatever the number of output tiles
     // large batches (the per-layer launches, from 16 384 tiles on): WG_REG_WAVES workgroups per CU (wgrad_regs_b3_kernel)
     int64_t c = (int64_t)(4 * ((n_tiles >= WG_PER_LAYER_TILES && out_pad == 128) ? WG_REG_WAVES : 1) * mh_cu_count()) / (out_pad / 32);
@@ -1802,6 +1802,10 @@ static inline int wg_chunks(int out_pad, int64_t n_tiles) {
         // partials against 250 MB of operands.  At least 8 tiles per chunk, but never fewer than 32 chunks per layer.
         const int64_t cap = n_tiles / 8 > 32 ? n_tiles / 8 : 32;
         if (c > cap) c = cap;
+        // ... and the merged launch needs no more than ~4 workgroups per CU over ALL its layers: at 4 400 tiles 12 x 256 chunks
+        // wrote 168 MB of partials (44 us of reduction) where 12 x 85 fill the chip as well
+        const int64_t fill = (4 * (int64_t)mh_cu_count() + n_layers - 1) / (n_layers > 0 ? n_layers : 1);
+        if (c > fill && fill >= 32) c = fill;
     }
     if (c > n_tiles) c = n_tiles;
     return (int)(c < 1 ? 1 : c);
@@ -1811,7 +1815,7 @@ extern "C" int64_t mh_mlp_wgrad_workspace_floats(int32_t n_layers, const int32_t
                                                  const int32_t *out_feats_host, int64_t n_tiles) {
     int64_t tot = 0;
     for (int l = 0; l < n_layers; l++)
-        tot += (int64_t)wg_chunks(out_feats_host[l], n_tiles) * ((int64_t)in_feats_host[l] * out_feats_host[l] + out_feats_host[l]);
+        tot += (int64_t)wg_chunks(out_feats_host[l], n_tiles, n_layers) * ((int64_t)in_feats_host[l] * out_feats_host[l] + out_feats_host[l]);
     return tot;
 }
 
@@ -1835,11 +1839,11 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
     int64_t dw_poff[WG_MAX_LAYERS], db_poff[WG_MAX_LAYERS];
     for (int l = 0; l < n_layers; l++) {
         dw_poff[l] = woff;
-        woff += (int64_t)wg_chunks(out_feats_host[l], n_tiles) * in_feats_host[l] * out_feats_host[l];
+        woff += (int64_t)wg_chunks(out_feats_host[l], n_tiles, n_layers) * in_feats_host[l] * out_feats_host[l];
     }
     for (int l = 0; l < n_layers; l++) {
         db_poff[l] = woff;
-        woff += (int64_t)wg_chunks(out_feats_host[l], n_tiles) * out_feats_host[l];
+        woff += (int64_t)wg_chunks(out_feats_host[l], n_tiles, n_layers) * out_feats_host[l];
     }
     int64_t dw_total = 0;
     for (int l = 0; l < n_layers; l++) dw_total += (int64_t)in_feats_host[l] * out_feats_host[l];
@@ -1855,7 +1859,7 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
     all.first_block[0] = 0;
     for (int l = 0; l < n_layers; l++) {
         const int in = in_feats_host[l], out = out_feats_host[l];
-        const int chunks = wg_chunks(out, n_tiles);
+        const int chunks = wg_chunks(out, n_tiles, n_layers);
         all.act_off[l] = act_off_host[l];
         all.dpre_off[l] = dpre_off_host[l];
         all.out_pad[l] = out;
