@@ -250,14 +250,16 @@ __global__ __launch_bounds__(256) void sdf_losses_kernel(const float *__restrict
                                                          const float *__restrict__ rays_depth, const float *__restrict__ rays_mask,
                                                          float trunc, int64_t M, const int32_t *__restrict__ n_valid,
                                                          float *__restrict__ sums /*[3]: fs, sl, nd*/) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride over the samples, then ONE set of atomics per workgroup (<= 128 workgroups): a wave-level atomicAdd per 64
+    // samples serialised 6 900 same-address atomics at the 140 000 samples of a training step (80 us; now 6)
+    const int64_t rows = n_valid ? min((int64_t)max(*n_valid, 0), M) : M;
     float fs = 0.f, sl = 0.f, nd = 0.f;
-    if (m < M && (!n_valid || m < (int64_t)*n_valid)) {
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < rows; m += (int64_t)gridDim.x * blockDim.x) {
         const int r = ray_idx[m];
         const SdfLossTerm o = sdf_loss_term((ts[m] + te[m]) / 2.0f, rays_depth[r], pred[m], trunc, rays_mask ? rays_mask[r] > 0.5f : true);
-        fs = o.fs;
-        sl = o.sl;
-        nd = o.nz ? 1.0f : 0.0f;
+        fs += o.fs;
+        sl += o.sl;
+        nd += o.nz ? 1.0f : 0.0f;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -265,11 +267,14 @@ __global__ __launch_bounds__(256) void sdf_losses_kernel(const float *__restrict
         sl += __shfl_xor(sl, o);
         nd += __shfl_xor(nd, o);
     }
+    __shared__ float red[3][4];
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(sums + 0, fs);
-        atomicAdd(sums + 1, sl);
-        atomicAdd(sums + 2, nd);
+        red[0][threadIdx.x >> 6] = fs;
+        red[1][threadIdx.x >> 6] = sl;
+        red[2][threadIdx.x >> 6] = nd;
     }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(sums + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
 }
 
 // g_pred[m] = (g_fs * dfs_m + g_sl * dsl_m) / nd;  g = [g_fs, g_sl] on the device, nd = sums[2] of the forward launch
@@ -384,7 +389,8 @@ extern "C" int mh_sdf_losses_fwd(const float *pred_sdf, const float *t_starts, c
     if (!mh_zero_async(sums, 3 * sizeof(float), mh_stream(stream))) return MH_ERR_LAUNCH;
     if (M == 0) return MH_OK;
     if (M < 0 || !pred_sdf || !t_starts || !t_ends || !ray_idx || !rays_depth) return MH_ERR_ARG;
-    hipLaunchKernelGGL(sdf_losses_kernel, dim3(blocks_for(M)), dim3(256), 0, mh_stream(stream), pred_sdf, t_starts, t_ends, ray_idx,
+    const unsigned blocks = blocks_for(M) < 128u ? blocks_for(M) : 128u;
+    hipLaunchKernelGGL(sdf_losses_kernel, dim3(blocks), dim3(256), 0, mh_stream(stream), pred_sdf, t_starts, t_ends, ray_idx,
                        rays_depth, rays_mask, trunc, M, n_valid, sums);
     MH_CHECK_LAUNCH();
     return MH_OK;
