@@ -47,6 +47,20 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mh_composite_fwd(*([None] * 10), 5, None) == 1
     assert lib.mh_warp_fwd(*([None] * 8), 6, None, None, None, 128, None) == 1
     assert lib.mh_field_fwd(*([None] * 7), 7, 1, None, None, None, None, 128, None) == 1        # n_bands > 6
+    # round-3 entry points: the caller-side glue kernels and the graph pass
+    assert lib.mh_masked_mean_fwd(9, None, None, None, 0, 1, None, None, None, None) == 1                # unknown kind
+    assert lib.mh_masked_mean_fwd(4, None, None, None, 0, 2, None, None, None, None) == 1                # eikonal rows are [M,3]
+    assert lib.mh_masked_mean_fwd(5, None, None, None, 8, 3, None, None, None, None) == 1                # |a - b| needs b
+    assert lib.mh_masked_mean_bwd(2, None, None, None, 0, 1, None, None, None, None, None, None) == 1    # no output asked for
+    assert lib.mh_masked_mean_workspace_floats() == 1024
+    assert lib.mh_ortho_perturb_fwd(None, None, None, 0.1, 0, None, None) == 0 and lib.mh_ortho_perturb_fwd(None, None, None, 0.1, 4, None, None) == 1
+    assert lib.mh_pose_apply_fwd(None, None, None, None, 0, 128, None, None, None) == 0
+    assert lib.mh_pose_apply_fwd(None, None, None, None, 2, 128, None, None, None) == 1
+    assert lib.mh_pose_apply_bwd(None, None, None, 70000, 1, 10, None, None, None, None, None) == 1      # more rows than a grid dimension
+    assert lib.mh_pose_bwd_workspace_floats(3, 2500) == 3 * 3 * 12
+    assert lib.mh_render_loss_fwd(*([None] * 9), 5, 1.0, 1.0, 1.0, None, None, None, None) == 1
+    assert lib.mh_render_loss_bwd(*([None] * 7), 0, 1.0, 1.0, 1.0, None, None, None, None, None) == 0
+    assert lib.mh_graph_count_memset_nodes(None, None, None, None) == 1 and lib.mh_graph_replace_memset_nodes(None, None) == 1
 
 
 def test_no_cpu_fallback():
