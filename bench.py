@@ -16,13 +16,18 @@ torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE as given.
 
 Other workloads (parity / tier cases, not the headline): cfg2 (canonical field only), cfg3b (deform + FD normals),
 train_real (the reference's real-view training step, morpheus.py:1147-1236: 2048 rays of one frame, occupancy-marched
-ragged samples, albedo_normal, shipped regularisers, point loss, pose optimisation, occupancy refresh every 16 steps),
-density128 (forward-only model.density on a 128^3 grid: export_mesh / update_occ_grid's query, morpheus.py:367-408).
+ragged samples, albedo_normal, shipped regularisers, point loss, pose optimisation, occupancy refresh every 16 steps;
+--glue reference keeps the reference's own caller-side loss code), train_virtual (its virtual-view step, :1393-1408: a whole
+72^2 .. 180^2 novel view, random shading, SDS replaced by an injected pred_rgb gradient), density128 (forward-only
+model.density on a 128^3 grid: export_mesh / update_occ_grid's query, morpheus.py:367-408).  The default run
+(`python bench.py`) carries train_real (eager, HIP-graph replay, reference glue) and train_virtual (72^2, 180^2) beside the
+cfg3 headline under the keys `train_real` / `train_virtual`, per-kernel timers off.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the step's LARGEST time item (the weight-gradient group included), SURVEY 8(d): algorithmic FLOPs / HIP-event
-                  time vs the peak of the matrix pipe the kernels issue on, next to the HBM view (parked bytes, algorithmic
-                  bytes, PMC traffic)
+  roofline     -- the step's LARGEST time item (the weight-gradient group included), SURVEY 8(d): top-level frac = algorithmic
+                  FLOPs / HIP-event time / (dense peak of the matrix pipe the kernels issue on / slice products per fp32 MAC);
+                  beside it the HBM view (parked bytes, algorithmic bytes, PMC traffic) and `per_kernel` with the same numbers
+                  for every MLP entry of the step
   cpu_baseline -- the CPU oracle ("port") timed on a bounded sample of the same workload
   modes        -- N=1: the three arithmetic modes (b3 / f32 / h2), each timed in its own process; the top-level numbers are
                   the faster fp32-faithful one's
@@ -49,7 +54,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 L2_PEAK_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 bandwidth
 GRID_FWD_BYTES, GRID_BWD_BYTES = 1164, 2188   # per point per encoder
 GRID_GATHERS_PER_POINT = 16 * 8   # 8 corners x 16 levels, one 8-byte row each -> one 64-byte L2 sector each (worst case)
-WORKLOADS = ["cfg3", "cfg2", "cfg3b", "train_real", "density128"]
+WORKLOADS = ["cfg3", "cfg2", "cfg3b", "train_real", "train_virtual", "density128"]
 
 
 def parse_args(argv=None):
@@ -60,9 +65,21 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=None, help="default 5 (15 for cfg2)")
     ap.add_argument("--workload", default="cfg3", choices=WORKLOADS,
                     help="cfg3: deform field, albedo (headline); cfg2: canonical only; cfg3b: deform + albedo_normal "
-                         "shading (FD normals); train_real: the reference's real-view training step; density128: "
+                         "shading (FD normals); train_real: the reference's real-view training step; train_virtual: its "
+                         "virtual-view step (whole novel view, SDS replaced by an injected pred_rgb gradient); density128: "
                          "forward-only field query on a 128^3 grid")
-    ap.add_argument("--rays", type=int, default=None, help="rays per GPU per step (default 16384; 2048 for train_real)")
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU per step (default 16384; 2048 for train_real; "
+                                                           "--virtual-res squared for train_virtual)")
+    ap.add_argument("--virtual-res", type=int, default=72,
+                    help="train_virtual: side of the rendered novel view (datasets/dataset.py:538-541: novel_view_scale x 360 "
+                         "= 72 at the start of training, 180 at novel_view_scale_final)")
+    ap.add_argument("--glue", default="fused", choices=["fused", "reference"],
+                    help="train_real: caller-side loss code.  fused = this build's rewrite (one launch per loss group, one operand "
+                         "scope per step); reference = the reference's own operator chains and a loss.item() per step around the "
+                         "swapped-in render_rays -- what INTEGRATION.md's three edits alone give")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default run only: skip the extra workloads (train_real eager / replayed / reference glue, train_virtual) "
+                         "that ride beside the cfg3 headline")
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024)
@@ -79,11 +96,13 @@ def parse_args(argv=None):
                          "disables the per-kernel event timers")
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = {"train_real": 32, "cfg2": 60}.get(args.workload, 20)
+        args.steps = {"train_real": 32, "train_virtual": 32, "cfg2": 60}.get(args.workload, 20)
     if args.warmup is None:
         args.warmup = 15 if args.workload == "cfg2" else 5
     if args.rays is None:
-        args.rays = 2048 if args.workload == "train_real" else 128 * 128
+        args.rays = {"train_real": 2048, "train_virtual": args.virtual_res ** 2}.get(args.workload, 128 * 128)
+    if args.workload == "train_virtual":
+        args.rays = args.virtual_res ** 2
     return args
 
 
@@ -229,7 +248,7 @@ def build_train_real(args, rank, world, dev):
     grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(dev)
     rend = HotPathRenderer(model, cfg, grid, 200)
     frames = trainstep.make_frames([(25 * rank + 8 * k) % 200 for k in range(8)], 256, 256, dev)
-    ts = trainstep.RealViewTrainStep(rend, frames, ray_num=args.rays)
+    ts = trainstep.RealViewTrainStep(rend, frames, ray_num=args.rays, glue=args.glue)
     ts.epoch = 1000                                       # mid-training: progressive level 0.75
     opt = FlatAdam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
     bucket = opt.bucket
@@ -247,10 +266,22 @@ def build_train_real(args, rank, world, dev):
         graphed = trainstep.GraphedRealViewStep(ts, bucket)
         graphed.prepare()                    # capture the capacity buckets of the frames' batches up front (not in the timed region)
 
+        assert args.glue == "fused", "--graph replays this build's own step; the reference's glue synchronises every step"
+
         def step():
             loss = graphed()                 # render + losses + backward + gradient gather: one graph replay
             opt.step()
             sample_log.append(ts.last_samples)
+            return loss
+    elif args.glue == "reference":
+        def step():
+            bucket.zero()
+            loss = ts()
+            loss.backward()
+            bucket.allreduce_mean()
+            opt.step()
+            sample_log.append(ts.last_samples)
+            loss.item()                      # the reference reads the loss back on the host (morpheus.py:1426)
             return loss
     else:
         def step():
@@ -266,9 +297,70 @@ def build_train_real(args, rank, world, dev):
             f"occupancy-marched ragged samples (step 0.01, {occ * 100:.1f}% of 128^3 cells occupied), albedo_normal, "
             "normal_smooth_3d + normal_smoothness + code_reg, depth/mask/sdf/surface-point losses, pose optimisation, "
             "occupancy refresh every 16 steps, Adam")
+    desc += {"fused": "; caller-side losses: this build's fused glue (morpheus_amd/trainstep.py)",
+             "reference": "; caller-side losses: the reference's own operator chains + loss.item() per step (INTEGRATION.md's three "
+                          "edits only)"}[args.glue]
     return dict(step=step, rays_per_step=args.rays, bucket=bucket, desc=desc + (", captured in a HIP graph" if graphed else ""),
                 samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ,
-                graphed=graphed)
+                graphed=graphed, glue=args.glue)
+
+
+def build_train_virtual(args, rank, world, dev):
+    """The reference's VIRTUAL-view training step (morpheus.py:1393-1408: one step in eleven): all res x res rays of a novel view
+    of a random frame, random lambertian / textureless shading at a random ambient ratio (:873-885), random / no background
+    colour, orientation loss + normal_smooth_3d + normal_smoothness + code_reg, occupancy-marched ragged samples, no pose
+    optimisation, no depth / mask terms; the SDS guidance is replaced by its interface, a fixed gradient on pred_rgb
+    (trainstep.InjectedGuidance) -- the render forward + backward under it is what is timed.  With the deformation learning
+    rates frozen for the virtual step (epochs <= freeze_epoch, :1394-1409) the reference steps the optimiser after it: so does
+    this step, with those groups' learning rate at 0."""
+    import torch
+    from morpheus_amd import harness, trainstep
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.optim import FlatAdam
+    from morpheus_amd.render import HotPathRenderer
+    model = harness.build_model("b", dev).train()
+    cfg = model.config
+    grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(dev)
+    rend = HotPathRenderer(model, cfg, grid, 200)
+    res = args.virtual_res
+    vs = trainstep.VirtualViewTrainStep(rend, res=res, seed=2024 + rank)
+    vs.epoch = 1000                                      # mid-training: progressive level 0.75, random shading
+    groups = model.get_params_all(cfg["train"]["lr"])
+    for g in groups:                                      # freeze_lr_deform (morpheus.py:504-511)
+        if g["name"] in ("code_deform", "decoder_deform", "decoder_topo"):
+            g["lr"] = 0.0
+    opt = FlatAdam(groups, betas=(0.9, 0.99), eps=1e-15)
+    bucket = opt.bucket
+    if world > 1 and not args.no_overlap:
+        bucket.overlap_early([model.encoder.embeddings, model.encoder_c.embeddings])
+    # trained-like occupancy from the field's own density (the real-view step's helper: same grid, same update rule)
+    frames = trainstep.make_frames([(25 * rank) % 200], 64, 64, dev)
+    warm = trainstep.RealViewTrainStep(rend, frames, ray_num=64)
+    warm.epoch = 1000
+    with torch.no_grad():
+        trainstep.warm_up_occupancy(warm)
+    vs.global_step = 4096
+    occ = float(grid.binaries.float().mean())
+    sample_log, shade_log = [], []
+    inv_freq = 1.0 / cfg["train"]["virtual_freq"]
+
+    def step():
+        bucket.zero()
+        loss = vs() * inv_freq                            # morpheus.py:1401
+        loss.backward()
+        bucket.allreduce_mean()
+        opt.step()
+        sample_log.append(vs.last_samples)
+        shade_log.append(vs.last_shading[0])
+        return loss
+
+    desc = (f"snoopy.yaml virtual-view training step (morpheus.py:1393-1408): all {res} x {res} rays of one novel view per GPU, "
+            f"occupancy-marched ragged samples (step 0.01, {occ * 100:.1f}% of 128^3 cells occupied), random lambertian / "
+            "textureless shading + ambient ratio, orientation loss + normal_smooth_3d + normal_smoothness + code_reg, SDS replaced "
+            "by an injected pred_rgb gradient (its interface), deform learning rates frozen, occupancy refresh every 16 steps, Adam")
+    return dict(step=step, rays_per_step=res * res, bucket=bucket, desc=desc,
+                samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ,
+                shadings=lambda: {k: shade_log[-args.steps:].count(k) for k in sorted(set(shade_log[-args.steps:]))})
 
 
 def build_density128(args, rank, world, dev):
@@ -326,7 +418,7 @@ def pmc_step_bytes(symbols, mode):
     same arithmetic mode (profiles/r0N_pmc_summary[_mode].csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB
     units, separate passes).  None when no matching profile is committed."""
     import csv
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         for name in (f"{rnd}_pmc_summary_{mode}.csv", f"{rnd}_pmc_summary.csv"):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
@@ -348,25 +440,13 @@ def pmc_step_bytes(symbols, mode):
     return None, None, False
 
 
-def build_roofline(ktab, mode, M, workload, full_size):
-    """SURVEY 8(d) roofline of the step's LARGEST time item (weight-gradient group included):
-    mfma view  -- algorithmic FLOPs (2 per MAC of the reference's dense layers) / time vs the peak of the pipe the kernels
-                  issue on, divided by the slice products they issue per MAC (stated in peak_note);
-    hbm view   -- the bytes the design moves by construction ("parked") / time vs 8 TB/s, next to the algorithmic bytes of
-                  8(d) and the PMC-measured traffic, so that the waste ratio is visible."""
-    warp_f = 2.0 * (MACS["deform"] + MACS["topo"]) * M
-    field_f = 2.0 * (MACS["sdf"] + MACS["color"]) * M
-    flops = {"mh_warp_fwd": warp_f, "mh_warp_bwd_data": warp_f, "mh_mlp_wgrad[warp]": warp_f, "mh_field_fwd": field_f,
-             "mh_field_bwd_fused": 2.0 * field_f}
-    if workload == "cfg3b":
-        flops = {k: v for k, v in flops.items() if k.startswith(("mh_warp", "mh_mlp"))}   # field entries mix 1-point and 6-tap calls
-    cands = [(v["ms_per_step"], k) for k, v in ktab.items() if k in flops and v.get("calls_per_step", 0) > 0]
-    if not cands:
-        return None
-    _, name = max(cands)
-    e = ktab[name]
+def _kernel_roofline(name, e, flops_per_call, mode, M, workload, full_size):
+    """SURVEY 8(d) numbers of ONE timed C-ABI entry: algorithmic FLOPs (2 per MAC of the reference's dense layers) / HIP-event
+    time against the dense peak of the matrix pipe its kernels issue on divided by the slice products they issue per fp32 MAC;
+    beside it the HBM view (bytes the design parks by construction / time vs 8 TB/s), SURVEY 8(d)'s algorithmic bytes and the
+    PMC-measured traffic of the committed rocprofv3 passes."""
     secs = e["ms_per_step"] * 1e-3
-    per_step_flops = flops[name] * e["calls_per_step"]      # flops[] is per call on the step's M points
+    per_step_flops = flops_per_call * e["calls_per_step"]
     fused_fp32 = name == "mh_field_bwd_fused"
     kmode = "f32" if fused_fp32 else mode
     prod = PRODUCTS[kmode]
@@ -374,31 +454,51 @@ def build_roofline(ktab, mode, M, workload, full_size):
     alg_tflops = per_step_flops / secs / 1e12
     peak = unit_peak / prod
     io = IO_BYTES[name]
-    parked = io["parked"] * M
-    algb = io["algorithmic"] * M
+    parked, algb = io["parked"] * M, io["algorithmic"] * M
     hbm_gbs = parked / secs / 1e9
-    traffic, src, complete = pmc_step_bytes(SYMBOLS[name][kmode if not fused_fp32 else mode], mode) if (full_size and workload == "cfg3") else (None, None, False)
-    mfma = dict(bound="mfma", achieved=round(alg_tflops, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(alg_tflops / peak, 4),
+    traffic, src, complete = (pmc_step_bytes(SYMBOLS[name][kmode if not fused_fp32 else mode], mode)
+                              if (full_size and workload == "cfg3") else (None, None, False))
+    return dict(kernel=name, launches_per_step=e["calls_per_step"], ms_per_step=e["ms_per_step"], mode=kmode,
+                bound="mfma", achieved=round(alg_tflops, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(alg_tflops / peak, 4),
                 peak_note=f"{pipe} dense peak {unit_peak} TFLOP/s (MI355X_MICROARCH.md) / {prod:g} slice product(s) issued per fp32 "
                           f"MAC = {peak:.1f} TFLOP/s of ALGORITHMIC fp32 work",
-                issued_tflops=round(alg_tflops * prod, 1), unit_peak=unit_peak, flops_per_step=per_step_flops)
-    hbm = dict(bound="hbm", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_gbs / HBM_PEAK_GBS, 4),
-               bytes_per_step=round(parked),
-               note="bytes this design moves by construction (parked activation / pre-activation-gradient tiles, each row written or "
-                    "read once); a streaming read reaches 5.6-6.6 TB/s and a streaming write 6.8 TB/s on this box "
-                    "(profiles/r02_micro_hbm_read.txt, r02_micro_hbm_rates.txt)")
-    near = mfma if mfma["frac"] >= hbm["frac"] else hbm
-    out = dict(kernel=name, launches_per_step=e["calls_per_step"], ms_per_step=e["ms_per_step"], mode=kmode,
-               largest_item_of_step=True)
-    out.update({k: near[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
-    out.update(traffic=traffic, algorithmic_bytes=round(algb), parked_bytes=round(parked),
-               waste_ratio_traffic_over_algorithmic=None if not traffic else round(traffic / algb, 1),
-               traffic_note=("HBM bytes per step of this item's kernels from the committed rocprofv3 --pmc passes (profiles/" +
-                             str(src) + (")" if complete else "; some kernels of the group missing in that file)")) if traffic else
-               "null: no committed PMC profile matches this workload / mode (traffic is collected by tools/gpu/r3_prof.sh)",
-               algorithmic_bytes_note="SURVEY 8(d): inputs in + results out per point (everything else is recomputable on the chip); "
-                                      "traffic far above it is the design's activation parking (DESIGN.md section 3)",
-               mfma=mfma, hbm=hbm)
+                issued_tflops=round(alg_tflops * prod, 1), flops_per_step=per_step_flops,
+                traffic=traffic, algorithmic_bytes=round(algb), parked_bytes=round(parked),
+                waste_ratio_traffic_over_algorithmic=None if not traffic else round(traffic / algb, 1),
+                traffic_source=(str(src) + ("" if complete else " (some kernels of the group missing in that file)")) if traffic else None,
+                hbm=dict(bound="hbm", achieved=round(hbm_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_gbs / HBM_PEAK_GBS, 4),
+                         bytes_per_step=round(parked)))
+
+
+def build_roofline(ktab, mode, M, workload, full_size):
+    """`roofline` is the step's LARGEST time item (weight-gradient group included); its top-level bound / achieved /
+    peak / frac are the ALGORITHMIC-FLOP view -- FLOPs of the reference's dense layers / HIP-event time / (dense peak of the
+    matrix pipe the kernels issue on / slice products per fp32 MAC).  The bytes this design parks, SURVEY 8(d)'s algorithmic
+    bytes and the PMC-measured traffic ride beside it (`hbm`, `parked_bytes`, `algorithmic_bytes`, `traffic`,
+    `waste_ratio_traffic_over_algorithmic`); `per_kernel` holds the same numbers for every MLP entry of the step."""
+    warp_f = 2.0 * (MACS["deform"] + MACS["topo"]) * M
+    field_f = 2.0 * (MACS["sdf"] + MACS["color"]) * M
+    flops = {"mh_warp_fwd": warp_f, "mh_warp_bwd_data": warp_f, "mh_mlp_wgrad[warp]": warp_f, "mh_field_fwd": field_f,
+             "mh_field_bwd_fused": 2.0 * field_f}
+    if workload == "cfg3b":
+        flops = {k: v for k, v in flops.items() if k.startswith(("mh_warp", "mh_mlp"))}   # field entries mix 1-point and 6-tap calls
+    per = {k: _kernel_roofline(k, ktab[k], flops[k], mode, M, workload, full_size)
+           for k in flops if k in ktab and ktab[k].get("calls_per_step", 0) > 0}
+    if not per:
+        return None
+    name = max(per, key=lambda k: per[k]["ms_per_step"])
+    out = dict(per[name])
+    out["largest_item_of_step"] = True
+    out["traffic_note"] = ("HBM bytes per step of this item's kernels from the committed rocprofv3 --pmc passes (profiles/" +
+                           str(out.pop("traffic_source")) + ")") if out["traffic"] else \
+        "null: no committed PMC profile matches this workload / mode (tools/gpu/r4_round.sh collects it)"
+    out["algorithmic_bytes_note"] = ("SURVEY 8(d): inputs in + results out per point (everything else is recomputable on the chip); "
+                                     "traffic far above it is the design's activation parking (DESIGN.md section 3)")
+    out["hbm"]["note"] = ("bytes this design moves by construction (parked activation / pre-activation-gradient tiles, each row written "
+                          "or read once); a streaming read reaches 5.6-6.6 TB/s and a streaming write 6.8 TB/s on this box "
+                          "(profiles/r02_micro_hbm_read.txt, r02_micro_hbm_rates.txt)")
+    out["per_kernel"] = {k: {kk: v[kk] for kk in ("ms_per_step", "launches_per_step", "mode", "achieved", "peak", "unit", "frac",
+                                                  "traffic", "algorithmic_bytes", "parked_bytes", "hbm")} for k, v in per.items()}
     return out
 
 
@@ -458,10 +558,20 @@ def run_one(args):
             raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-        builder = {"train_real": build_train_real, "density128": build_density128}.get(args.workload, build_render_workload)
+        builder = {"train_real": build_train_real, "train_virtual": build_train_virtual,
+                   "density128": build_density128}.get(args.workload, build_render_workload)
         wl = builder(args, rank, world, dev)
     step = wl["step"]
     sync = (lambda: None) if stub else torch.cuda.synchronize
+    if world > 1 and not stub and "MORPHEUS_DIST_BACKEND" not in os.environ:
+        # a scaling data point is N ranks on N devices over RCCL; anything else (ranks sharing a device, gloo) has to be asked
+        # for with MORPHEUS_DIST_BACKEND (bench.py's own launcher sets it when the box has fewer GPUs than ranks)
+        if dist.get_backend() != "nccl":
+            raise SystemExit(f"bench.py --gpus {world}: backend {dist.get_backend()!r}, expected 'nccl' (RCCL); set MORPHEUS_DIST_BACKEND to override")
+        devs = [None] * world
+        dist.all_gather_object(devs, (socket.gethostname(), torch.cuda.current_device()))
+        if len(set(devs)) != world:
+            raise SystemExit(f"bench.py --gpus {world}: ranks share devices {devs}; set MORPHEUS_DIST_BACKEND=gloo for a functional run")
 
     timers_on = rank == 0 and not stub and not args.no_kernel_timers and not args.graph
     ops.TIMER.reset(enabled=timers_on)          # warm-up steps also fill the timer's event pool
@@ -501,6 +611,7 @@ def run_one(args):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    own_ms = elapsed / args.steps * 1e3          # this rank's own clock (the reported time is the MAX over ranks)
     if world > 1:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -510,7 +621,8 @@ def run_one(args):
 
     # who ran where: rank 0 prints it so that a multi-GPU run can be checked for "N ranks, N devices, backend nccl"
     n_dev = 0 if stub else torch.cuda.device_count()
-    me = dict(rank=rank, device=str(dev), name=(torch.cuda.get_device_name(dev) if not stub else "cpu"), host_pid=os.getpid())
+    me = dict(rank=rank, device=str(dev), name=(torch.cuda.get_device_name(dev) if not stub else "cpu"), host_pid=os.getpid(),
+              ms_per_step=round(own_ms, 3))       # per rank: a scaling run shows its stragglers
     ranks = [me]
     if world > 1:
         gathered = [None] * world
@@ -547,6 +659,7 @@ def run_one(args):
     out = {
         "metric": "rays/sec (fwd+bwd, 128 samples/ray)" if headline else
                   {"train_real": "rays/sec (real-view training step, ragged occupancy samples)",
+                   "train_virtual": "rays/sec (virtual-view training step, whole novel view, ragged occupancy samples)",
                    "density128": "points/sec (forward-only field query)"}[args.workload],
         "value": round(total_rays / elapsed, 1), "unit": "rays/s" if args.workload != "density128" else "points/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -575,6 +688,11 @@ def run_one(args):
     }
     if "occupied" in wl:
         out["config"]["occupied_fraction"] = round(wl["occupied"], 4)
+    if "glue" in wl:
+        out["config"]["glue"] = wl["glue"]
+    if "shadings" in wl:
+        out["config"]["shadings_of_timed_steps"] = wl["shadings"]()
+    out["config"]["kernel_timers"] = bool(timers_on)      # per-C-ABI-call HIP events inside the timed region (host cost per call)
     if wl.get("graphed") is not None:
         g = wl["graphed"]
         out["config"]["hip_graph"] = dict(capacity_buckets=sorted(c for c, _ in g.graphs), bucket_step=g.bucket_step,
@@ -582,7 +700,8 @@ def run_one(args):
                                           overflowed_batches=int(g.check_overflow()) + g.overflows, margin=g.margin,
                                           graphs_captured=g.n_captures, captures_inside_the_timed_region=g.n_captures - captures0,
                                           memset_nodes_replaced_by_fill_kernels=g.memset_nodes_replaced, nodes_per_replayed_step=g.last_graph_nodes,
-                                          note="sample_points_per_step_per_gpu is the mean CAPACITY the kernels ran on (padding "
+                                          note="sample_points_per_step_per_gpu is the mean COUNTED sample number of the batches (as in the "
+                                               "eager run); the kernels ran on the bucket capacity (capacity_of_last_step: padding "
                                                "included); each batch is drawn and counted one step ahead on a side stream to pick its bucket")
     elif args.graph:
         out["config"]["hip_graph"] = dict(note="render + loss + backward + Adam captured once, replayed per step")
@@ -645,11 +764,52 @@ def run_modes(args, argv):
             out["hip_graph_replay"] = {"error": (run.stderr or run.stdout)[-300:]}
     except Exception as e:      # noqa: BLE001
         out["hip_graph_replay"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if args.workload == "cfg3" and not args.no_extras:
+        out.update(run_extras(best))
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_rays, args.samples)
         if out["cpu_baseline"]["value"]:
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     return out
+
+
+def run_extras(mode):
+    """The training-step workloads beside the cfg3 headline, each in its own process, per-kernel timers OFF (a real-view step
+    issues ~360 launches: two event records around each C-ABI call cost it more than they cost cfg3's 13), library defaults for
+    steps / warm-up:
+      train_real     the reference's real-view step (morpheus.py:1147-1236) -- eager with this build's fused caller-side glue,
+                     the same replayed from HIP graphs, and eager with the REFERENCE's own glue + loss.item() per step (what
+                     INTEGRATION.md's three edits alone give);
+      train_virtual  its virtual-view step (:1393-1408) at 72 x 72 and 180 x 180 rays, SDS replaced by an injected pred_rgb
+                     gradient (the UNet is not part of the hot path and its weights are not available offline)."""
+    def sub(flags, timeout=600):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--mode", mode, "--no-kernel-timers", "--no-cpu-baseline"] + flags
+        try:
+            run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env={**os.environ, "MORPHEUS_MLP": mode})
+            lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+            if run.returncode != 0 or not lines:
+                return {"error": (run.stderr or run.stdout)[-300:]}
+            r = json.loads(lines[-1])
+            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype")}
+            c = r["config"]
+            keep.update(workload=c["workload"], rays_per_gpu=c["rays_per_gpu"], sample_points_per_step=c["sample_points_per_step_per_gpu"],
+                        kernel_timers=c.get("kernel_timers"), loss_mean_of_timed_steps=c.get("loss_mean_of_timed_steps"))
+            for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction"):
+                if k in c:
+                    keep[k] = c[k]
+            return keep
+        except Exception as e:      # noqa: BLE001 -- the extras never fail the headline
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    real = ["--workload", "train_real"]
+    return {"train_real": {"eager_fused_glue": sub(real), "hip_graph_replay": sub(real + ["--graph"]),
+                           "eager_reference_glue": sub(real + ["--glue", "reference"]),
+                           "note": "rays/s of the reference's real-view training step, 2048 rays per step; `eager_reference_glue` "
+                                   "is the drop-in number (reference caller untouched), the other two need this build's caller"},
+            "train_virtual": {"res72": sub(["--workload", "train_virtual", "--virtual-res", "72"]),
+                              "res180": sub(["--workload", "train_virtual", "--virtual-res", "180"]),
+                              "note": "rays/s of the reference's virtual-view training step (render fwd + bwd + Adam under an "
+                                      "injected pred_rgb gradient standing for Zero-1-to-3 SDS)"}}
 
 
 # ------------------------------------------------------------------------------------------------ main

@@ -71,8 +71,10 @@ def _i32arr(a):
     """host int32 array + its ctypes pointer for the C ABI's *_host arguments.  The arrays the hot path passes are static
     geometry (level tables, tile offsets, layer lists): lists / tuples and read-only numpy arrays are converted once and cached
     by value -- a training step makes ~150 of these calls."""
-    if isinstance(a, (list, tuple)):
-        key = tuple(a)
+    # one key form for every source kind: (length, values...) of Python ints -- a list [3, 1, 2, 3] and the array [1, 2, 3] must
+    # not meet in one entry
+    if isinstance(a, (list, tuple)) and all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in a):
+        key = (len(a),) + tuple(int(v) for v in a)
     elif isinstance(a, np.ndarray) and a.dtype == np.int32 and a.ndim == 1 and a.size <= 64:
         key = (a.size,) + tuple(a.tolist())
     else:
@@ -316,7 +318,7 @@ def sample_uniform(rays_o, rays_d, jitter, S: int, bound: float, with_xyz: bool 
     """-> ray_idx int32 [N*S], t_starts, t_ends, xyz|None, ray_start, ray_cnt (no_grad, like morpheus.py:628)."""
     require_gpu(rays_o, rays_d, jitter)
     lib = _lib.load()
-    o, d, j = rays_o.detach().contiguous(), rays_d.detach().contiguous(), jitter.contiguous()
+    o, d, j = rays_o.detach().contiguous(), rays_d.detach().contiguous(), _ray_jitter(jitter, rays_o.shape[0])
     N, dev = o.shape[0], o.device
     ri = torch.empty(N * S, dtype=torch.int32, device=dev)
     ts, te = torch.empty(N * S, device=dev), torch.empty(N * S, device=dev)
@@ -358,6 +360,17 @@ def rays_sample_uniform(fx, fy, cx, cy, c2w, H: int, W: int, pix, jitter, S: int
     return o, d, ri, ts, te, xyz, rs, rc
 
 
+def _ray_jitter(jitter, n_rays: int):
+    """the per-ray near-plane jitter as the marcher reads it: float32 [n_rays], one value per ray -- the kernels index it by ray
+    without a length of their own, so a buffer sized for another batch (a graphed step's static jitter met by an eager render)
+    must not get through"""
+    if jitter is None:
+        return None
+    if jitter.numel() != n_rays or jitter.dtype != torch.float32:
+        raise ValueError(f"per-ray jitter: expected float32 [{n_rays}], got {jitter.dtype} {tuple(jitter.shape)}")
+    return jitter.reshape(-1).contiguous()
+
+
 def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.Tensor):
     """Occupancy-grid marcher -> (ray_idx int32 [M], t_starts [M], t_ends [M], ray_start [N], ray_cnt [N]).
     One host sync on the path: M = total sample count sizes the packed arrays (nerfacc synchronises at the same point).
@@ -366,7 +379,7 @@ def march_rays(rays_o, rays_d, jitter, step: float, bound: float, binary: torch.
     require_gpu(rays_o, rays_d, jitter, binary)
     lib = _lib.load()
     o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
-    j = None if jitter is None else jitter.contiguous()
+    j = _ray_jitter(jitter, rays_o.shape[0])
     assert binary.dtype == torch.uint8 and binary.is_contiguous() and binary.dim() == 3
     N, R, dev = o.shape[0], binary.shape[0], o.device
     if N == 0:
@@ -406,7 +419,7 @@ def march_count(rays_o, rays_d, jitter, step: float, bound: float, binary: torch
     require_gpu(rays_o, rays_d, jitter, binary)
     lib = _lib.load()
     o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
-    j = None if jitter is None else jitter.contiguous()
+    j = _ray_jitter(jitter, rays_o.shape[0])
     N, R, dev = o.shape[0], binary.shape[0], o.device
     cap = int(lib.mh_march_cap(float(step), float(bound)))
     cnt_ovf = torch.zeros(N + 1, dtype=torch.int32, device=dev)
@@ -426,7 +439,7 @@ def march_rays_capped(rays_o, rays_d, jitter, step: float, bound: float, binary:
     require_gpu(rays_o, rays_d, jitter, binary)
     lib = _lib.load()
     o, d = rays_o.detach().contiguous(), rays_d.detach().contiguous()
-    j = None if jitter is None else jitter.contiguous()
+    j = _ray_jitter(jitter, rays_o.shape[0])
     assert binary.dtype == torch.uint8 and binary.is_contiguous() and binary.dim() == 3
     N, R, dev = o.shape[0], binary.shape[0], o.device
     assert N > 0 and capacity > 0

@@ -21,7 +21,9 @@ the density only (`return_color=False`; the reference evaluates and discards the
 """
 from __future__ import annotations
 
+import collections
 import math
+import random
 from typing import Dict, List, Optional
 
 import torch
@@ -166,17 +168,111 @@ def get_regularization_loss(tr, model, outputs, pred_normal, global_step: int, e
     return ops.weighted_sum(terms)
 
 
+# ------------------------------------------------------------------------------------------ the caller's glue AS THE REFERENCE WRITES IT
+class ReferenceGlue:
+    """The three caller-side loss groups of `train_step` written the way the reference writes them -- chains of elementwise torch
+    operators, `loss = loss + w * term`, in-place mask assignments, the boolean index of :1018 (a device->host sync) -- for
+    `bench.py --workload train_real --glue reference`: the number a maintainer gets from INTEGRATION.md's three edits ALONE
+    (model, occupancy grid, render_rays swapped; morpheus.py:915-1029 and :1090-1145 left as they are).  The functions above
+    (`get_real_view_render_loss` ... with ops.masked_mean / ops.weighted_sum / ops.real_view_render_loss) are this build's
+    rewrite of the same code and need a changed caller."""
+
+    @staticmethod
+    def gt_from_data(data, bg_color, B, H, W):                                        # morpheus.py:930-945
+        gt_rgb, gt_depth, gt_mask = data["image"], data["depth"], data["mask"].clone()
+        gt_mask[gt_mask > 0.5] = 1.0
+        gt_mask[gt_mask <= 0.5] = 0.0
+        bg = bg_color.reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+        return gt_rgb * gt_mask[:, None].float() + bg * (1 - gt_mask[:, None].float()), gt_depth, gt_mask
+
+    @staticmethod
+    def _depth_mask(gt_depth, gt_mask, rays_o, rays_d):                               # :966-976 / :1001-1011
+        depth_mask = torch.ones_like(gt_depth)
+        depth_mask[gt_depth <= 0] = 0
+        xyzs = rays_o + gt_depth.reshape(1, -1, 1) * rays_d
+        outside = torch.linalg.norm(xyzs, ord=2, dim=-1, keepdim=True) > 1.1
+        depth_mask[outside.view(*depth_mask.shape)] = 0
+        depth_mask[gt_mask <= 0.5] = 0
+        return depth_mask, xyzs
+
+    @staticmethod
+    def render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask, rays_o, rays_d):     # :946-983
+        loss = 0
+        if tr["rgb_weight"] > 0:
+            loss = loss + tr["rgb_weight"] * F.mse_loss(pred_rgb, gt_rgb)
+        if tr["mask_weight"] > 0:
+            loss = loss + tr["mask_weight"] * F.binary_cross_entropy(pred_mask[:, 0].clip(1e-5, 1.0 - 1e-5), gt_mask.float())
+        if tr["depth_weight"] > 0:
+            depth_mask, _ = ReferenceGlue._depth_mask(gt_depth, gt_mask, rays_o, rays_d)
+            loss = loss + tr["depth_weight"] * F.mse_loss(pred_depth[:, 0] * depth_mask, gt_depth * depth_mask)
+        return loss
+
+    @staticmethod
+    def point_loss(tr, model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs):               # :985-1029
+        loss = 0
+        if tr["sdf_weight"] > 0:
+            loss = loss + tr["sdf_weight"] * outputs["sdf_loss"]
+        if tr["sdf_reg"] > 0:
+            loss = loss + tr["sdf_reg"] * torch.mean(outputs["sdf"] ** 2)
+        if tr["fs_weight"] > 0:
+            loss = loss + tr["fs_weight"] * outputs["fs_loss"]
+        if tr["surf_sdf_weight"] > 0:
+            depth_mask, xyzs = ReferenceGlue._depth_mask(gt_depth, gt_mask, rays_o, rays_d)
+            results = model.density(xyzs.reshape(-1, 3), t=rays_t.reshape(-1, 1))     # per-sample times, as the reference passes them
+            masked_sdf = results["sdf"].view(*depth_mask.shape)[depth_mask.to(torch.bool)]            # the sync of :1018
+            masked_color = results["albedo"].view(*depth_mask.shape, 3).permute(0, 3, 1, 2).contiguous()
+            loss = loss + tr["surf_sdf_weight"] * F.mse_loss(masked_sdf, torch.zeros_like(masked_sdf)) + \
+                tr["surf_color_weight"] * F.mse_loss(masked_color * depth_mask[None, ...], gt_rgb * depth_mask[None, ...])
+        return loss
+
+    @staticmethod
+    def regularization_loss(tr, model, outputs, pred_normal, global_step, end_iter, cano=False):           # :1090-1145
+        loss = 0
+        if tr["entropy_weight"] > 0:
+            a = outputs["weights"].clamp(1e-5, 1 - 1e-5)
+            ent = (-a * torch.log2(a) - (1 - a) * torch.log2(1 - a)).mean()
+            loss = loss + tr["entropy_weight"] * min(1, 2 * global_step / end_iter) * ent
+        if tr["normal_smooth_2d"] > 0 and pred_normal is not None:
+            loss = loss + tr["normal_smooth_2d"] * ((pred_normal[:, 1:] - pred_normal[:, :-1]).square().mean() +
+                                                    (pred_normal[:, :, 1:] - pred_normal[:, :, :-1]).square().mean())
+        for w, k in (("ori_weight", "loss_orient"), ("normal_smooth_3d", "loss_normal_perturb"),
+                     ("normal_smooth_3d_t", "loss_normal_perturb_t")):
+            if tr[w] > 0 and k in outputs:
+                loss = loss + tr[w] * outputs[k]
+        if outputs["normal_raw"] is not None and tr["eik_weight"] > 0:
+            loss = loss + tr["eik_weight"] * torch.mean((torch.linalg.norm(outputs["normal_raw"], ord=2, dim=-1) - 1.0) ** 2)
+        if tr["beta_weight"] > 0:
+            loss = loss + tr["beta_weight"] * torch.mean(model.sdf2density.get_beta())
+        if tr["normal_smoothness"] > 0:
+            loss = loss + tr["normal_smoothness"] * outputs["normal_reg"]
+        if tr["deform_weight"] > 0:
+            loss = loss + tr["deform_weight"] * outputs["deform"].abs().mean()
+        for w, k in (("deform_smooth", "loss_deform_perturb"), ("deform_smooth_t", "loss_deform_perturb_t"),
+                     ("topo_smooth_t", "loss_topo_perturb_t")):
+            if tr[w] > 0 and k in outputs:
+                loss = loss + tr[w] * outputs[k]
+        if tr["code_reg"] > 0 and not cano and "loss_code" in outputs:
+            loss = loss + tr["code_reg"] * outputs["loss_code"]
+        return loss
+
+
 # ------------------------------------------------------------------------------------------ the step
 class RealViewTrainStep:
     """`MorpheuS.train_step(real_view=True, cano=False, optimize_pose=True)` (morpheus.py:1147-1236) on synthetic frames.
 
     renderer: morpheus_amd.render.HotPathRenderer whose `occupancy_grid` is a morpheus_amd.occgrid.OccupancyGrid."""
 
-    def __init__(self, renderer, frames, ray_num: int = 2048, n_epochs: int = 2000, end_iter: int = 220000):
+    def __init__(self, renderer, frames, ray_num: int = 2048, n_epochs: int = 2000, end_iter: int = 220000, glue: str = "fused"):
+        """glue: "fused" -- this build's caller-side losses (one launch per loss group, one operand scope around render + point
+        loss: needs a changed caller); "reference" -- the reference's own operator chains around the swapped-in render_rays
+        (ReferenceGlue: what INTEGRATION.md's three edits alone give)."""
+        assert glue in ("fused", "reference")
+        self.glue = glue
         self.r, self.model, self.cfg = renderer, renderer.model, renderer.config
         self.frames, self.ray_num = frames, ray_num
         self.global_step, self.epoch, self.n_epochs, self.end_iter = 0, 0, n_epochs, end_iter
         self.last_samples = 0
+        self.last_capacity = None      # set by GraphedRealViewStep: the padded sample capacity the replayed kernels ran on
 
     def update_occ_grid(self, rays_t, cano=False):
         """morpheus.py:905-913."""
@@ -191,8 +287,34 @@ class RealViewTrainStep:
         self.begin_step()
         fi = self.frame_of_step() if frame_index is None else frame_index
         self.update_occ_grid(self.frames[fi]["rays_t"][None, :1], cano=False)
+        data = sample_real_view_rays(self.frames[fi], self.ray_num, pixel_index)
+        if self.glue == "reference":          # the reference's train_step knows nothing of operand scopes
+            return self._step_reference_glue(data, self.global_step)
         with self.model.operand_scope():      # render_rays and the point loss share one set of prepared weight operands
-            return self._step(sample_real_view_rays(self.frames[fi], self.ray_num, pixel_index), self.global_step)
+            return self._step(data, self.global_step)
+
+    def _step_reference_glue(self, data, global_step):
+        """morpheus.py:1147-1236 around the swapped-in render_rays, everything else as the reference has it (ReferenceGlue)."""
+        tr = self.cfg["train"]
+        rays_o, rays_d, rays_t, rays_id = data["rays_o"], data["rays_d"], data["rays_t"], data["rays_id"]
+        B, N = rays_o.shape[:2]
+        H, W = data["H"], data["W"]
+        rays_depth, rays_mask = data["depth"].view(B, -1, 1), data["mask"].view(B, -1, 1)
+        bg_color = torch.rand((B * N, 3), device=rays_o.device)
+        outputs = self.r.render_rays(rays_o, rays_d, rays_t, rays_id, H, W, perturb=True, bg_color=bg_color, ambient_ratio=1.0,
+                                     shading="albedo_normal", real_view=True, cano=False, rays_depth=rays_depth,
+                                     rays_mask=rays_mask, optimize_pose=True)
+        self.last_samples = 0 if outputs["sdf"] is None else outputs["sdf"].shape[0]
+        pred_depth = outputs["depth"].reshape(B, 1, H, W)                              # get_pred_from_outputs :915-928
+        pred_mask = outputs["weights_sum"].reshape(B, 1, H, W)
+        pred_normal = outputs["normal_image"].reshape(B, H, W, 3) if "normal_image" in outputs else None
+        pred_rgb = outputs["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()
+        gt_rgb, gt_depth, gt_mask = ReferenceGlue.gt_from_data(data, bg_color, B, H, W)
+        loss = 0
+        loss = loss + ReferenceGlue.render_loss(tr, pred_rgb, pred_depth, pred_mask, gt_rgb, gt_depth, gt_mask, rays_o, rays_d)
+        loss = loss + ReferenceGlue.point_loss(tr, self.model, gt_rgb, gt_depth, gt_mask, rays_o, rays_d, rays_t, outputs)
+        loss = loss + ReferenceGlue.regularization_loss(tr, self.model, outputs, pred_normal, global_step, self.end_iter)
+        return loss
 
     def begin_step(self):
         """host-side bookkeeping of one iteration (morpheus.py:808-813, 1377-1399)"""
@@ -243,6 +365,140 @@ class RealViewTrainStep:
         return loss
 
 
+# ------------------------------------------------------------------------------------------ the virtual-view step
+class InjectedGuidance:
+    """Stands where the Zero-1-to-3 SDS guidance stands in the virtual-view step (morpheus.py:1044-1088 ->
+    models/guidance/zero123_utils.py:138-236).  To the renderer, SDS is a gradient on `pred_rgb` and nothing else: train_step
+    builds `targets = (latents - grad).detach()` and returns `0.5 * mse(latents, targets, 'sum') / B`, whose derivative with
+    respect to the latents is `grad`; VAE encoder and 256 x 256 resize carry it back to the [B,3,H,W] image.  The UNet, its
+    weights and the `ldm` package stay on stock PyTorch-ROCm (north_star) and are not available offline, so this object
+    supplies that interface with a FIXED closed-form gradient image: loss = sum(pred_rgb * G), d loss / d pred_rgb = G.
+    The render forward + backward under it is the hot path's, which is what `bench.py --workload train_virtual` times and
+    tests/test_gpu_render.py checks against the reference's own virtual-view render_rays."""
+
+    def __init__(self, H: int, W: int, device, scale: float = 1e-3, stream: int = 9100):
+        self.H, self.W = H, W
+        self.grad = synth.hash_tensor((1, 3, H, W), stream, scale).to(device)
+
+    def __call__(self, pred_rgb):
+        assert pred_rgb.shape == self.grad.shape, (pred_rgb.shape, self.grad.shape)
+        return (pred_rgb * self.grad).sum()
+
+
+def virtual_view_rays(frame_id: int, H: int, W: int, theta: float, phi: float, radius: float, device, num_frames: int = 200,
+                      focal_mult: float = 1.2):
+    """`DeformDataset.get_virtual_view_rays` (datasets/dataset.py:503-578) for a closed-form camera: ALL H*W rays of one
+    view of frame `frame_id` from (theta, phi, radius) looking at the origin, generated on the device by the hot path's own
+    ray kernel (mh_generate_rays = get_camera_rays + the c2w application, :546-557).  -> the reference's data dict (bs = 1)."""
+    fx = fy = focal_mult * W
+    o, d = ops.generate_rays(fx, fy, 0.5 * W, 0.5 * H, synth.look_at_pose(theta, phi, radius), H, W, device)
+    n = H * W
+    return dict(H=H, W=W, rays_o=o[None], rays_d=d[None],
+                rays_t=torch.full((1, n, 1), frame_id / num_frames, device=device),
+                rays_id=torch.full((1, n, 1), frame_id, device=device, dtype=torch.int64))
+
+
+class VirtualViewTrainStep:
+    """`MorpheuS.train_step(real_view=False, cano=False, optimize_pose=False)` (morpheus.py:1147-1236) -- the one step in
+    eleven the reference renders a whole novel view for (train_one_epoch :1393-1408: `virtual_freq` = 1 virtual step, then
+    `real_freq` = 10 real ones) -- on closed-form cameras, with the SDS guidance replaced by its interface (InjectedGuidance):
+
+        sample_view            datasets/dataset.py:503-578   one random frame, random (theta, phi) in the configured ranges,
+                                                              H = W = novel_view_scale * 360 (72 at the start, 180 at the end)
+        get_shading            morpheus.py:864-885           albedo for the first albedo_iter_ratio of training, then a random
+                                                              ambient ratio with lambertian / textureless shading
+        get_bg_color           morpheus.py:887-903           a random colour, or None (-> white: bg_net only renders `cano`)
+        update_occ_grid        morpheus.py:905-913
+        render_rays            morpheus.py:558-794           real_view=False: + orientation loss, no depth / mask terms, no pose
+        get_virtual_view_loss  morpheus.py:1044-1088         -> InjectedGuidance
+        get_regularization_loss morpheus.py:1090-1145
+
+    The caller scales the loss by 1 / virtual_freq and runs backward (morpheus.py:1401); while the deformation learning rates
+    are frozen for the virtual step (the first `freeze_epoch` epochs, :1394-1409) it also steps the optimiser."""
+
+    def __init__(self, renderer, res: int = 72, n_epochs: int = 2000, end_iter: int = 220000, num_frames: int = 200,
+                 radius: float = 1.5, seed: int = 2024, guidance: Optional[InjectedGuidance] = None):
+        self.r, self.model, self.cfg = renderer, renderer.model, renderer.config
+        self.res, self.num_frames, self.radius = int(res), num_frames, radius
+        self.global_step, self.epoch, self.n_epochs, self.end_iter = 0, 0, n_epochs, end_iter
+        self.rng = random.Random(seed)          # the reference draws shading / background choices with `random` (:878-900)
+        self.guidance = guidance
+        self.last_samples, self.last_shading = 0, None
+        self.keep_outputs, self.last_outputs = False, None      # tests: keep render_rays' result dict of the last step
+
+    def begin_step(self):
+        self.global_step += 1
+        if self.cfg["train"]["progressive_level"]:                    # morpheus.py:808-813
+            self.model.max_level = min(1.0, 0.5 + 0.5 * self.epoch / self.n_epochs)
+
+    def get_shading(self):
+        """morpheus.py:864-885, real_view=False."""
+        tr = self.cfg["train"]
+        if self.epoch / self.n_epochs <= tr["albedo_iter_ratio"]:
+            return 1.0, "albedo"
+        ambient = tr["min_ambient_ratio"] + (1.0 - tr["min_ambient_ratio"]) * self.rng.random()
+        return ambient, ("textureless" if self.rng.random() >= 1.0 - tr["textureless_ratio"] else "lambertian")
+
+    def get_bg_color(self, device):
+        """morpheus.py:887-903, real_view=False."""
+        if self.cfg["model"]["bg_radius"] > 0 and self.rng.random() > 0.5:
+            return None
+        return torch.rand(3, device=device)
+
+    def sample_view(self, device):
+        dc = self.cfg.get("data", {})
+        th = dc.get("theta_range", [45, 105])
+        ph = dc.get("phi_range", [-180, 180])
+        frame = self.rng.randrange(self.num_frames)
+        theta = th[0] + (th[1] - th[0]) * self.rng.random()
+        phi = ph[0] + (ph[1] - ph[0]) * self.rng.random()
+        return virtual_view_rays(frame, self.res, self.res, theta, phi, self.radius, device, self.num_frames)
+
+    def update_occ_grid(self, rays_t):
+        step_size = self.cfg["render"]["step_size"]
+
+        def occ_eval_fn(x):
+            return self.model.density(x, rays_t, allow_shape=True, cano=False, return_color=False)["sigma"] * step_size
+
+        self.r.occupancy_grid.update_every_n_steps(step=self.global_step - 1, occ_eval_fn=occ_eval_fn)
+
+    def __call__(self, data=None, shading=None, ambient_ratio=None, bg_color="draw", light_d=None):
+        """-> loss (before the caller's 1 / virtual_freq).  The keyword arguments pin what the reference draws at random
+        (parity tests); by default everything is drawn as the reference does."""
+        self.begin_step()
+        dev = next(self.model.parameters()).device
+        if data is None:
+            data = self.sample_view(dev)
+        if shading is None:
+            ambient_ratio, shading = self.get_shading()
+        if isinstance(bg_color, str):
+            bg_color = self.get_bg_color(dev)
+        self.last_shading = (shading, ambient_ratio)
+        if hasattr(self.r.occupancy_grid, "update_every_n_steps"):
+            self.update_occ_grid(data["rays_t"][:, :1])
+        return self._step(data, shading, ambient_ratio, bg_color, light_d)
+
+    def _step(self, data, shading, ambient_ratio, bg_color, light_d=None):
+        rays_o, rays_d, rays_t, rays_id = data["rays_o"], data["rays_d"], data["rays_t"], data["rays_id"]
+        B, N = rays_o.shape[:2]
+        H, W = data["H"], data["W"]
+        outputs = self.r.render_rays(rays_o, rays_d, rays_t, rays_id, H, W, perturb=True, bg_color=bg_color,
+                                     ambient_ratio=ambient_ratio, light_d=light_d, shading=shading, real_view=False, cano=False,
+                                     rays_depth=None, rays_mask=None, optimize_pose=False)
+        self.last_samples = 0 if outputs["sdf"] is None else outputs["sdf"].shape[0]
+        if self.keep_outputs:
+            self.last_outputs = outputs
+        pred_rgb = outputs["image"].reshape(B, H, W, 3).permute(0, 3, 1, 2).contiguous()          # get_pred_from_outputs :915-928
+        pred_normal = outputs["normal_image"].reshape(B, H, W, 3) if "normal_image" in outputs else None
+        guidance = self.guidance
+        if guidance is None or (guidance.H, guidance.W) != (H, W):
+            guidance = self.guidance = InjectedGuidance(H, W, rays_o.device)
+        loss = guidance(pred_rgb)
+        if outputs["sdf"] is not None:
+            loss = loss + get_regularization_loss(self.cfg["train"], self.model, outputs, pred_normal, self.global_step, self.end_iter)
+        return loss
+
+
 class GraphedRealViewStep:
     """The real-view step -- render_rays, the three loss groups, backward, the gather of the gradients into the flat bucket --
     captured in HIP graphs and replayed: ~700 launches per step issued by the GPU's own scheduler instead of the Python
@@ -263,11 +519,13 @@ class GraphedRealViewStep:
         constants are built once (render.HotPathRenderer._const).
     What stays outside the graphs: the occupancy refresh every 16 steps (morpheus.py:905-913; the batch of a refresh step is
     counted after it, synchronously), the optimiser step (its per-parameter step counts are host integers) and the
-    learning-rate schedule.  Graphs are keyed by (capacity bucket, progressive level), each with its own memory pool.
+    learning-rate schedule.  Graphs are keyed by (capacity bucket, frequency bands, hash-grid levels) -- what the kernels read of
+    the progressive level -- each with its own memory pool, least recently used evicted beyond `max_graphs`.
 
     Usage:  gs = GraphedRealViewStep(ts, opt.bucket);  loss = gs();  opt.step()        (loss: a 0-dim device tensor)"""
 
-    def __init__(self, step: RealViewTrainStep, bucket, bucket_step: int = 8192, margin: float = 0.02, lookahead: bool = True):
+    def __init__(self, step: RealViewTrainStep, bucket, bucket_step: int = 8192, margin: float = 0.02, lookahead: bool = True,
+                 max_graphs: int = 24):
         self.ts, self.bucket = step, bucket
         self.grid = step.r.occupancy_grid
         dev = step.frames[0]["rays_o"].device
@@ -284,9 +542,14 @@ class GraphedRealViewStep:
         self.ev_staged, self.ev_taken = torch.cuda.Event(), torch.cuda.Event()
         self.staged_for = None      # (frame, global step) the staging buffers hold a batch for
         self.bucket_step, self.margin, self.lookahead = int(bucket_step), float(margin), bool(lookahead)
-        self.graphs = {}            # (capacity, max_level) -> dict(graph, loss, n_valid, missing)
+        # (capacity, frequency bands, hash-grid levels) -> dict(graph, loss, n_valid, missing), least recently used first.  The key
+        # holds what the captured kernels depend on: progressive_level moves model.max_level by a new float every epoch
+        # (morpheus.py:808-813), but the kernels only see int(max_level * 6) bands and ceil(max_level * 16) levels -- a handful
+        # of distinct values over a whole run.  At most `max_graphs` graphs stay alive (each owns a multi-GB private pool).
+        self.graphs = collections.OrderedDict()
+        self.max_graphs = int(max_graphs)
         self.last_capacity, self.last_samples, self.overflows, self.n_captures = None, None, 0, 0
-        self.memset_nodes_replaced, self.last_graph_nodes = 0, 0
+        self.memset_nodes_replaced, self.last_graph_nodes, self.n_evicted = 0, 0, 0
 
     # ---- the batch: drawn one step ahead on a side stream, handed to the graphs through static buffers ---------------------
     def _stage(self, fi: int, for_step: int, after_main: bool):
@@ -321,13 +584,26 @@ class GraphedRealViewStep:
         need = int(m * (1.0 + self.margin)) + 512
         return max(self.bucket_step, -(-need // self.bucket_step) * self.bucket_step)
 
+    def level_key(self):
+        """what the captured kernels read of model.max_level: (frequency bands, hash-grid levels)"""
+        m = self.ts.model
+        return (m._n_bands(), ops.effective_levels(m.max_level, m.encoder.num_levels))
+
     def _body(self, capacity: int):
-        self.grid.sample_capacity, self.grid.fixed_jitter = capacity, self.jitter
-        self.bucket.zero()
-        with self.ts.model.operand_scope():
-            loss = self.ts._step(sample_real_view_rays(self.table, self.ts.ray_num, self.index), self.gs)
-        loss.backward()
-        self.bucket.collect()
+        # fixed capacity and the static jitter buffer are properties of THIS body, not of the renderer's shared occupancy grid:
+        # an eager render_rays on the same renderer afterwards (the reference's 1-in-11 virtual-view step, eval_step chunks)
+        # must find the ragged sampler it expects
+        grid = self.grid
+        saved = (grid.sample_capacity, grid.fixed_jitter)
+        grid.sample_capacity, grid.fixed_jitter = capacity, self.jitter
+        try:
+            self.bucket.zero()
+            with self.ts.model.operand_scope():
+                loss = self.ts._step(sample_real_view_rays(self.table, self.ts.ray_num, self.index), self.gs)
+            loss.backward()
+            self.bucket.collect()
+        finally:
+            grid.sample_capacity, grid.fixed_jitter = saved
         return loss
 
     def capture(self, capacity: int):
@@ -358,8 +634,19 @@ class GraphedRealViewStep:
         # stream (gradients of a later-captured bucket silently stale)
         entry = dict(graph=graph, loss=loss.detach(), n_valid=self.grid.n_valid, missing=set(self.bucket.missing))
         del loss
-        self.graphs[(capacity, self.ts.model.max_level)] = entry
+        self.graphs[(capacity,) + self.level_key()] = entry
         self.n_captures += 1
+        while len(self.graphs) > self.max_graphs:      # least recently replayed first; never while a replay may be in flight
+            torch.cuda.synchronize()
+            self.graphs.popitem(last=False)
+            self.n_evicted += 1
+        return entry
+
+    def _lookup(self, capacity: int):
+        key = (capacity,) + self.level_key()
+        entry = self.graphs.get(key)
+        if entry is not None:
+            self.graphs.move_to_end(key)
         return entry
 
     def prepare(self, probes_per_frame: int = 3):
@@ -373,7 +660,7 @@ class GraphedRealViewStep:
                 c = self._capacity_for(self._take())
                 caps.update(max(self.bucket_step, c + k * self.bucket_step) for k in (-2, -1, 0, 1, 2))
         for c in sorted(caps):
-            if (c, self.ts.model.max_level) not in self.graphs:
+            if self._lookup(c) is None:
                 self.capture(c)
         self.staged_for = None
         return sorted(caps)
@@ -408,12 +695,12 @@ class GraphedRealViewStep:
             self._stage(fi, ts.global_step, after_main=True)      # first step / refreshed grid: count now, against the new grid
         m = self._take()
         cap = self._capacity_for(m)
-        entry = self.graphs.get((cap, ts.model.max_level)) or self.capture(cap)
+        entry = self._lookup(cap) or self.capture(cap)
         self.gs.fill_(float(ts.global_step))
         entry["graph"].replay()
         self.bucket.missing = set(entry["missing"])
         self.last_capacity, self.last_samples = cap, m
-        ts.last_samples = cap
+        ts.last_samples, ts.last_capacity = m, cap      # m: the batch's counted samples (un-posed rays); cap: what the kernels ran on
         # the next batch is drawn and counted on the side stream while this replay runs (not across an occupancy refresh)
         if self.lookahead and ts.global_step % 16 != 0:
             self._stage(((ts.global_step + 1) * 7) % len(ts.frames), ts.global_step + 1, after_main=False)

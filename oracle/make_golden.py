@@ -517,6 +517,115 @@ def gen_extras():
     print("extras.npz", len(g), "arrays")
 
 
+# ----------------------------------------------------------------------------- round-4 fixtures (round4.npz)
+def build_ref_model_f64(state, max_level=None):
+    """The imported reference model in DOUBLE: same constructor, same weights (fp32 values, exactly representable), the hash
+    grid evaluated by oracle/hashgrid_f64.py.  Forward only."""
+    from oracle.hashgrid_f64 import OracleGridEncoderF64
+    grid_mod = sys.modules["external.encoders.gridencoder.grid"]
+    saved = grid_mod.GridEncoder
+    grid_mod.GridEncoder = OracleGridEncoderF64
+    try:
+        m, cfg = build_ref_model(state, max_level)
+    finally:
+        grid_mod.GridEncoder = saved
+    return m.double().eval(), cfg
+
+
+def keep_mask_of_smoothness_points(res_depth, rays_o, rays_d, trunc, offsets_draw):
+    """which of the npts x N surface-band points of get_normal_smoothness_loss (morpheus.py:530-556) the reference keeps
+    (inside the 1.1 sphere), from its own rendered depth and its first draw -- stored so that the HIP-side test can hand the
+    reference's [n_kept, 1] angle draw to the same points."""
+    npts = int(trunc * 100 + 1)
+    off = torch.linspace(-0.5 * trunc, 0.5 * trunc, npts) + 0.01 * offsets_draw
+    pts = (res_depth.reshape(1, -1) + off[:, None])[..., None] * rays_d[None] + rays_o[None]
+    return (torch.linalg.norm(pts.view(-1, 3), ord=2, dim=-1) < 1.1)
+
+
+def gen_round4():
+    import morpheus as ref_morpheus
+    from morpheus_amd import trainstep
+    g = {}
+    # ---- (1) float64 yardstick of the counted gate: the six evaluation renders of the parity table (2 weight states x
+    #      {cfg1 deform, cfg1 canonical, cfg3-head deform}) by the imported reference in double
+    for kind in ("a", "b"):
+        st = synth.make_state(kind)
+        for case, (hw, S, nray) in (("cfg1", (32, 64, None)), ("cfg3head", (128, 128, 256))):
+            o, d, t, rid = synth.frame_rays(25, hw, hw)
+            if nray is not None:
+                o, d, t, rid = o[:, :nray], d[:, :nray], t[:, :nray], rid[:, :nray]
+            N = o.shape[1]
+            ri, ts, te = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
+            light = ofield.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+            for mode in ("eval_albedo_deform", "eval_albedo_cano"):
+                m, cfg = build_ref_model_f64(st, None)
+                sampler = _PresetSampler()
+                sampler.samples = (ri, ts.double(), te.double())
+                fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg,
+                                             dataset=types.SimpleNamespace(num_frames=200))
+                with torch.no_grad():
+                    res = ref_morpheus.MorpheuS.render_rays(fake, o.double(), d.double(), t.double(), rid, hw, hw, ambient_ratio=0.3,
+                                                            light_d=light.double(), shading="albedo", cano="cano" in mode)
+                key = f"{kind}_{case}_{mode}|f64"
+                assert res["image"].dtype == torch.float64 and res["sdf"].dtype == torch.float64
+                g[key + "|image"] = res["image"].numpy()
+                g[key + "|depth"] = res["depth"].numpy()
+                g[key + "|weights_sum"] = res["weights_sum"].numpy()
+                g[key + "|sdf_s16"] = res["sdf"][::16].numpy()
+    print("round4: f64 yardstick done", len(g))
+    # ---- (2) the virtual-view step at 72 x 72 (datasets/dataset.py:503-578 at novel_view_scale 0.2 of 360): ALL rays of one
+    #      novel view, shipped regularisers on (orientation loss, normal_smooth_3d, normal_smoothness, code_reg), random draws
+    #      injected; the SDS guidance replaced by its interface (trainstep.InjectedGuidance: a fixed gradient on pred_rgb);
+    #      the reference's own get_regularization_loss; backward.  Two of get_shading's outcomes (morpheus.py:864-885).
+    hw, S = 72, 24
+    for tag, (frame, theta, phi, shading, ambient, bg) in (
+            ("lam", (140, 70.0, 35.0, "lambertian", 0.55, torch.tensor([0.2, 0.5, 0.7]))),
+            ("tex", (31, 95.0, -120.0, "textureless", 0.3, None))):
+        o, d = synth.camera_rays(hw, hw, synth.look_at_pose(theta, phi, 1.5))
+        N = o.shape[0]
+        o, d = o[None], d[None]
+        t = torch.full((1, N, 1), frame / 200)
+        rid = torch.full((1, N, 1), frame, dtype=torch.int64)
+        samples = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
+        light = ofield.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+        m, cfg = build_ref_model(synth.make_state("b"), 0.75)
+        m.train()
+        sampler = _PresetSampler()
+        sampler.samples = samples
+        fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg, dataset=types.SimpleNamespace(num_frames=200),
+                                     global_step=1000)
+        fake.get_ortho_normal_dir = types.MethodType(ref_morpheus.MorpheuS.get_ortho_normal_dir, fake)
+        fake.get_normal_smoothness_loss = types.MethodType(ref_morpheus.MorpheuS.get_normal_smoothness_loss, fake)
+        with DrawInjector() as inj:
+            res = ref_morpheus.MorpheuS.render_rays(fake, o, d, t, rid, hw, hw, bg_color=bg, ambient_ratio=ambient, light_d=light,
+                                                    shading=shading, real_view=False, cano=False)
+            n_draws = inj.k
+        key = "virt72_" + tag
+        g[key + "|n_draws"] = np.int32(n_draws)
+        assert n_draws == 3, n_draws          # randn_like(xyzs); rand_like(trunc offsets); rand([n_kept, 1])
+        draw2 = synth.hash_tensor((int(cfg["train"]["trunc"] * 100 + 1),), 8000 + 2, 0.5) + 0.5
+        keep = keep_mask_of_smoothness_points(res["depth"].detach(), o[0], d[0], cfg["train"]["trunc"], draw2)
+        g[key + "|keep_bits"] = np.packbits(keep.numpy())
+        g[key + "|n_keep"] = np.int32(int(keep.sum()))
+        for lk in ("loss_orient", "loss_normal_perturb", "normal_reg", "loss_code"):
+            g[key + "|" + lk] = npf(res[lk])
+        g[key + "|image"], g[key + "|depth"] = npf(res["image"]), npf(res["depth"])
+        g[key + "|weights_sum"], g[key + "|sdf_s16"] = npf(res["weights_sum"]), npf(res["sdf"][::16])
+        g[key + "|normal_s16"] = npf(res["normal"][::16])
+        pred_rgb, pred_depth, pred_mask, pred_normal, pred_sdf = ref_morpheus.MorpheuS.get_pred_from_outputs(fake, res, 1, hw, hw)
+        l_guid = trainstep.InjectedGuidance(hw, hw, "cpu", scale=5e-3)(pred_rgb)
+        l_reg = ref_morpheus.MorpheuS.get_regularization_loss(fake, res, pred_normal, cano=False)
+        total = l_guid + l_reg
+        m.zero_grad()
+        total.backward()
+        g[key + "|loss_guidance"], g[key + "|loss_reg"], g[key + "|loss"] = npf(l_guid), npf(l_reg), npf(total)
+        for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
+            g[key + "|grad|" + kk] = v
+        print("round4:", key, "kept", int(keep.sum()), "of", keep.numel(), "loss", float(total))
+    np.savez_compressed(os.path.join(OUT, "round4.npz"), **g)
+    print("round4.npz", len(g), "arrays")
+
+
 def main():
     assert os.path.isdir(REF), "make_golden.py needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -525,12 +634,16 @@ def main():
     if "--variants-only" in sys.argv:      # round 3: only the model-switch fixtures (the others are unchanged)
         gen_variants()
         return
+    if "--round4-only" in sys.argv:        # round 4: float64 yardstick + the 72 x 72 virtual-view step (the others are unchanged)
+        gen_round4()
+        return
     if "--extras-only" not in sys.argv:
         gen_operators()
         gen_model()
         gen_render()
     gen_extras()
     gen_variants()
+    gen_round4()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ import torch
 
 from morpheus_amd import synth
 from oracle import field as of
-from tests.util import assert_close, assert_close_counted, grad_digest_check, load_golden, max_rel
+from tests.util import assert_close, assert_close_counted, assert_close_vs_f64, grad_digest_check, load_golden, max_rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -50,6 +50,7 @@ MODES = ("eval_albedo_deform", "eval_albedo_cano", "eval_lambertian_deform", "tr
 @pytest.mark.parametrize("case", ["cfg1", "cfg3head"])
 def test_render_rays_vs_reference_goldens(kind, case):
     g = load_golden("render.npz")
+    g4 = load_golden("round4.npz")
     for mode in MODES:
         train = mode.startswith("train")
         model, rend, rays, light, hw, S, N, jit = _setup(kind, case, train=train)
@@ -76,6 +77,12 @@ def test_render_rays_vs_reference_goldens(kind, case):
             assert_close_counted(res["image"], g[key + "|image"], key + " image @1e-3")
             assert_close_counted(res["depth"], g[key + "|depth"], key + " depth @1e-3", max_frac=0.02)
             assert_close_counted(res["weights_sum"], g[key + "|weights_sum"], key + " opacity @1e-3", max_frac=0.02)
+        if mode in ("eval_albedo_deform", "eval_albedo_cano"):
+            # ... and against the reference run in DOUBLE on the same inputs, with the allowance derived from the reference's own
+            # fp32 error at each output (tests/util.py: assert_close_vs_f64): the counted gate's numbers are not fitted to this path
+            for out, gk in ((res["sdf"][::16], "sdf_s16"), (res["image"], "image"), (res["depth"], "depth"),
+                            (res["weights_sum"], "weights_sum")):
+                assert_close_vs_f64(out, g[key + "|" + gk], g4[key + "|f64|" + gk], key + " " + gk + " vs float64")
         assert_close(res["weights"][::16], g[key + "|weights_s16"], 5e-4, key + " weights", floor=1e-3)
         if res["deform"] is not None:
             assert_close(res["deform"][::16], g[key + "|deform_s16"], TOL, key + " deform", floor=1e-3)
@@ -626,6 +633,65 @@ def test_virtual_view_training_outputs_vs_reference_golden():
     total.backward()
     n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, "virt", 3e-2)
     assert n_ok >= 40, n_ok
+
+
+VIRT72 = {"lam": (140, 70.0, 35.0, "lambertian", 0.55, [0.2, 0.5, 0.7]), "tex": (31, 95.0, -120.0, "textureless", 0.3, None)}
+
+
+@pytest.mark.parametrize("tag", ["lam", "tex"])
+def test_virtual_view_step_72_vs_reference_golden(tag):
+    """The virtual-view half of the reference's loop (morpheus.py:1393-1408: one step in eleven): ALL 72 x 72 rays of a novel view
+    (datasets/dataset.py:503-578 at novel_view_scale 0.2), get_shading's two random outcomes (lambertian / textureless at a
+    random ambient ratio, :873-885), a colour / no background, the orientation loss, normal_smooth_3d, normal_smoothness and
+    code_reg ON, the SDS guidance replaced by its interface -- a fixed gradient on pred_rgb (trainstep.InjectedGuidance) --
+    then the regularisation loss and backward.  Fixture: the reference's OWN render_rays + get_regularization_loss on the same
+    rays / samples / weights with the random draws injected (oracle/make_golden.py:gen_round4).  The reference draws the
+    smoothness angles on the boolean-indexed points inside the 1.1 sphere; its keep mask rides in the fixture so that the
+    same points get the same angles here (tests/util.py: DrawInjector remap)."""
+    import numpy as np
+    from morpheus_amd import harness, trainstep
+    from tests.util import DrawInjector
+    g = load_golden("round4.npz")
+    frame, theta, phi, shading, ambient, bg = VIRT72[tag]
+    hw, S = 72, 24
+    o, d = synth.camera_rays(hw, hw, synth.look_at_pose(theta, phi, 1.5))
+    N = o.shape[0]
+    smp = of.uniform_samples(o, d, synth.ray_jitter(N), S, 1.01)
+    light = of.safe_normalize(o + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
+    model = harness.build_model("b", DEV, 0.75).train()
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    ts = trainstep.VirtualViewTrainStep(rend, res=hw, guidance=trainstep.InjectedGuidance(hw, hw, DEV, scale=5e-3))
+    ts.epoch, ts.keep_outputs = 1000, True                        # progressive level 0.75, as the fixture
+    data = dict(H=hw, W=hw, rays_o=o[None].to(DEV), rays_d=d[None].to(DEV), rays_t=torch.full((1, N, 1), frame / 200, device=DEV),
+                rays_id=torch.full((1, N, 1), frame, device=DEV, dtype=torch.int64))
+    key = "virt72_" + tag
+    npts = int(model.config["train"]["trunc"] * 100 + 1)
+    keep = np.unpackbits(g[key + "|keep_bits"])[:npts * N].astype(bool)
+    assert int(keep.sum()) == int(g[key + "|n_keep"])
+    model.zero_grad()
+    with DrawInjector(remap={3: keep}) as inj:
+        loss = ts(data=data, shading=shading, ambient_ratio=ambient, bg_color=None if bg is None else torch.tensor(bg, device=DEV),
+                  light_d=light)
+        assert inj.k == int(g[key + "|n_draws"]), "the HIP path must draw what the reference draws, in its order"
+    assert abs(model.max_level - 0.75) < 1e-12
+    res = ts.last_outputs
+    lam = 5e-3                       # colours shaded through FD normals: x250 round-off gain (see the module docstring)
+    assert_close(res["image"], g[key + "|image"], lam, "image", floor=FLOOR)
+    assert_close(res["depth"], g[key + "|depth"], TOL, "depth", floor=DEPTH_FLOOR)
+    assert_close(res["weights_sum"], g[key + "|weights_sum"], TOL, "opacity", floor=FLOOR)
+    assert_close(res["sdf"][::16], g[key + "|sdf_s16"], TOL, "sdf", floor=FLOOR)
+    assert_close(res["normal"][::16], g[key + "|normal_s16"], 2e-2, "normal (FD)", floor=5e-2)
+    assert_close(res["loss_code"], g[key + "|loss_code"], TOL, "loss_code")
+    assert_close(res["loss_orient"], g[key + "|loss_orient"], 1e-2, "loss_orient")
+    assert_close(res["loss_normal_perturb"], g[key + "|loss_normal_perturb"], 2e-2, "loss_normal_perturb")
+    assert_close(res["normal_reg"], g[key + "|normal_reg"], 2e-2, "normal_reg")
+    assert_close(loss, g[key + "|loss"], 1e-2, "guidance + regularisation loss")
+    loss.backward()
+    n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, key, 3e-2)
+    assert n_ok >= 35, n_ok
+    for k in ("encoder.embeddings", "encoder_c.embeddings", "deform_code.volumes.2", "color_net.net.2.weight_v"):
+        assert dict(model.named_parameters())[k].grad.abs().sum() > 0, k
+    assert model.pose_array.data.grad is None                    # optimize_pose=False on virtual views
 
 
 def test_two_frames_vs_reference_golden():

@@ -46,6 +46,32 @@ def assert_close_counted(a, b, what="", tol=1e-4, floor=REL_FLOOR, max_tol=5e-4,
     return worst, n_bad
 
 
+def rel_err(a, b, floor=REL_FLOOR):
+    a = torch.as_tensor(a).detach().double().reshape(-1).cpu()
+    b = torch.as_tensor(b).detach().double().reshape(-1).cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return (a - b).abs() / b.abs().clamp(min=floor)
+
+
+def assert_close_vs_f64(hip, ref32, f64, what="", tol=1e-4, floor=REL_FLOOR, factor=2.0, slack=2):
+    """The 1e-4 bar at SURVEY 8(d)'s floor with the allowance DERIVED from the reference itself: `f64` is the imported
+    reference run in double on the same inputs (tests/golden/round4.npz, oracle/make_golden.py:gen_round4), `ref32` the same
+    reference in its own fp32.  Wherever the reference's fp32 value is itself further than `tol` from the double value (an SDF
+    sample next to its zero crossing carries one or two fp32 ulps of the O(1) pre-activations that cancel to it), no fp32
+    implementation can be held to `tol` against it; so the HIP result is held to the double value instead:
+        * its worst element within `factor` x the reference's own worst (or `tol`, whichever is larger), and
+        * at most `factor` x as many elements above `tol` as the reference's own fp32 result has (+ `slack`).
+    -> (worst_hip, n_hip, worst_ref, n_ref)."""
+    e_hip, e_ref = rel_err(hip, f64, floor), rel_err(ref32, f64, floor)
+    worst_hip, worst_ref = float(e_hip.max()), float(e_ref.max())
+    n_hip, n_ref = int((e_hip > tol).sum()), int((e_ref > tol).sum())
+    assert worst_hip <= max(factor * worst_ref, tol), \
+        f"{what}: max rel err vs float64 {worst_hip:.3e} > {factor:g} x the reference's own fp32 error {worst_ref:.3e} (floor {floor:g})"
+    assert n_hip <= int(factor * n_ref) + slack, \
+        f"{what}: {n_hip} elements above {tol:.0e} vs float64; the reference's own fp32 result has {n_ref} (floor {floor:g})"
+    return worst_hip, n_hip, worst_ref, n_ref
+
+
 def probe_points(n, stream=300, scale=1.15):
     return synth.hash_tensor((n, 3), stream, scale)
 
@@ -78,13 +104,26 @@ class DrawInjector:
     of shape `shape` is synth.hash_tensor(shape, 8000 + k), so the HIP path sees exactly the random perturbations the
     reference saw when the fixture was generated -- provided it draws in the same order with the same shapes."""
 
-    def __init__(self, base=8000):
-        self.k, self.base = 0, base
+    def __init__(self, base=8000, remap=None):
+        """remap: {draw number k: bool mask [n]} -- where the reference made draw k on a boolean-indexed SUBSET of n rows (shape
+        [n_kept, ...]: get_normal_smoothness_loss drops the points outside the 1.1 sphere before it draws their angles,
+        morpheus.py:543-549) and the HIP path keeps all n rows (the dropped ones leave through a zero weight), the reference's
+        values go to the kept rows in their order and the others get 0."""
+        self.k, self.base, self.remap = 0, base, dict(remap or {})
 
     def _next(self, shape, normal, device=None):
         self.k += 1
-        v = synth.hash_tensor(tuple(shape), self.base + self.k, 0.5)
-        v = v * 3.4 if normal else v + 0.5
+        mask = self.remap.get(self.k)
+        if mask is not None:
+            mask = torch.as_tensor(mask).reshape(-1).bool().cpu()
+            assert int(shape[0]) == mask.numel(), (tuple(shape), mask.numel())
+            sub = synth.hash_tensor((int(mask.sum()),) + tuple(shape[1:]), self.base + self.k, 0.5)
+            v = torch.zeros(tuple(shape), dtype=sub.dtype)
+            v[mask] = sub if normal else sub + 0.5
+            v = v * 3.4 if normal else v
+        else:
+            v = synth.hash_tensor(tuple(shape), self.base + self.k, 0.5)
+            v = v * 3.4 if normal else v + 0.5
         return v.to(device) if device is not None else v
 
     def __enter__(self):
