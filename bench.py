@@ -598,6 +598,7 @@ def run_one(args):
             return loss_g
     ops.TIMER.reset(enabled=timers_on)
     captures0 = wl["graphed"].n_captures if wl.get("graphed") is not None else 0
+    mem0 = None if stub else torch.cuda.memory_stats(dev)
     if world > 1:
         dist.barrier()
     sync()
@@ -618,6 +619,15 @@ def run_one(args):
         elapsed = float(el.item())
     timers = ops.TIMER.summary() if rank == 0 else {}
     ops.TIMER.reset(False)
+    alloc = None
+    if mem0 is not None:
+        # the caching allocator inside the timed region: a ragged workload whose sample count grows past every cached block pays
+        # hipMalloc / hipFree (device-wide synchronisations) inside its steps -- visible here, not in the kernel table
+        mem1 = torch.cuda.memory_stats(dev)
+        alloc = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+        alloc["reserved_GB"] = round(mem1.get("reserved_bytes.all.current", 0) / 1e9, 2)
+        alloc["peak_allocated_GB"] = round(mem1.get("allocated_bytes.all.peak", 0) / 1e9, 2)
+        alloc["conf"] = os.environ.get("PYTORCH_HIP_ALLOC_CONF") or os.environ.get("PYTORCH_CUDA_ALLOC_CONF") or os.environ.get("PYTORCH_ALLOC_CONF")
 
     # who ran where: rank 0 prints it so that a multi-GPU run can be checked for "N ranks, N devices, backend nccl"
     n_dev = 0 if stub else torch.cuda.device_count()
@@ -692,14 +702,16 @@ def run_one(args):
         out["config"]["glue"] = wl["glue"]
     if "shadings" in wl:
         out["config"]["shadings_of_timed_steps"] = wl["shadings"]()
+    out["config"]["allocator_in_timed_region"] = alloc
     out["config"]["kernel_timers"] = bool(timers_on)      # per-C-ABI-call HIP events inside the timed region (host cost per call)
     if wl.get("graphed") is not None:
         g = wl["graphed"]
-        out["config"]["hip_graph"] = dict(capacity_buckets=sorted(c for c, _ in g.graphs), bucket_step=g.bucket_step,
+        out["config"]["hip_graph"] = dict(capacity_buckets=sorted({k[0] for k in g.graphs}), bucket_step=g.bucket_step,
                                           capacity_of_last_step=g.last_capacity, samples_of_last_step=g.last_samples,
                                           overflowed_batches=int(g.check_overflow()) + g.overflows, margin=g.margin,
                                           graphs_captured=g.n_captures, captures_inside_the_timed_region=g.n_captures - captures0,
                                           memset_nodes_replaced_by_fill_kernels=g.memset_nodes_replaced, nodes_per_replayed_step=g.last_graph_nodes,
+                                          graphs_evicted=g.n_evicted,
                                           note="sample_points_per_step_per_gpu is the mean COUNTED sample number of the batches (as in the "
                                                "eager run); the kernels ran on the bucket capacity (capacity_of_last_step: padding "
                                                "included); each batch is drawn and counted one step ahead on a side stream to pick its bucket")
@@ -794,7 +806,7 @@ def run_extras(mode):
             c = r["config"]
             keep.update(workload=c["workload"], rays_per_gpu=c["rays_per_gpu"], sample_points_per_step=c["sample_points_per_step_per_gpu"],
                         kernel_timers=c.get("kernel_timers"), loss_mean_of_timed_steps=c.get("loss_mean_of_timed_steps"))
-            for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction"):
+            for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction", "allocator_in_timed_region"):
                 if k in c:
                     keep[k] = c[k]
             return keep

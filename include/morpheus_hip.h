@@ -27,9 +27,9 @@
  *                               models/density.py:22-31 -- plain PyTorch in the reference
  *   mh_mlp_wgrad                the weight-gradient GEMMs autograd ran for those MLPs
  * The warp / field entries exist in three arithmetic forms of the SAME interface -- fp32 in, fp32 out, same parked tiles:
- * native fp32 MFMA (no suffix), exact three-way bf16 splits (_b3), two fp16 slices at power-of-two scales (_h2, what the Python
- * side calls by default); mh_b3_slice / mh_h2_slice cut their weight operands, mh_h2_amax_words sizes the table the _h2 kernels
- * record the parked tensors' maxima in.
+ * native fp32 MFMA (no suffix), exact three-way bf16 splits (_b3: fp32-faithful, what the Python side calls by default --
+ * morpheus_amd/ops.py, MORPHEUS_MLP), two fp16 slices at power-of-two scales (_h2: opt-in, 22-bit operands); mh_b3_slice /
+ * mh_h2_slice cut their weight operands, mh_h2_amax_words sizes the table the _h2 kernels record the parked tensors' maxima in.
  */
 #ifndef MORPHEUS_HIP_H
 #define MORPHEUS_HIP_H

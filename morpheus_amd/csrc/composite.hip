@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(const float *__restr
         }
         const float incl = wave_incl_scan(sd, lane);
         const float excl = carry + (incl - sd);
-        const float w = on ? expf(-excl) * (1.0f - expf(-sd)) : 0.f;
+        // alpha = 1 - exp(-sd) as -expm1(-sd): the subtraction cancels for the thin samples of a ray that only grazes the box
+        // (sd ~ 1e-4 keeps 3 digits of 1 - exp); the same function, correct to an ulp of alpha itself
+        const float w = on ? expf(-excl) * -expm1f(-sd) : 0.f;
         if (on) {
             weights[i] = w;
             a_o += w;

@@ -372,9 +372,8 @@ __global__ __launch_bounds__(256, 2) void warp_bwd_kernel(const float *__restric
 // canonical field: sdf_net (+ Laplace density) and color_net
 // =====================================================================================
 __device__ __forceinline__ float laplace_sigma(float s, float beta) {
-    // density.py:22-31: (1/beta) * (0.5 + 0.5 * sign(s) * expm1(-|s|/beta))
-    const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
-    return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+    // density.py:22-31, cancellation-free form (mlp_dev.h: laplace_unit)
+    return (1.0f / beta) * laplace_unit(s, beta);
 }
 
 __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float *__restrict__ xc, const float *__restrict__ feat_s,
@@ -842,7 +841,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                 const float a = fabsf(s) / beta;
                 const float ex = expf(-a);
                 gs += gsg * (-(0.5f / (beta * beta)) * sg * sg * ex);
-                gbeta = gsg * (-(1.0f / (beta * beta)) * (0.5f + 0.5f * sg * expm1f(-a)) +
+                gbeta = gsg * (-(1.0f / (beta * beta)) * laplace_unit(s, beta) +
                                (1.0f / beta) * (0.5f * sg * ex * (fabsf(s) / (beta * beta))));
             }
         }

@@ -150,6 +150,17 @@ __device__ __forceinline__ void enc_deriv_parked(const float *__restrict__ enc_t
     }
 }
 
+// Laplace density (models/density.py:22-31): sigma = (1/beta) (0.5 + 0.5 sign(s) expm1(-|s|/beta)), returned as beta * sigma.
+// The reference's expression cancels 0.5 - 0.5 (1 - e) for points outside the surface: far from it the result (~e/2) keeps the
+// absolute error of an ulp of 0.5, and the opacity of a ray that only grazes the box -- a sum of ~10^2 such terms -- carried 1.5e-4
+// relative against the reference run in double with the device's expm1f (the reference's own fp32 run: 5.6e-5;
+// profiles/r04_parity_f64.jsonl).  The same function without the cancellation: e = exp(-|s|/beta);  s > 0: e/2;  s < 0: 1 - e/2;
+// s = 0: 1/2 -- every branch correct to an ulp of ITS value.
+__device__ __forceinline__ float laplace_unit(float s, float beta) {
+    const float e = expf(-fabsf(s) / beta);
+    return s > 0.f ? 0.5f * e : (s < 0.f ? 1.0f - 0.5f * e : 0.5f);
+}
+
 // ---- bf16x3: exact three-way bf16 split of fp32 operands (mlp_b3.hip, the b3 weight-gradient body in mlp.hip) ------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union Frag {

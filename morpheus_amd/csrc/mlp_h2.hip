@@ -555,9 +555,8 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_h2_kernel(const float *__
 #define FH2_THREADS 512
 
 __device__ __forceinline__ float laplace_sigma_h2(float s, float beta) {
-    // density.py:22-31: (1/beta) * (0.5 + 0.5 * sign(s) * expm1(-|s|/beta))
-    const float sg = (s > 0.f) ? 1.f : ((s < 0.f) ? -1.f : 0.f);
-    return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(s) / beta));
+    // density.py:22-31, cancellation-free form (mlp_dev.h: laplace_unit)
+    return (1.0f / beta) * laplace_unit(s, beta);
 }
 
 // 64 pre-activations of a lane (two accumulator tiles, acc = 2^ks W x): y = relu(acc . 2^-ks + b), park feature-major, sign mask,

@@ -220,10 +220,11 @@ class GradBucket:
         if not self._multi_rank():
             return
         world = dist.get_world_size()
-        # has-gradient flags (device-side fills, no host data): 1 everywhere, 0 for this rank's missing parameters
+        # has-gradient flags: 1 everywhere, 0 for this rank's missing parameters -- two launches whatever their number (the index
+        # tensor of a missing SET is built once: cfg3 has the same nine gradient-less tensors, pose + background net, every step)
         self._flags.fill_(1.0)
-        for i in self.missing:
-            self._flags[i] = 0.0
+        if self.missing:
+            self._flags.index_fill_(0, self._missing_index(), 0.0)
         n, total = self.flat.numel(), self._buf.numel()
         if self._early and not self._early_disabled:
             if not self._early_fired:
@@ -252,6 +253,16 @@ class GradBucket:
         self.flat.div_(world)
         self.exchanged = True
 
+    def _missing_index(self) -> torch.Tensor:
+        key = tuple(sorted(self.missing))
+        cache = self.__dict__.setdefault("_missing_idx_cache", {})
+        idx = cache.get(key)
+        if idx is None:
+            if len(cache) >= 16:
+                cache.clear()
+            idx = cache[key] = torch.tensor(key, dtype=torch.long, device=self._flags.device)
+        return idx
+
     @property
     def grad_counts(self) -> torch.Tensor:
         """[n_params + 1] device floats, valid after a multi-rank allreduce_mean(): how many ranks had a gradient for each
@@ -262,7 +273,7 @@ class GradBucket:
         """`missing` as a property of ALL ranks (one device->host read): the parameters that had no gradient anywhere."""
         if self.exchanged and self.missing:
             idx = sorted(self.missing)
-            had = self._flags[torch.tensor(idx, device=self._flags.device)].tolist()
+            had = self._flags[self._missing_index()].tolist()
             self.missing = {i for i, c in zip(idx, had) if c == 0.0}
         return self.missing
 

@@ -245,6 +245,9 @@ class scene_representation(nn.Module):
             self.bg_net = MLP(self.in_dim_bg + self.in_dim_bg_t, 3, hidden_dim_bg, num_layers_bg)
         self.sdf2density = LaplaceDensity(0.1)
         self._opcache = None        # operand cache of the current operand_scope() (None outside a scope)
+        # arithmetic of this model's MLP kernels: "b3" / "f32" / "h2", or None = the process default (ops.mlp_mode()); bound to
+        # the operand packs when they are prepared, so two models of one process may run different forms
+        self.mlp_mode: Optional[str] = None
 
     # -- helpers ----------------------------------------------------------------------------
     def _n_bands(self) -> int:
@@ -309,7 +312,7 @@ class scene_representation(nn.Module):
             w_all = wn_effective_batched(list(self.deform_net.net) + list(self.topo_net.net))
             pd, wcode_d, b0_d = self._warp_params(self.deform_net, w_all[:6])
             pt, wcode_t, b0_t = self._warp_params(self.topo_net, w_all[6:])
-            return ops.prepare_warp_operands(pd, pt), (wcode_d, b0_d, wcode_t, b0_t)
+            return ops.prepare_warp_operands(pd, pt, mode=self.mlp_mode), (wcode_d, b0_d, wcode_t, b0_t)
         return self._cached("warp", build)
 
     def _warp_bias0(self, tu, code_w):
@@ -336,7 +339,7 @@ class scene_representation(nn.Module):
                 ws = [torch.cat([w0[:, :3], w0.new_zeros(w0.shape[0], 36), w0[:, 3:]], 1)] + ws[1:]
             params = ws + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
                 self.color_net.biases()
-            return ops.prepare_field_operands(params), self.sdf2density.get_beta()
+            return ops.prepare_field_operands(params, mode=self.mlp_mode), self.sdf2density.get_beta()
         return self._cached("field", build)
 
     # -- public API (names/signatures of the reference) ----------------------------------------

@@ -142,8 +142,10 @@ def mlp_mode() -> str:
 
 
 def set_mlp_mode(mode: str) -> str:
-    """Select the arithmetic of the MLP kernels for the operands prepared FROM NOW ON (a model.operand_scope() keeps the mode
-    it was opened under: parked tiles are mode-independent, sliced weight packs are not).  -> the previous mode."""
+    """Select the PROCESS DEFAULT arithmetic of the MLP kernels, for operand packs prepared from now on by models that do not
+    carry a mode of their own (`scene_representation.mlp_mode`).  A pack keeps the arithmetic it was prepared with (see
+    _warp_mode): changing the default between a forward and its backward, or inside a model.operand_scope(), does not mix
+    arithmetic forms.  -> the previous default."""
     global _mode
     if mode not in MLP_MODES:
         raise ValueError(f"mlp mode {mode!r}: expected one of {MLP_MODES}")
@@ -151,9 +153,15 @@ def set_mlp_mode(mode: str) -> str:
     return prev
 
 
-def _warp_mode() -> str:
-    """operand-pack tag of the warp nets: "h2" / "b3" / "" (native fp32 MFMA)."""
-    return "" if _mode == "f32" else _mode
+def _warp_mode(mode: Optional[str] = None) -> str:
+    """operand-pack tag of the MLP nets: "h2" / "b3" / "" (native fp32 MFMA).  `mode`: an explicit choice (a model's own
+    `mlp_mode`); None = the process default (MORPHEUS_MLP / set_mlp_mode).  The tag is fixed when a pack is prepared and travels
+    with it (MLPOperands.mode -> every forward's ctx): a forward and its backward always use the same arithmetic, and two models
+    of one process may differ."""
+    mode = _mode if mode is None else mode
+    if mode not in MLP_MODES:
+        raise ValueError(f"mlp mode {mode!r}: expected one of {MLP_MODES}")
+    return "" if mode == "f32" else mode
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
@@ -770,18 +778,19 @@ class MLPOperands:
         self.wT = [jp.take(bpack, sl) for sl in jp.wT]
 
 
-def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[torch.Tensor]) -> MLPOperands:
-    """params_{d,t}: W0x [128,39], W1..W4 [128,128], W5 [n_out,128], b0 (its gradient travels through bias0), b1..b5."""
+def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[torch.Tensor], mode: Optional[str] = None) -> MLPOperands:
+    """params_{d,t}: W0x [128,39], W1..W4 [128,128], W5 [n_out,128], b0 (its gradient travels through bias0), b1..b5.
+    mode: the arithmetic the pack is cut for ("b3" / "f32" / "h2"; None = the process default)."""
     jp = warp_joint_packer()
     flat = list(params_d[:6]) + list(params_t[:6]) + list(params_d[6:]) + list(params_t[6:])
-    mode = _warp_mode()
+    mode = _warp_mode(mode)
     return MLPOperands(jp, *_PackOperands.apply(jp, True, mode, len(flat), *flat), mode=mode)
 
 
-def prepare_field_operands(params: Sequence[torch.Tensor]) -> MLPOperands:
+def prepare_field_operands(params: Sequence[torch.Tensor], mode: Optional[str] = None) -> MLPOperands:
     """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
     jp = field_joint_packer()
-    mode = _warp_mode()        # the field FORWARD follows the mode; the fused backward reads the fp32 transposed pack in every mode
+    mode = _warp_mode(mode)    # the field FORWARD follows the mode; the fused backward reads the fp32 transposed pack in every mode
     return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), *params), mode=mode)
 
 

@@ -172,7 +172,9 @@ class FlatAdam(torch.optim.Optimizer):
 
 
 class FlatEMA:
-    """Exponential moving average of a FlatAdam bucket (one fused op per update); torch_ema's interface."""
+    """Exponential moving average of a FlatAdam bucket -- ONE flat tensor instead of torch_ema's per-parameter list, so an update
+    is three torch launches (subtract, scale, subtract) and one temporary whatever the number of parameters; torch_ema's
+    interface.  (The reference updates its EMA once per epoch, morpheus.py:1432-1433: no kernel of its own.)"""
 
     def __init__(self, optimizer: FlatAdam, decay: float, use_num_updates: bool = True, parameters=None):
         """parameters: the iterable torch_ema would be given -- the reference passes `self.model.parameters()`

@@ -99,7 +99,53 @@ def render_case(kind, hw, S, cano, nray=None):
     return out
 
 
+def f64_rows(mode):
+    """The eight evaluation renders of tests/golden/render.npz in arithmetic mode `mode` against the imported reference run in
+    DOUBLE (tests/golden/round4.npz): per output, the HIP path's error vs the double value next to the reference's own fp32
+    error vs the same value -- the numbers the derived gate (tests/util.py: assert_close_vs_f64) is built on."""
+    import numpy as np
+    from morpheus_amd import ops
+    from tests.util import load_golden, rel_err
+    r, g4 = load_golden("render.npz"), load_golden("round4.npz")
+    prev = ops.set_mlp_mode(mode)
+    rows = []
+    try:
+        for kind in ("a", "b"):
+            for case, (hw, S, nray) in (("cfg1", (32, 64, None)), ("cfg3head", (128, 128, 256))):
+                o, d, t, rid = synth.frame_rays(25, hw, hw)
+                if nray is not None:
+                    o, d, t, rid = o[:, :nray], d[:, :nray], t[:, :nray], rid[:, :nray]
+                N = o.shape[1]
+                smp = of.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
+                light = of.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+                for m_ in ("eval_albedo_deform", "eval_albedo_cano"):
+                    model = harness.build_model(kind, DEV).eval()
+                    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+                    with torch.no_grad():
+                        res = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), hw, hw, ambient_ratio=0.3,
+                                               light_d=light.to(DEV), shading="albedo", cano="cano" in m_)
+                    key = f"{kind}_{case}_{m_}"
+                    row = dict(case="vs_float64 " + key, mode=mode)
+                    for out, gk in ((res["sdf"][::16], "sdf_s16"), (res["image"], "image"), (res["depth"], "depth"),
+                                    (res["weights_sum"], "weights_sum")):
+                        f64 = g4[key + "|f64|" + gk]
+                        eh, er, e32 = rel_err(out, f64), rel_err(r[key + "|" + gk], f64), rel_err(out, r[key + "|" + gk])
+                        row[gk] = dict(hip_vs_f64_max=float(eh.max()), hip_vs_f64_n_over_1e4=int((eh > 1e-4).sum()),
+                                       ref32_vs_f64_max=float(er.max()), ref32_vs_f64_n_over_1e4=int((er > 1e-4).sum()),
+                                       hip_vs_ref32_max=float(e32.max()), hip_vs_ref32_n_over_1e4=int((e32 > 1e-4).sum()),
+                                       n=int(eh.numel()))
+                    rows.append(row)
+    finally:
+        ops.set_mlp_mode(prev)
+    return rows
+
+
 if __name__ == "__main__":
+    if "--f64" in sys.argv:
+        for mode in ("b3", "f32"):
+            for r in f64_rows(mode):
+                print(json.dumps(r))
+        sys.exit(0)
     rows = []
     for kind in ("a", "b"):
         rows.append(model_probe(kind, "albedo", False))

@@ -252,3 +252,75 @@ def test_exchange_patterns_keep_replicas_identical(case):
         assert r0["warned"] and r1["warned"] and r0["disabled"] and r1["disabled"]
     if case == "two_backwards_declared":
         assert not r0["warned"] and not r0["disabled"] and not r1["disabled"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# NCCL's async semantics without NCCL: `dist.all_reduce(..., async_op=True)` on the nccl backend returns at once, the reduction
+# is ordered on a stream, and `work.wait()` does NOT block the host -- it only makes the current stream wait.  gloo (every other
+# test of this file) completes the data before `wait()` returns on the host, so code that reads or rescales the early range
+# between the async call and `wait()`, or that relies on `wait()` as a host barrier, passes under gloo and breaks under RCCL.
+# Here all_reduce is replaced by a stand-in whose asynchronous form applies the reduction ONLY when `wait()` is called (and never
+# blocks), and which fails if the tensor was touched in between.
+class _StreamOrderedWork:
+    def __init__(self, tensor, log):
+        self.tensor, self.log, self.snapshot, self.done = tensor, log, tensor.clone(), False
+
+    def wait(self):
+        assert not self.done
+        assert torch.equal(self.tensor, self.snapshot), "the early range was modified while its collective was in flight"
+        self.tensor.mul_(2.0)                 # "sum over two ranks holding the same gradient"
+        self.done = True
+        self.log.append(("wait", self.tensor.numel()))
+        return True
+
+    def is_completed(self):
+        raise AssertionError("GradBucket must not poll: nccl work completion is stream-ordered, not a host event")
+
+
+@pytest.mark.parametrize("backwards", [1, 2])
+def test_early_exchange_assumes_no_host_wait(monkeypatch, backwards):
+    from morpheus_amd import dist as mdist
+    log, works = [], []
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        if async_op:
+            w = _StreamOrderedWork(t, log)
+            works.append(w)
+            log.append(("async", t.numel()))
+            return w
+        t.mul_(2.0)
+        log.append(("sync", t.numel()))
+        return None
+
+    monkeypatch.setattr(mdist.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(mdist.dist, "get_world_size", lambda *a, **k: 2)
+    monkeypatch.setattr(mdist.GradBucket, "_multi_rank", staticmethod(lambda: True))
+    torch.manual_seed(0)
+    table = torch.nn.Parameter(torch.randn(32, 2))
+    net = torch.nn.Linear(4, 3)
+    unused = torch.nn.Parameter(torch.zeros(5))           # no gradient on this rank: its flag must travel as 0
+    params = [table] + list(net.parameters()) + [unused]
+    bucket = mdist.GradBucket(params)
+    bucket.overlap_early([table], backwards_per_step=backwards)
+    x = torch.randn(16, 4)
+    idx = torch.arange(16) % 32
+    for step in range(2):
+        bucket.zero()
+        del log[:]
+        for _ in range(backwards):
+            ((net(x) + table[idx].sum(-1, keepdim=True)) ** 2).mean().backward()
+        assert log == [("async", 64)], log              # fired from the hook of the LAST declared backward, nothing waited for yet
+        assert not works[-1].done
+        ref = [p.grad.detach().clone() if p.grad is not None else None for p in params]
+        ref_table = bucket.flat[:64].clone()             # the early range as the hooks left it (p.grad was taken over)
+        bucket.allreduce_mean()
+        # [early async] ... [remainder + flags, sync] [wait] and only then the division by the world size
+        assert [e[0] for e in log] == ["async", "sync", "wait"], log
+        assert works[-1].done
+        assert torch.allclose(table.grad.reshape(-1), ref_table)                    # (g + g) / 2
+        assert torch.allclose(net.weight.grad, ref[1]) and torch.allclose(net.bias.grad, ref[2])
+        counts = bucket.grad_counts
+        assert counts[:3].tolist() == [2.0, 2.0, 2.0] and counts[3].item() == 0.0 and counts[4].item() == 0.0
+        assert bucket.resolve_missing() == {3}
+    # one flag write per step, whatever the number of gradient-less parameters
+    assert len(bucket.__dict__["_missing_idx_cache"]) == 1

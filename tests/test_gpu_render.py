@@ -72,11 +72,16 @@ def test_render_rays_vs_reference_goldens(kind, case):
         assert_close(res["weights_sum"], g[key + "|weights_sum"], TOL, key + " opacity", floor=FLOOR)
         assert_close(res["sdf"][::16], g[key + "|sdf_s16"], TOL, key + " sdf", floor=FLOOR)
         if not lam:
-            # the contract floor (1e-3), counted: SDF per sample, image / depth / opacity per ray
+            # the contract floor (1e-3).  Rendered RGB / depth / opacity: STRICT 1e-4 (round 4: the Laplace density and the
+            # compositor's alpha are evaluated without their cancelling subtractions -- csrc/mlp_dev.h: laplace_unit,
+            # csrc/composite.hip -- measured <= 5.6e-5, all of it the reference's own fp32 error against its double run); SDF
+            # per sample: counted, every element within 3e-4 (measured 1.6e-4; the reference's own fp32 SDF is up to 4.6e-4 off
+            # its double value on these samples: tests/test_oracle_golden.py)
             assert_close_counted(res["sdf"][::16], g[key + "|sdf_s16"], key + " sdf @1e-3")
-            assert_close_counted(res["image"], g[key + "|image"], key + " image @1e-3")
-            assert_close_counted(res["depth"], g[key + "|depth"], key + " depth @1e-3", max_frac=0.02)
-            assert_close_counted(res["weights_sum"], g[key + "|weights_sum"], key + " opacity @1e-3", max_frac=0.02)
+            strict = 1e-4 if not train else 2e-4      # the pose-optimising training render moves the rays by an ulp
+            assert_close(res["image"], g[key + "|image"], strict, key + " image @1e-3", floor=1e-3)
+            assert_close(res["depth"], g[key + "|depth"], strict, key + " depth @1e-3", floor=1e-3)
+            assert_close(res["weights_sum"], g[key + "|weights_sum"], strict, key + " opacity @1e-3", floor=1e-3)
         if mode in ("eval_albedo_deform", "eval_albedo_cano"):
             # ... and against the reference run in DOUBLE on the same inputs, with the allowance derived from the reference's own
             # fp32 error at each output (tests/util.py: assert_close_vs_f64): the counted gate's numbers are not fitted to this path
@@ -689,7 +694,8 @@ def test_virtual_view_step_72_vs_reference_golden(tag):
     loss.backward()
     n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, key, 3e-2)
     assert n_ok >= 35, n_ok
-    for k in ("encoder.embeddings", "encoder_c.embeddings", "deform_code.volumes.2", "color_net.net.2.weight_v"):
+    live = ("encoder.embeddings", "deform_code.volumes.2") + (("encoder_c.embeddings", "color_net.net.2.weight_v") if tag == "lam" else ())
+    for k in live:                                               # textureless shading does not read the albedo
         assert dict(model.named_parameters())[k].grad.abs().sum() > 0, k
     assert model.pose_array.data.grad is None                    # optimize_pose=False on virtual views
 
@@ -885,8 +891,87 @@ def test_graphed_real_view_step_replays_the_eager_step():
     n0 = len(gs.graphs)
     ts.epoch = 0
     losses.append(float(gs()))
-    assert len(gs.graphs) == n0 + 1 and {lv for _, lv in gs.graphs} == {0.75, 0.5} and losses[-1] == losses[-1]
+    assert len(gs.graphs) == n0 + 1 and {k[1:] for k in gs.graphs} == {(4, 12), (3, 8)} and losses[-1] == losses[-1]
+    # ... but a level change that leaves the band / level counts alone does NOT (progressive_level yields a new float every epoch,
+    # morpheus.py:808-813: keyed on the raw float, every epoch would re-capture every bucket and keep the old pools)
+    n1, c1 = len(gs.graphs), gs.n_captures
+    ts.epoch = 8                                         # max_level 0.502: still 3 bands, 9 levels? -> ceil(0.502 * 16) = 9: a new key
+    gs()
+    ts.epoch = 9                                         # 0.50225: the same counts as epoch 8 -> at most a new capacity bucket
+    gs()
+    lv = {k[1:] for k in gs.graphs}
+    assert lv == {(4, 12), (3, 8), (3, 9)}, lv
+    # the capacity and the static jitter belong to the captured body, not to the renderer's shared occupancy grid: an eager
+    # render_rays of another batch size on the same renderer afterwards runs ragged and un-truncated
+    assert grid.sample_capacity is None and grid.fixed_jitter is None
+    o, d, t, rid = [v.to(DEV) for v in synth.frame_rays(25, 24, 24)]
+    with torch.no_grad():
+        res = ts.r.render_rays(o, d, t, rid, 24, 24, ambient_ratio=1.0, shading="albedo")
+    assert res["image"].shape == (1, 576, 3) and "n_valid" not in res
+    # least-recently-used eviction beyond max_graphs
+    gs.max_graphs = len(gs.graphs)
+    ts.epoch = 2000
+    gs()
+    assert len(gs.graphs) == gs.max_graphs and gs.n_evicted == 1
     gs.release()
+
+
+def test_reference_glue_equals_fused_glue():
+    """bench.py --workload train_real --glue reference: the reference's own caller-side loss code (trainstep.ReferenceGlue: operator
+    chains, in-place masks, the boolean index of morpheus.py:1018) around the swapped-in render_rays gives the loss and the
+    gradients of this build's fused glue (ops.real_view_render_loss / masked_mean / weighted_sum) on the same batch and draws."""
+    from morpheus_amd import harness, trainstep
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.render import HotPathRenderer
+    out = {}
+    for glue in ("fused", "reference"):
+        model = harness.build_model("b", DEV).train()
+        grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(DEV)
+        rend = HotPathRenderer(model, model.config, grid, 200)
+        ts = trainstep.RealViewTrainStep(rend, trainstep.make_frames([25], 64, 64, DEV), ray_num=512, glue=glue)
+        ts.epoch = 1000
+        torch.manual_seed(11)                   # the occupancy warm-up draws one jittered point per cell: same grid for both
+        with torch.no_grad():
+            trainstep.warm_up_occupancy(ts)
+        ts.global_step = 4096 + 3
+        loss = ts(frame_index=0)
+        model.zero_grad()
+        loss.backward()
+        out[glue] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    (lf, gf), (lr_, gr) = out["fused"], out["reference"]
+    assert abs(lf - lr_) <= 2e-5 * abs(lr_), (lf, lr_)
+    assert set(gf) == set(gr)
+    for k in gf:
+        rel = float((gf[k] - gr[k]).norm() / gr[k].norm().clamp_min(1e-30))
+        assert rel <= 2e-3, (k, rel)          # same terms, other summation orders; FD-normal terms amplify round-off
+
+
+def test_two_models_with_their_own_arithmetic_in_one_process():
+    """`scene_representation.mlp_mode` binds the arithmetic form to a model's operand packs: two models of one process run
+    different forms side by side, and changing the process default between a forward and its backward changes nothing."""
+    from morpheus_amd import harness, ops
+    hw, S = 16, 32
+    o, d, t, rid = [v.to(DEV) for v in synth.frame_rays(25, hw, hw)]
+    N = o.shape[1]
+    timg, tdep = [v.to(DEV) for v in synth.targets(N)]
+    res, grads = {}, {}
+    models = {m: harness.build_model("b", DEV).eval() for m in ("b3", "f32")}
+    for m, model in models.items():
+        model.mlp_mode = m
+    rends = {m: harness.make_renderer(model, S, jitter=synth.ray_jitter(N).to(DEV)) for m, model in models.items()}
+    outs = {m: rends[m].render_rays(o, d, t, rid, hw, hw, ambient_ratio=1.0, shading="albedo") for m in models}   # both graphs alive
+    prev = ops.set_mlp_mode("h2")                        # a changed default must not reach the packs already prepared
+    try:
+        for m, model in models.items():
+            harness.bench_loss(outs[m], timg, tdep).backward()
+            grads[m] = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    finally:
+        ops.set_mlp_mode(prev)
+    assert not torch.equal(outs["b3"]["sdf"], outs["f32"]["sdf"])          # two arithmetic forms really ran ...
+    assert_close(outs["b3"]["image"], outs["f32"]["image"], 1e-5, "image b3 vs f32", floor=FLOOR)   # ... and agree to fp32 round-off
+    for k in grads["f32"]:
+        rel = float((grads["b3"][k] - grads["f32"][k]).norm() / grads["f32"][k].norm().clamp_min(1e-30))
+        assert rel <= 1e-3, (k, rel)
 
 
 @pytest.mark.parametrize("tag", ["use_t", "no_joint", "use_t_no_joint"])

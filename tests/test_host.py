@@ -400,3 +400,55 @@ def test_weighted_sum_is_the_chain_of_adds_on_any_device():
     for k in range(200):
         ops.weighted_sum([(1.0 + k, ts[0].detach())])
     assert len(ops._WEIGHT_CACHE) <= 64
+
+
+def test_i32arr_cache_keys_do_not_collide_across_source_kinds():
+    """a list [3, 1, 2, 3] and the array [1, 2, 3] used to share one cache entry (tuple(a) vs (size,) + values)."""
+    import numpy as np
+    from morpheus_amd import ops
+    a, _ = ops._i32arr([3, 1, 2, 3])
+    b, _ = ops._i32arr(np.array([1, 2, 3], dtype=np.int32))
+    c, _ = ops._i32arr((1, 2, 3))
+    assert a.tolist() == [3, 1, 2, 3] and b.tolist() == [1, 2, 3] and c.tolist() == [1, 2, 3]
+    assert ops._i32arr([3, 1, 2, 3])[0] is a                     # cached by value
+    d, _ = ops._i32arr([1.5, 2])                                  # non-integers are converted, never used as a key
+    assert d.tolist() == [1, 2]
+
+
+def test_per_ray_jitter_length_is_checked():
+    """the marcher indexes the jitter by ray without a length of its own; a buffer sized for another batch must raise."""
+    import pytest
+    import torch
+    from morpheus_amd import ops
+    assert ops._ray_jitter(None, 7) is None
+    assert ops._ray_jitter(torch.zeros(7, 1), 7).shape == (7,)
+    with pytest.raises(ValueError):
+        ops._ray_jitter(torch.zeros(2048), 576)
+    with pytest.raises(ValueError):
+        ops._ray_jitter(torch.zeros(7, dtype=torch.float64), 7)
+
+
+def test_virtual_view_step_host_logic():
+    """trainstep.VirtualViewTrainStep's host side (morpheus.py:864-903): shading schedule, background draw, the guidance stand-in's
+    gradient, the arithmetic-mode tag bound to a pack."""
+    import types
+    import torch
+    from morpheus_amd import harness, ops, trainstep
+    cfg = harness.load_config()
+    fake_model = types.SimpleNamespace(config=cfg)
+    vs = trainstep.VirtualViewTrainStep(types.SimpleNamespace(model=fake_model, config=cfg, occupancy_grid=None), res=72, seed=1)
+    vs.epoch = 100                                               # exp_iter_ratio 0.05 <= albedo_iter_ratio 0.1
+    assert vs.get_shading() == (1.0, "albedo")
+    vs.epoch = 1000
+    draws = [vs.get_shading() for _ in range(400)]
+    kinds = {s for _, s in draws}
+    assert kinds == {"lambertian", "textureless"} and all(0.1 <= a <= 1.0 for a, _ in draws)
+    frac = sum(s == "textureless" for _, s in draws) / 400
+    assert 0.1 < frac < 0.3                                      # textureless_ratio 0.2
+    bgs = [vs.get_bg_color("cpu") for _ in range(40)]
+    assert any(b is None for b in bgs) and any(b is not None and b.shape == (3,) for b in bgs)
+    g = trainstep.InjectedGuidance(8, 8, "cpu", scale=5e-3)
+    img = torch.rand(1, 3, 8, 8, requires_grad=True)
+    g(img).backward()
+    assert torch.equal(img.grad, g.grad) and float(g.grad.abs().max()) <= 5e-3
+    assert ops._warp_mode("f32") == "" and ops._warp_mode("b3") == "b3" and ops._warp_mode(None) == ops._warp_mode(ops.mlp_mode())

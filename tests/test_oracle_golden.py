@@ -133,3 +133,24 @@ def test_render_rays(kind, case):
         n_ok = grad_digest_check({k: v.grad for k, v in p.items() if v.is_floating_point() and v.grad is not None},
                                  g, key, 3e-4)
         assert n_ok >= 10
+
+
+def test_reference_fp32_is_itself_off_the_float64_value_by_more_than_1e4():
+    """The fact behind the counted parity gate: run in DOUBLE on the same inputs (tests/golden/round4.npz,
+    oracle/make_golden.py:gen_round4), the imported reference differs from its OWN fp32 result by more than 1e-4 at SURVEY 8(d)'s
+    floor on a few SDF samples next to the zero crossing -- no fp32 implementation can be held to 1e-4 against those fp32 values.
+    Rendered RGB / depth / opacity of the reference's fp32 run stay within 6e-5 of the double values."""
+    import numpy as np
+    from tests.util import load_golden, rel_err
+    r, g4 = load_golden("render.npz"), load_golden("round4.npz")
+    worst, n_over = 0.0, 0
+    for kind in "ab":
+        for case in ("cfg1", "cfg3head"):
+            for mode in ("eval_albedo_deform", "eval_albedo_cano"):
+                key = f"{kind}_{case}_{mode}"
+                e = rel_err(r[key + "|sdf_s16"], g4[key + "|f64|sdf_s16"])
+                worst, n_over = max(worst, float(e.max())), n_over + int((e > 1e-4).sum())
+                for q in ("image", "depth", "weights_sum"):
+                    assert float(rel_err(r[key + "|" + q], g4[key + "|f64|" + q]).max()) < 1e-4, (key, q)
+                assert g4[key + "|f64|sdf_s16"].dtype == np.float64
+    assert 1e-4 < worst < 6e-4 and 3 <= n_over <= 20, (worst, n_over)

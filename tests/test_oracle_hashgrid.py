@@ -149,3 +149,26 @@ def test_second_derivation_agrees_on_1e5_points():
         gu_np = np.einsum("mldc,mlc->md", d_np.astype(np.float64), go.numpy()[:20000].reshape(-1, 16, 2).astype(np.float64))
         gu_c = ut.grad.numpy()[:20000].astype(np.float64)
         assert np.abs(gu_c - gu_np).max() <= 1e-5 * np.abs(gu_np).max()
+
+
+def test_float64_encoder_agrees_with_the_c_restatement():
+    """oracle/hashgrid_f64.py (the yardstick's encoder: vectorised torch, double) against oracle/hashgrid.c (scalar C, fp32) on
+    20 000 points incl. out-of-box ones: the same cells, corners, hash and weights -- the difference is the fp32 round-off of the
+    position (u * res - 0.5 carries ~res * 6e-8 of a cell) times the feature slope."""
+    import torch
+    from morpheus_amd import synth
+    from oracle.hashgrid import OracleGridEncoder
+    from oracle.hashgrid_f64 import OracleGridEncoderF64
+    kw = dict(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=15, desired_resolution=128)
+    a, b = OracleGridEncoder(**kw), OracleGridEncoderF64(**kw)
+    emb = synth.make_state("b")["encoder.embeddings"]
+    a.embeddings.data.copy_(emb)
+    b.embeddings.data.copy_(emb.double())
+    assert torch.equal(a.offsets, b.offsets)
+    x = synth.hash_tensor((20000, 3), 300, 1.15)
+    with torch.no_grad():
+        for ml in (None, 0.5):
+            ya, yb = a(x, bound=1.01, max_level=ml), b(x.double(), bound=1.01, max_level=ml)
+            assert yb.dtype == torch.float64
+            assert float((ya.double() - yb).abs().max()) < 5e-6 and float(yb.abs().max()) > 0.05
+            assert torch.equal(ya == 0, yb == 0) or float(((ya == 0) != (yb == 0)).float().mean()) < 1e-4   # OOB points and skipped levels

@@ -26,11 +26,12 @@ def assert_close(a, b, tol, what="", floor=REL_FLOOR):
     assert r <= tol, f"{what}: max rel err {r:.3e} > {tol:.1e}"
 
 
-def assert_close_counted(a, b, what="", tol=1e-4, floor=REL_FLOOR, max_tol=5e-4, max_frac=1.0 / 512.0, min_count=4):
+def assert_close_counted(a, b, what="", tol=1e-4, floor=REL_FLOOR, max_tol=3e-4, max_frac=1.0 / 512.0, min_count=4):
     """The 1e-4 bar AT SURVEY 8(d)'s floor (rel = |a-b| / max(|b|, 1e-3)), stated as what fp32 can keep: every element within
-    `max_tol`, and at most max(min_count, ceil(n * max_frac)) elements above `tol` (default 0.2 %: measured 1..14 of 65 536
-    SDF samples on the evaluation renders and 4 of 4 096 strided samples on the pose-optimising training render, worst
-    2.6e-4; profiles/r03_parity_report.jsonl).  The elements above 1e-4 are reference
+    `max_tol` (3e-4), and at most max(min_count, ceil(n * max_frac)) elements above `tol` (default 0.2 %: measured 0..2 of 4 096
+    strided SDF samples on the evaluation renders, worst 1.6e-4 -- profiles/r04_parity_f64.jsonl -- and 4 of 4 096 on the
+    pose-optimising training render, worst 2.6e-4).  Used for the SDF only; the allowance is not fitted: assert_close_vs_f64
+    below derives it from the reference's own fp32 error against its double run.  The elements above 1e-4 are reference
     values below ~1e-3 in magnitude (an SDF sample next to its zero crossing, the opacity / depth of a ray that only grazes
     the box) whose ABSOLUTE error is one or two fp32 ulps of the O(1) quantities that cancel to them (DESIGN.md section 4);
     the gate counts them instead of moving the floor."""
