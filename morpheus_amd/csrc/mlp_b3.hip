@@ -388,263 +388,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     }
 }
 
-// ---- the same forward, weight staging pipelined (round 4) ------------------------------------------------------------
-// warp_fwd_b3_kernel above stages ONE layer's slices (96 KB) at a time: the next layer's DMA can only be issued after every wave
-// has left the current layer, so each layer pays the DMA's flight (stage wait: 11.8 % of a layer with parking,
-// profiles/r03_phase_trace_warp_fwd_bf16x3.txt) and the epilogue of the layer's last two output tiles, which has nothing to
-// hide under (8.7 %).  Here the LDS holds THREE 48 KB slots, a slot = one k-half of a 128 x 128 layer (the packs are
-// [k-half][plane][tile][k16 step][lane] already: packing.py), and the weight blocks of both nets form one sequence
-//      L0d | L1d.k0 | L1d.k1 | ... | L4d.k1 | L5d | L0t | L1t.k0 | ... | L5t              (block q lives in slot q mod 3)
-// A hidden layer is   Q1 (tiles 0,1 x k-half 0)  Q2 (tiles 2,3 x k0)  --M--  Q3 (tiles 0,1 x k1)  Q4 (tiles 2,3 x k1)  --E--
-//   * at M every wave has left k-half 0: its slot takes the block three ahead (k1 of the NEXT layer, a whole layer before it is
-//     read); at E every wave has left k-half 1: its slot takes k0 of the layer after next.  So when a layer starts, both of its
-//     k-halves are in the LDS or about to land, and the only wait of a layer, `s_waitcnt vmcnt(0)` at M, asks for DMAs issued
-//     half a layer to a layer earlier -- and for parking stores that are at least a quarter old (E has a bare barrier: the
-//     stores of Q4's epilogue are not waited for);
-//   * the B slices of k16 steps 0..3 come from output tiles 0, 1 of the previous layer and those of steps 4..7 from tiles 2, 3:
-//     Q1 and Q2 need only the former.  The epilogue of tiles 2, 3 (ReLU, park, mask bits, slicing) therefore runs in eighths
-//     UNDER Q1 of the next layer, as the epilogue of tiles 0, 1 runs under Q4 -- no epilogue is exposed.
-// Every accumulator sees the same sequence of slice products as in warp_fwd_b3_kernel: results are bit-identical.
-#define B3P_SLOT_F4 B3_KH_F4                            // 3072 float4 = 48 KB: one k-half; L0 (2560) and L5 (1536) fit
-#define B3P_BIAS_F4 (3 * B3P_SLOT_F4)                   // three bias rows of 32 float4 behind the slots
-#define B3P_LDS_BYTES ((3 * B3P_SLOT_F4 + 3 * 32) * 16)  // 148 992 B
-
-// `base` + `off_f4` (both wave-uniform) -> slot.  The offset passes through an empty asm statement: the address arithmetic of the
-// blocks whose source does not depend on the layer index is loop-invariant, and hipcc otherwise hoists it out of the layer loop
-// and SPILLS it -- a spill reload inside the loop waits (vmcnt is in-order) for every DMA and parking store issued before it,
-// which is exactly the wait this kernel exists to remove.
-template <int N_F4, int NTHR>
-__device__ __forceinline__ void b3p_issue(const f32x4 *__restrict__ base, int off_f4, int slot) {
-    static_assert(N_F4 % NTHR == 0, "whole rounds of the block");
-    asm volatile("" : "+s"(off_f4), "+s"(slot));
-    const f32x4 *src = base + off_f4 + threadIdx.x;
-    f32x4 *dst = lds_b3 + slot * B3P_SLOT_F4 + (threadIdx.x >> 6) * 64;
-#pragma unroll
-    for (int k = 0; k < N_F4 / NTHR; k++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * NTHR),
-                                         (__attribute__((address_space(3))) void *)(dst + k * NTHR), 16, 0, 0);
-}
-__device__ __forceinline__ void b3p_stage_bias(const float *__restrict__ bias, int off_floats, int n_f4, int bslot) {
-    asm volatile("" : "+s"(off_floats), "+s"(bslot));
-    if ((int)threadIdx.x < n_f4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const f32x4 *>(bias + off_floats) + threadIdx.x),
-                                         (__attribute__((address_space(3))) void *)(lds_b3 + B3P_BIAS_F4 + bslot * 32), 16, 0, 0);
-}
-// accumulators of output tiles T0 .. T0 + NT - 1 <- the layer's bias row in bias slot `bslot`
-template <int T0, int NT, int MT>
-__device__ __forceinline__ void b3p_acc_bias(f32x16 (&acc)[MT], int h, int bslot) {
-    const f32x4 *b = lds_b3 + B3P_BIAS_F4 + bslot * 32;
-#pragma unroll
-    for (int t = T0; t < T0 + NT; t++)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const f32x4 v = b[8 * t + 2 * r4 + h];
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[t - T0 + (MT == 4 ? T0 : 0)][4 * r4 + c] = v[c];
-        }
-}
-// E point: every wave has left the k-half it was reading.  A bare barrier: `__syncthreads()` would carry vmcnt(0) while an LDS-DMA
-// is in flight (the workgroup release covers LDS writes) -- and with it the wait for the parking stores just issued.  This wave's
-// own LDS reads have returned (lgkmcnt); the empty asm statements keep memory operations on their side of the barrier.
-__device__ __forceinline__ void b3p_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-// one k16 step `s` (B slices bh[s] ...) of output tiles T0, T0+1 against the k-half block `wk` (12 MFMAs)
-template <int T0>
-__device__ __forceinline__ void b3p_step(const f32x4 *__restrict__ wk, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
-                                         f32x16 (&acc)[4], int lane, int s) {
-    constexpr int PLH = 4 * 4 * 64;
-    Frag ah[2], am[2], al[2];
-    const f32x4 *w = wk + (s & 3) * 64 + lane;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        ah[t].f = w[0 * PLH + (T0 + t) * 256];
-        am[t].f = w[1 * PLH + (T0 + t) * 256];
-        al[t].f = w[2 * PLH + (T0 + t) * 256];
-    }
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
-}
-// a whole quarter: k16 steps S0 .. S0 + 3
-template <int T0, int S0>
-__device__ __forceinline__ void b3p_quarter(const f32x4 *__restrict__ wk, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
-                                            f32x16 (&acc)[4], int lane) {
-#pragma unroll
-    for (int s = S0; s < S0 + 4; s++) b3p_step<T0>(wk, bh, bm, bl, acc, lane, s);
-}
-// one k16 step of the single-tile output layer (pack [plane][k16 step 0..7][lane]); the six products chain on one accumulator in
-// b3_layer<8, 1>'s order
-__device__ __forceinline__ void b3p_l5_step(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
-                                            f32x16 &o, int lane, int s) {
-    Frag ah, am, al;
-    ah.f = w[0 * 512 + s * 64 + lane];
-    am.f = w[1 * 512 + s * 64 + lane];
-    al.f = w[2 * 512 + s * 64 + lane];
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh[s].h, o, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bm[s].h, o, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl[s].h, o, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bh[s].h, o, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bm[s].h, o, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh[s].h, o, 0, 0, 0);
-}
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3p_kernel(
-    const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
-    const float *__restrict__ bias0_t, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
-    const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
-    float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
-    constexpr int NT = NW * 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pt = lane & 31, h = lane >> 5;
-    const int64_t tile_id = (int64_t)blockIdx.x * NW + wave;
-    const int64_t p = tile_id * TILE + pt;
-    const int64_t pc = p < M ? p : M - 1;
-    float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
-    const int sl = slot ? slot[pc] : 0;
-    float *tile = (acts && tile_id < n_tiles) ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
-
-    // blocks 0, 1, 2 (L0d, L1d.k0, L1d.k1) and L1d's bias row
-    b3p_issue<B3_L0_F4, NT>(w3_d, 0, 0);
-    b3p_issue<B3_KH_F4, NT>(w3_d, B3_L0_F4, 1);
-    b3p_issue<B3_KH_F4, NT>(w3_d, B3_L0_F4 + B3_KH_F4, 2);
-    b3p_stage_bias(bias_d, 0, 32, 0);
-    uint2 *mk = tile ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
-
-    int q = 0;        // block index of the current net's L0 (0, then 10)
-    int gb = 0;       // bias-row index of the current net's L1 row (0, then 5); a row lives in bias slot (index mod 3)
-    for (int net = 0; net < 2; net++) {
-        const f32x4 *wn = net ? w3_t : w3_d;
-        const float *bs = net ? bias_t : bias_d;
-        int slo = sl;
-        asm volatile("" : "+v"(slo));                     // (the 16 row addresses are formed here, not hoisted and spilled)
-        const float *b0 = (net ? bias0_t : bias0_d) + (int64_t)slo * 128;
-        float *ht = tile ? tile + (64 + net * 640) * TILE : nullptr;
-        f32x16 acc[4];
-        Frag bh[8], bm[8], bl[8];
-        // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot.  The encoding is evaluated again for the second
-        // net (18 sincosf, ~1 % of the kernel) rather than held in 24 registers across the first: the layer loop has none to spare
-        {
-            float bin0[24];
-            float xo[3] = {xv[0], xv[1], xv[2]};
-            asm volatile("" : "+v"(xo[0]), "+v"(xo[1]), "+v"(xo[2]));     // (not CSE'd with the first evaluation)
-            enc_bin(xo, h, n_bands, bin0, nullptr);
-#pragma unroll
-            for (int k = 20; k < 24; k++) bin0[k] = 0.f;
-            if (tile && net == 0) {
-                float *tp = tile + h * TILE + pt;
-                asm volatile("" : "+v"(tp));              // (row addresses beyond the 4 KB immediate range are formed here)
-#pragma unroll
-                for (int k = 0; k < 32; k++) tp[2 * k * TILE] = k < 20 ? bin0[k] : 0.f;  // k-step ordered, rows 40..63 pad
-            }
-#pragma unroll
-            for (int s = 0; s < 3; s++)
-#pragma unroll
-                for (int e2 = 0; e2 < 4; e2++) split2(bin0[8 * s + 2 * e2], bin0[8 * s + 2 * e2 + 1], bh[s].u[e2], bm[s].u[e2], bl[s].u[e2]);
-        }
-        acc_bias<4>(acc, b0, h);
-        if (net == 0) b3_stage_wait();                    // blocks 0, 1, 2 and the bias row have landed (net 1: confirmed after L5d)
-        b3_layer<3, 4>(lds_b3 + (q % 3) * B3P_SLOT_F4, bh, bm, bl, acc, lane);
-        b3p_barrier();                                    // every wave has left block q
-        b3p_issue<B3_KH_F4, NT>(wn, B3_L0_F4 + 2 * B3_KH_F4, q % 3);          // block q + 3 = L2.k0
-        b3p_stage_bias(bs, 128, 32, (gb + 1) % 3);                             // L2's bias row
-        // layer 0's tiles 0, 1 now (exposed: a 72-MFMA layer has nothing to hide them under); its tiles 2, 3 under layer 1's Q1
-        uint32_t mt[4] = {0u, 0u, 0u, 0u};
-        b3_epilogue_half<0>(acc, ht, mt, pt, h, bh, bm, bl);
-        for (int l = 1; l <= 4; l++) {
-            const int qa = q + 2 * l - 1;                 // this layer's k-half 0; k-half 1 is block qa + 1
-            const f32x4 *wk0 = lds_b3 + (qa % 3) * B3P_SLOT_F4, *wk1 = lds_b3 + ((qa + 1) % 3) * B3P_SLOT_F4;
-            const int bsl = (gb + l - 1) % 3;
-            float *hl = ht ? ht + l * 128 * TILE : nullptr;
-            b3p_acc_bias<0, 2, 4>(acc, h, bsl);
-            {
-                // Q1 in four k16 steps, each followed by an eighth of the PREVIOUS layer's tiles 2, 3 epilogue (their slices feed
-                // k16 steps 4..7, first read in Q3)
-                float *hp = ht ? ht + (l - 1) * 128 * TILE : nullptr;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    b3p_step<0>(wk0, bh, bm, bl, acc, lane, c);
-                    b3_epilogue_eighth(acc, hp, mt, pt, h, bh, bm, bl, 2 + (c >> 1), c & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (mk) mk[(net * 5 + l - 1) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
-            }
-            b3p_acc_bias<2, 2, 4>(acc, h, bsl);
-            b3p_quarter<2, 0>(wk0, bh, bm, bl, acc, lane);
-            // ---- M: k-half 0 is free; k-half 1 (issued a layer ago) and everything older has landed
-            b3_stage_wait();
-            if (l < 4)
-                b3p_issue<B3_KH_F4, NT>(wn, B3_L0_F4 + (2 * l + 1) * B3_KH_F4, qa % 3);   // block qa + 3 = k1 of layer l + 1
-            else if (net == 0)
-                b3p_issue<B3_L0_F4, NT>(w3_t, 0, qa % 3);                                       // block 10 = L0t
-            b3p_quarter<0, 4>(wk1, bh, bm, bl, acc, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            mt[0] = mt[1] = mt[2] = mt[3] = 0u;
-            // Q4 in four k16 steps, each followed by an eighth of tiles 0, 1's epilogue (slices of k16 steps 0..3, dead since Q2)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                b3p_step<2>(wk1, bh, bm, bl, acc, lane, 4 + c);
-                b3_epilogue_eighth(acc, hl, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- E: k-half 1 is free
-            b3p_barrier();
-            if (l <= 2) {
-                b3p_issue<B3_KH_F4, NT>(wn, B3_L0_F4 + (2 * l + 2) * B3_KH_F4, (qa + 1) % 3);   // block qa + 4 = k0 of layer l + 2
-                b3p_stage_bias(bs, (l + 1) * 128, 32, (gb + l + 1) % 3);                        // its bias row
-            } else if (l == 3) {
-                b3p_issue<B3_L5_F4, NT>(wn, B3_L0_F4 + 8 * B3_KH_F4, (qa + 1) % 3);             // block q + 9 = L5
-                b3p_stage_bias(bs, 4 * 128, 8, (gb + 4) % 3);                                   // b5 is one 32-row tile
-            } else if (net == 0) {
-                b3p_issue<B3_KH_F4, NT>(w3_t, B3_L0_F4, (qa + 1) % 3);                          // block 11 = L1t.k0
-                b3p_stage_bias(bias_t, 0, 32, (gb + 5) % 3);                                        // L1t's bias row
-            }
-        }
-        // layer 5: 128 -> 3 | 2 (one padded tile); k16 steps 0..3 under the epilogue of layer 4's tiles 2, 3
-        f32x16 o[1];
-        b3p_acc_bias<0, 1, 1>(o, h, (gb + 4) % 3);
-        const f32x4 *w5 = lds_b3 + ((q + 9) % 3) * B3P_SLOT_F4;
-        {
-            float *hp = ht ? ht + 4 * 128 * TILE : nullptr;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                b3p_l5_step(w5, bh, bm, bl, o[0], lane, c);
-                b3_epilogue_eighth(acc, hp, mt, pt, h, bh, bm, bl, 2 + (c >> 1), c & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (mk) mk[(net * 5 + 4) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
-        }
-#pragma unroll
-        for (int s = 4; s < 8; s++) b3p_l5_step(w5, bh, bm, bl, o[0], lane, s);
-        b3_stage_wait();                                  // L5's slot is free; L0t, L1t.k0 and L1t's bias row have landed
-        if (net == 0) b3p_issue<B3_KH_F4, NT>(w3_t, B3_L0_F4 + B3_KH_F4, (q + 9) % 3);          // block 12 = L1t.k1
-        if (h == 0 && p < M) {
-            if (net == 0) {
-                out_deform[p * 3 + 0] = o[0][0];
-                out_deform[p * 3 + 1] = o[0][1];
-                out_deform[p * 3 + 2] = o[0][2];
-            } else {
-                out_topo[p * 2 + 0] = o[0][0];
-                out_topo[p * 2 + 1] = o[0][1];
-            }
-        }
-        q += 10;
-        gb += 5;
-    }
-}
-
 // ---- backward-data -------------------------------------------------------------------------------------------------
 // Same chain, transposed packs (T5, T4..T1, T0), ReLU derivative from the sign masks the forward parked; parks dPre tiles in
 // mlp.hip's layout for mh_mlp_wgrad.
@@ -1040,10 +783,6 @@ static int b3_lds_opt_in() {
             hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_fwd_b3p_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3P_LDS_BYTES) !=
-                hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_fwd_b3p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3P_LDS_BYTES) !=
                 hipSuccess)
             return MH_ERR_LAUNCH;
         done.mark(dev);
@@ -1116,20 +855,6 @@ extern "C" int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *
     const int64_t blocks = small ? (M + BLOCK_PTS - 1) / BLOCK_PTS : (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    const char *pipe_env = getenv("MH_B3_PIPE");        // A/B while the pipelined form is measured (read per call: a test flips it)
-    const bool pipe = !pipe_env || pipe_env[0] != '0';
-    if (pipe) {
-        if (small)
-            hipLaunchKernelGGL(warp_fwd_b3p_kernel<4>, dim3((unsigned)blocks), dim3(256), B3P_LDS_BYTES, mh_stream(stream), x, slot,
-                               bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
-                               bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
-        else
-            hipLaunchKernelGGL(warp_fwd_b3p_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3P_LDS_BYTES, mh_stream(stream), x,
-                               slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
-                               bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
-        MH_CHECK_LAUNCH();
-        return MH_OK;
-    }
     if (small)
         hipLaunchKernelGGL(warp_fwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LDS_BYTES, mh_stream(stream), x, slot,
                            bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
