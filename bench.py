@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 L2_PEAK_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 bandwidth
 GRID_FWD_BYTES, GRID_BWD_BYTES = 1164, 2188   # per point per encoder
 GRID_GATHERS_PER_POINT = 16 * 8   # 8 corners x 16 levels, one 8-byte row each -> one 64-byte L2 sector each (worst case)
-WORKLOADS = ["cfg3", "cfg2", "cfg3b", "train_real", "train_virtual", "density128"]
+WORKLOADS = ["cfg3", "cfg2", "cfg3b", "train_real", "train_virtual", "train_loop", "density128"]
 
 
 def parse_args(argv=None):
@@ -96,11 +96,11 @@ def parse_args(argv=None):
                          "disables the per-kernel event timers")
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = {"train_real": 32, "train_virtual": 32, "cfg2": 60}.get(args.workload, 20)
+        args.steps = {"train_real": 32, "train_virtual": 32, "train_loop": 6, "cfg2": 60}.get(args.workload, 20)
     if args.warmup is None:
-        args.warmup = 15 if args.workload == "cfg2" else 5
+        args.warmup = {"cfg2": 15, "train_loop": 2}.get(args.workload, 5)
     if args.rays is None:
-        args.rays = {"train_real": 2048, "train_virtual": args.virtual_res ** 2}.get(args.workload, 128 * 128)
+        args.rays = {"train_real": 2048, "train_loop": 2048, "train_virtual": args.virtual_res ** 2}.get(args.workload, 128 * 128)
     if args.workload == "train_virtual":
         args.rays = args.virtual_res ** 2
     return args
@@ -363,6 +363,66 @@ def build_train_virtual(args, rank, world, dev):
                 shadings=lambda: {k: shade_log[-args.steps:].count(k) for k in sorted(set(shade_log[-args.steps:]))})
 
 
+def build_train_loop(args, rank, world, dev):
+    """BASELINE configs[3] ("cfg4": teddy.yaml, the full optimisation loop, end-to-end iterations per second) with the one piece that
+    is not available offline -- the Zero-1-to-3 UNet and its weights -- replaced by its interface (trainstep.InjectedGuidance: a fixed
+    gradient on pred_rgb).  One "step" = one iteration of train_one_epoch's loop (morpheus.py:1390-1428): `virtual_freq` = 1
+    virtual-view step (whole --virtual-res^2 view; past freeze_epoch its gradient is ACCUMULATED into the next optimiser step) followed
+    by `real_freq` = 10 real-view steps of 2048 rays with an optimiser step each, then the reference's loss.item().  Both kinds of
+    step share the model, the occupancy grid (refreshed every 16 global steps) and the optimiser."""
+    import torch
+    from morpheus_amd import harness, trainstep
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.optim import FlatAdam
+    from morpheus_amd.render import HotPathRenderer
+    cfg = harness.load_config("teddy")
+    model = harness.build_model("b", dev, config=cfg).train()
+    grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(dev)
+    rend = HotPathRenderer(model, cfg, grid, 200)
+    frames = trainstep.make_frames([(25 * rank + 8 * k) % 200 for k in range(8)], 256, 256, dev)
+    ts = trainstep.RealViewTrainStep(rend, frames, ray_num=args.rays, glue=args.glue)
+    vs = trainstep.VirtualViewTrainStep(rend, res=args.virtual_res, seed=2024 + rank)
+    ts.epoch = vs.epoch = 1000                            # mid-training: level 0.75, random shading, freeze_lr off
+    opt = FlatAdam(model.get_params_all(cfg["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
+    bucket = opt.bucket      # (no early exchange here: the number of backward passes per optimiser step alternates between 2 and 1)
+    with torch.no_grad():
+        trainstep.warm_up_occupancy(ts)
+    ts.global_step = 4096
+    occ = float(grid.binaries.float().mean())
+    n_virtual, n_real = cfg["train"]["virtual_freq"], cfg["train"]["real_freq"]
+    sample_log = []
+
+    def step():
+        bucket.zero()
+        n = 0
+        for _ in range(n_virtual):
+            vs.global_step = ts.global_step
+            loss = vs() * (1.0 / n_virtual)               # morpheus.py:1401
+            loss.backward()                               # epoch > freeze_epoch: no optimiser step of its own (:1403-1409)
+            ts.global_step = vs.global_step
+            n += vs.last_samples
+        for k in range(n_real):
+            if k > 0:
+                bucket.zero()                             # the first real step's update carries the virtual-view gradient
+            loss = ts()
+            loss.backward()
+            bucket.allreduce_mean()
+            opt.step()
+            n += ts.last_samples
+        sample_log.append(n)
+        loss.item()                                       # morpheus.py:1426
+        return loss
+
+    rays_per_iter = n_virtual * args.virtual_res ** 2 + n_real * args.rays
+    desc = (f"teddy.yaml optimisation loop (morpheus.py:1390-1428): per iteration {n_virtual} virtual-view step ({args.virtual_res} x "
+            f"{args.virtual_res} rays, SDS replaced by an injected pred_rgb gradient: the Zero-1-to-3 UNet and its weights are not available "
+            f"offline) + {n_real} real-view steps ({args.rays} rays each, Adam step each), occupancy refresh every 16 steps "
+            f"({occ * 100:.1f}% of 128^3 cells occupied), loss.item() per iteration; glue: {args.glue}")
+    return dict(step=step, rays_per_step=rays_per_iter, bucket=bucket, desc=desc,
+                samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ, glue=args.glue,
+                iters=True)
+
+
 def build_density128(args, rank, world, dev):
     """Forward-only dense field query: export_mesh / update_occ_grid call model.density on grid points
     (morpheus.py:367-408, 905-913).  A 'step' = all 128^3 points in chunks of 2^21, no_grad, colour included."""
@@ -558,7 +618,7 @@ def run_one(args):
             raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-        builder = {"train_real": build_train_real, "train_virtual": build_train_virtual,
+        builder = {"train_real": build_train_real, "train_virtual": build_train_virtual, "train_loop": build_train_loop,
                    "density128": build_density128}.get(args.workload, build_render_workload)
         wl = builder(args, rank, world, dev)
     step = wl["step"]
@@ -670,6 +730,7 @@ def run_one(args):
         "metric": "rays/sec (fwd+bwd, 128 samples/ray)" if headline else
                   {"train_real": "rays/sec (real-view training step, ragged occupancy samples)",
                    "train_virtual": "rays/sec (virtual-view training step, whole novel view, ragged occupancy samples)",
+                   "train_loop": "rays/sec over whole iterations of the optimisation loop (1 virtual + 10 real training steps, SDS stubbed)",
                    "density128": "points/sec (forward-only field query)"}[args.workload],
         "value": round(total_rays / elapsed, 1), "unit": "rays/s" if args.workload != "density128" else "points/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -696,6 +757,9 @@ def run_one(args):
         "roofline": roofline, "roofline_hashgrid": roof_hash, "kernels": ktab,
         "kernel_sum_ms_per_step": kernel_sum, "timed_launches_per_step": round(sum(v["calls_per_step"] for v in ktab.values()), 1),
     }
+    if wl.get("iters"):
+        out["iters_per_s"] = round(args.steps / elapsed, 3)       # BASELINE configs[3]'s unit: end-to-end iterations per second
+        out["train_steps_per_s"] = round(args.steps * 11 / elapsed, 2)
     if "occupied" in wl:
         out["config"]["occupied_fraction"] = round(wl["occupied"], 4)
     if "glue" in wl:
@@ -802,7 +866,7 @@ def run_extras(mode):
             if run.returncode != 0 or not lines:
                 return {"error": (run.stderr or run.stdout)[-300:]}
             r = json.loads(lines[-1])
-            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype")}
+            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "iters_per_s", "train_steps_per_s") if k in r}
             c = r["config"]
             keep.update(workload=c["workload"], rays_per_gpu=c["rays_per_gpu"], sample_points_per_step=c["sample_points_per_step_per_gpu"],
                         kernel_timers=c.get("kernel_timers"), loss_mean_of_timed_steps=c.get("loss_mean_of_timed_steps"))
@@ -821,11 +885,14 @@ def run_extras(mode):
             "train_virtual": {"res72": sub(["--workload", "train_virtual", "--virtual-res", "72"]),
                               "res180": sub(["--workload", "train_virtual", "--virtual-res", "180"]),
                               "note": "rays/s of the reference's virtual-view training step (render fwd + bwd + Adam under an "
-                                      "injected pred_rgb gradient standing for Zero-1-to-3 SDS)"}}
+                                      "injected pred_rgb gradient standing for Zero-1-to-3 SDS)"},
+            "train_loop": {"res72": sub(["--workload", "train_loop", "--virtual-res", "72"]),
+                           "note": "BASELINE configs[3] (teddy.yaml, end-to-end iterations per second) with the UNet replaced by its interface: "
+                                   "iters_per_s of (1 virtual + 10 real) training steps"}}
 
 
 # ------------------------------------------------------------------------------------------------ main
-RAGGED = ("train_real", "train_virtual")
+RAGGED = ("train_real", "train_virtual", "train_loop")
 
 
 def main(argv=None):

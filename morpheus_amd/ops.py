@@ -1239,8 +1239,9 @@ class _RenderLoss(torch.autograd.Function):
         ctx.save_for_backward(pr, pd, op, gt_rgb, dp, mk, valid)
         ctx.w = (float(w_rgb), float(w_mask), float(w_depth))
         ctx.shapes = (pred_rgb.shape, pred_depth.shape, opacity.shape)
-        ctx.mark_non_differentiable(gt_rgb, valid)
-        return out[0], out[1:], gt_rgb, valid
+        terms = out[1:]
+        ctx.mark_non_differentiable(terms, gt_rgb, valid)     # the three terms are VALUES for logging: the gradient travels through out[0] only
+        return out[0], terms, gt_rgb, valid
 
     @staticmethod
     def backward(ctx, g, _g_terms, _g_gt, _g_valid):
