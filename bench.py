@@ -50,6 +50,10 @@ sys.path.insert(0, ROOT)
 MACS = dict(deform=77056, topo=76928, sdf=10880, color=8384)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (the bf16x3 warp kernels issue 6 per fp32 MAC)
+# what the bf16 matrix pipe SUSTAINS chip-wide on live operand slices in the kernels' configuration (A fragments from LDS, 8 waves per
+# 96 KB copy), measured by tools/micro/mfma_bf16_rate.hip: 1575 TFLOP/s at a power-limited 1.68 GHz (profiles/r04_micro_mfma_bf16_rate.txt;
+# 1788 from registers, 2223 on all-zero operands).  Reported BESIDE the nominal peak, never instead of it.
+BF16_MFMA_SUSTAINED_TFLOPS = 1575.0
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 L2_PEAK_GBS = 34500.0             # MI355X_MICROARCH.md: aggregate L2 bandwidth
 GRID_FWD_BYTES, GRID_BWD_BYTES = 1164, 2188   # per point per encoder
@@ -523,6 +527,7 @@ def _kernel_roofline(name, e, flops_per_call, mode, M, workload, full_size):
                 peak_note=f"{pipe} dense peak {unit_peak} TFLOP/s (MI355X_MICROARCH.md) / {prod:g} slice product(s) issued per fp32 "
                           f"MAC = {peak:.1f} TFLOP/s of ALGORITHMIC fp32 work",
                 issued_tflops=round(alg_tflops * prod, 1), flops_per_step=per_step_flops,
+                frac_of_sustained=(None if kmode == "f32" else round(alg_tflops * prod / BF16_MFMA_SUSTAINED_TFLOPS, 4)),
                 traffic=traffic, algorithmic_bytes=round(algb), parked_bytes=round(parked),
                 waste_ratio_traffic_over_algorithmic=None if not traffic else round(traffic / algb, 1),
                 traffic_source=(str(src) + ("" if complete else " (some kernels of the group missing in that file)")) if traffic else None,
@@ -557,7 +562,10 @@ def build_roofline(ktab, mode, M, workload, full_size):
     out["hbm"]["note"] = ("bytes this design moves by construction (parked activation / pre-activation-gradient tiles, each row written "
                           "or read once); a streaming read reaches 5.6-6.6 TB/s and a streaming write 6.8 TB/s on this box "
                           "(profiles/r02_micro_hbm_read.txt, r02_micro_hbm_rates.txt)")
-    out["per_kernel"] = {k: {kk: v[kk] for kk in ("ms_per_step", "launches_per_step", "mode", "achieved", "peak", "unit", "frac",
+    out["frac_of_sustained_note"] = (f"issued slice-product TFLOP/s over the {BF16_MFMA_SUSTAINED_TFLOPS:g} TFLOP/s the bf16 / fp16 matrix pipe sustains "
+                                     "chip-wide on live operands under the power budget (tools/micro/mfma_bf16_rate.hip, "
+                                     "profiles/r04_micro_mfma_bf16_rate.txt); `frac` stays against the nominal dense peak")
+    out["per_kernel"] = {k: {kk: v[kk] for kk in ("ms_per_step", "launches_per_step", "mode", "achieved", "peak", "unit", "frac", "frac_of_sustained",
                                                   "traffic", "algorithmic_bytes", "parked_bytes", "hbm")} for k, v in per.items()}
     return out
 

@@ -5,7 +5,8 @@
 //   operands   zero | live (hi / mid / lo slices of N(0,1) values: what split2 produces)
 //   A from     registers | LDS (three ds_read_b128 per six MFMAs, the kernels' ratio)
 //   fillers    none | ds_read_b64_tr_b16 (two per MFMA: the LDS transpose read a fused backward-data + weight-gradient tile
-//              would use) | 8 VALU (v_fma_f32) per MFMA (an epilogue's density)
+//              would use) | 4 or 8 VALU (v_fma_f32) per MFMA (the chain kernels average ~4 non-MFMA
+//              instructions per MFMA over a layer, ~7 in the quarter that carries an epilogue)
 //   occupancy  1 | 2 waves per SIMD
 // and prints TFLOP/s of slice products, the effective shader clock (s_memtime / s_memrealtime) and the pipe use at THAT clock.
 // Build: hipcc --offload-arch=gfx950 -O3 -o mfma_bf16_rate mfma_bf16_rate.hip
@@ -26,7 +27,7 @@ union Frag {
 };
 extern __shared__ f32x4 lds[];
 
-// LDSA: A fragments from LDS (6144 float4 = one 128 x 128 layer's three planes);  FILL: 0 none, 1 tr_b16 reads, 2 VALU
+// LDSA: A fragments from LDS (6144 float4 = one 128 x 128 layer's three planes);  FILL: 0 none, 1 tr_b16 reads, 2 / 3: 8 / 4 VALU per MFMA
 template <int LDSA, int FILL, int OCC>
 __global__ __launch_bounds__(256 * OCC, OCC) void k(float *out, const f32x4 *__restrict__ frags, int iters, unsigned long long *clk) {
     const int lane = threadIdx.x & 63;          // OCC waves per SIMD = one workgroup of 4 * OCC waves sharing one 96 KB LDS copy
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(256 * OCC, OCC) void k(float *out, const f32x4 *__r
             const unsigned addr = (unsigned)((lane & 15) * 8 + (lane >> 4) * 128 + s * 512);                          \
             asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048" : "=v"(d0), "=v"(d1) : "v"(addr)); \
             asm volatile("" ::"v"(d0), "v"(d1));                                                                      \
-        } else if (FILL == 2) {                                                                                       \
-            _Pragma("unroll") for (int q = 0; q < 2; q++) {                                                           \
+        } else if (FILL >= 2) {                                                                                       \
+            _Pragma("unroll") for (int q = 0; q < (FILL == 2 ? 2 : 1); q++) {                                                           \
                 v0 = __builtin_fmaf(v0, 0.999f, v1);                                                                  \
                 v1 = __builtin_fmaf(v1, 0.998f, v2);                                                                  \
                 v2 = __builtin_fmaf(v2, 0.997f, v3);                                                                  \
@@ -177,6 +178,8 @@ int main() {
     run<1, 0, 2>("live operands, A from LDS, 2 waves/SIMD  [the kernels' configuration]", dl, cu);
     run<1, 1, 2>("live operands, A from LDS, 2 waves/SIMD + 2 ds_read_b64_tr_b16 per MFMA", dl, cu);
     run<0, 1, 1>("live operands, A from registers, 1 wave/SIMD + 2 ds_read_b64_tr_b16 per MFMA", dl, cu);
+    run<1, 3, 2>("live operands, A from LDS, 2 waves/SIMD + 4 v_fma_f32 per MFMA  [the kernels' density]", dl, cu);
+    run<0, 3, 1>("live operands, A from registers, 1 wave/SIMD + 4 v_fma_f32 per MFMA", dl, cu);
     run<1, 2, 2>("live operands, A from LDS, 2 waves/SIMD + 8 v_fma_f32 per MFMA", dl, cu);
     run<0, 2, 1>("live operands, A from registers, 1 wave/SIMD + 8 v_fma_f32 per MFMA", dl, cu);
     return 0;
