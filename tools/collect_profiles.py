@@ -3,7 +3,7 @@
 
   python tools/collect_profiles.py [round-tag, default r01]
 
-Inputs (written by tools/gpu/r3_round.sh on the GPU box):
+Inputs (written by tools/gpu/r4_round.sh on the GPU box):
   gpurun_out/bench.log, bench_cfg2.log, bench_cfg3b.log   -> profiles/<tag>_bench_<workload>.json (the JSON line)
   gpurun_out/prof/runc/*_kernel_stats.csv                  -> profiles/<tag>_bench_cfg3_kernel_stats.csv
   gpurun_out/prof_cfg3b/runc/*_kernel_stats.csv            -> profiles/<tag>_bench_cfg3b_kernel_stats.csv
@@ -25,13 +25,24 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 
 
+def run_start():
+    """gpurun_out/ is scratch that survives rounds: only what THIS collection run wrote may be copied under this round's tag (a stale
+    file copied under a new name is a mislabelled profile).  The round script writes gpu_tests_full.log first."""
+    ref = os.path.join(OUT, "gpu_tests_full.log")
+    return os.path.getmtime(ref) - 300.0 if os.path.exists(ref) else 0.0
+
+
+def fresh(path):
+    return bool(path) and os.path.exists(path) and os.path.getmtime(path) >= run_start()
+
+
 def latest(pattern):
-    files = glob.glob(os.path.join(OUT, pattern))
+    files = [f for f in glob.glob(os.path.join(OUT, pattern)) if fresh(f)]
     return max(files, key=os.path.getmtime) if files else None
 
 
 def json_line(path):
-    if not path or not os.path.exists(path):
+    if not fresh(path):
         return None
     for line in open(path):
         if line.startswith("{"):
@@ -49,15 +60,20 @@ def pmc_summary(tag, suffix="", steps_in_run=3):
     gpurun_out/pmc_{sq,fetch,write}_<mode>.  steps_in_run: warm-up + timed steps of the profiled bench command (its
     launches / steps_in_run = launches per step)."""
     per = defaultdict(lambda: defaultdict(list))
-    for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
-        f = latest(f"{d}{suffix}/runc/*_counter_collection.csv")
+    for d in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_lds", "pmc_lds2"):
+        f = latest(f"{d}{suffix}/*/*_counter_collection.csv")
         if not f:
+            if d.startswith("pmc_lds"):      # the LDS passes are collected for the default mode only (and a pass with a counter the
+                continue                     # box does not know fails alone)
             return False
         for row in csv.DictReader(open(f)):
             per[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     mean = lambda v: sum(v) / len(v) if v else 0.0
     cols = ["k", "hbm_read_MB_per_launch", "hbm_write_MB_per_launch", "mfma_busy_frac", "l2_hit_rate", "SQ_WAVE_CYCLES",
             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "launches_per_step"]
+    lds_cols = [c for c in ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT",
+                            "SQ_LDS_ATOMIC_RETURN", "SQ_INSTS_VALU") if any(c in v for v in per.values())]
+    cols += lds_cols
     with open(os.path.join(PROF, f"{tag}_pmc_summary{suffix}.csv"), "w", newline="") as fo:
         w = csv.writer(fo)
         w.writerow(cols)
@@ -72,28 +88,29 @@ def pmc_summary(tag, suffix="", steps_in_run=3):
                         round(busy / gui, 4) if gui else 0.0, round(hit / (hit + miss), 4) if hit + miss else 0.0,
                         round(mean(c["SQ_WAVE_CYCLES"]), 4), round(mean(c["SQ_WAIT_ANY"]), 4),
                         round(mean(c["SQ_WAIT_INST_ANY"]), 4), round(mean(c["GRBM_GUI_ACTIVE"]), 4),
-                        round(len(c["FETCH_SIZE"]) / float(steps_in_run), 3)])
+                        round(len(c["FETCH_SIZE"]) / float(steps_in_run), 3)] + [round(mean(c[k]), 1) for k in lds_cols])
     return True
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     os.makedirs(PROF, exist_ok=True)
     for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b"),
                     ("bench_train_real.log", "train_real"), ("bench_train_real_graph.log", "train_real_hip_graph"),
+                    ("bench_train_virtual.log", "train_virtual_72"), ("bench_train_virtual_180.log", "train_virtual_180"),
                     ("bench_density128.log", "density128"), ("bench_n2.log", "n2_one_gpu_gloo"),
                     ("bench_cfg3_f32.log", "cfg3_fp32_mfma_kernels"), ("bench_cfg3_b3.log", "cfg3_bf16x3_kernels")):
         line = json_line(os.path.join(OUT, log))
         if line:
             open(os.path.join(PROF, f"{tag}_bench_{wl}.json"), "w").write(line)
             print("bench", wl)
-    for d, wl in (("prof", "cfg3"), ("prof_cfg3b", "cfg3b"), ("prof_train_real", "train_real")):
-        f = latest(f"{d}/runc/*_kernel_stats.csv")
+    for d, wl in (("prof", "cfg3"), ("prof_h2", "cfg3_h2"), ("prof_f32", "cfg3_f32"), ("prof_train_real", "train_real")):
+        f = latest(f"{d}/*/*_kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(PROF, f"{tag}_bench_{wl}_kernel_stats.csv"))
             print("kernel stats", wl, os.path.basename(f))
     p = os.path.join(OUT, "parity.log")
-    if os.path.exists(p):
+    if fresh(p):
         lines = [l for l in open(p) if l.startswith("{")]
         if lines:
             open(os.path.join(PROF, f"{tag}_parity_report.jsonl"), "w").writelines(lines)
@@ -101,12 +118,14 @@ def main():
     for log, name in (("phase_trace.log", "phase_trace_warp_fwd_fp32_mfma.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd_bf16x3.txt"),
                       ("phase_trace_h2.log", "phase_trace_warp_fwd.txt"),
                       ("hbm_rates.log", "micro_hbm_rates.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
+                      ("mfma_bf16_rate.log", "micro_mfma_bf16_rate.txt"), ("hbm_read.log", "micro_hbm_read.txt"),
+                      ("parity_f64.jsonl", "parity_f64.jsonl"),
                       ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt"),
                       ("precision_report.jsonl", "precision_report.jsonl"),
                       ("timeline_train_real_graph.txt", "timeline_train_real_hip_graph.txt"),
                       ("graph_memset_probe.txt", "graph_memset_probe.txt")):
         src = os.path.join(OUT, log)
-        if os.path.exists(src):
+        if fresh(src):
             shutil.copy(src, os.path.join(PROF, f"{tag}_{name}"))
             print("copied", name)
     print("pmc summary", pmc_summary(tag), [pmc_summary(tag, "_" + m) for m in ("h2", "f32")])
