@@ -309,6 +309,24 @@ def build_train_real(args, rank, world, dev):
                 graphed=graphed, glue=args.glue)
 
 
+def pretouch_vram(dev, fraction: float = 0.85):
+    """Touch most of the device's free memory once, then hand it back.  On a FRESH box the first process that reaches deep into
+    the 288 GB pays for it inside its steps: a 180 x 180 virtual-view step (104 GB allocated at its peak, 243 GB reserved by the
+    caching allocator) runs 270-350 ms in the first such process and 55.6 ms in every later one, whatever the allocator
+    configuration (profiles/r04_first_touch_ab.txt) -- a property of the box's first use of that memory, not of the step, which a
+    220 k-step run pays once.  So the workload touches the memory before its warm-up steps."""
+    import torch
+    free, _ = torch.cuda.mem_get_info(dev)
+    n = int(free * fraction) // 4
+    t0 = time.perf_counter()
+    x = torch.empty(n, dtype=torch.float32, device=dev)
+    x.fill_(0.0)
+    torch.cuda.synchronize(dev)
+    del x
+    torch.cuda.empty_cache()
+    return dict(touched_GB=round(n * 4 / 1e9, 1), seconds=round(time.perf_counter() - t0, 2))
+
+
 def build_train_virtual(args, rank, world, dev):
     """The reference's VIRTUAL-view training step (morpheus.py:1393-1408: one step in eleven): all res x res rays of a novel view
     of a random frame, random lambertian / textureless shading at a random ambient ratio (:873-885), random / no background
@@ -322,11 +340,12 @@ def build_train_virtual(args, rank, world, dev):
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.optim import FlatAdam
     from morpheus_amd.render import HotPathRenderer
+    res = args.virtual_res
+    touched = pretouch_vram(dev) if res * res > 20000 else None      # whole-view steps at the final resolution: ~100 GB per step
     model = harness.build_model("b", dev).train()
     cfg = model.config
     grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(dev)
     rend = HotPathRenderer(model, cfg, grid, 200)
-    res = args.virtual_res
     vs = trainstep.VirtualViewTrainStep(rend, res=res, seed=2024 + rank)
     vs.epoch = 1000                                      # mid-training: progressive level 0.75, random shading
     groups = model.get_params_all(cfg["train"]["lr"])
@@ -364,7 +383,8 @@ def build_train_virtual(args, rank, world, dev):
             "by an injected pred_rgb gradient (its interface), deform learning rates frozen, occupancy refresh every 16 steps, Adam")
     return dict(step=step, rays_per_step=res * res, bucket=bucket, desc=desc,
                 samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ,
-                shadings=lambda: {k: shade_log[-args.steps:].count(k) for k in sorted(set(shade_log[-args.steps:]))})
+                shadings=lambda: {k: shade_log[-args.steps:].count(k) for k in sorted(set(shade_log[-args.steps:]))},
+                pretouch=touched)
 
 
 def build_train_loop(args, rank, world, dev):
@@ -689,8 +709,8 @@ def run_one(args):
     ops.TIMER.reset(False)
     alloc = None
     if mem0 is not None:
-        # the caching allocator inside the timed region: a ragged workload whose sample count grows past every cached block pays
-        # hipMalloc / hipFree (device-wide synchronisations) inside its steps -- visible here, not in the kernel table
+        # the caching allocator inside the timed region (segment allocations, retries, footprint): a ragged workload's memory behaviour
+        # is part of what its step costs and is not visible in the kernel table
         mem1 = torch.cuda.memory_stats(dev)
         alloc = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
         alloc["reserved_GB"] = round(mem1.get("reserved_bytes.all.current", 0) / 1e9, 2)
@@ -774,6 +794,8 @@ def run_one(args):
         out["config"]["glue"] = wl["glue"]
     if "shadings" in wl:
         out["config"]["shadings_of_timed_steps"] = wl["shadings"]()
+    if wl.get("pretouch") is not None:
+        out["config"]["vram_pretouch_before_warmup"] = wl["pretouch"]
     out["config"]["allocator_in_timed_region"] = alloc
     out["config"]["kernel_timers"] = bool(timers_on)      # per-C-ABI-call HIP events inside the timed region (host cost per call)
     if wl.get("graphed") is not None:
@@ -878,7 +900,7 @@ def run_extras(mode):
             c = r["config"]
             keep.update(workload=c["workload"], rays_per_gpu=c["rays_per_gpu"], sample_points_per_step=c["sample_points_per_step_per_gpu"],
                         kernel_timers=c.get("kernel_timers"), loss_mean_of_timed_steps=c.get("loss_mean_of_timed_steps"))
-            for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction", "allocator_in_timed_region"):
+            for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction", "allocator_in_timed_region", "vram_pretouch_before_warmup"):
                 if k in c:
                     keep[k] = c[k]
             return keep
@@ -900,22 +922,9 @@ def run_extras(mode):
 
 
 # ------------------------------------------------------------------------------------------------ main
-RAGGED = ("train_real", "train_virtual", "train_loop")
-
-
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
-    if args.workload in RAGGED:
-        # Ragged workloads draw a new sample count every step, so the scratch tensors of a step (tens of GB at 180 x 180 rays) never
-        # match the caching allocator's cached blocks: with the default configuration the reserved pool grows to 243 of 288 GB and a
-        # 180 x 180 virtual-view step takes 269 ms against 55 with expandable segments (profiles/r04_allocator_ab.txt).  The setting is
-        # the caller's; the bench applies it unless the environment already chose, and reports it.
-        for k in ("PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF", "PYTORCH_ALLOC_CONF"):
-            if os.environ.get(k):
-                break
-        else:
-            os.environ["PYTORCH_HIP_ALLOC_CONF"] = "expandable_segments:True"
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args, argv))
     stub = bool(os.environ.get("MORPHEUS_BENCH_STUB"))

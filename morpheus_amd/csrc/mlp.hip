@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void warp_fwd_kernel(const float *__restric
     float *tile = acts ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
 
     float bin0[20];
-    enc_bin(xv, h, n_bands, bin0, nullptr);
+    enc_bin(xv, h, n_bands, bin0);
     if (tile) {
         store_kk_rows<20>(tile, bin0, pt, h);
 #pragma unroll
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
     float *tile = acts ? acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE) : nullptr;
 
     float bin0[40];
-    enc_bin(xv, h, n_bands, bin0, nullptr);
+    enc_bin(xv, h, n_bands, bin0);
     {
         const f32x4 *fs = reinterpret_cast<const f32x4 *>(feat_s + pc * 32 + 16 * h);
 #pragma unroll

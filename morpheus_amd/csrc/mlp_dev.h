@@ -116,17 +116,28 @@ __device__ __forceinline__ void store_kk_rows(float *__restrict__ tile, const fl
 
 // frequency encoding of one point as B operands: k-step kk<18 = (band kk/3, dim kk%3): sin on
 // lanes 0-31, cos on lanes 32-63; kk 18 = (x0 | x1); kk 19 = (x2 | 0).   encodings.py:35-57
-__device__ __forceinline__ void enc_bin(const float (&x)[3], int h, int n_bands, float *__restrict__ bin /*[20]*/,
-                                        float *__restrict__ dsc /*[18] d(feature)/dx or null*/) {
+// The two lanes of a point need the SAME 18 sincosf (one keeps the sines, the other the cosines), and an accurate sincosf is
+// ~100 instructions: lane h evaluates the k-steps of parity h only and hands the half it does not keep to its partner (lane ^ 32)
+// -- 9 sincosf + 9 cross-lane moves per lane instead of 18; the same function on the same argument, so the encoding is bit for
+// bit what it was.  k-step pairs whose bands are both switched off (progressive level: n_bands < 6) are not evaluated at all.
+// (Round 4: the field forward spent a third of its VALU issue here, and VALU issue is what bounds it -- DESIGN.md section 3.)
+__device__ __forceinline__ void enc_bin(const float (&x)[3], int h, int n_bands, float *__restrict__ bin /*[20]*/) {
 #pragma unroll
-    for (int k = 0; k < 18; k++) {
-        const int band = k / 3, dim = k % 3;
-        const float f = (float)(1 << band);
-        float s, c;
-        sincosf(x[dim] * f, &s, &c);
-        const bool on = band < n_bands;
-        bin[k] = on ? (h ? c : s) : 0.f;
-        if (dsc) dsc[k] = on ? (h ? -f * s : f * c) : 0.f;
+    for (int m = 0; m < 9; m++) {
+        const int k0 = 2 * m, k1 = 2 * m + 1;                       // lane h = 0 evaluates k0, lane h = 1 evaluates k1
+        const int b0 = k0 / 3, d0 = k0 % 3, b1 = k1 / 3, d1 = k1 % 3;
+        if (b0 < n_bands) {                                         // wave-uniform (b0 <= b1)
+            const float arg = h ? x[d1] * (float)(1 << b1) : x[d0] * (float)(1 << b0);
+            float s, c;
+            sincosf(arg, &s, &c);
+            const float got = __shfl_xor(h ? s : c, 32);           // lane 0 receives sin(k1), lane 1 receives cos(k0)
+            const bool on1 = b1 < n_bands;
+            bin[k0] = h ? got : s;
+            bin[k1] = on1 ? (h ? c : got) : 0.f;
+        } else {
+            bin[k0] = 0.f;
+            bin[k1] = 0.f;
+        }
     }
     bin[18] = h ? x[1] : x[0];
     bin[19] = h ? 0.f : x[2];

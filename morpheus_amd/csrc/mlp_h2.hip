@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_fwd_h2_kernel(
     int cb = 0;                                           // LDS buffer of the layer about to run
     h2_stage<H2_L0_F4, NW>(cb, w2_d);
     float bin0[24];
-    enc_bin(xv, h, n_bands, bin0, nullptr);
+    enc_bin(xv, h, n_bands, bin0);
 #pragma unroll
     for (int k = 20; k < 24; k++) bin0[k] = 0.f;
     if (tile) {
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(FH2_THREADS, 2) void field_fwd_h2_kernel(
         {
             // sdf L0 input, k-step ordered: 20 encoding steps | 16 hash-feature steps (level pairs) | topo | zero pad
             float bin0[40];
-            enc_bin(xv, h, n_bands, bin0, nullptr);
+            enc_bin(xv, h, n_bands, bin0);
             const f32x4 *fs = reinterpret_cast<const f32x4 *>(feat_s + pc * 32 + 16 * h);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
