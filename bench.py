@@ -881,7 +881,7 @@ def run_modes(args, argv):
 
 def run_extras(mode):
     """The training-step workloads beside the cfg3 headline, each in its own process, per-kernel timers OFF (a real-view step
-    issues ~360 launches: two event records around each C-ABI call cost it more than they cost cfg3's 13), library defaults for
+    issues ~360 launches: the event pairs around its 50 C-ABI calls cost it ~0.25 ms of 7.35, nothing on cfg3's 13), library defaults for
     steps / warm-up:
       train_real     the reference's real-view step (morpheus.py:1147-1236) -- eager with this build's fused caller-side glue,
                      the same replayed from HIP graphs, and eager with the REFERENCE's own glue + loss.item() per step (what
