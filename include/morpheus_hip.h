@@ -44,7 +44,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 4   /* 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*, mh_render_loss_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
+#define MH_ABI_VERSION 5   /* 5: accumulate flags of mh_grid_encode_bwd_binned (d/dx) and mh_field_bwd_fused (raw; d(beta) is raw[24 928]); 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*, mh_render_loss_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -78,7 +78,9 @@ int mh_grid_encode_bwd(const float *grad, const float *x, const float *emb,
  *   few scratch words used by the backward (max |grad| for its fixed-point on-chip accumulation).
  * One binning serves every encoder evaluated at the same x (sdf and colour tables).
  * mh_grid_encode_bwd_binned: one workgroup per brick accumulates all levels in LDS, then flushes the
- * touched vertices with one global atomic each. L must be 16. grad_x (optional) is fully written.
+ * touched vertices with one global atomic each (grad_emb is ADDED to: zero it, or hand over the running sum of several
+ * queries of one table). L must be 16. grad_x (optional): accumulate_dx == 0 -> fully written; != 0 -> the points' d/dx is
+ * added to what grad_x holds (the field nets' d/dx of the same points: saves the caller one pass and one launch).
  * gmax_bits: NULL, or a DEVICE word holding max |grad| as raw float bits (the producer of `grad` may compute it on
  * the fly, see mh_field_bwd_fused); NULL costs one extra pass over `grad`. */
 int64_t mh_grid_bin_workspace_ints(void);
@@ -88,8 +90,8 @@ int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_t *workspac
                        int32_t *brick_start, void *stream);
 int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *emb,
                               const int32_t *offsets_host, const int32_t *res_host, const int32_t *perm,
-                              const int32_t *brick_start, float *grad_emb, float *grad_x, int64_t M,
-                              int32_t L, int32_t n_levels, float bound, const uint32_t *gmax_bits, void *stream);
+                              const int32_t *brick_start, float *grad_emb, float *grad_x, int32_t accumulate_dx,
+                              int64_t M, int32_t L, int32_t n_levels, float bound, const uint32_t *gmax_bits, void *stream);
 
 /* ---- packed transmittance compositor -------------------------------------------------------
  * Samples of ray r are the contiguous range [ray_start[r], ray_start[r]+ray_cnt[r]) of the packed
@@ -322,20 +324,22 @@ int mh_weight_norm_bwd(int32_t n_layers, const float *const *v_host, const float
 /* Backward of the field nets: backward-data AND weight gradients in one pass per net; the weight-gradient accumulators
  * stay in registers, so the pre-activation gradients never reach HBM (no `dpre` buffer).
  *   g_sdf, g_sigma [M], g_albedo [M,3] (any may be NULL) -> g_xc [M,3] or NULL (freq path only; the hash path's d/dx comes
- *   from mh_grid_encode_bwd), g_feat_s, g_feat_c [M,32], g_topo [M,2], g_beta_partial [mh_mlp_tiles(M)] (per-tile partial
- *   sums of dL/dbeta).  sdf / albedo are the forward's outputs (Laplace and sigmoid derivatives are formed from them).
+ *   from mh_grid_encode_bwd), g_feat_s, g_feat_c [M,32], g_topo [M,2].  sdf / albedo are the forward's outputs (Laplace and
+ *   sigmoid derivatives are formed from them).
  *   gmax_bits: NULL, or 2 DEVICE words zeroed by the caller that receive max |g_feat_s| and max |g_feat_c| as raw float
  *   bits (atomicMax) -- what mh_grid_encode_bwd_binned needs for its fixed-point accumulation.
  *   dgeo_scratch [mh_field_dgeo_floats(M)] (d(geo) handed from the colour launch to the sdf launch; may be NULL when
  *   with_color == 0), workspace [mh_field_bwd_fused_workspace_floats(M)] (per-wave partial sums), and
- *   raw [24 928] = the weight gradient in mh_mlp_wgrad's tile-row format for the layer list s0, s1, s2, c0, c1, c2
- *   (dW tiles | db tiles; the colour part is zero-filled when with_color == 0). */
+ *   raw [24 928 + 1] = the weight gradient in mh_mlp_wgrad's tile-row format for the layer list s0, s1, s2, c0, c1, c2
+ *   (dW tiles | db tiles; the colour part is zero when with_color == 0) followed by dL/dbeta (one float, summed in a fixed
+ *   order).  accumulate == 0: raw is written; != 0: this call's gradients are ADDED to raw -- the field queries of one
+ *   training step (render, finite-difference taps, regularisers) sum their weight gradients in place, no caller-side adds. */
 int64_t mh_field_bwd_fused_workspace_floats(int64_t M);
 int64_t mh_field_dgeo_floats(int64_t M);
 int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf, const float *g_sigma,
                        const float *g_albedo, const float *wpackT, const float *beta, int32_t n_bands, int32_t with_color,
-                       const float *acts, float *dgeo_scratch, float *workspace, float *raw, float *g_xc, float *g_feat_s,
-                       float *g_feat_c, float *g_topo, float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream);
+                       const float *acts, float *dgeo_scratch, float *workspace, float *raw, int32_t accumulate, float *g_xc,
+                       float *g_feat_s, float *g_feat_c, float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream);
 /* ---- optimiser step over the flat parameter bucket (the step after the path) ---- */
 /* Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9,0.99), eps=1e-15).step() of morpheus.py:154-155,
  * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned.

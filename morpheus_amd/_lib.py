@@ -27,7 +27,7 @@ _SIGS = {
     "mh_grid_bin_bricks": (_I32, []),
     "mh_grid_bin_index_ints": (_I32, []),
     "mh_grid_bin_points": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P, _P]),
-    "mh_grid_encode_bwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _P]),
+    "mh_grid_encode_bwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _F, _P, _P]),
     "mh_composite_fwd": (ctypes.c_int, [_P] * 10 + [_I32, _P]),
     "mh_composite_bwd": (ctypes.c_int, [_P] * 13 + [_I32, _P]),
     "mh_generate_rays": (ctypes.c_int, [_F, _F, _F, _F, _P, _I32, _I32, _P, _P, _P]),
@@ -76,7 +76,7 @@ _SIGS = {
     "mh_field_fwd": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_field_bwd_fused_workspace_floats": (_I64, [_I64]),
     "mh_field_dgeo_floats": (_I64, [_I64]),
-    "mh_field_bwd_fused": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 10 + [_I64, _P]),
+    "mh_field_bwd_fused": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 4 + [_I32] + [_P] * 5 + [_I64, _P]),
     "mh_mlp_wgrad_workspace_floats": (_I64, [_I32, _P, _P, _I64]),
     "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mh_mlp_wgrad_b3": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
@@ -118,7 +118,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mh_abi_version() != 4:
+        if lib.mh_abi_version() != 5:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
         _lib = lib
     return _lib

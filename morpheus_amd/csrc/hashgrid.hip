@@ -392,7 +392,7 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
 // accumulator; two workgroups per CU): 0.66 -> 0.52 ms (1.03 -> 0.87 ms with d/dx).  What is left is the LDS atomic
 // pipe: the 4 points a wave carries share their coarse-level cells, so every ds_add_u64 pays the 4-way same-address rate.
 #define BRK_THREADS 1024
-template <bool NEED_DX>
+template <int NEED_DX>      // 0: no d/dx; 1: grad_x = d/dx (pre-zeroed by the host side); 2: grad_x += d/dx
 __global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float2 *__restrict__ grad, const float *__restrict__ x,
                                                              const float2 *__restrict__ emb, GridMeta meta, BrickMeta bm,
                                                              const int32_t *__restrict__ perm,
@@ -484,9 +484,15 @@ __global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float
             const float sx = sum16(dx[0]), sy = sum16(dx[1]), sz = sum16(dx[2]);
             if (live && l == 0) {
                 const float inv = 1.0f / two_bound;
-                grad_x[p * 3 + 0] = sx * inv;
-                grad_x[p * 3 + 1] = sy * inv;
-                grad_x[p * 3 + 2] = sz * inv;
+                if (NEED_DX == 2) {
+                    grad_x[p * 3 + 0] += sx * inv;
+                    grad_x[p * 3 + 1] += sy * inv;
+                    grad_x[p * 3 + 2] += sz * inv;
+                } else {
+                    grad_x[p * 3 + 0] = sx * inv;
+                    grad_x[p * 3 + 1] = sy * inv;
+                    grad_x[p * 3 + 2] = sz * inv;
+                }
             }
         }
     }
@@ -607,8 +613,8 @@ extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_
 
 extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *emb, const int32_t *offsets_host,
                                          const int32_t *res_host, const int32_t *perm, const int32_t *brick_start,
-                                         float *grad_emb, float *grad_x, int64_t M, int32_t L, int32_t n_levels,
-                                         float bound, const uint32_t *gmax_bits, void *stream) {
+                                         float *grad_emb, float *grad_x, int32_t accumulate_dx, int64_t M, int32_t L,
+                                         int32_t n_levels, float bound, const uint32_t *gmax_bits, void *stream) {
     if (M == 0) return MH_OK;
     if (!grad || !x || !emb || !grad_emb || !perm || !brick_start || M < 0 || n_levels < 0 || n_levels > L || L != 16 ||
         !(bound > 0.f))
@@ -636,14 +642,19 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
         hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, mh_stream(stream), grad, M * (int64_t)L * 2, own);
         gmax = own;
     }
-    if (grad_x) {
+    if (grad_x && accumulate_dx) {
+        // grad_x already holds a gradient of the same points (the field nets' d/dx): each visited point adds to its own row
+        hipLaunchKernelGGL(grid_bwd_brick_kernel<2>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
+                           reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
+                           brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
+    } else if (grad_x) {
         // points outside the box are never visited by a brick: their d/dx is zero
         if (!mh_zero_async(grad_x, sizeof(float) * 3 * (size_t)M, mh_stream(stream))) return MH_ERR_LAUNCH;
-        hipLaunchKernelGGL(grid_bwd_brick_kernel<true>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
+        hipLaunchKernelGGL(grid_bwd_brick_kernel<1>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
                            reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
                            brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
     } else {
-        hipLaunchKernelGGL(grid_bwd_brick_kernel<false>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
+        hipLaunchKernelGGL(grid_bwd_brick_kernel<0>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
                            reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
                            brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
     }

@@ -621,6 +621,7 @@ __device__ __forceinline__ const float *acc_add_lds(f32x16 (&a)[N], const float 
 struct FusedPart {            // where this launch's per-wave partial sums go (float offsets into the workspace)
     int64_t dw[3];            // layer-major: [n_chunks][out_pad * in_pad]
     int64_t db[3];            // [n_chunks][out_pad]
+    int64_t gb;               // sdf launch: [n_chunks] partial sums of d(loss)/d(beta)
 };
 
 // ---- color_net: Q2 (3 rows) <- g_albedo, Q1, Q0; hands d(geo) to the sdf launch ------------------------------------
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ g_sdf,
     const float *__restrict__ g_sigma, const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands,
     const float *__restrict__ acts, const float *__restrict__ dgeo_scr, float *__restrict__ g_xc,
-    float *__restrict__ g_feat_s, float *__restrict__ g_topo, float *__restrict__ g_beta_partial, float *__restrict__ ws,
+    float *__restrict__ g_feat_s, float *__restrict__ g_topo, float *__restrict__ ws,
     FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5, i = lane & 31;
@@ -818,6 +819,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     acc_zero<3>(w0[1]);
     float b2[2] = {0.f, 0.f}, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
     uint32_t max_s = 0;
+    float gb_acc = 0.f;                                    // d(loss)/d(beta) of this lane's points (lanes h == 0 carry it)
     const float beta = *beta_p;
     const int chunk = blockIdx.x * (FUSED_THREADS / 64) + wave, n_chunks = gridDim.x * (FUSED_THREADS / 64);
     for (int64_t tile_id = chunk; tile_id < n_tiles; tile_id += n_chunks) {
@@ -845,12 +847,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                                (1.0f / beta) * (0.5f * sg * ex * (fabsf(s) / (beta * beta))));
             }
         }
-        if (g_beta_partial) {
-            float tot = gbeta;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-            if (lane == 0) g_beta_partial[tile_id] = tot;
-        }
+        gb_acc += gbeta;
         const uint32_t mw1 = masks[1 * 64 + lane], mw0 = masks[0 * 64 + lane];
         float d2[32];
         if (WITH_COLOR) {
@@ -1012,6 +1009,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                 q[(2 + mt) * 64 + lane] = b1[mt];
                 q[(4 + mt) * 64 + lane] = b0[mt];
             }
+            q[6 * 64 + lane] = gb_acc;
         }
         __syncthreads();
         if (wave == 0) {
@@ -1028,9 +1026,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                 b1[mt] += q[(2 + mt) * 64 + lane];
                 b0[mt] += q[(4 + mt) * 64 + lane];
             }
+            gb_acc += q[6 * 64 + lane];
         }
     }
     if (wave != 0) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gb_acc += __shfl_xor(gb_acc, o);
+    if (lane == 0) ws[part.gb + blockIdx.x] = gb_acc;
     // partial sums of this workgroup: layers s0, s1, s2 = part.dw[0..2]; the sdf-only pass fills tile 1 of s2 only (tile 0 = zeros)
     const int64_t pchunk = blockIdx.x;
 #pragma unroll
@@ -1662,6 +1664,7 @@ __global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_all_regs_b3_kernel(co
 // sum the per-chunk partials of every layer in one launch
 struct WgReduce {
     int32_t n;
+    int32_t accumulate;                    // 0: out = sum of the partials; 1: out += sum (a later call of a shared accumulator)
     int32_t chunks[2 * WG_MAX_LAYERS];
     int32_t len[2 * WG_MAX_LAYERS];
     int64_t part_off[2 * WG_MAX_LAYERS];
@@ -1699,7 +1702,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
     red[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && live) out[d.out_off[s] + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && live) {
+        const float sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float *o = out + d.out_off[s] + j;
+        *o = d.accumulate ? *o + sum : sum;
+    }
 }
 
 // =====================================================================================
@@ -1834,6 +1841,7 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
     // workspace: [dW partials of layer 0 | 1 | ...][db partials of layer 0 | 1 | ...]; outputs: dw_raw | db_raw
     WgReduce rd;
     rd.n = 2 * n_layers;
+    rd.accumulate = 0;
     int64_t woff = 0, dw_out = 0, db_out = 0;
     int64_t dw_poff[WG_MAX_LAYERS], db_poff[WG_MAX_LAYERS];
     for (int l = 0; l < n_layers; l++) {
@@ -2011,15 +2019,15 @@ extern "C" int64_t mh_field_bwd_fused_workspace_floats(int64_t M) {
     const int64_t chunks = (int64_t)fused_blocks(n_tiles_for(M));     // one partial per workgroup
     int64_t per = 0;
     for (int l = 0; l < 6; l++) per += (int64_t)FUSED_IN[l] * FUSED_OUT[l] + FUSED_OUT[l];
-    return chunks * per;
+    return chunks * (per + 1);                                        // + the d(beta) partial of each workgroup
 }
 extern "C" int64_t mh_field_dgeo_floats(int64_t M) { return n_tiles_for(M) * 64 * 16; }
 
 static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
                                 const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
                                 int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
-                                float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
-                                float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
+                                float *workspace, float *raw, int32_t accumulate, float *g_xc, float *g_feat_s, float *g_feat_c,
+                                float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !xc || !sdf || !wpackT || !acts || !workspace || !raw || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && (!albedo || !dgeo_scratch)) return MH_ERR_ARG;
@@ -2056,10 +2064,12 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
         pc.dw[k] = dw_off[3 + k];
         pc.db[k] = db_off[3 + k];
     }
+    ps.gb = off;                                    // [chunks] d(beta) partials behind the bias partials
+    pc.gb = off;
     hipStream_t st = mh_stream(stream);
 #define FUSED_LAUNCH_SDF(WC, DGEO)                                                                                           \
     hipLaunchKernelGGL((field_fused_sdf_kernel<WC>), dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf,      \
-                       g_sigma, wpackT, beta, (int)n_bands, acts, (const float *)(DGEO), g_xc, g_feat_s, g_topo, g_beta_partial, \
+                       g_sigma, wpackT, beta, (int)n_bands, acts, (const float *)(DGEO), g_xc, g_feat_s, g_topo,                 \
                        workspace, ps, gmax_bits, M, n_tiles)
     if (with_color) {
         hipLaunchKernelGGL(field_fused_color_kernel, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT,
@@ -2075,7 +2085,8 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
     // colour net's segments are reduced over ZERO chunks, i.e. written as 0 by the same launch (no separate memsets)
     const int n_l = with_color ? 6 : 3;
     WgReduce rd;
-    rd.n = 12;
+    rd.n = 13;
+    rd.accumulate = accumulate ? 1 : 0;
     int64_t dw_out = 0, db_out = 0;
     rd.first[0] = 0;
     for (int l = 0; l < 6; l++) {
@@ -2091,6 +2102,10 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
         dw_out += (int64_t)FUSED_IN[l] * FUSED_OUT[l];
         db_out += FUSED_OUT[l];
     }
+    rd.chunks[12] = (int32_t)chunks;                // d(beta): one element behind the 24 928 weight / bias gradients
+    rd.len[12] = 1;
+    rd.part_off[12] = ps.gb;
+    rd.out_off[12] = dw_total + db_total;
     for (int sgm = 0; sgm < rd.n; sgm++) rd.first[sgm + 1] = rd.first[sgm] + rd.len[sgm];
     const int64_t total = rd.first[rd.n];
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace, raw, rd);
@@ -2101,10 +2116,10 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
 extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
                                   const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
                                   int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
-                                  float *workspace, float *raw, float *g_xc, float *g_feat_s, float *g_feat_c, float *g_topo,
-                                  float *g_beta_partial, uint32_t *gmax_bits, int64_t M, void *stream) {
+                                  float *workspace, float *raw, int32_t accumulate, float *g_xc, float *g_feat_s,
+                                  float *g_feat_c, float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream) {
     return field_bwd_fused_impl(xc, sdf, albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, n_bands, with_color, acts, dgeo_scratch,
-                                workspace, raw, g_xc, g_feat_s, g_feat_c, g_topo, g_beta_partial, gmax_bits, M, stream);
+                                workspace, raw, accumulate, g_xc, g_feat_s, g_feat_c, g_topo, gmax_bits, M, stream);
 }
 
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }

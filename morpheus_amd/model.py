@@ -339,7 +339,9 @@ class scene_representation(nn.Module):
                 ws = [torch.cat([w0[:, :3], w0.new_zeros(w0.shape[0], 36), w0[:, 3:]], 1)] + ws[1:]
             params = ws + wn_effective_batched(list(self.color_net.net)) + self.sdf_net.biases() + \
                 self.color_net.biases()
-            return ops.prepare_field_operands(params, mode=self.mlp_mode), self.sdf2density.get_beta()
+            beta = self.sdf2density.get_beta()
+            tables = (self.encoder.embeddings, self.encoder_c.embeddings)
+            return ops.prepare_field_operands(params, mode=self.mlp_mode, beta=beta, tables=tables), beta
         return self._cached("field", build)
 
     # -- public API (names/signatures of the reference) ----------------------------------------

@@ -178,37 +178,47 @@ def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
     return outs
 
 
-def _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gmax_ptrs=None):
+def _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gmax_ptrs=None, sums=None, g_x_into=None):
     """Embedding (and position) gradients of several tables evaluated at the same points: ONE brick binning shared by all
     tables.  gmax_ptrs[k]: device address of max|grads[k]| as float bits when its producer reduced it on the fly
-    (mh_field_bwd_data), else None -> the kernel reduces it itself.  -> (g_x or None, [g_emb or None])."""
+    (mh_field_bwd_data), else None -> the kernel reduces it itself.
+    sums[k]: device ADDRESS of a running table-gradient sum this call adds into (the brick kernel's flush is an atomic add
+    anyway), or None -> a fresh zero-filled table.  g_x_into: a [M,3] gradient of the same points that the tables' d/dx is added
+    to in the kernel (brick path only), or None.
+    -> (g_x or None, [g_emb; None where the gradient went into sums[k]])."""
     M = x.shape[0]
-    g_x_total, g_embs, binned = None, [], None
+    g_x_total, g_embs, binned = g_x_into, [], None
+    brick = M > 0 and L == 16          # the brick kernel's level table is sized for the shipped 16-level geometry
     for k, (emb, grad) in enumerate(zip(embs, grads)):
         if grad is None:
             g_embs.append(None)
             continue
         grad = grad.contiguous()
-        g_emb = torch.zeros_like(emb)
-        g_x = torch.empty_like(x) if need_dx else None
-        if M > 0 and L == 16:      # the brick kernel's level table is sized for the shipped 16-level geometry
+        into = None if sums is None else sums[k]
+        g_emb = torch.zeros_like(emb) if into is None else None
+        g_emb_p = ptr(g_emb) if into is None else ctypes.c_void_p(into)
+        if brick:
             if binned is None:
                 binned = _bin_points(lib, x, bound)
+            acc_dx = need_dx and g_x_total is not None
+            g_x = g_x_total if acc_dx else (torch.empty_like(x) if need_dx else None)
             _e = TIMER.start()
             check(lib.mh_grid_encode_bwd_binned(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(binned[0]), ptr(binned[1]),
-                                                ptr(g_emb), ptr(g_x), M, L, n_levels, bound,
+                                                g_emb_p, ptr(g_x), int(acc_dx), M, L, n_levels, bound,
                                                 None if gmax_ptrs is None else gmax_ptrs[k], stream()),
                   "mh_grid_encode_bwd_binned")
             TIMER.stop("mh_grid_encode_bwd_binned", _e)
+            g_x_total = g_x
         else:
+            g_x = torch.empty_like(x) if need_dx else None
             _e = TIMER.start()
-            check(lib.mh_grid_encode_bwd(ptr(grad), ptr(x), ptr(emb), o_p, r_p, ptr(g_emb), ptr(g_x), M, L, n_levels,
+            check(lib.mh_grid_encode_bwd(ptr(grad), ptr(x), ptr(emb), o_p, r_p, g_emb_p, ptr(g_x), M, L, n_levels,
                                          bound, stream()), "mh_grid_encode_bwd")
             TIMER.stop("mh_grid_encode_bwd", _e)
+            if need_dx:
+                g_x_total = g_x if g_x_total is None else g_x_total + g_x
         g_embs.append(g_emb)
-        if need_dx:
-            g_x_total = g_x if g_x_total is None else g_x_total + g_x
-    return g_x_total, g_embs
+    return (g_x_total if need_dx else None), g_embs
 
 
 class _GridEncode(torch.autograd.Function):
@@ -687,6 +697,67 @@ WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640 + 40, 2 * 672     # csrc/mlp.hip: a
 FIELD_ACT_ROWS = 96 + 64 * 5 + 8   # activations + 8 rows of ReLU masks
 
 
+# A/B and test switch: False = every field query returns its own gradient tensors and autograd adds them up (the round-3 form)
+ACCUMULATE_IN_PLACE = True
+
+
+class _QueryAccumulator:
+    """Running gradient sums of ONE backward pass, shared by the field queries that were given the same prepared operands
+    (`MLPOperands.acc`; a real-view training step issues six: render, finite-difference taps, regularisers, point loss).
+
+    Each query's backward produces (a) the raw weight / bias / beta gradient [24 929], (b) a full table gradient [419 640, 2] per
+    hash table.  Handed to autograd one tensor per query, that is a zero fill per table and an add per tensor per extra query
+    (about 30 launches of 0.1 - 3.4 MB per step).  Instead the queries ADD INTO ONE TENSOR EACH inside their own kernels
+    (mh_field_bwd_fused's reduction launch with accumulate = 1; the brick kernel's flush is an atomic add anyway) and return None
+    for token, beta and tables; `_PackOperands.backward` -- the node behind the token every query takes, which autograd runs only
+    after ALL of them have run, None gradients included -- hands the finished sums to beta and the tables (its extra inputs) and
+    maps the raw sum to the parameters.  Gradients that reach beta or a table along other paths are added by autograd as usual:
+    the sums are complete when they are handed over, nothing is modified afterwards.
+
+    A query joins only if it uses the very beta tensor and table parameters the operands were prepared with; any other query gets
+    its own tensors as before.  State is keyed on the autograd graph task: a new backward pass starts empty, whatever the last
+    one left behind."""
+
+    def __init__(self, beta=None, tables=()):
+        self.bound = beta is not None
+        self.keep = (beta, tuple(tables))            # the ids below stay theirs for as long as the accumulator lives
+        self.ids = (id(beta),) + tuple(id(t) for t in tables)
+        self.task = None
+        self.reset()
+
+    def reset(self):
+        self.raw = None                              # [raw_len + 1] running sum: weight / bias gradients, then d(loss)/d(beta)
+        self.tab = [None] * (len(self.ids) - 1)      # running table-gradient sums
+        self.gmax = None                             # pool of zeroed int32 pairs (max |feature gradient| words of the queries)
+        self.gmax_used = 0
+
+    def enter(self) -> bool:
+        task = torch._C._current_graph_task_id()
+        if task != self.task:
+            self.reset()
+            self.task = task
+        return task >= 0           # -1: not inside a backward pass (a Function's backward called by hand): nobody would collect
+
+    def joins(self, ids) -> bool:
+        """ids = (id(beta), id(emb_s), id(emb_c) or id(None)) of a query: same beta, same tables (a colourless query: its one)"""
+        return self.bound and ids[0] == self.ids[0] and ids[1] == self.ids[1] and (ids[2] == id(None) or ids[2:] == self.ids[2:])
+
+    def gmax_words(self, dev):
+        if self.gmax is None or self.gmax_used + 2 > self.gmax.numel():
+            self.gmax, self.gmax_used = torch.zeros(64, dtype=torch.int32, device=dev), 0
+        w = self.gmax[self.gmax_used:self.gmax_used + 2]
+        self.gmax_used += 2
+        return w
+
+    def collect(self):
+        """-> (raw or None, [table sums or None]) of the running backward pass; the accumulator is empty afterwards"""
+        if self.task != torch._C._current_graph_task_id():
+            self.reset()
+        out = (self.raw, self.tab)
+        self.reset()
+        return out
+
+
 class _PackOperands(torch.autograd.Function):
     """Natural (effective) weights + biases of the nets of one JointPacker -> the kernels' operands, ONCE per step:
 
@@ -701,8 +772,11 @@ class _PackOperands(torch.autograd.Function):
     bias0 (model.warp), so its slot in the raw gradient is dropped here."""
 
     @staticmethod
-    def forward(ctx, jp, zero_bias0, b3, n_w, *params):
+    def forward(ctx, jp, zero_bias0, b3, n_w, acc, *params):
         ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
+        # behind the n_w weights / biases: the tensors whose gradients the queries sum in `acc` (field nets: beta, the hash tables)
+        params, extras = params[:n_w], params[n_w:]
+        ctx.acc, ctx.n_extra = acc, len(extras)
         require_gpu(*params)
         weights, biases, o = [], [], 0
         for pk in jp.packers:
@@ -753,18 +827,25 @@ class _PackOperands(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _gf, _gb, _g3, g_token):
+        n = ctx.jp.raw_len
+        raw, tabs = ctx.acc.collect() if ctx.acc is not None else (None, [])
+        g_extra = [None] * ctx.n_extra
+        if raw is not None:                   # the joined queries' sum: [weights, biases | d beta]
+            g_token = raw[:n] if g_token is None else g_token + raw[:n]
+            g_extra = [raw[n].reshape(())] + list(tabs)
         if g_token is None:
-            return (None,) * (4 + sum(2 * len(pk.specs) for pk in ctx.jp.packers))
+            return (None,) * (5 + sum(2 * len(pk.specs) for pk in ctx.jp.packers)) + tuple(g_extra)
         nat_w, nat_b = ctx.jp.unpack_grads(g_token, zero_bias0=ctx.zero_bias0)
         flat = [g for net in nat_w for g in net] + [g for net in nat_b for g in net]
-        return (None, None, None, None, *flat)
+        return (None, None, None, None, None, *flat, *g_extra)
 
 
 class MLPOperands:
     """Prepared operands of the warp nets (deform_net + topo_net) or of the field nets (sdf_net + color_net)."""
 
-    def __init__(self, jp, fpack, bpack, w3, token, mode=""):
+    def __init__(self, jp, fpack, bpack, w3, token, mode="", acc=None):
         self.jp, self.fpack, self.bpack, self.token = jp, fpack, bpack, token
+        self.acc = acc                                     # running gradient sums of the queries that share these operands
         self.mode = mode if w3.numel() else ""             # "b3" / "h2": which sliced kernels the operands are cut for
         # slices per net (float32 storage, 4 floats per float4 unit), or None when the fp32-MFMA kernels serve
         if self.mode == "h2":
@@ -784,14 +865,21 @@ def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[t
     jp = warp_joint_packer()
     flat = list(params_d[:6]) + list(params_t[:6]) + list(params_d[6:]) + list(params_t[6:])
     mode = _warp_mode(mode)
-    return MLPOperands(jp, *_PackOperands.apply(jp, True, mode, len(flat), *flat), mode=mode)
+    return MLPOperands(jp, *_PackOperands.apply(jp, True, mode, len(flat), None, *flat), mode=mode)
 
 
-def prepare_field_operands(params: Sequence[torch.Tensor], mode: Optional[str] = None) -> MLPOperands:
-    """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective)."""
+def prepare_field_operands(params: Sequence[torch.Tensor], mode: Optional[str] = None, beta=None, tables=()) -> MLPOperands:
+    """params: Ws0 [64,73], Ws1, Ws2 [33,64], Wc0, Wc1, Wc2 [3,64], bs0, bs1, bs2, bc0, bc1, bc2 (natural, effective).
+    beta (0-dim) and tables (the sdf and the colour hash table): when given, the field queries that are handed THESE tensors sum
+    their beta / table / weight gradients in place and the pack hands the sums over once (_QueryAccumulator)."""
     jp = field_joint_packer()
     mode = _warp_mode(mode)    # the field FORWARD follows the mode; the fused backward reads the fp32 transposed pack in every mode
-    return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), *params), mode=mode)
+    if beta is None:
+        return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), None, *params), mode=mode)
+    if len(tables) != 2:
+        raise ValueError("prepare_field_operands: tables = (sdf table, colour table)")
+    acc = _QueryAccumulator(beta, tables)
+    return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), acc, *params, beta, *tables), mode=mode, acc=acc)
 
 
 class _WarpMLP(torch.autograd.Function):
@@ -929,31 +1017,35 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
 
 
 def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-               need_dx, jp):
+               need_dx, jp, raw_into=None, gmax=None):
     """mh_field_bwd_fused: backward-data and weight gradients of the field nets in one pass per net (the pre-activation
-    gradients stay on the chip).
-    -> g_xc|None, g_fs, g_fc|None, g_tp|None, g_beta, raw (tile-order weight gradient), gmax (int32[2]: max|g_fs|, max|g_fc|
-    as float bits, reduced on the fly by the kernel for the hash-grid backward's fixed point)."""
+    gradients stay on the chip).  raw_into: device ADDRESS of a running [raw_len + 1] sum this call adds its weight / bias /
+    beta gradients to (the reduction launch adds instead of writing), or None -> a fresh tensor.  gmax: 2 zeroed int32 words.
+    -> g_xc|None, g_fs, g_fc|None, g_tp|None, raw|None (tile-order weight gradient followed by d(loss)/d(beta); None when it
+    went into raw_into), gmax (int32[2]: max|g_fs|, max|g_fc| as float bits, reduced on the fly by the kernel for the hash-grid
+    backward's fixed point)."""
     M, dev = xc.shape[0], xc.device
-    n_tiles = lib.mh_mlp_tiles(M)
     if not with_color:
         g_albedo = None
     g_xc = torch.empty(M, 3, device=dev) if need_dx else None
     g_fs = torch.empty(M, 32, device=dev)
     g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
     g_tp = torch.empty(M, 2, device=dev) if has_topo else None
-    g_bp = torch.empty(n_tiles, device=dev)
-    gmax = torch.zeros(2, dtype=torch.int32, device=dev)
+    if gmax is None:
+        gmax = torch.zeros(2, dtype=torch.int32, device=dev)
     dgeo = torch.empty(lib.mh_field_dgeo_floats(M), device=dev) if with_color else None
     ws = torch.empty(lib.mh_field_bwd_fused_workspace_floats(M), device=dev)
-    raw = torch.empty(jp.raw_len, device=dev) if M > 0 else torch.zeros(jp.raw_len, device=dev)   # empty query: see _wgrad
+    raw = None
+    if raw_into is None:      # an empty query returns MH_OK without writing: the gradient must then be zeros, not heap contents
+        raw = torch.empty(jp.raw_len + 1, device=dev) if M > 0 else torch.zeros(jp.raw_len + 1, device=dev)
     c = lambda t: None if t is None else t.contiguous()
     _e = TIMER.start()
     check(lib.mh_field_bwd_fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT),
-                                 ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws), ptr(raw), ptr(g_xc),
-                                 ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(g_bp), ptr(gmax), M, stream()), "mh_field_bwd_fused")
+                                 ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws),
+                                 ptr(raw) if raw_into is None else ctypes.c_void_p(raw_into), int(raw_into is not None), ptr(g_xc),
+                                 ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(gmax), M, stream()), "mh_field_bwd_fused")
     TIMER.stop("mh_field_bwd_fused", _e)
-    return g_xc, g_fs, g_fc, g_tp, g_bp.sum().reshape(()), raw, gmax
+    return g_xc, g_fs, g_fc, g_tp, raw, gmax
 
 
 class _FieldMLP(torch.autograd.Function):
@@ -988,10 +1080,10 @@ class _FieldMLP(torch.autograd.Function):
         lib = _lib.load()
         xc, wT, beta_c, acts, sdf, albedo = ctx.saved_tensors
         n_bands, with_color, has_topo, has_fc = ctx.cfg
-        g_xc, g_fs, g_fc, g_tp, g_beta, raw, _ = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
-                                                            n_bands, with_color, has_topo, has_fc, ctx.needs_input_grad[0],
-                                                            ctx.jp)
-        return (g_xc, g_fs, g_fc, g_tp, g_beta, raw, None, None, None)
+        g_xc, g_fs, g_fc, g_tp, raw, _ = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
+                                                    n_bands, with_color, has_topo, has_fc, ctx.needs_input_grad[0], ctx.jp)
+        n = ctx.jp.raw_len
+        return (g_xc, g_fs, g_fc, g_tp, raw[n].reshape(()), raw[:n], None, None, None)
 
 
 def field_mlp(xc, feat_s, feat_c, topo, beta, n_bands, with_color, opnd: MLPOperands):
@@ -1023,7 +1115,8 @@ class _FieldQuery(torch.autograd.Function):
                                               with_color, opnd, any(ctx.needs_input_grad))
         ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo, *embs)
         ctx.cfg = (n_bands, with_color, topo is not None, o_np, r_np, n_levels, float(bound), L)
-        ctx.jp = opnd.jp
+        ctx.jp, ctx.acc = opnd.jp, opnd.acc
+        ctx.ids = (id(beta), id(emb_s), id(emb_c))       # identities of the shared inputs (see _QueryAccumulator.joins)
         if albedo is None:
             albedo = torch.zeros(0, device=xc.device)
             ctx.mark_non_differentiable(albedo)
@@ -1035,14 +1128,26 @@ class _FieldQuery(torch.autograd.Function):
         xc, wT, beta_c, acts, sdf, albedo, *embs = ctx.saved_tensors
         n_bands, with_color, has_topo, o_np, r_np, n_levels, bound, L = ctx.cfg
         need_dx = ctx.needs_input_grad[0]
-        g_xc, g_fs, g_fc, g_tp, g_beta, raw, gmax = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
-                                                               n_bands, with_color, has_topo, with_color, need_dx, ctx.jp)
+        acc, n = ctx.acc, ctx.jp.raw_len
+        # joined: this query's weight / beta / table gradients go into the pass's running sums (handed over by _PackOperands.backward)
+        joined = (ACCUMULATE_IN_PLACE and acc is not None and xc.shape[0] > 0 and ctx.needs_input_grad[3] and acc.joins(ctx.ids)
+                  and acc.enter())
+        g_xc, g_fs, g_fc, g_tp, raw, gmax = _field_bwd(
+            lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, with_color, need_dx, ctx.jp,
+            raw_into=acc.raw.data_ptr() if joined and acc.raw is not None else None, gmax=acc.gmax_words(xc.device) if joined else None)
         o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
         grads = [g_fs] + ([g_fc] if with_color else [])
         gptrs = [gmax.data_ptr(), gmax.data_ptr() + 4][:len(grads)]
-        g_x_grid, g_embs = _grid_bwd(lib, xc, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gptrs)
-        g_x = (g_xc + g_x_grid) if need_dx else None
-        return (g_x, g_tp, g_beta, raw, g_embs[0], g_embs[1] if with_color else None, None, None, None, None, None, None, None)
+        sums = [acc.tab[k].data_ptr() if acc.tab[k] is not None else None for k in range(len(grads))] if joined else None
+        g_x, g_embs = _grid_bwd(lib, xc, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gptrs, sums=sums, g_x_into=g_xc)
+        if joined:
+            if raw is not None:
+                acc.raw = raw
+            for k, g in enumerate(g_embs):
+                if g is not None:
+                    acc.tab[k] = g
+            return (g_x, g_tp) + (None,) * 11
+        return (g_x, g_tp, raw[n].reshape(()), raw[:n], g_embs[0], g_embs[1] if with_color else None, None, None, None, None, None, None, None)
 
 
 def field_query(xc, topo, beta, emb_s, emb_c, offsets_np, res_np, bound, max_level, group, n_bands, opnd: MLPOperands):

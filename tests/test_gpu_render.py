@@ -946,6 +946,58 @@ def test_reference_glue_equals_fused_glue():
         assert rel <= 2e-3, (k, rel)          # same terms, other summation orders; FD-normal terms amplify round-off
 
 
+def test_field_queries_accumulate_gradients_in_place():
+    """ops._QueryAccumulator: the six field queries of a real-view step add their weight / beta / table gradients into ONE tensor
+    each inside their kernels (first query returns it to autograd, later ones return None) -- the same gradients as one tensor per
+    query summed by autograd, with fewer launches."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from morpheus_amd import harness, ops, trainstep
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.render import HotPathRenderer
+
+    class CountAdds(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.big = 0
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = getattr(func, "__name__", "")
+            if name.startswith(("add", "zeros_like", "zero_")) and args and isinstance(args[0], torch.Tensor) and args[0].numel() >= 24928:
+                self.big += 1
+            return func(*args, **(kwargs or {}))
+
+    out, seen = {}, {}
+    for in_place in (True, False):
+        ops.ACCUMULATE_IN_PLACE = in_place
+        try:
+            model = harness.build_model("b", DEV).train()
+            grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(DEV)
+            rend = HotPathRenderer(model, model.config, grid, 200)
+            ts = trainstep.RealViewTrainStep(rend, trainstep.make_frames([25], 64, 64, DEV), ray_num=512)
+            ts.epoch = 1000
+            torch.manual_seed(11)
+            with torch.no_grad():
+                trainstep.warm_up_occupancy(ts)
+            ts.global_step = 4096 + 3
+            for p in model.parameters():
+                p.grad = None
+            loss = ts(frame_index=0)
+            cnt = CountAdds()
+            with cnt:
+                loss.backward()
+            out[in_place] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+            seen[in_place] = cnt.big
+        finally:
+            ops.ACCUMULATE_IN_PLACE = True
+    (l1, g1), (l0, g0) = out[True], out[False]
+    assert l1 == l0 and set(g1) == set(g0)
+    for k in g0:
+        rel = float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30))
+        assert rel <= 2e-5, (k, rel)                      # same terms, summed in another order
+    assert torch.count_nonzero(g1["encoder.embeddings"]) > 0 and torch.count_nonzero(g1["sdf2density.beta"]) == 1
+    assert seen[True] + 15 <= seen[False], seen           # table fills + table adds + token adds that no longer exist
+
+
 def test_two_models_with_their_own_arithmetic_in_one_process():
     """`scene_representation.mlp_mode` binds the arithmetic form to a model's operand packs: two models of one process run
     different forms side by side, and changing the process default between a forward and its backward changes nothing."""

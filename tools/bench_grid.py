@@ -35,7 +35,7 @@ def run(x, tag):
     print(f"[{tag}] M={M} bin {t_bin:.3f} ms; bricks nonempty {(cnt[:4096] > 0).sum().item()}, max {cnt[:4096].max().item()}, mean(nonempty) {cnt[:4096][cnt[:4096] > 0].float().mean().item():.0f}, oob {cnt[4096].item()}")
     for nl in (16,):
         for dx in (False, True):
-            t = timeit(lambda: lib.mh_grid_encode_bwd_binned(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), perm.data_ptr(), bs.data_ptr(), g_emb.data_ptr(), g_x.data_ptr() if dx else None, M, 16, nl, 1.01, None, st))
+            t = timeit(lambda: lib.mh_grid_encode_bwd_binned(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), perm.data_ptr(), bs.data_ptr(), g_emb.data_ptr(), g_x.data_ptr() if dx else None, 0, M, 16, nl, 1.01, None, st))
             print(f"   binned n_levels={nl:2d} dx={int(dx)}: {t:.3f} ms")
     t = timeit(lambda: lib.mh_grid_encode_bwd(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), g_emb.data_ptr(), None, M, 16, 16, 1.01, st), 2)
     print(f"   naive  n_levels=16 dx=0: {t:.3f} ms")
