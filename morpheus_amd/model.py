@@ -6,9 +6,10 @@ optimisation loop, EMA, checkpoints and LR schedule address it unchanged.  Under
 field, canonical field and hash grids run on the HIP kernels of libmorpheus_hip.so through
 morpheus_amd.ops; there is no PyTorch fallback for those (CPU tensors raise).
 
-Only the configuration every shipped YAML uses is wired to the fused kernels
-(use_t=False, use_app=False, use_joint=True, color_grid=True, encode_topo=False); other switches
-raise NotImplementedError instead of silently taking a slow path.
+Every constructor switch of the reference is accepted.  use_t and use_joint (either value) run on the fused kernels (they
+change per-frame constants or zero first-layer columns); use_app=True, encode_topo=True and color_grid=False -- set by no
+shipped YAML -- change what the field nets read per point and take the composed field path (`composed_field`: hash grids,
+warp nets, finite-difference taps and compositor on the HIP kernels, the two 3 x 64 field nets through torch / rocBLAS).
 """
 from __future__ import annotations
 
@@ -209,12 +210,6 @@ class scene_representation(nn.Module):
                  num_frames=None, use_app=False, use_t=False, color_grid=True, use_joint=False, encode_topo=False,
                  encode_deform=True):
         super().__init__()
-        if use_app or encode_topo or not color_grid:
-            # these change what the kernels read PER POINT (an appearance code per sample in the colour net, an encoded topology
-            # vector, a frequency-encoded colour input); use_t / use_joint are covered: they only change per-frame constants or
-            # zero out first-layer columns (see _warp_bias0 / _field_operands)
-            raise NotImplementedError("fused HIP path: use_app=True, encode_topo=True and color_grid=False are not supported "
-                                      "(no shipped config uses them); use_t and use_joint (either value) are")
         if not encode_deform:
             raise NotImplementedError("encode_deform=False: the reference itself cannot run it (models/model.py:253,422 call the "
                                       "encoder that get_encodings returned as None)")
@@ -225,21 +220,32 @@ class scene_representation(nn.Module):
         self.num_layers, self.hidden_dim, self.geo_dim, self.num_frames = num_layers, hidden_dim, geo_dim, num_frames
         self.use_t, self.use_app, self.use_joint = use_t, use_app, use_joint
         self.encode_topo, self.encode_deform = encode_topo, encode_deform
-        self.in_dim_t, self.in_dim_amb = (13 if use_t else 0), amb_dim                   # model.py:98-103
+        self.color_grid = bool(color_grid)
+        # use_app / encode_topo / color_grid=False change what the field nets read PER POINT (an appearance code per sample behind
+        # the colour net's input, the 18-column encoding of the topology coordinates, a frequency-encoded colour input): the fused
+        # field kernels are cut for the shipped layout [enc(x) 39 | hash 32 | topo 2] -> [hash_c 32 | geo 32], so these switches --
+        # set by no shipped YAML -- take the COMPOSED field path (_sigma_albedo_composed): warp nets, hash grids, finite-difference
+        # taps and compositor on the HIP kernels, the two 3 x 64 field nets as rocBLAS products through torch
+        self.composed_field = bool(use_app or encode_topo or not color_grid)
+        self.in_dim_t = 13 if use_t else 0                                                # model.py:98-103
+        self.in_dim_amb = (amb_dim + 2 * 4 * amb_dim) if encode_topo else amb_dim        # :111-115 (multires 4)
         self.in_dim_deform, self.in_dim_xyz = 39, (39 if use_joint else 3)               # :114-119, :162-167
-        self.deform_dim, self.app_dim = 3 * deform_dim, 0
-        self.encoder_t = self.encoder_topo = self.app_code = None
+        self.deform_dim = 3 * deform_dim
+        self.app_dim = 3 * deform_dim if use_app else 0                                   # :132-136
+        self.encoder_t = self.encoder_topo = None
 
         self.pose_array = PoseArray(num_frames)
         self.deform_code = MultiCode([num_frames // 8, num_frames // 4, num_frames], deform_dim)
+        self.app_code = MultiCode([num_frames // 8, num_frames // 4, num_frames], deform_dim) if use_app else None
         self.deform_net = MLP(self.in_dim_t + self.in_dim_deform + self.deform_dim, 3, hidden_dim_t, num_layers_t)
         self.topo_net = MLP(self.in_dim_t + self.in_dim_deform + self.deform_dim, amb_dim, hidden_dim_tpo, num_layers_t)
         self.encoder = GridEncoder()
-        self.encoder_c = GridEncoder()
-        self.in_dim = self.in_dim_c = self.encoder.output_dim
+        self.encoder_c = GridEncoder() if color_grid else None                           # else frequency_torch(x), 39 columns (:151-157)
+        self.in_dim = self.encoder.output_dim
+        self.in_dim_c = self.encoder.output_dim if color_grid else 39
         self.sdf_net = MLP(self.in_dim + self.in_dim_amb + self.in_dim_xyz, 1 + geo_dim, hidden_dim, num_layers,
                            geo_init=True, geo_bias=0.4, weight_norm=False)
-        self.color_net = MLP(self.in_dim_c + geo_dim, 3, hidden_dim, num_layers)
+        self.color_net = MLP(self.in_dim_c + geo_dim + self.app_dim, 3, hidden_dim, num_layers)
         if self.config["model"]["bg_radius"] > 0:
             self.in_dim_bg, self.in_dim_bg_t = 39, 13
             self.bg_net = MLP(self.in_dim_bg + self.in_dim_bg_t, 3, hidden_dim_bg, num_layers_bg)
@@ -347,7 +353,7 @@ class scene_representation(nn.Module):
     # -- public API (names/signatures of the reference) ----------------------------------------
     def get_deform_code(self, t, app=False):
         if app:
-            raise NotImplementedError("use_app=False in every shipped config")
+            return self.app_code.sample(t)
         return self.deform_code.sample(t)
 
     def get_RT(self, frame_ids):
@@ -374,12 +380,19 @@ class scene_representation(nn.Module):
         return rays_o + t, (rays_d[..., None, :] * R).sum(-1)
 
     def warp(self, x, t, frame_slots=None):
-        """-> deform [M,3], topo [M,2], app_code (None)   (model.py:412-437).  `frame_slots`: see `_slots`."""
+        """-> deform [M,3], topo [M,2] (its 18-column encoding with encode_topo), app_code ([M,48] with use_app, else None)
+        (model.py:412-437).  `frame_slots`: see `_slots`."""
         tu, slot, identity = self._slots(t, frame_slots)
         opnd, code_w = self._warp_operands()
         bias0_d, bias0_t = self._warp_bias0(tu, code_w)                   # per-frame first-layer bias
         deform, topo = ops.warp_mlp(x, slot, bias0_d, bias0_t, self._n_bands(), opnd, slots_are_identity=identity)
-        return deform, topo, None
+        app_code = None
+        if self.use_app:                                                  # model.py:418-420: one code row per sample
+            rows = self.app_code.sample(tu[:, None])                      # [F,48], F = distinct frames / slots
+            app_code = rows.expand(x.shape[0], -1) if slot is None else rows[slot.long()]
+        if self.encode_topo:                                              # :434-435
+            topo = _freq_encode_torch(topo, 4, self.max_level)
+        return deform, topo, app_code
 
     def get_topo(self, x, t, frame_slots=None):
         return self.warp(x, t, frame_slots)[1]
@@ -387,16 +400,39 @@ class scene_representation(nn.Module):
     def get_sigma_albedo(self, x, topo=None, app_code=None, return_color=True, _group=1):
         """hash grid(s) -> sdf_net -> Laplace density (-> color_net)   (model.py:273-307), one autograd node
         (ops._FieldQuery).  _group: every `_group` consecutive points are neighbours (6 = finite-difference taps)."""
+        if self.composed_field:
+            return self._sigma_albedo_composed(x, topo, app_code, return_color, _group)
         opnd, beta = self._field_operands()
         sdf, sigma, albedo = ops.field_query(x, topo, beta, self.encoder.embeddings,
                                              self.encoder_c.embeddings if return_color else None, self.encoder._offsets_np,
                                              self.encoder._res_np, self.bound, self.max_level, _group, self._n_bands(), opnd)
         return sdf, sigma, (albedo if return_color else None)
 
+    def _sigma_albedo_composed(self, x, topo, app_code, return_color, group):
+        """get_sigma_albedo (model.py:273-307) for the switches the fused field kernels are not cut for: the same operator
+        chain -- hash grid(s) on the HIP kernels, sdf_net / color_net as torch products, the reference's Laplace density."""
+        enc = self.encoder(x, bound=self.bound, max_level=self.max_level, group=group)
+        if topo is None:
+            topo = x.new_zeros(x.shape[0], self.in_dim_amb)
+        xyz = _freq_encode_torch(x, 6, self.max_level) if self.use_joint else x
+        h = self.sdf_net(torch.cat([xyz, enc, topo], -1))
+        sdf = h[..., 0]
+        sigma = self.sdf2density(sdf)
+        if not return_color:
+            return sdf, sigma, None
+        if self.color_grid:
+            enc_c = self.encoder_c(x, bound=self.bound, max_level=self.max_level, group=group)
+        else:
+            enc_c = _freq_encode_torch(x, 6, self.max_level)
+        feat = [enc_c, h[..., 1:]]
+        if self.use_app:
+            feat.append(x.new_zeros(x.shape[0], self.app_dim) if app_code is None else app_code)
+        return sdf, sigma, torch.sigmoid(self.color_net(torch.cat(feat, -1)))
+
     def get_params_all(self, lr):
         groups = [
             {"name": "encoder_sdf", "params": self.encoder.parameters(), "lr": lr},
-            {"name": "encoder_color", "params": self.encoder_c.parameters(), "lr": lr},
+            {"name": "encoder_color", "params": self.encoder_c.parameters() if self.color_grid else [], "lr": lr},
             {"name": "decoder_sdf", "params": self.sdf_net.parameters(), "lr": lr},
             {"name": "decoder_topo", "params": self.topo_net.parameters(), "lr": lr},
             {"name": "decoder_color", "params": self.color_net.parameters(), "lr": lr},
@@ -407,6 +443,8 @@ class scene_representation(nn.Module):
         ]
         if self.config["model"]["bg_radius"] > 0:
             groups.append({"name": "decoder_bg", "params": self.bg_net.parameters(), "lr": lr})
+        if self.use_app:
+            groups.append({"name": "code_app", "params": self.app_code.parameters(), "lr": lr})
         return groups
 
     def _fd_normals(self, x, epsilon=2e-3, topo=None):
@@ -433,7 +471,7 @@ class scene_representation(nn.Module):
         return torch.sigmoid(self.bg_net(h))
 
     def density(self, x, t=None, cano=False, allow_shape=False, return_color=True):
-        topo = None
+        topo = app_code = None
         if not (cano or t is None):
             # a single time for all points travels as an expanded scalar: `_slots` sees one frame, no per-sample work
             if isinstance(t, float):
@@ -442,19 +480,19 @@ class scene_representation(nn.Module):
                 if not allow_shape:
                     raise Exception("Shape inconsistent!!!")
                 t = t.reshape(-1)[:1].view(1, 1).expand(x.shape[0], 1)
-            deform, topo, _ = self.warp(x, t)
+            deform, topo, app_code = self.warp(x, t)
             x = x + deform
-        sdf, sigma, albedo = self.get_sigma_albedo(x, topo=topo, return_color=return_color)
+        sdf, sigma, albedo = self.get_sigma_albedo(x, topo=topo, app_code=app_code, return_color=return_color)
         return {"sdf": sdf, "sigma": sigma, "albedo": albedo}
 
     def forward(self, x, t, light_dir=None, ratio=1, shading="albedo", cano=False, return_color=True, *,
                 frame_slots=None):
-        deform = topo = None
+        deform = topo = app_code = None
         xc = x
         if not cano:
-            deform, topo, _ = self.warp(x, t, frame_slots)
+            deform, topo, app_code = self.warp(x, t, frame_slots)
             xc = x + deform
-        sdf, sigma, albedo = self.get_sigma_albedo(xc, topo, None, return_color)
+        sdf, sigma, albedo = self.get_sigma_albedo(xc, topo, app_code, return_color)
         if shading == "albedo":
             return sdf, sigma, albedo, None, deform, None
         normal, raw = self.normal(x, topo=topo)        # un-warped x, warped point's topo (model.py:515-521)

@@ -133,11 +133,14 @@ def make_state(kind: str = "b", num_frames: int = 200, bg: bool = True) -> Dict[
     return sd
 
 
-def variant_state(kind: str = "b", num_frames: int = 200, use_t: bool = False, use_joint: bool = True) -> Dict[str, torch.Tensor]:
+def variant_state(kind: str = "b", num_frames: int = 200, use_t: bool = False, use_joint: bool = True, use_app: bool = False,
+                  encode_topo: bool = False, color_grid: bool = True) -> Dict[str, torch.Tensor]:
     """make_state() for the model switches that change first-layer shapes (models/model.py:36-53, :195-227):
-    use_t (13 time-encoding columns between the position encoding and the deform code of deform_net / topo_net) and
-    use_joint=False (raw x instead of its 39-column encoding in front of sdf_net).  Only the affected first layers get new
-    closed-form tensors."""
+    use_t (13 time-encoding columns between the position encoding and the deform code of deform_net / topo_net),
+    use_joint=False (raw x instead of its 39-column encoding in front of sdf_net), encode_topo (the 2 topology coordinates enter
+    sdf_net as their 18-column frequency encoding), use_app (a second MultiCode whose 48 columns follow the colour net's input) and
+    color_grid=False (the colour net reads the 39-column frequency encoding of x instead of a second hash table).  Only the
+    affected first layers (and the appearance code) get new closed-form tensors."""
     sd = make_state(kind, num_frames)
     st = [7300 if kind == "a" else 7600]
 
@@ -152,13 +155,30 @@ def variant_state(kind: str = "b", num_frames: int = 200, use_t: bool = False, u
             v = hash_tensor((128, din), nxt(), bound)
             sd[f"{prefix}.net.0.weight_v"] = v
             sd[f"{prefix}.net.0.weight_g"] = (v.norm(dim=1, keepdim=True) * (1.0 + hash_tensor((128, 1), nxt(), 0.2))).contiguous()
-    if not use_joint:
-        w0 = hash_tensor((64, 3 + 32 + 2), nxt(), math.sqrt(2) / math.sqrt(64) * 1.7)
+    n_xyz, n_amb = (39 if use_joint else 3), (18 if encode_topo else 2)
+    if (n_xyz, n_amb) != (39, 2):
+        st[0] += 10 * (n_amb == 18)          # the no-joint stream of earlier fixtures stays what it was
+        w0 = hash_tensor((64, n_xyz + 32 + n_amb), nxt(), math.sqrt(2) / math.sqrt(64) * 1.7)
         if kind == "a":
             w0[:, 3:] = 0.0
         else:
-            w0[:, 3:] *= 0.6
+            if n_xyz == 39:
+                w0[:, 3:39] *= 0.15
+            w0[:, n_xyz:] *= 0.6
         sd["sdf_net.net.0.weight"] = w0
+    n_c = (32 if color_grid else 39) + 32 + (48 if use_app else 0)
+    if n_c != 64:
+        st[0] = (7400 if kind == "a" else 7700) + n_c
+        bound = 1.0 / math.sqrt(n_c)
+        v = hash_tensor((64, n_c), nxt(), bound)
+        sd["color_net.net.0.weight_v"] = v
+        sd["color_net.net.0.weight_g"] = (v.norm(dim=1, keepdim=True) * (1.0 + hash_tensor((64, 1), nxt(), 0.2))).contiguous()
+    if use_app:
+        F = num_frames
+        for k, size in enumerate((F // 8, F // 4, F)):
+            sd[f"app_code.volumes.{k}"] = hash_tensor((1, 16, size, 1), nxt(), 1.0)
+    if not color_grid:
+        del sd["encoder_c.embeddings"], sd["encoder_c.offsets"]
     return sd
 
 

@@ -312,13 +312,19 @@ def gen_render():
 
 # ----------------------------------------------------------------------------- round-3 fixtures (variants.npz)
 VARIANTS = {"use_t": dict(use_t=True, use_joint=True), "no_joint": dict(use_t=False, use_joint=False),
-            "use_t_no_joint": dict(use_t=True, use_joint=False)}
+            "use_t_no_joint": dict(use_t=True, use_joint=False),
+            # round 4: the switches that change the field nets' per-point inputs (composed field path of morpheus_amd/model.py)
+            "use_app": dict(use_app=True), "encode_topo": dict(encode_topo=True), "no_color_grid": dict(color_grid=False),
+            "app_topo_freqcolor_no_joint": dict(use_app=True, encode_topo=True, color_grid=False, use_joint=False)}
+ROUND4_VARIANTS = ("use_app", "encode_topo", "no_color_grid", "app_topo_freqcolor_no_joint")
 
 
 def gen_variants():
     """The model switches no shipped YAML sets but the reference's constructor takes (models/model.py:36-53): use_t=True
-    (time encoding next to the deform code) and use_joint=False (raw x in front of sdf_net), through the reference's own
-    forward() / density() / warp() on 1024 probe points at two frame times, with gradient digests."""
+    (time encoding next to the deform code), use_joint=False (raw x in front of sdf_net), use_app=True (appearance code behind
+    the colour net's input), encode_topo=True (18-column topology encoding) and color_grid=False (frequency-encoded colour
+    input), through the reference's own forward() / density() / warp() / normal() on 1024 probe points at two frame times,
+    with gradient digests."""
     g = {}
     n = 1024
     x = probe_points(n, 360)
@@ -333,6 +339,10 @@ def gen_variants():
                 key = f"{tag}_{kind}_{ml_tag}"
                 g[key + "|sdf"], g[key + "|sigma"], g[key + "|color"], g[key + "|deform"] = npf(sdf), npf(sig), npf(col), npf(dfm)
                 g[key + "|topo"] = npf(m.warp(x, t)[1])
+                if tag in ROUND4_VARIANTS:       # + the finite-difference normals through the same field, and a canonical query
+                    g[key + "|normal_raw"] = npf(m.normal(x, t)[1])
+                    dc = m.density(x, cano=True)
+                    g[key + "|cano_sdf"], g[key + "|cano_albedo"] = npf(dc["sdf"]), npf(dc["albedo"])
                 if ml is None:
                     probe = (col ** 2).sum() + 0.01 * (sig ** 2).mean() + (sdf ** 2).sum() + (dfm ** 2).sum()
                     probe.backward()

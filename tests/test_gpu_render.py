@@ -1026,16 +1026,24 @@ def test_two_models_with_their_own_arithmetic_in_one_process():
         assert rel <= 1e-3, (k, rel)
 
 
-@pytest.mark.parametrize("tag", ["use_t", "no_joint", "use_t_no_joint"])
+@pytest.mark.parametrize("tag", ["use_t", "no_joint", "use_t_no_joint", "use_app", "encode_topo", "no_color_grid",
+                                 "app_topo_freqcolor_no_joint"])
 def test_model_switch_variants_vs_reference_goldens(tag):
     """The constructor switches of models/model.py:36-53 that no shipped YAML sets but a caller may: use_t=True (13 time-encoding
     columns between position encoding and deform code: folded into the per-frame first-layer bias) and use_joint=False (raw x in
-    front of sdf_net: the encoding's sin / cos columns get zero weights).  forward() / warp() on 1024 probe points at two frame
-    times against fixtures from the reference's own model built with the same switches (oracle/make_golden.py:gen_variants)."""
+    front of sdf_net: the encoding's sin / cos columns get zero weights) on the fused kernels; use_app=True, encode_topo=True and
+    color_grid=False (the field nets read other per-point inputs) on the composed field path.  forward() / warp() -- and for the
+    composed path normal() and a canonical density() -- on 1024 probe points at two frame times against fixtures from the
+    reference's own model built with the same switches (oracle/make_golden.py:gen_variants)."""
     from morpheus_amd import harness
     from morpheus_amd.model import scene_representation
     sw = {"use_t": dict(use_t=True, use_joint=True), "no_joint": dict(use_t=False, use_joint=False),
-          "use_t_no_joint": dict(use_t=True, use_joint=False)}[tag]
+          "use_t_no_joint": dict(use_t=True, use_joint=False), "use_app": dict(use_app=True), "encode_topo": dict(encode_topo=True),
+          "no_color_grid": dict(color_grid=False),
+          "app_topo_freqcolor_no_joint": dict(use_app=True, encode_topo=True, color_grid=False, use_joint=False)}[tag]
+    full = dict(use_t=False, use_joint=True, use_app=False, encode_topo=False, color_grid=True)
+    full.update(sw)
+    composed = full["use_app"] or full["encode_topo"] or not full["color_grid"]
     g = load_golden("variants.npz")
     n = 1024
     x = synth.hash_tensor((n, 3), 360, 1.15).to(DEV)
@@ -1043,11 +1051,11 @@ def test_model_switch_variants_vs_reference_goldens(tag):
     cfg = harness.load_config()
     for kind in ("a", "b"):
         for ml_tag, ml in (("full", None), ("half", 0.5)):
-            model = scene_representation(cfg, 1.01, num_frames=200, deform_dim=16, amb_dim=2, color_grid=True, encode_topo=False,
-                                         use_app=False, **sw)
+            model = scene_representation(cfg, 1.01, num_frames=200, deform_dim=16, amb_dim=2, **full)
             model.load_state_dict(synth.variant_state(kind, 200, **sw), strict=True)
             model.max_level = ml
             model = model.to(DEV).eval()
+            assert model.composed_field == composed
             model.zero_grad()
             sdf, sig, col, _, dfm, _ = model(x, t, None, ratio=1.0, shading="albedo", cano=False)
             key = f"{tag}_{kind}_{ml_tag}"
@@ -1056,7 +1064,76 @@ def test_model_switch_variants_vs_reference_goldens(tag):
             assert_close(col, g[key + "|color"], TOL, key + " color", floor=FLOOR)
             assert_close(dfm, g[key + "|deform"], TOL, key + " deform", floor=1e-3)
             assert_close(model.warp(x, t)[1], g[key + "|topo"], TOL, key + " topo", floor=1e-3)
+            if composed:
+                with torch.no_grad():
+                    assert_close(model.normal(x, t)[1], g[key + "|normal_raw"], 5e-3, key + " normal_raw (FD, x250 gain)", floor=5e-2)
+                    dc = model.density(x, cano=True)
+                assert_close(dc["sdf"], g[key + "|cano_sdf"], TOL, key + " canonical sdf", floor=FLOOR)
+                assert_close(dc["albedo"], g[key + "|cano_albedo"], TOL, key + " canonical albedo", floor=FLOOR)
             if ml is None:
                 ((col ** 2).sum() + 0.01 * (sig ** 2).mean() + (sdf ** 2).sum() + (dfm ** 2).sum()).backward()
                 n_ok = grad_digest_check({k: p.grad for k, p in model.named_parameters() if p.grad is not None}, g, key, 5e-3)
                 assert n_ok >= 10, n_ok
+
+
+def test_composed_field_path_equals_fused_path_through_a_training_render():
+    """The composed field path (use_app / encode_topo / color_grid=False: model._sigma_albedo_composed) inside render_rays'
+    training block -- FD normals, normal_smooth_3d, normal_smoothness, code_reg, pose optimisation.  A model with use_app=True
+    and encode_topo=True whose extra first-layer columns are ZERO computes the shipped model's function (same weights otherwise),
+    so its real-view training render, loss terms and gradients must equal the fused kernels' -- through rocBLAS instead of the
+    MFMA kernels -- and the appearance code gets an exactly-zero gradient."""
+    from morpheus_amd import harness, trainstep
+    from morpheus_amd.model import scene_representation
+    from tests.util import DrawInjector
+    hw, S, N = 16, 32, 96
+    o, d, t, rid = [v[:, :N] for v in synth.frame_rays(25, hw, hw)]
+    smp = of.uniform_samples(o[0], d[0], synth.ray_jitter(hw * hw)[:N], S, 1.01)
+    frame = trainstep.make_frames([25], hw, hw, DEV)[0]
+    data = trainstep.sample_real_view_rays(frame, N, torch.arange(N, device=DEV))
+    cfg = harness.load_config()
+    base = synth.make_state("b", 200)
+    out = {}
+    for tag in ("fused", "composed"):
+        if tag == "fused":
+            model = harness.build_model("b", DEV, 0.75)
+        else:
+            model = scene_representation(cfg, 1.01, num_frames=200, deform_dim=16, amb_dim=2, use_t=False, use_joint=True,
+                                         color_grid=True, use_app=True, encode_topo=True)
+            sd = synth.variant_state("b", 200, use_app=True, encode_topo=True)
+            w0 = torch.zeros(64, 39 + 32 + 18)
+            w0[:, :39 + 32 + 2] = base["sdf_net.net.0.weight"]                 # [enc(x) | hash | topo(2) | its 16 sin / cos: 0]
+            sd["sdf_net.net.0.weight"] = w0
+            v = torch.zeros(64, 64 + 48)
+            v[:, :64] = base["color_net.net.0.weight_v"]                       # [hash_c | geo | app code: 0]
+            sd["color_net.net.0.weight_v"], sd["color_net.net.0.weight_g"] = v, base["color_net.net.0.weight_g"]
+            model.load_state_dict(sd, strict=True)
+            model.max_level = 0.75
+            model = model.to(DEV)
+            assert model.composed_field
+        model.train()
+        rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+        with DrawInjector():
+            res = rend.render_rays(o.to(DEV), d.to(DEV), t.to(DEV), rid.to(DEV), N, 1, ambient_ratio=1.0,
+                                   light_d=of.safe_normalize(o[0] + 0.3).to(DEV), shading="albedo_normal", real_view=True,
+                                   cano=False, rays_depth=data["depth"].view(1, -1, 1), rays_mask=data["mask"].view(1, -1, 1),
+                                   optimize_pose=True)
+        terms = {k: res[k] for k in ("loss_code", "sdf_loss", "fs_loss", "loss_normal_perturb", "normal_reg")}
+        loss = (res["image"] ** 2).mean() + res["depth"].mean() + sum(terms.values())
+        model.zero_grad()
+        loss.backward()
+        out[tag] = (res, terms, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    (rf, tf, gf), (rc, tc, gc) = out["fused"], out["composed"]
+    assert_close(rc["image"], rf["image"], TOL, "image", floor=FLOOR)
+    assert_close(rc["depth"], rf["depth"], TOL, "depth", floor=DEPTH_FLOOR)
+    assert_close(rc["sdf"], rf["sdf"], TOL, "sdf", floor=FLOOR)
+    for k in tf:
+        assert_close(tc[k], tf[k], 2e-2 if "normal" in k else 1e-3, k)
+    assert float(gc["app_code.volumes.0"].abs().max()) == 0.0 and set(gf) <= set(gc)
+    for k in gf:
+        a, b = gc[k], gf[k]
+        if k == "sdf_net.net.0.weight":
+            a = a[:, :73]
+        if k == "color_net.net.0.weight_v":
+            a = a[:, :64]
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        assert rel <= 5e-3, (k, rel)          # FD-normal terms amplify the two arithmetic forms' round-off

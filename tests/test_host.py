@@ -100,10 +100,11 @@ def test_state_dict_and_param_groups_match_reference_layout():
     assert n_in_groups == sum(p.numel() for p in model.parameters())
     assert float(model.sdf2density.get_beta()) == pytest.approx(0.1001)
     assert model.encoder._res_np.tolist() == [16, 19, 22, 25, 28, 32, 37, 43, 49, 56, 64, 74, 85, 98, 112, 128]
-    # unsupported switches fail loudly instead of silently taking another path
+    # a switch the reference itself cannot run fails loudly instead of silently taking another path
     from morpheus_amd.model import scene_representation
     with pytest.raises(NotImplementedError):
-        scene_representation(model.config, 1.01, num_frames=200, use_app=True, use_joint=True)
+        scene_representation(model.config, 1.01, num_frames=200, encode_deform=False, use_joint=True)
+    assert not model.composed_field
 
 
 def _mfma_emulate(wpack, KS, MT, bin_lanes):
@@ -363,25 +364,31 @@ def test_fp16_slice_arithmetic_model():
 
 
 def test_model_switches_shapes_and_refusals():
-    """scene_representation's constructor switches (models/model.py:36-53): use_t and use_joint (either value) build the
-    reference's state_dict shapes (the fixtures' states load strictly); the switches whose per-point inputs the kernels do not
-    read, and the one the reference itself cannot run, are refused loudly."""
+    """scene_representation's constructor switches (models/model.py:36-53) build the reference's state_dict shapes (the fixtures'
+    states load strictly) and parameter groups; use_t / use_joint stay on the fused kernels, use_app / encode_topo /
+    color_grid=False select the composed field path; the one switch the reference itself cannot run is refused loudly."""
     import pytest
     from morpheus_amd import harness, synth
     from morpheus_amd.model import scene_representation
     cfg = harness.load_config()
-    base = dict(num_frames=200, deform_dim=16, amb_dim=2, color_grid=True, encode_topo=False, use_app=False)
-    for sw, d0, s0 in ((dict(use_t=True, use_joint=True), 100, 73), (dict(use_t=False, use_joint=False), 87, 37),
-                       (dict(use_t=True, use_joint=False), 100, 37)):
-        m = scene_representation(cfg, 1.01, **base, **sw)
+    base = dict(num_frames=200, deform_dim=16, amb_dim=2)
+    off = dict(use_t=False, use_joint=True, use_app=False, encode_topo=False, color_grid=True)
+    #        switches                                   deform in, sdf in, colour in, composed
+    cases = ((dict(use_t=True, use_joint=True), 100, 73, 64, False), (dict(use_t=False, use_joint=False), 87, 37, 64, False),
+             (dict(use_t=True, use_joint=False), 100, 37, 64, False), (dict(use_app=True), 87, 73, 112, True),
+             (dict(encode_topo=True), 87, 89, 64, True), (dict(color_grid=False), 87, 73, 71, True),
+             (dict(use_app=True, encode_topo=True, color_grid=False, use_joint=False), 87, 53, 119, True))
+    for sw, d0, s0, c0, composed in cases:
+        m = scene_representation(cfg, 1.01, **base, **dict(off, **sw))
         m.load_state_dict(synth.variant_state("b", 200, **sw), strict=True)
         assert tuple(m.deform_net.net[0].weight_v.shape) == (128, d0) and tuple(m.topo_net.net[0].weight_v.shape) == (128, d0)
-        assert tuple(m.sdf_net.net[0].weight.shape) == (64, s0)
-    for bad in (dict(use_app=True), dict(encode_topo=True), dict(color_grid=False), dict(encode_deform=False)):
-        kw = dict(base, use_t=False, use_joint=True)
-        kw.update(bad)
-        with pytest.raises(NotImplementedError):
-            scene_representation(cfg, 1.01, **kw)
+        assert tuple(m.sdf_net.net[0].weight.shape) == (64, s0) and tuple(m.color_net.net[0].weight_v.shape) == (64, c0)
+        assert m.composed_field == composed
+        names = [g["name"] for g in m.get_params_all(1e-3)]
+        assert ("code_app" in names) == bool(sw.get("use_app")) and names[-1] == ("code_app" if sw.get("use_app") else "decoder_bg")
+        assert sum(p.numel() for g in m.get_params_all(1.0) for p in g["params"]) == sum(p.numel() for p in m.parameters())
+    with pytest.raises(NotImplementedError):
+        scene_representation(cfg, 1.01, **base, **dict(off, encode_deform=False))
 
 
 def test_weighted_sum_is_the_chain_of_adds_on_any_device():
