@@ -340,6 +340,14 @@ int mh_field_bwd_fused(const float *xc, const float *sdf, const float *albedo, c
                        const float *g_albedo, const float *wpackT, const float *beta, int32_t n_bands, int32_t with_color,
                        const float *acts, float *dgeo_scratch, float *workspace, float *raw, int32_t accumulate, float *g_xc,
                        float *g_feat_s, float *g_feat_c, float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream);
+/* The same pass with exact fp32 products from three bf16 slices on the bf16 matrix pipe (see mh_warp_fwd_b3): w3T = the sliced
+ * TRANSPOSED pack of the six field layers (packing.py field_joint_packer().b3T_layers: TC2 | TC1 | TC0 | TS2 | TS1 | TS0,
+ * mh_field_w3T_bytes() bytes, cut by mh_b3_slice).  Same arguments otherwise, same outputs up to fp32 summation order. */
+int64_t mh_field_w3T_bytes(void);
+int mh_field_bwd_fused_b3(const float *xc, const float *sdf, const float *albedo, const float *g_sdf, const float *g_sigma,
+                          const float *g_albedo, const void *w3T, const float *beta, int32_t n_bands, int32_t with_color,
+                          const float *acts, float *dgeo_scratch, float *workspace, float *raw, int32_t accumulate, float *g_xc,
+                          float *g_feat_s, float *g_feat_c, float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream);
 /* ---- optimiser step over the flat parameter bucket (the step after the path) ---- */
 /* Replaces torch.optim.Adam(model.get_params_all(lr), betas=(0.9,0.99), eps=1e-15).step() of morpheus.py:154-155,
  * :1401-1424 (no weight decay, no amsgrad).  params/grads/exp_avg/exp_avg_sq: [n] fp32 device buffers, 16-byte aligned.

@@ -558,7 +558,7 @@ __device__ __forceinline__ void row_load_async(RowFrag &f, const float *__restri
 // waits for the rows loaded by row_load_async and passes their registers through an empty volatile asm, so that no
 // register-only use of them can be moved above the wait (see landed() further down)
 template <int N>
-__device__ __forceinline__ void fused_wait(RowFrag (&B)[N]) {
+__device__ __forceinline__ void fused_wait(RowFrag *__restrict__ B) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int n = 0; n < N; n++) asm volatile("" : "+v"(B[n].v[0]), "+v"(B[n].v[1]), "+v"(B[n].v[2]), "+v"(B[n].v[3]));
@@ -568,7 +568,7 @@ __device__ __forceinline__ void fused_wait(RowFrag (&B)[N]) {
 // dW[out tile][in tile n] += dPre rows (A, from the scratch) x H rows (B, from HBM) over the tile's 32 points;
 // bsum += row sums of dPre (the bias gradient)
 template <int NI>
-__device__ __forceinline__ void dw_mma(const RowFrag &a, const RowFrag (&b)[NI], f32x16 (&acc)[NI], float &bsum) {
+__device__ __forceinline__ void dw_mma(const RowFrag &a, const RowFrag *__restrict__ b, f32x16 (&acc)[NI], float &bsum) {
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -608,15 +608,136 @@ __device__ __forceinline__ const float *acc_add_lds(f32x16 (&a)[N], const float 
     return p + N * 1024;
 }
 
-#define FUSED_LAYER(KS, MT, w, bin, acc) mfma_layer_z<KS, MT>(w, bin, acc, lane)
-#define FUSED_DW(NI, A, B, acc, bsum) dw_mma<NI>(A, B, acc, bsum)
-// float4 sizes of the transposed fp32 fragment blocks in LDS (packing.py pads every block to 512)
-#define FUSED_TC2 512
-#define FUSED_TC1 1024
-#define FUSED_TC0 1024
-#define FUSED_TS2 1024
-#define FUSED_TS1 1024
-#define FUSED_TS0 1536
+// ---- the same two primitives with exact fp32 products on the bf16 matrix pipe (mlp_b3.hip's arithmetic) -------------------
+// weights: [plane hi|mid|lo][out tile][k16 step][lane][8 bf16] (packing.py: bwd3 blocks of the field packer); `bin` holds what
+// the fp32 chain carries per 2-wide k-step, so k16 step s takes bin[8s .. 8s+7]
+template <int KS, int MT>
+__device__ __forceinline__ void mfma_layer_z_b3(const f32x4 *__restrict__ w, const float (&bin)[KS], f32x16 (&acc)[MT], int lane) {
+    static_assert(KS % 8 == 0, "k16 steps");
+    constexpr int S = KS / 8, PL = MT * S * 64;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        Frag bh, bm, bl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) split2(bin[8 * s + 2 * e2], bin[8 * s + 2 * e2 + 1], bh.u[e2], bm.u[e2], bl.u[e2]);
+        Frag ah[MT], am[MT], al[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            ah[t].f = w[0 * PL + (t * S + s) * 64 + lane];
+            am[t].f = w[1 * PL + (t * S + s) * 64 + lane];
+            al[t].f = w[2 * PL + (t * S + s) * 64 + lane];
+        }
+        // slice products in ascending magnitude, the MT accumulators in rotation (no back-to-back dependent MFMAs)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh.h, s == 0 ? zero : acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm.h, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl.h, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh.h, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm.h, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh.h, acc[t], 0, 0, 0);
+    }
+}
+
+// ONE k16 step `s` of a layer of S steps, accumulators = that step's products alone (every other step's B operand is zero)
+template <int S, int MT>
+__device__ __forceinline__ void mfma_kstep_z_b3(const f32x4 *__restrict__ w, int s, const float *__restrict__ bin8, f32x16 (&acc)[MT], int lane) {
+    constexpr int PL = MT * S * 64;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Frag bh, bm, bl;
+#pragma unroll
+    for (int e2 = 0; e2 < 4; e2++) split2(bin8[2 * e2], bin8[2 * e2 + 1], bh.u[e2], bm.u[e2], bl.u[e2]);
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        Frag ah, am, al;
+        ah.f = w[0 * PL + (t * S + s) * 64 + lane];
+        am.f = w[1 * PL + (t * S + s) * 64 + lane];
+        al.f = w[2 * PL + (t * S + s) * 64 + lane];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh.h, zero, 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bm.h, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl.h, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bh.h, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bm.h, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh.h, acc[t], 0, 0, 0);
+    }
+}
+
+// K = points: k16 step s, lane half g, element e <-> point 16 g + 8 s + e, i.e. v[2s], v[2s+1] of a RowFrag (both operands)
+struct RowSl {
+    Frag h[2], m[2], l[2];
+};
+__device__ __forceinline__ void row_slices(const RowFrag &f, RowSl &o) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++)
+            split2(f.v[2 * s + (e2 >> 1)][2 * (e2 & 1)], f.v[2 * s + (e2 >> 1)][2 * (e2 & 1) + 1], o.h[s].u[e2], o.m[s].u[e2], o.l[s].u[e2]);
+}
+// the B rows (a layer's parked input activations) are sliced ONCE per tile and layer by the caller and serve every out tile
+template <int NI>
+__device__ __forceinline__ void dw_mma_b3(const RowFrag &a, const RowSl *__restrict__ b, f32x16 (&acc)[NI], float &bsum) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) bsum += (a.v[j][0] + a.v[j][1]) + (a.v[j][2] + a.v[j][3]);
+    RowSl as;
+    row_slices(a, as);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.l[s].h, b[n].h[s].h, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.m[s].h, b[n].m[s].h, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h[s].h, b[n].l[s].h, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.m[s].h, b[n].h[s].h, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h[s].h, b[n].m[s].h, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h[s].h, b[n].h[s].h, acc[n], 0, 0, 0);
+    }
+}
+// arithmetic selector of the fused kernels (B3 is their template parameter): LAYER(KS, MT, w, bin, acc); SLICE(N, B, Bs) after the
+// parked rows landed; DW(NI, A, B, Bs, acc, bsum)
+#define FUSED_LAYER(KS, MT, w, bin, acc) do { if (B3) mfma_layer_z_b3<KS, MT>(w, bin, acc, lane); else mfma_layer_z<KS, MT>(w, bin, acc, lane); } while (0)
+#define FUSED_SLICE(N, B, Bs) do { if (B3) { _Pragma("unroll") for (int n_ = 0; n_ < N; n_++) row_slices(B[n_], Bs[n_]); } } while (0)
+#define FUSED_DW(NI, A, B, Bs, acc, bsum) do { if (B3) dw_mma_b3<NI>(A, Bs, acc, bsum); else dw_mma<NI>(A, B, acc, bsum); } while (0)
+// float4 sizes of the transposed blocks in LDS: fp32 fragments / bf16x3 slices (packing.py pads every block to whole 512s)
+#ifndef FUSED_EARLY_ROWS
+#define FUSED_EARLY_ROWS 0            // A/B: sliced form requests a layer's rows one phase ahead (measured slower: more spills)
+#endif
+#define FUSED_TC2(B3) ((B3) ? 1024 : 512)
+#define FUSED_TC1(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TC0(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TS2(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TS1(B3) ((B3) ? 1536 : 1024)
+#define FUSED_TS0(B3) ((B3) ? 2560 : 1536)
+
+#ifdef MH_PHASE_TRACE
+// phase trace for tools/phase_trace_field_bwd.py (never compiled into the product library): wave 0 of every 8th workgroup stamps
+// s_memtime at the phase boundaries of its THIRD tile in field_fused_sdf_kernel (16 slots), s_memrealtime in 30/31
+__device__ long long mh_fused_trace[64 * 32];
+#define FUSED_STAMP(slot)                                                                                   \
+    do {                                                                                                    \
+        if (trace_it == 2 && threadIdx.x == 0 && (blockIdx.x % 8 == 0) && (blockIdx.x / 8 < 64))            \
+            mh_fused_trace[(blockIdx.x / 8) * 32 + (slot)] = (long long)__builtin_amdgcn_s_memtime();       \
+    } while (0)
+#define FUSED_STAMP_REAL(slot)                                                                              \
+    do {                                                                                                    \
+        if (trace_it == 2 && threadIdx.x == 0 && (blockIdx.x % 8 == 0) && (blockIdx.x / 8 < 64))            \
+            mh_fused_trace[(blockIdx.x / 8) * 32 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+extern "C" int mh_fused_trace_read(long long *dst_host) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(mh_fused_trace), sizeof(long long) * 64 * 32) == hipSuccess ? 0 : 2;
+}
+#else
+#define FUSED_STAMP(slot) do { } while (0)
+#define FUSED_STAMP_REAL(slot) do { } while (0)
+#endif
 
 struct FusedPart {            // where this launch's per-wave partial sums go (float offsets into the workspace)
     int64_t dw[3];            // layer-major: [n_chunks][out_pad * in_pad]
@@ -625,13 +746,14 @@ struct FusedPart {            // where this launch's per-wave partial sums go (f
 };
 
 // ---- color_net: Q2 (3 rows) <- g_albedo, Q1, Q0; hands d(geo) to the sdf launch ------------------------------------
+template <bool B3>
 __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
     const float *__restrict__ albedo, const float *__restrict__ g_albedo, const float *__restrict__ wpackT,
     const float *__restrict__ acts, float *__restrict__ dgeo_scr, float *__restrict__ g_feat_c, float *__restrict__ ws,
     FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5, i = lane & 31;
-    constexpr int W_F4 = FUSED_TC2 + FUSED_TC1 + FUSED_TC0;
+    constexpr int W_F4 = FUSED_TC2(B3) + FUSED_TC1(B3) + FUSED_TC0(B3);
     stage_fused<W_F4>(wpackT, 0);     // TC2 | TC1 | TC0 (fp32 fragments, or their bf16x3 slices)
     float *scr = reinterpret_cast<float *>(lds_fused + W_F4) + wave * SCR_FLOATS;
     __syncthreads();
@@ -644,13 +766,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
     float b2 = 0.f, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
     uint32_t max_c = 0;
     const int chunk = blockIdx.x * (FUSED_THREADS / 64) + wave, n_chunks = gridDim.x * (FUSED_THREADS / 64);
+    // EARLY (bf16x3 form): a layer's raw rows are dead once they are sliced, so the NEXT layer's rows -- after the last layer the
+    // next tile's first -- are requested right there, a whole weight-gradient phase before the old place.  The sliced layers are
+    // short (48 MFMAs of 32 cycles against 64 of 64): requested at the layer's start, the rows arrived after its MFMAs had
+    // finished and the one wave of the SIMD sat in s_waitcnt.
+    constexpr bool EARLY = B3 && FUSED_EARLY_ROWS;
+    bool rows_ahead = false;          // this tile's c2 rows are already in flight
+    RowFrag B[2];
     for (int64_t tile_id = chunk; tile_id < n_tiles; tile_id += n_chunks) {
         const int64_t p = tile_id * TILE + pt;
         const bool live = p < M;
         const float *atile = acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE);
         const uint32_t *masks = reinterpret_cast<const uint32_t *>(atile + FIELD_HID_ROWS * TILE);
         const f32x4 *wt = lds_fused;
-        RowFrag B[2], A;
+        RowFrag A;
+        RowSl Bs[2];
         f32x16 acc[2];
         float dbin[32];
         // dQ2 = g_albedo * a * (1 - a)
@@ -666,40 +796,56 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         }
         const uint32_t mw3 = masks[3 * 64 + lane], mw2 = masks[2 * 64 + lane];
         // ---- layer c2: input C2 = rows 352..415
-        row_load_async(B[0], atile, 352 + i, h);
-        row_load_async(B[1], atile, 384 + i, h);
+        if (!EARLY || !rows_ahead) {
+            row_load_async(B[0], atile, 352 + i, h);
+            row_load_async(B[1], atile, 384 + i, h);
+        }
         scr_put<1>(scr, d2, pt, h);
         FUSED_LAYER(16, 2, wt, d2, acc);
-        wt += FUSED_TC2;
+        wt += FUSED_TC2(B3);
 #pragma unroll
         for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw3, j, acc[j >> 4][j & 15]);   // mask C2 -> dQ1
         scr_get(A, scr, i, h);
-        fused_wait(B);
-        FUSED_DW(2, A, B, w2, b2);
+        fused_wait<2>(B);
+        FUSED_SLICE(2, B, Bs);
+        if (EARLY) {
+            row_load_async(B[0], atile, 288 + i, h);
+            row_load_async(B[1], atile, 320 + i, h);
+        }
+        FUSED_DW(2, A, B, Bs, w2, b2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- layer c1: input C1 = rows 288..351
-        row_load_async(B[0], atile, 288 + i, h);
-        row_load_async(B[1], atile, 320 + i, h);
+        if (!EARLY) {
+            row_load_async(B[0], atile, 288 + i, h);
+            row_load_async(B[1], atile, 320 + i, h);
+        }
         scr_put<2>(scr, dbin, pt, h);
         FUSED_LAYER(32, 2, wt, dbin, acc);
-        wt += FUSED_TC1;
+        wt += FUSED_TC1(B3);
         {
             float q1[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) q1[j] = mask_bit(mw2, j, acc[j >> 4][j & 15]);   // mask C1 -> dQ0
-            fused_wait(B);
+            fused_wait<2>(B);
+            FUSED_SLICE(2, B, Bs);
+            if (EARLY) {
+                row_load_async(B[0], atile, 224 + i, h);
+                row_load_async(B[1], atile, 256 + i, h);
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
-                FUSED_DW(2, A, B, w1[mt], b1[mt]);
+                FUSED_DW(2, A, B, Bs, w1[mt], b1[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 32; j++) dbin[j] = q1[j];
         }
         // ---- layer c0: input [hash_c | geo] = rows 224..287
-        row_load_async(B[0], atile, 224 + i, h);
-        row_load_async(B[1], atile, 256 + i, h);
+        if (!EARLY) {
+            row_load_async(B[0], atile, 224 + i, h);
+            row_load_async(B[1], atile, 256 + i, h);
+        }
         scr_put<2>(scr, dbin, pt, h);
         FUSED_LAYER(32, 2, wt, dbin, acc);
         if (live) {
@@ -726,11 +872,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
                 o[q] = v;
             }
         }
-        fused_wait(B);
+        fused_wait<2>(B);
+        FUSED_SLICE(2, B, Bs);
+        if (EARLY) {
+            const int64_t nt = tile_id + n_chunks;
+            rows_ahead = nt < n_tiles;
+            if (rows_ahead) {
+                const float *ntile = acts + nt * (int64_t)(FIELD_ACT_ROWS * TILE);
+                row_load_async(B[0], ntile, 352 + i, h);
+                row_load_async(B[1], ntile, 384 + i, h);
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
             scr_get(A, scr, 32 * mt + i, h);
-            FUSED_DW(2, A, B, w0[mt], b0[mt]);
+            FUSED_DW(2, A, B, Bs, w0[mt], b0[mt]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -795,7 +951,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
 }
 
 // ---- sdf_net (+ Laplace density): P2 <- [d(geo) | g_sdf, g_sigma], P1, P0, d(inputs) ---------------------------------
-template <bool WITH_COLOR>
+template <bool WITH_COLOR, bool B3>
 __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     const float *__restrict__ xc, const float *__restrict__ sdf, const float *__restrict__ g_sdf,
     const float *__restrict__ g_sigma, const float *__restrict__ wpackT, const float *__restrict__ beta_p, int n_bands,
@@ -804,25 +960,37 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     FusedPart part, uint32_t *__restrict__ gmax, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5, i = lane & 31;
-    constexpr int W_F4 = FUSED_TS2 + FUSED_TS1 + FUSED_TS0;
+    constexpr int W_F4 = FUSED_TS2(B3) + FUSED_TS1(B3) + FUSED_TS0(B3);
     // TS2 | TS1 | TS0 behind the colour net's three blocks (fp32 fragments, or their bf16x3 slices)
-    stage_fused<W_F4>(wpackT + 4 * (FUSED_TC2 + FUSED_TC1 + FUSED_TC0), 0);
+    stage_fused<W_F4>(wpackT + 4 * (FUSED_TC2(B3) + FUSED_TC1(B3) + FUSED_TC0(B3)), 0);
     float *scr = reinterpret_cast<float *>(lds_fused + W_F4) + wave * SCR_FLOATS;
     __syncthreads();
-    constexpr int MT2 = WITH_COLOR ? 2 : 1;                // sdf-only pass: dP2 has ONE non-zero row (tile 1, row 0)
-    f32x16 w2[MT2][2], w1[2][2], w0[2][3];                 // 64 (32) + 64 + 96 = 224 (192) registers
+    // dP2 = [d geo (32 rows, tile 0; zero on the sdf-only pass) | d sdf (ONE row: tile 1, row 0)].  The sdf row's weight gradient
+    // dW2[sdf][in] = sum_pt g[pt] H2[in][pt] is 2 x 16 fused multiply-adds per lane on the rows the lane holds anyway (`wsdf`),
+    // not a 32 x 64 matrix tile of which one row is not zero: 32 accumulator registers and 32 (24) MFMAs per tile less
+    constexpr int MT2 = WITH_COLOR ? 1 : 0;
+    f32x16 w2[MT2 ? MT2 : 1][2], w1[2][2], w0[2][3];       // 32 (0) + 64 + 96 = 192 (160) registers
+    float wsdf[2] = {0.f, 0.f}, bsdf = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT2; mt++) acc_zero<2>(w2[mt]);
     acc_zero<2>(w1[0]);
     acc_zero<2>(w1[1]);
     acc_zero<3>(w0[0]);
     acc_zero<3>(w0[1]);
-    float b2[2] = {0.f, 0.f}, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
+    float b2[1] = {0.f}, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
     uint32_t max_s = 0;
     float gb_acc = 0.f;                                    // d(loss)/d(beta) of this lane's points (lanes h == 0 carry it)
     const float beta = *beta_p;
     const int chunk = blockIdx.x * (FUSED_THREADS / 64) + wave, n_chunks = gridDim.x * (FUSED_THREADS / 64);
+    constexpr bool EARLY = B3 && FUSED_EARLY_ROWS;   // see field_fused_color_kernel
+    RowFrag B[3];                     // a layer's parked input rows (requested one phase ahead when EARLY)
+    bool rows_ahead = false;          // EARLY: this tile's s2 rows are already in flight
+    int trace_it = -1;
+    (void)trace_it;
     for (int64_t tile_id = chunk; tile_id < n_tiles; tile_id += n_chunks) {
+        trace_it++;
+        FUSED_STAMP_REAL(30);
+        FUSED_STAMP(0);
         const int64_t p = tile_id * TILE + pt;
         const bool live = p < M;
         const int64_t pc = live ? p : M - 1;
@@ -867,13 +1035,18 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         d2[16] = gs;  // tile 1, row 0 (only h == 0 lanes carry a non-zero gs)
         // ---- layer s2: input S2 = rows 160..223
         {
-            RowFrag B[2];
-            row_load_async(B[0], atile, 160 + i, h);
-            row_load_async(B[1], atile, 192 + i, h);
+            RowSl Bs[2];
+            if (!EARLY || !rows_ahead) {
+                row_load_async(B[0], atile, 160 + i, h);
+                row_load_async(B[1], atile, 192 + i, h);
+            }
+            FUSED_STAMP(1);
             scr_put<2>(scr, d2, pt, h);
             if (WITH_COLOR) {
-                // (the bf16x3 form of the sdf-only pass runs the whole layer: 48 short MFMAs, d2 is zero but for g_sdf)
                 FUSED_LAYER(32, 2, wt, d2, acc);
+            } else if (B3) {
+                // d2 is zero but for g_sdf = d2[16]: the k16 step 2 of the layer's 4 (12 MFMAs instead of 48)
+                mfma_kstep_z_b3<4, 2>(wt, 2, &d2[16], acc, lane);
             } else {
                 // dH2 = W2[sdf,:]^T g_sdf is the single k-step 16 of the 32 (2 MFMAs instead of 64)
 #pragma unroll
@@ -883,49 +1056,85 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], gs, z, 0, 0, 0);
                 }
             }
-            wt += FUSED_TS2;
+            wt += FUSED_TS2(B3);
 #pragma unroll
             for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw1, j, acc[j >> 4][j & 15]);   // mask S2 -> dP1
-            fused_wait(B);
+            FUSED_STAMP(2);
+            fused_wait<2>(B);
+            FUSED_STAMP(3);
+            {   // the sdf row (scratch row 32: every lane reads the same 16 points of its half -- an LDS broadcast)
+                RowFrag G;
+                scr_get(G, scr, 32, h);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float g = G.v[j][q];
+                        wsdf[0] = fmaf(g, B[0].v[j][q], wsdf[0]);
+                        wsdf[1] = fmaf(g, B[1].v[j][q], wsdf[1]);
+                        bsdf += g;
+                    }
+            }
+            if (WITH_COLOR) FUSED_SLICE(2, B, Bs);
+            FUSED_STAMP(4);
+            if (EARLY) {
+                row_load_async(B[0], atile, 96 + i, h);
+                row_load_async(B[1], atile, 128 + i, h);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT2; mt++) {
-                scr_get(A, scr, 32 * (WITH_COLOR ? mt : 1) + i, h);
-                FUSED_DW(2, A, B, w2[mt], b2[WITH_COLOR ? mt : 1]);
+                scr_get(A, scr, 32 * mt + i, h);
+                FUSED_DW(2, A, B, Bs, w2[mt], b2[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            FUSED_STAMP(5);
         }
         // ---- layer s1: input S1 = rows 96..159
         {
-            RowFrag B[2];
-            row_load_async(B[0], atile, 96 + i, h);
-            row_load_async(B[1], atile, 128 + i, h);
+            RowSl Bs[2];
+            if (!EARLY) {
+                row_load_async(B[0], atile, 96 + i, h);
+                row_load_async(B[1], atile, 128 + i, h);
+            }
             scr_put<2>(scr, dbin, pt, h);
             FUSED_LAYER(32, 2, wt, dbin, acc);
-            wt += FUSED_TS1;
+            wt += FUSED_TS1(B3);
             float q0[32];
 #pragma unroll
             for (int j = 0; j < 32; j++) q0[j] = mask_bit(mw0, j, acc[j >> 4][j & 15]);     // mask S1 -> dP0
-            fused_wait(B);
+            FUSED_STAMP(6);
+            fused_wait<2>(B);
+            FUSED_STAMP(7);
+            FUSED_SLICE(2, B, Bs);
+            FUSED_STAMP(8);
+            if (EARLY) {
+                row_load_async(B[0], atile, 0 + i, h);
+                row_load_async(B[1], atile, 32 + i, h);
+                row_load_async(B[2], atile, 64 + i, h);
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
-                FUSED_DW(2, A, B, w1[mt], b1[mt]);
+                FUSED_DW(2, A, B, Bs, w1[mt], b1[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            FUSED_STAMP(9);
 #pragma unroll
             for (int j = 0; j < 32; j++) dbin[j] = q0[j];
         }
         // ---- layer s0: input [enc | hash | topo] = rows 0..95 (k-step order)
         {
-            RowFrag B[3];
-            row_load_async(B[0], atile, 0 + i, h);
-            row_load_async(B[1], atile, 32 + i, h);
-            row_load_async(B[2], atile, 64 + i, h);
+            RowSl Bs[3];
+            if (!EARLY) {
+                row_load_async(B[0], atile, 0 + i, h);
+                row_load_async(B[1], atile, 32 + i, h);
+                row_load_async(B[2], atile, 64 + i, h);
+            }
             scr_put<2>(scr, dbin, pt, h);
             // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
             f32x16 e[3];
-            if (g_xc) {
-                FUSED_LAYER(32, 3, wt, dbin, e);
+            if (g_xc || B3) {
+                FUSED_LAYER(32, 3, wt, dbin, e);       // (the bf16x3 planes of the three out tiles are not contiguous per tile)
             } else {
                 f32x16 e12[2];
                 mfma_layer_z<32, 2>(wt + 8 * 64, dbin, e12, lane);
@@ -933,13 +1142,27 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                 e[2] = e12[1];
             }
             // the weight gradient first (it frees the 48 registers of the activation rows), the sincos stage after it
-            fused_wait(B);
+            FUSED_STAMP(10);
+            fused_wait<3>(B);
+            FUSED_STAMP(11);
+            FUSED_SLICE(3, B, Bs);
+            FUSED_STAMP(12);
+            if (EARLY) {
+                const int64_t nt = tile_id + n_chunks;
+                rows_ahead = nt < n_tiles;
+                if (rows_ahead) {
+                    const float *ntile = acts + nt * (int64_t)(FIELD_ACT_ROWS * TILE);
+                    row_load_async(B[0], ntile, 160 + i, h);
+                    row_load_async(B[1], ntile, 192 + i, h);
+                }
+            }
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
-                FUSED_DW(3, A, B, w0[mt], b0[mt]);
+                FUSED_DW(3, A, B, Bs, w0[mt], b0[mt]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            FUSED_STAMP(13);
             float gx[3] = {0.f, 0.f, 0.f};
             if (g_xc) {
                 float dsc[18];
@@ -979,15 +1202,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                 }
             }
         }
+        FUSED_STAMP(14);
+        FUSED_STAMP_REAL(31);
     }
     if (gmax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
         if (lane == 0 && max_s) atomicMax(gmax + 0, max_s);
     }
+    b2[0] += __shfl_xor(b2[0], 32);
+    wsdf[0] += __shfl_xor(wsdf[0], 32);
+    wsdf[1] += __shfl_xor(wsdf[1], 32);
+    bsdf += __shfl_xor(bsdf, 32);
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
-        b2[mt] += __shfl_xor(b2[mt], 32);
         b1[mt] += __shfl_xor(b1[mt], 32);
         b0[mt] += __shfl_xor(b0[mt], 32);
     }
@@ -1003,11 +1231,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             q = acc_to_lds<2>(w1[1], q, lane);
             q = acc_to_lds<3>(w0[0], q, lane);
             q = acc_to_lds<3>(w0[1], q, lane);
+            q[0 * 64 + lane] = b2[0];
+            q[1 * 64 + lane] = bsdf;
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
-                q[(0 + mt) * 64 + lane] = b2[mt];
                 q[(2 + mt) * 64 + lane] = b1[mt];
                 q[(4 + mt) * 64 + lane] = b0[mt];
+                q[(7 + mt) * 64 + lane] = wsdf[mt];
             }
             q[6 * 64 + lane] = gb_acc;
         }
@@ -1020,11 +1250,13 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             q = acc_add_lds<2>(w1[1], q, lane);
             q = acc_add_lds<3>(w0[0], q, lane);
             q = acc_add_lds<3>(w0[1], q, lane);
+            b2[0] += q[0 * 64 + lane];
+            bsdf += q[1 * 64 + lane];
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
-                b2[mt] += q[(0 + mt) * 64 + lane];
                 b1[mt] += q[(2 + mt) * 64 + lane];
                 b0[mt] += q[(4 + mt) * 64 + lane];
+                wsdf[mt] += q[(7 + mt) * 64 + lane];
             }
             gb_acc += q[6 * 64 + lane];
         }
@@ -1040,19 +1272,22 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         dw_store<3>(ws + part.dw[0] + pchunk * 64 * 96, w0[mt], mt, 96, i, h);
         dw_store<2>(ws + part.dw[1] + pchunk * 64 * 64, w1[mt], mt, 64, i, h);
     }
-    if (WITH_COLOR) {
-#pragma unroll
-        for (int mt = 0; mt < MT2; mt++) dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, w2[mt], mt, 64, i, h);
-    } else {
+    {
         f32x16 z[2];
         acc_zero<2>(z);
-        dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, z, 0, 64, i, h);
-        dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, w2[0], 1, 64, i, h);
+        if (WITH_COLOR) dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, w2[0], 0, 64, i, h);
+        else dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, z, 0, 64, i, h);
+        if (h == 0) {                 // tile 1: row 0 = the sdf row (accumulator row r = 0 of the lanes h == 0), the other 31 are zero
+            z[0][0] = wsdf[0];
+            z[1][0] = wsdf[1];
+        }
+        dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, z, 1, 64, i, h);
     }
     if (h == 0) {
+        ws[part.db[2] + pchunk * 64 + i] = WITH_COLOR ? b2[0] : 0.f;
+        ws[part.db[2] + pchunk * 64 + 32 + i] = i == 0 ? bsdf : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
-            ws[part.db[2] + pchunk * 64 + 32 * mt + i] = b2[mt];
             ws[part.db[1] + pchunk * 64 + 32 * mt + i] = b1[mt];
             ws[part.db[0] + pchunk * 64 + 32 * mt + i] = b0[mt];
         }
@@ -2027,18 +2262,23 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
                                 const float *g_sigma, const float *g_albedo, const float *wpackT, const float *beta,
                                 int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
                                 float *workspace, float *raw, int32_t accumulate, float *g_xc, float *g_feat_s, float *g_feat_c,
-                                float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream) {
+                                float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream, bool b3) {
     if (M == 0) return MH_OK;
     if (M < 0 || !xc || !sdf || !wpackT || !acts || !workspace || !raw || n_bands < 0 || n_bands > 6 || !beta) return MH_ERR_ARG;
     if (with_color && (!albedo || !dgeo_scratch)) return MH_ERR_ARG;
     static MhOncePerDevice opted;
-    const size_t lds_c = (size_t)(FUSED_TC2 + FUSED_TC1 + FUSED_TC0) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
-    const size_t lds_s = (size_t)(FUSED_TS2 + FUSED_TS1 + FUSED_TS0) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
+    const size_t lds_c = (size_t)(FUSED_TC2(b3) + FUSED_TC1(b3) + FUSED_TC0(b3)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
+    const size_t lds_s = (size_t)(FUSED_TS2(b3) + FUSED_TS1(b3) + FUSED_TS0(b3)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float);
     const int dev = mh_device();
     if (opted.need(dev)) {
-        if (hipFuncSetAttribute((const void *)field_fused_color_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess ||
-            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess)
+        const int big_c = (int)((size_t)(FUSED_TC2(1) + FUSED_TC1(1) + FUSED_TC0(1)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float));
+        const int big_s = (int)((size_t)(FUSED_TS2(1) + FUSED_TS1(1) + FUSED_TS0(1)) * 16 + (size_t)(4 * SCR_FLOATS) * sizeof(float));
+        if (hipFuncSetAttribute((const void *)field_fused_color_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_c) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_color_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_c) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess ||
+            hipFuncSetAttribute((const void *)field_fused_sdf_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_s) != hipSuccess)
             return MH_ERR_LAUNCH;
         opted.mark(dev);
     }
@@ -2067,18 +2307,21 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
     ps.gb = off;                                    // [chunks] d(beta) partials behind the bias partials
     pc.gb = off;
     hipStream_t st = mh_stream(stream);
-#define FUSED_LAUNCH_SDF(WC, DGEO)                                                                                           \
-    hipLaunchKernelGGL((field_fused_sdf_kernel<WC>), dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf,      \
-                       g_sigma, wpackT, beta, (int)n_bands, acts, (const float *)(DGEO), g_xc, g_feat_s, g_topo,                 \
+#define FUSED_LAUNCH_COLOR(B3_)                                                                                             \
+    hipLaunchKernelGGL(field_fused_color_kernel<B3_>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT, \
+                       acts, dgeo_scratch, g_feat_c, workspace, pc, gmax_bits, M, n_tiles)
+#define FUSED_LAUNCH_SDF(WC, B3_, DGEO)                                                                                      \
+    hipLaunchKernelGGL((field_fused_sdf_kernel<WC, B3_>), dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_s, st, xc, sdf, g_sdf, \
+                       g_sigma, wpackT, beta, (int)n_bands, acts, (const float *)(DGEO), g_xc, g_feat_s, g_topo,             \
                        workspace, ps, gmax_bits, M, n_tiles)
     if (with_color) {
-        hipLaunchKernelGGL(field_fused_color_kernel, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT,
-                           acts, dgeo_scratch, g_feat_c, workspace, pc, gmax_bits, M, n_tiles);
+        if (b3) FUSED_LAUNCH_COLOR(true); else FUSED_LAUNCH_COLOR(false);
         MH_CHECK_LAUNCH();
-        FUSED_LAUNCH_SDF(true, dgeo_scratch);
+        if (b3) FUSED_LAUNCH_SDF(true, true, dgeo_scratch); else FUSED_LAUNCH_SDF(true, false, dgeo_scratch);
     } else {
-        FUSED_LAUNCH_SDF(false, nullptr);
+        if (b3) FUSED_LAUNCH_SDF(false, true, nullptr); else FUSED_LAUNCH_SDF(false, false, nullptr);
     }
+#undef FUSED_LAUNCH_COLOR
 #undef FUSED_LAUNCH_SDF
     MH_CHECK_LAUNCH();
     // reduce the per-workgroup partials into raw = [dW s0..c2 | db s0..c2] (mh_mlp_wgrad's output format).  On the sdf-only pass the
@@ -2119,7 +2362,22 @@ extern "C" int mh_field_bwd_fused(const float *xc, const float *sdf, const float
                                   float *workspace, float *raw, int32_t accumulate, float *g_xc, float *g_feat_s,
                                   float *g_feat_c, float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream) {
     return field_bwd_fused_impl(xc, sdf, albedo, g_sdf, g_sigma, g_albedo, wpackT, beta, n_bands, with_color, acts, dgeo_scratch,
-                                workspace, raw, accumulate, g_xc, g_feat_s, g_feat_c, g_topo, gmax_bits, M, stream);
+                                workspace, raw, accumulate, g_xc, g_feat_s, g_feat_c, g_topo, gmax_bits, M, stream, false);
+}
+
+// The same pass with exact fp32 products from three bf16 slices on the bf16 matrix pipe: w3T = the sliced TRANSPOSED pack of the
+// six field layers (packing.py field_joint_packer().b3T_layers: TC2 | TC1 | TC0 | TS2 | TS1 | TS0).  Same arguments otherwise.
+extern "C" int64_t mh_field_w3T_bytes(void) {
+    return (int64_t)(FUSED_TC2(1) + FUSED_TC1(1) + FUSED_TC0(1) + FUSED_TS2(1) + FUSED_TS1(1) + FUSED_TS0(1)) * 16;
+}
+extern "C" int mh_field_bwd_fused_b3(const float *xc, const float *sdf, const float *albedo, const float *g_sdf,
+                                     const float *g_sigma, const float *g_albedo, const void *w3T, const float *beta,
+                                     int32_t n_bands, int32_t with_color, const float *acts, float *dgeo_scratch,
+                                     float *workspace, float *raw, int32_t accumulate, float *g_xc, float *g_feat_s,
+                                     float *g_feat_c, float *g_topo, uint32_t *gmax_bits, int64_t M, void *stream) {
+    return field_bwd_fused_impl(xc, sdf, albedo, g_sdf, g_sigma, g_albedo, reinterpret_cast<const float *>(w3T), beta, n_bands,
+                                with_color, acts, dgeo_scratch, workspace, raw, accumulate, g_xc, g_feat_s, g_feat_c, g_topo,
+                                gmax_bits, M, stream, true);
 }
 
 extern "C" int mh_abi_version(void) { return MH_ABI_VERSION; }

@@ -1016,8 +1016,28 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     return sdf, sigma, albedo, acts
 
 
+# Arithmetic of the fused field backward in the b3 mode, per pass (measured on one box, profiles/r04_ab_field_bwd_b3.txt):
+#   * the sdf-only pass (the finite-difference taps: 4 of a real-view step's 6 field queries, 12 of every 13 points) runs on the
+#     bf16 pipe like every other MLP kernel of the mode (mh_field_bwd_fused_b3): 72 x 72 virtual-view step 2.31 -> 1.99 ms;
+#   * the colour + sdf pass stays on the native fp32 MFMA (mh_field_bwd_fused): its sliced form needs more live registers than the
+#     one wave per SIMD has beside its 192 weight-gradient accumulators, and the spills cost what the shorter MFMAs save
+#     (cfg3 2.13 vs 2.15 ms).
+# MORPHEUS_FIELD_BWD = "b3" forces the sliced form for both passes, "f32" the fp32 form (A/B; the f32 and h2 modes always use it).
+FIELD_BWD = os.environ.get("MORPHEUS_FIELD_BWD", "auto")
+if FIELD_BWD not in ("auto", "b3", "f32"):
+    raise ValueError(f"MORPHEUS_FIELD_BWD={FIELD_BWD!r}: expected 'auto', 'b3' or 'f32'")
+
+
+def _field_wT(opnd, with_color: bool):
+    """-> (transposed weight operand of the fused field backward, is it the bf16x3 pack?)"""
+    sliced = FIELD_BWD == "b3" or (FIELD_BWD == "auto" and not with_color)
+    if sliced and opnd.mode == "b3" and opnd.wT3 is not None:
+        return opnd.wT3[0], True
+    return opnd.wT[0], False
+
+
 def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, has_fc,
-               need_dx, jp, raw_into=None, gmax=None):
+               need_dx, jp, raw_into=None, gmax=None, b3=False):
     """mh_field_bwd_fused: backward-data and weight gradients of the field nets in one pass per net (the pre-activation
     gradients stay on the chip).  raw_into: device ADDRESS of a running [raw_len + 1] sum this call adds its weight / bias /
     beta gradients to (the reduction launch adds instead of writing), or None -> a fresh tensor.  gmax: 2 zeroed int32 words.
@@ -1040,7 +1060,8 @@ def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
         raw = torch.empty(jp.raw_len + 1, device=dev) if M > 0 else torch.zeros(jp.raw_len + 1, device=dev)
     c = lambda t: None if t is None else t.contiguous()
     _e = TIMER.start()
-    check(lib.mh_field_bwd_fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT),
+    fused = lib.mh_field_bwd_fused_b3 if b3 else lib.mh_field_bwd_fused
+    check(fused(ptr(xc), ptr(sdf), ptr(albedo if with_color else None), ptr(c(g_sdf)), ptr(c(g_sigma)), ptr(c(g_albedo)), ptr(wT),
                                  ptr(beta_c), n_bands, int(with_color), ptr(acts), ptr(dgeo), ptr(ws),
                                  ptr(raw) if raw_into is None else ctypes.c_void_p(raw_into), int(raw_into is not None), ptr(g_xc),
                                  ptr(g_fs), ptr(g_fc), ptr(g_tp), ptr(gmax), M, stream()), "mh_field_bwd_fused")
@@ -1067,7 +1088,8 @@ class _FieldMLP(torch.autograd.Function):
         tp = None if topo is None else topo.detach().contiguous()
         beta_c = beta.detach().reshape(1).contiguous().float()
         sdf, sigma, albedo, acts = _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, any(ctx.needs_input_grad))
-        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo)
+        wT_sel, ctx.bwd_b3 = _field_wT(opnd, bool(with_color))
+        ctx.save_for_backward(xc, wT_sel, beta_c, acts, sdf, albedo)
         ctx.cfg = (n_bands, bool(with_color), topo is not None, feat_c is not None)
         ctx.jp = opnd.jp
         if albedo is None:
@@ -1081,7 +1103,8 @@ class _FieldMLP(torch.autograd.Function):
         xc, wT, beta_c, acts, sdf, albedo = ctx.saved_tensors
         n_bands, with_color, has_topo, has_fc = ctx.cfg
         g_xc, g_fs, g_fc, g_tp, raw, _ = _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
-                                                    n_bands, with_color, has_topo, has_fc, ctx.needs_input_grad[0], ctx.jp)
+                                                    n_bands, with_color, has_topo, has_fc, ctx.needs_input_grad[0], ctx.jp,
+                                                    b3=ctx.bwd_b3)
         n = ctx.jp.raw_len
         return (g_xc, g_fs, g_fc, g_tp, raw[n].reshape(()), raw[:n], None, None, None)
 
@@ -1113,7 +1136,8 @@ class _FieldQuery(torch.autograd.Function):
         beta_c = beta.detach().reshape(1).contiguous().float()
         sdf, sigma, albedo, acts = _field_fwd(lib, xc, feats[0], feats[1] if with_color else None, tp, beta_c, n_bands,
                                               with_color, opnd, any(ctx.needs_input_grad))
-        ctx.save_for_backward(xc, opnd.wT[0], beta_c, acts, sdf, albedo, *embs)
+        wT_sel, ctx.bwd_b3 = _field_wT(opnd, bool(with_color))
+        ctx.save_for_backward(xc, wT_sel, beta_c, acts, sdf, albedo, *embs)
         ctx.cfg = (n_bands, with_color, topo is not None, o_np, r_np, n_levels, float(bound), L)
         ctx.jp, ctx.acc = opnd.jp, opnd.acc
         ctx.ids = (id(beta), id(emb_s), id(emb_c))       # identities of the shared inputs (see _QueryAccumulator.joins)
@@ -1134,7 +1158,8 @@ class _FieldQuery(torch.autograd.Function):
                   and acc.enter())
         g_xc, g_fs, g_fc, g_tp, raw, gmax = _field_bwd(
             lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo, n_bands, with_color, has_topo, with_color, need_dx, ctx.jp,
-            raw_into=acc.raw.data_ptr() if joined and acc.raw is not None else None, gmax=acc.gmax_words(xc.device) if joined else None)
+            raw_into=acc.raw.data_ptr() if joined and acc.raw is not None else None, gmax=acc.gmax_words(xc.device) if joined else None,
+            b3=ctx.bwd_b3)
         o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
         grads = [g_fs] + ([g_fc] if with_color else [])
         gptrs = [gmax.data_ptr(), gmax.data_ptr() + 4][:len(grads)]

@@ -522,5 +522,5 @@ def warp_joint_packer() -> JointPacker:
 
 def field_joint_packer() -> JointPacker:
     if "field_joint" not in _PACKERS:
-        _PACKERS["field_joint"] = JointPacker([field_packer()], skip_first_bias=False, sliced_bwd=False)
+        _PACKERS["field_joint"] = JointPacker([field_packer()], skip_first_bias=False)
     return _PACKERS["field_joint"]

@@ -990,7 +990,7 @@ def test_field_queries_accumulate_gradients_in_place():
         finally:
             ops.ACCUMULATE_IN_PLACE = True
     (l1, g1), (l0, g0) = out[True], out[False]
-    assert l1 == l0 and set(g1) == set(g0)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0) and set(g1) == set(g0)     # (the forward's atomic loss sums may differ in the last bit)
     for k in g0:
         rel = float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30))
         assert rel <= 2e-5, (k, rel)                      # same terms, summed in another order
