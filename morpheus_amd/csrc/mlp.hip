@@ -438,14 +438,21 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
     wp += 1024;
     // sdf L2: 64 -> [geo(32) | sdf], no activation
     if (!with_color) {
-        // sdf-only pass (finite-difference taps): the geo tile feeds nothing -- evaluate the tile holding the sdf row only
-        f32x16 a1[1];
-        acc_bias<1>(a1, bias + 128 + 32, h);
-        mfma_layer_at<32, 1>(wp + 8 * 64, bin, a1, lane);
+        // sdf-only pass (finite-difference taps): the geo tile feeds nothing and of the other tile only row 0, the sdf, is wanted:
+        // a 64-term dot product per point -- 32 fused multiply-adds per lane on the k-steps it holds (row 0's A-fragment values sit
+        // in lane 32 h of tile 1: the same LDS address for every lane of a half) instead of 32 MFMAs of 64 cycles
+        float sv = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const f32x4 w4 = wp[(8 + q) * 64 + 32 * h];
+#pragma unroll
+            for (int j = 0; j < 4; j++) sv = fmaf(w4[j], bin[4 * q + j], sv);
+        }
+        sv += __shfl_xor(sv, 32);
+        sv += bias[128 + 32];
         if (h == 0 && live) {
-            const float s = a1[0][0];
-            sdf[p] = s;
-            if (sigma) sigma[p] = laplace_sigma(s, *beta_p);
+            sdf[p] = sv;
+            if (sigma) sigma[p] = laplace_sigma(sv, *beta_p);
         }
         continue;
     }

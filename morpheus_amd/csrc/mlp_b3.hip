@@ -595,6 +595,26 @@ __device__ __forceinline__ void fb3_epilogue(f32x16 (&acc)[2], float *__restrict
     if (mk) *mk = m;
 }
 
+// the same without the slices: the layer in front of a VALU-evaluated row (sdf-only pass)
+__device__ __forceinline__ void fb3_epilogue_plain(f32x16 (&acc)[2], float *__restrict__ ht, uint32_t *__restrict__ mk, int pt, int h) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int t = 1; t >= 0; t--) {
+#pragma unroll
+        for (int r = 15; r >= 0; r--) {
+            acc[t][r] = relu_i(acc[t][r]);
+            m = push_nz(m, acc[t][r]);
+        }
+    }
+    if (ht) {
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+    }
+    if (mk) *mk = m;
+}
+
 __global__ __launch_bounds__(FB3_THREADS, 2) void field_fwd_b3_kernel(
     const float *__restrict__ xc, const float *__restrict__ feat_s, const float *__restrict__ feat_c, const float *__restrict__ topo,
     const f32x4 *__restrict__ w3, const float *__restrict__ bias, const float *__restrict__ beta_p, int n_bands, int with_color,
@@ -607,6 +627,26 @@ __global__ __launch_bounds__(FB3_THREADS, 2) void field_fwd_b3_kernel(
         for (int i = threadIdx.x; i < n; i += FB3_THREADS) lds_b3[i] = w3[i];
     }
     __syncthreads();
+    // sdf-only pass: of the last layer's 33 outputs only the sdf row is wanted -- a 64-term dot product per point, 32 fused
+    // multiply-adds per lane on the activations it holds, instead of slicing them (176 instructions) for 24 dependent MFMAs.
+    // Its weights as fp32, once per block: hi + mid + lo of the slices IS the fp32 weight; [half h][k-step order] behind the sdf
+    // net's blocks (the colour blocks are not staged on this pass).  A-fragment lane 32 h of tile 1 holds row 0's steps.
+    float *wsdf = reinterpret_cast<float *>(lds_b3 + FB3_C0);
+    if (!with_color) {
+        if (threadIdx.x < 64) {
+            const int hh = threadIdx.x >> 5, kk = threadIdx.x & 31, s = kk >> 3, e = kk & 7;
+            float v[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                Frag f;
+                f.f = lds_b3[FB3_S2 + 4 * 64 + pl * 512 + s * 64 + 32 * hh];
+                const uint32_t w = f.u[e >> 1];
+                v[pl] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+            }
+            wsdf[hh * 32 + kk] = (v[0] + v[1]) + v[2];
+        }
+        __syncthreads();
+    }
     for (int64_t tile_id = (int64_t)blockIdx.x * (FB3_THREADS / 64) + wave; tile_id < n_tiles;
          tile_id += (int64_t)gridDim.x * (FB3_THREADS / 64)) {
         const int64_t p = tile_id * TILE + pt;
@@ -646,34 +686,26 @@ __global__ __launch_bounds__(FB3_THREADS, 2) void field_fwd_b3_kernel(
         // sdf L1: 64 -> 64
         acc_bias<2>(acc, bias + 64, h);
         b3_layer<4, 2>(lds_b3 + FB3_S1, bh, bm, bl, acc, lane);
-        fb3_epilogue(acc, tile ? tile + 160 * TILE : nullptr, mk ? mk + 1 * 64 : nullptr, pt, h, bh, bm, bl);
         // sdf L2: 64 -> [geo(32) | sdf], no activation
         if (!with_color) {
-            // sdf-only pass: the geo tile feeds nothing -- evaluate the tile holding the sdf row only (plane stride of the
-            // two-tile pack: 2 * 4 * 64)
-            f32x16 a1[1];
-            acc_bias<1>(a1, bias + 128 + 32, h);
-            const f32x4 *w = lds_b3 + FB3_S2 + 4 * 64;      // tile 1 of each plane
+            fb3_epilogue_plain(acc, tile ? tile + 160 * TILE : nullptr, mk ? mk + 1 * 64 : nullptr, pt, h);
+            const f32x4 *wv = reinterpret_cast<const f32x4 *>(wsdf + 32 * h);      // the same address in every lane of a half
+            float sv = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                Frag ah, am, al;
-                ah.f = w[0 * 512 + s * 64 + lane];
-                am.f = w[1 * 512 + s * 64 + lane];
-                al.f = w[2 * 512 + s * 64 + lane];
-                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh[s].h, a1[0], 0, 0, 0);
-                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bm[s].h, a1[0], 0, 0, 0);
-                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl[s].h, a1[0], 0, 0, 0);
-                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bh[s].h, a1[0], 0, 0, 0);
-                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bm[s].h, a1[0], 0, 0, 0);
-                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh[s].h, a1[0], 0, 0, 0);
+            for (int q = 0; q < 8; q++) {
+                const f32x4 w4 = wv[q];
+#pragma unroll
+                for (int c = 0; c < 4; c++) sv = fmaf(w4[c], acc[q >> 2][4 * (q & 3) + c], sv);
             }
+            sv += __shfl_xor(sv, 32);
+            sv += bias[128 + 32];
             if (h == 0 && live) {
-                const float sv = a1[0][0];
                 sdf[p] = sv;
                 if (sigma) sigma[p] = laplace_sigma_b3(sv, *beta_p);
             }
             continue;
         }
+        fb3_epilogue(acc, tile ? tile + 160 * TILE : nullptr, mk ? mk + 1 * 64 : nullptr, pt, h, bh, bm, bl);
         acc_bias<2>(acc, bias + 128, h);
         b3_layer<4, 2>(lds_b3 + FB3_S2, bh, bm, bl, acc, lane);
         if (h == 0 && live) {
