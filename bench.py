@@ -483,7 +483,9 @@ SYMBOLS = {
                            "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"],
                            "h2": ["wgrad_regs_h2_kernel<4>", "wgrad_regs_h2_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"]},
     "mh_field_fwd": {"f32": ["field_fwd_kernel"], "b3": ["field_fwd_b3_kernel"], "h2": ["field_fwd_h2_kernel"]},
-    "mh_field_bwd_fused": {m: ["field_fused_color_kernel", "field_fused_sdf_kernel<true>"] for m in ("f32", "b3", "h2")},
+    # (the colour + sdf pass -- the one cfg3 issues -- runs the fp32 form in every mode; the sdf-only pass of the b3 mode runs
+    # field_fused_sdf_kernel<false, true>, ops.FIELD_BWD)
+    "mh_field_bwd_fused": {m: ["field_fused_color_kernel<false>", "field_fused_sdf_kernel<true, false>"] for m in ("f32", "b3", "h2")},
 }
 # bytes per sample point.  "algorithmic" = what the operator must move if everything recomputable stayed on the chip (SURVEY 8d:
 # inputs in, results out); "parked" = what THIS design moves by construction (activations / pre-activation gradients parked

@@ -116,7 +116,8 @@ def main():
             open(os.path.join(PROF, f"{tag}_parity_report.jsonl"), "w").writelines(lines)
             print("parity", len(lines), "records")
     for log, name in (("phase_trace.log", "phase_trace_warp_fwd_fp32_mfma.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd_bf16x3.txt"),
-                      ("phase_trace_h2.log", "phase_trace_warp_fwd.txt"),
+                      ("phase_trace_h2.log", "phase_trace_warp_fwd.txt"), ("phase_trace_field_bwd.log", "phase_trace_field_bwd.txt"),
+                      ("census_fused.log", "launch_census_train_real.txt"), ("census_ref.log", "launch_census_train_real_reference_glue.txt"),
                       ("hbm_rates.log", "micro_hbm_rates.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
                       ("mfma_bf16_rate.log", "micro_mfma_bf16_rate.txt"), ("hbm_read.log", "micro_hbm_read.txt"),
                       ("parity_f64.jsonl", "parity_f64.jsonl"),

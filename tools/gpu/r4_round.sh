@@ -36,6 +36,10 @@ cd "$REPO"
 ( python tools/phase_trace_b3.py 2>&1 | tail -14; MH_TRACE_NOPARK=1 python tools/phase_trace_b3.py 2>&1 | tail -12 ) | grep -v amdgpu > gpurun_out/phase_trace_b3.log
 ( echo '--- two workgroups per CU (product configuration)'; python tools/phase_trace.py 2>&1 | grep -v amdgpu; echo '--- no activation parking'; MH_TRACE_NOPARK=1 python tools/phase_trace.py 2>&1 | grep -v amdgpu ) > gpurun_out/phase_trace.log
 ( python tools/phase_trace_h2.py 2>&1 | tail -12; MH_TRACE_NOPARK=1 python tools/phase_trace_h2.py 2>&1 | tail -12 ) | grep -v amdgpu > gpurun_out/phase_trace_h2.log
+MORPHEUS_HIP_LIB=$REPO/morpheus_amd/_build/libmorpheus_trace.so bash tools/gpu/trace_field_bwd.sh 2>&1 | grep -v "amdgpu\|^{" > gpurun_out/phase_trace_field_bwd.log
+# which torch launches are left in a real-view step (C-ABI kernels not counted), by the project line that issues them
+timeout 200 python tools/gpu/launch_census.py --top 60 2>&1 | grep -v "amdgpu\|Anomaly\|detect_anomaly" > gpurun_out/census_fused.log
+timeout 200 python tools/gpu/launch_census.py --glue reference --top 60 2>&1 | grep -v "amdgpu\|Anomaly\|detect_anomaly" > gpurun_out/census_ref.log
 ( cd tools/micro && ./mfma_power ) > gpurun_out/mfma_power.log 2>&1
 ( cd tools/micro && ./mfma_bf16_rate ) > gpurun_out/mfma_bf16_rate.log 2>&1
 ( cd tools/micro && ./hbm_read ) > gpurun_out/hbm_read.log 2>&1
