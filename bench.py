@@ -77,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--virtual-res", type=int, default=72,
                     help="train_virtual: side of the rendered novel view (datasets/dataset.py:538-541: novel_view_scale x 360 "
                          "= 72 at the start of training, 180 at novel_view_scale_final)")
-    ap.add_argument("--glue", default="fused", choices=["fused", "reference"],
+    ap.add_argument("--glue", default="fused", choices=["fused", "reference", "reference_scoped"],
                     help="train_real: caller-side loss code.  fused = this build's rewrite (one launch per loss group, one operand "
                          "scope per step); reference = the reference's own operator chains and a loss.item() per step around the "
                          "swapped-in render_rays -- what INTEGRATION.md's three edits alone give")
@@ -277,7 +277,7 @@ def build_train_real(args, rank, world, dev):
             opt.step()
             sample_log.append(ts.last_samples)
             return loss
-    elif args.glue == "reference":
+    elif args.glue in ("reference", "reference_scoped"):
         def step():
             bucket.zero()
             loss = ts()
@@ -303,7 +303,9 @@ def build_train_real(args, rank, world, dev):
             "occupancy refresh every 16 steps, Adam")
     desc += {"fused": "; caller-side losses: this build's fused glue (morpheus_amd/trainstep.py)",
              "reference": "; caller-side losses: the reference's own operator chains + loss.item() per step (INTEGRATION.md's three "
-                          "edits only)"}[args.glue]
+                          "edits only)",
+             "reference_scoped": "; caller-side losses: the reference's own operator chains + loss.item() per step, plus ONE line: "
+                                 "`with model.operand_scope():` around the step"}[args.glue]
     return dict(step=step, rays_per_step=args.rays, bucket=bucket, desc=desc + (", captured in a HIP graph" if graphed else ""),
                 samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ,
                 graphed=graphed, glue=args.glue)
@@ -912,8 +914,10 @@ def run_extras(mode):
     real = ["--workload", "train_real"]
     return {"train_real": {"eager_fused_glue": sub(real), "hip_graph_replay": sub(real + ["--graph"]),
                            "eager_reference_glue": sub(real + ["--glue", "reference"]),
+                           "eager_reference_glue_one_scope": sub(real + ["--glue", "reference_scoped"]),
                            "note": "rays/s of the reference's real-view training step, 2048 rays per step; `eager_reference_glue` "
-                                   "is the drop-in number (reference caller untouched), the other two need this build's caller"},
+                                   "is the drop-in number (reference caller untouched), `..._one_scope` adds one `with "
+                                   "model.operand_scope():` line around the step, the other two need this build's caller"},
             "train_virtual": {"res72": sub(["--workload", "train_virtual", "--virtual-res", "72"]),
                               "res180": sub(["--workload", "train_virtual", "--virtual-res", "180"]),
                               "note": "rays/s of the reference's virtual-view training step (render fwd + bwd + Adam under an "

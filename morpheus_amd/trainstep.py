@@ -265,8 +265,10 @@ class RealViewTrainStep:
     def __init__(self, renderer, frames, ray_num: int = 2048, n_epochs: int = 2000, end_iter: int = 220000, glue: str = "fused"):
         """glue: "fused" -- this build's caller-side losses (one launch per loss group, one operand scope around render + point
         loss: needs a changed caller); "reference" -- the reference's own operator chains around the swapped-in render_rays
-        (ReferenceGlue: what INTEGRATION.md's three edits alone give)."""
-        assert glue in ("fused", "reference")
+        (ReferenceGlue: what INTEGRATION.md's three edits alone give); "reference_scoped" -- the same with ONE more line in the
+        caller, `with model.operand_scope():` around the step, so that render_rays and the point loss's density() share one set of
+        prepared weight operands (without it each call outside render_rays prepares its own: weight norm, packs, slices)."""
+        assert glue in ("fused", "reference", "reference_scoped")
         self.glue = glue
         self.r, self.model, self.cfg = renderer, renderer.model, renderer.config
         self.frames, self.ray_num = frames, ray_num
@@ -290,6 +292,9 @@ class RealViewTrainStep:
         data = sample_real_view_rays(self.frames[fi], self.ray_num, pixel_index)
         if self.glue == "reference":          # the reference's train_step knows nothing of operand scopes
             return self._step_reference_glue(data, self.global_step)
+        if self.glue == "reference_scoped":
+            with self.model.operand_scope():
+                return self._step_reference_glue(data, self.global_step)
         with self.model.operand_scope():      # render_rays and the point loss share one set of prepared weight operands
             return self._step(data, self.global_step)
 

@@ -924,7 +924,7 @@ def test_reference_glue_equals_fused_glue():
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.render import HotPathRenderer
     out = {}
-    for glue in ("fused", "reference"):
+    for glue in ("fused", "reference", "reference_scoped"):
         model = harness.build_model("b", DEV).train()
         grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(DEV)
         rend = HotPathRenderer(model, model.config, grid, 200)
@@ -938,12 +938,14 @@ def test_reference_glue_equals_fused_glue():
         model.zero_grad()
         loss.backward()
         out[glue] = (float(loss), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
-    (lf, gf), (lr_, gr) = out["fused"], out["reference"]
-    assert abs(lf - lr_) <= 2e-5 * abs(lr_), (lf, lr_)
-    assert set(gf) == set(gr)
-    for k in gf:
-        rel = float((gf[k] - gr[k]).norm() / gr[k].norm().clamp_min(1e-30))
-        assert rel <= 2e-3, (k, rel)          # same terms, other summation orders; FD-normal terms amplify round-off
+    (lr_, gr) = out["reference"]
+    for other in ("fused", "reference_scoped"):      # (scoped: one `with model.operand_scope():` line around the reference's step)
+        lf, gf = out[other]
+        assert abs(lf - lr_) <= 2e-5 * abs(lr_), (other, lf, lr_)
+        assert set(gf) == set(gr)
+        for k in gf:
+            rel = float((gf[k] - gr[k]).norm() / gr[k].norm().clamp_min(1e-30))
+            assert rel <= 2e-3, (other, k, rel)          # same terms, other summation orders; FD-normal terms amplify round-off
 
 
 def test_field_queries_accumulate_gradients_in_place():
