@@ -60,4 +60,4 @@ for f in ["bench", "bench_cfg2", "bench_cfg3b", "bench_train_real", "bench_train
     except Exception as e:
         print(f, "FAILED", e); print(open(f"gpurun_out/{f}.log").read()[-1200:])
 PY
-grep -c . gpurun_out/parity.log gpurun_out/parity_f64.jsonl; ls gpurun_out/pmc_fetch*/*/ gpurun_out/pmc_lds*/*/ 2>/dev/null | head -20; tail -3 gpurun_out/pmc_lds.log gpurun_out/pmc_lds2.log
+grep -c . gpurun_out/parity.log gpurun_out/parity_f64.jsonl; ls gpurun_out/pmc_fetch*/*/ gpurun_out/pmc_lds*/*/ 2>/dev/null | head -20; tail -n 3 gpurun_out/pmc_lds.log; tail -n 3 gpurun_out/pmc_lds2.log
