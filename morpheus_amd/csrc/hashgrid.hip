@@ -379,6 +379,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ g
 // fast, 8.1 cycles, but its same-address rate is 40 vs 26 cycles and the kernel came out 25 % slower with it, even
 // without the max|grad| pre-pass it makes unnecessary: measured, not kept.)
 #define FX_BITS 40
+#define FX_MAGIC 6755399441055744.0                 // 1.5 * 2^52
+#define FX_MAGIC_BITS 0x4338000000000000ULL
 __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float &from_fx) {
     int e = (int)(maxbits >> 23) + 1;   // biased exponent of the power of two above max|grad|
     e = max(e, 60);                     // gradients below 2^-67 are accumulated with a fixed (coarser) scale
@@ -449,13 +451,19 @@ __global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float
             const uint32_t g1[3] = {min(g[0] + 1, res - 1), min(g[1] + 1, res - 1), min(g[2] + 1, res - 1)};
             const int lx0 = (int)g[0] - lo[0], ly0 = (int)g[1] - lo[1], lz0 = (int)g[2] - lo[2];
             const int lx1 = (int)g1[0] - lo[0], ly1 = (int)g1[1] - lo[1], lz1 = (int)g1[2] - lo[2];
+            // fixed point of w * g: a float -> int64 conversion is ~11 VALU instructions and there are 16 per (point, level) -- a
+            // quarter of the loop.  In double, w * (g 2^k) + 1.5 * 2^52 has the integer (|q| <= 2^40 < 2^51, round to nearest of
+            // the EXACT 48-bit product) in its low bits: q = bits - bits(1.5 * 2^52), one v_fma_f64 and one 32-bit add.
+            const double gxd = (double)(gr.x * to_fx), gyd = (double)(gr.y * to_fx);
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const float w = ((c & 1) ? f[0] : 1.f - f[0]) * ((c & 2) ? f[1] : 1.f - f[1]) * ((c & 4) ? f[2] : 1.f - f[2]);
                 const int li = ((c & 1) ? lx1 : lx0) + nn * (((c & 2) ? ly1 : ly0) + nn * ((c & 4) ? lz1 : lz0));
-                const float ws = w * to_fx;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[2 * (base + li)]), (unsigned long long)(long long)(ws * gr.x));
-                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[2 * (base + li) + 1]), (unsigned long long)(long long)(ws * gr.y));
+                const double wd = (double)w;
+                const unsigned long long qx = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gxd, FX_MAGIC)) - FX_MAGIC_BITS;
+                const unsigned long long qy = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gyd, FX_MAGIC)) - FX_MAGIC_BITS;
+                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[2 * (base + li)]), qx);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[2 * (base + li) + 1]), qy);
             }
             if (NEED_DX) {
                 float2 v[8];
