@@ -697,8 +697,10 @@ WARP_ACT_ROWS, WARP_DPRE_ROWS = 64 + 2 * 640 + 40, 2 * 672     # csrc/mlp.hip: a
 FIELD_ACT_ROWS = 96 + 64 * 5 + 8   # activations + 8 rows of ReLU masks
 
 
-# A/B and test switch: False = every field query returns its own gradient tensors and autograd adds them up (the round-3 form)
-ACCUMULATE_IN_PLACE = True
+# A/B and test switch: False = every field query returns its own gradient tensors and autograd adds them up (the round-3 form).
+# The in-place sums are keyed on autograd's graph-task id (torch >= 2.1); without it the per-query form is used.
+_GRAPH_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)
+ACCUMULATE_IN_PLACE = _GRAPH_TASK_ID is not None
 
 
 class _QueryAccumulator:
@@ -732,7 +734,7 @@ class _QueryAccumulator:
         self.gmax_used = 0
 
     def enter(self) -> bool:
-        task = torch._C._current_graph_task_id()
+        task = _GRAPH_TASK_ID()
         if task != self.task:
             self.reset()
             self.task = task
@@ -751,7 +753,7 @@ class _QueryAccumulator:
 
     def collect(self):
         """-> (raw or None, [table sums or None]) of the running backward pass; the accumulator is empty afterwards"""
-        if self.task != torch._C._current_graph_task_id():
+        if _GRAPH_TASK_ID is None or self.task != _GRAPH_TASK_ID():
             self.reset()
         out = (self.raw, self.tab)
         self.reset()

@@ -459,3 +459,43 @@ def test_virtual_view_step_host_logic():
     g(img).backward()
     assert torch.equal(img.grad, g.grad) and float(g.grad.abs().max()) <= 5e-3
     assert ops._warp_mode("f32") == "" and ops._warp_mode("b3") == "b3" and ops._warp_mode(None) == ops._warp_mode(ops.mlp_mode())
+
+
+def test_query_accumulator_joins_by_identity_and_resets_per_backward_pass():
+    """ops._QueryAccumulator (host logic only): a field query joins the in-place sums only when it was handed the very beta tensor
+    and table parameters the operands were prepared with (a colourless query: its one table); outside a backward pass nothing
+    accumulates; state left behind by one backward pass is dropped when the next one starts; the private autograd call it keys on
+    is looked up once and its absence switches the in-place form off."""
+    from morpheus_amd import ops
+    beta, other_beta = torch.tensor(0.1), torch.tensor(0.1)
+    ts, tc, tx = torch.zeros(4, 2), torch.zeros(4, 2), torch.zeros(4, 2)
+    acc = ops._QueryAccumulator(beta, (ts, tc))
+    assert acc.joins((id(beta), id(ts), id(tc))) and acc.joins((id(beta), id(ts), id(None)))
+    assert not acc.joins((id(other_beta), id(ts), id(tc))) and not acc.joins((id(beta), id(tx), id(tc)))
+    assert not acc.joins((id(beta), id(ts), id(tx))) and not ops._QueryAccumulator().joins((id(None), id(ts), id(tc)))
+    assert ops._GRAPH_TASK_ID is not None and ops.ACCUMULATE_IN_PLACE
+    assert acc.enter() is False                      # no backward pass running: nobody would collect the sums
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            assert acc.enter()
+            seen.append((acc.task, acc.raw))
+            acc.raw = torch.ones(3)                  # what a query would leave behind
+            w = acc.gmax_words("cpu")
+            assert w.numel() == 2 and int(w.abs().sum()) == 0
+            return g * 2
+
+    for _ in range(2):
+        x = torch.ones(2, requires_grad=True)
+        (Probe.apply(x).sum() + Probe.apply(x).sum()).backward()
+    (t0, r0), (t1, r1), (t2, r2), (t3, r3) = seen
+    assert t0 == t1 and t2 == t3 and t0 != t2        # two nodes of one pass share the state, the next pass starts empty
+    assert r0 is None and r1 is not None and r2 is None and r3 is not None
+    raw, tabs = acc.collect()                        # a different (here: no) pass: nothing stale is handed over
+    assert raw is None and tabs == [None, None]
