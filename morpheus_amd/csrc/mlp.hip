@@ -714,9 +714,6 @@ __device__ __forceinline__ void dw_mma_b3(const RowFrag &a, const RowSl *__restr
 #define FUSED_SLICE(N, B, Bs) do { if (B3) { _Pragma("unroll") for (int n_ = 0; n_ < N; n_++) row_slices(B[n_], Bs[n_]); } } while (0)
 #define FUSED_DW(NI, A, B, Bs, acc, bsum) do { if (B3) dw_mma_b3<NI>(A, Bs, acc, bsum); else dw_mma<NI>(A, B, acc, bsum); } while (0)
 // float4 sizes of the transposed blocks in LDS: fp32 fragments / bf16x3 slices (packing.py pads every block to whole 512s)
-#ifndef FUSED_EARLY_ROWS
-#define FUSED_EARLY_ROWS 0            // A/B: sliced form requests a layer's rows one phase ahead (measured slower: more spills)
-#endif
 #define FUSED_TC2(B3) ((B3) ? 1024 : 512)
 #define FUSED_TC1(B3) ((B3) ? 1536 : 1024)
 #define FUSED_TC0(B3) ((B3) ? 1536 : 1024)
@@ -773,12 +770,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
     float b2 = 0.f, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
     uint32_t max_c = 0;
     const int chunk = blockIdx.x * (FUSED_THREADS / 64) + wave, n_chunks = gridDim.x * (FUSED_THREADS / 64);
-    // EARLY (bf16x3 form): a layer's raw rows are dead once they are sliced, so the NEXT layer's rows -- after the last layer the
-    // next tile's first -- are requested right there, a whole weight-gradient phase before the old place.  The sliced layers are
-    // short (48 MFMAs of 32 cycles against 64 of 64): requested at the layer's start, the rows arrived after its MFMAs had
-    // finished and the one wave of the SIMD sat in s_waitcnt.
-    constexpr bool EARLY = B3 && FUSED_EARLY_ROWS;
-    bool rows_ahead = false;          // this tile's c2 rows are already in flight
     RowFrag B[2];
     for (int64_t tile_id = chunk; tile_id < n_tiles; tile_id += n_chunks) {
         const int64_t p = tile_id * TILE + pt;
@@ -803,10 +794,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         }
         const uint32_t mw3 = masks[3 * 64 + lane], mw2 = masks[2 * 64 + lane];
         // ---- layer c2: input C2 = rows 352..415
-        if (!EARLY || !rows_ahead) {
-            row_load_async(B[0], atile, 352 + i, h);
-            row_load_async(B[1], atile, 384 + i, h);
-        }
+        row_load_async(B[0], atile, 352 + i, h);
+        row_load_async(B[1], atile, 384 + i, h);
         scr_put<1>(scr, d2, pt, h);
         FUSED_LAYER(16, 2, wt, d2, acc);
         wt += FUSED_TC2(B3);
@@ -815,17 +804,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         scr_get(A, scr, i, h);
         fused_wait<2>(B);
         FUSED_SLICE(2, B, Bs);
-        if (EARLY) {
-            row_load_async(B[0], atile, 288 + i, h);
-            row_load_async(B[1], atile, 320 + i, h);
-        }
         FUSED_DW(2, A, B, Bs, w2, b2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- layer c1: input C1 = rows 288..351
-        if (!EARLY) {
-            row_load_async(B[0], atile, 288 + i, h);
-            row_load_async(B[1], atile, 320 + i, h);
-        }
+        row_load_async(B[0], atile, 288 + i, h);
+        row_load_async(B[1], atile, 320 + i, h);
         scr_put<2>(scr, dbin, pt, h);
         FUSED_LAYER(32, 2, wt, dbin, acc);
         wt += FUSED_TC1(B3);
@@ -835,10 +818,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
             for (int j = 0; j < 32; j++) q1[j] = mask_bit(mw2, j, acc[j >> 4][j & 15]);   // mask C1 -> dQ0
             fused_wait<2>(B);
             FUSED_SLICE(2, B, Bs);
-            if (EARLY) {
-                row_load_async(B[0], atile, 224 + i, h);
-                row_load_async(B[1], atile, 256 + i, h);
-            }
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
@@ -849,10 +828,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
             for (int j = 0; j < 32; j++) dbin[j] = q1[j];
         }
         // ---- layer c0: input [hash_c | geo] = rows 224..287
-        if (!EARLY) {
-            row_load_async(B[0], atile, 224 + i, h);
-            row_load_async(B[1], atile, 256 + i, h);
-        }
+        row_load_async(B[0], atile, 224 + i, h);
+        row_load_async(B[1], atile, 256 + i, h);
         scr_put<2>(scr, dbin, pt, h);
         FUSED_LAYER(32, 2, wt, dbin, acc);
         if (live) {
@@ -881,15 +858,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         }
         fused_wait<2>(B);
         FUSED_SLICE(2, B, Bs);
-        if (EARLY) {
-            const int64_t nt = tile_id + n_chunks;
-            rows_ahead = nt < n_tiles;
-            if (rows_ahead) {
-                const float *ntile = acts + nt * (int64_t)(FIELD_ACT_ROWS * TILE);
-                row_load_async(B[0], ntile, 352 + i, h);
-                row_load_async(B[1], ntile, 384 + i, h);
-            }
-        }
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
             scr_get(A, scr, 32 * mt + i, h);
@@ -989,9 +957,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     float gb_acc = 0.f;                                    // d(loss)/d(beta) of this lane's points (lanes h == 0 carry it)
     const float beta = *beta_p;
     const int chunk = blockIdx.x * (FUSED_THREADS / 64) + wave, n_chunks = gridDim.x * (FUSED_THREADS / 64);
-    constexpr bool EARLY = B3 && FUSED_EARLY_ROWS;   // see field_fused_color_kernel
-    RowFrag B[3];                     // a layer's parked input rows (requested one phase ahead when EARLY)
-    bool rows_ahead = false;          // EARLY: this tile's s2 rows are already in flight
+    RowFrag B[3];                     // a layer's parked input rows
     int trace_it = -1;
     (void)trace_it;
     for (int64_t tile_id = chunk; tile_id < n_tiles; tile_id += n_chunks) {
@@ -1043,10 +1009,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         // ---- layer s2: input S2 = rows 160..223
         {
             RowSl Bs[2];
-            if (!EARLY || !rows_ahead) {
-                row_load_async(B[0], atile, 160 + i, h);
-                row_load_async(B[1], atile, 192 + i, h);
-            }
+            row_load_async(B[0], atile, 160 + i, h);
+            row_load_async(B[1], atile, 192 + i, h);
             FUSED_STAMP(1);
             scr_put<2>(scr, d2, pt, h);
             if (WITH_COLOR) {
@@ -1084,10 +1048,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             }
             if (WITH_COLOR) FUSED_SLICE(2, B, Bs);
             FUSED_STAMP(4);
-            if (EARLY) {
-                row_load_async(B[0], atile, 96 + i, h);
-                row_load_async(B[1], atile, 128 + i, h);
-            }
 #pragma unroll
             for (int mt = 0; mt < MT2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
@@ -1099,10 +1059,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         // ---- layer s1: input S1 = rows 96..159
         {
             RowSl Bs[2];
-            if (!EARLY) {
-                row_load_async(B[0], atile, 96 + i, h);
-                row_load_async(B[1], atile, 128 + i, h);
-            }
+            row_load_async(B[0], atile, 96 + i, h);
+            row_load_async(B[1], atile, 128 + i, h);
             scr_put<2>(scr, dbin, pt, h);
             FUSED_LAYER(32, 2, wt, dbin, acc);
             wt += FUSED_TS1(B3);
@@ -1114,11 +1072,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             FUSED_STAMP(7);
             FUSED_SLICE(2, B, Bs);
             FUSED_STAMP(8);
-            if (EARLY) {
-                row_load_async(B[0], atile, 0 + i, h);
-                row_load_async(B[1], atile, 32 + i, h);
-                row_load_async(B[2], atile, 64 + i, h);
-            }
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
@@ -1132,11 +1085,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         // ---- layer s0: input [enc | hash | topo] = rows 0..95 (k-step order)
         {
             RowSl Bs[3];
-            if (!EARLY) {
-                row_load_async(B[0], atile, 0 + i, h);
-                row_load_async(B[1], atile, 32 + i, h);
-                row_load_async(B[2], atile, 64 + i, h);
-            }
+            row_load_async(B[0], atile, 0 + i, h);
+            row_load_async(B[1], atile, 32 + i, h);
+            row_load_async(B[2], atile, 64 + i, h);
             scr_put<2>(scr, dbin, pt, h);
             // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
             f32x16 e[3];
@@ -1154,15 +1105,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             FUSED_STAMP(11);
             FUSED_SLICE(3, B, Bs);
             FUSED_STAMP(12);
-            if (EARLY) {
-                const int64_t nt = tile_id + n_chunks;
-                rows_ahead = nt < n_tiles;
-                if (rows_ahead) {
-                    const float *ntile = acts + nt * (int64_t)(FIELD_ACT_ROWS * TILE);
-                    row_load_async(B[0], ntile, 160 + i, h);
-                    row_load_async(B[1], ntile, 192 + i, h);
-                }
-            }
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
                 scr_get(A, scr, 32 * mt + i, h);
