@@ -128,7 +128,8 @@ def _bin_points(lib, x, bound):
 #         weights, per point for activations / gradients, per tensor for the weight-gradient operands), three slice products
 #         per MAC (csrc/mlp_h2.hip).  The fastest and NOT fp32-faithful (operands are narrower than fp32's 24 bits): an
 #         opt-in mode; bench.py reports it beside the headline with its own dtype string.
-# The field nets' backward (mh_field_bwd_fused) runs on the native fp32 MFMA in every mode.
+# The field nets' fused backward: its colour + sdf pass runs on the native fp32 MFMA in every mode (mh_field_bwd_fused), its sdf-only
+# pass follows the b3 mode (mh_field_bwd_fused_b3); see FIELD_BWD below.
 MLP_MODES = ("b3", "f32", "h2")
 MODE_DTYPE = {"f32": "f32", "b3": "f32 (exact 3 x bf16 operand split, 6 slice products per MAC on the bf16 MFMA pipe, fp32 accumulate)",
               "h2": "f32-emulated (2 x fp16 slices, 22-bit block-scaled operands, 3 slice products per MAC, fp32 accumulate)"}
@@ -875,7 +876,7 @@ def prepare_field_operands(params: Sequence[torch.Tensor], mode: Optional[str] =
     beta (0-dim) and tables (the sdf and the colour hash table): when given, the field queries that are handed THESE tensors sum
     their beta / table / weight gradients in place and the pack hands the sums over once (_QueryAccumulator)."""
     jp = field_joint_packer()
-    mode = _warp_mode(mode)    # the field FORWARD follows the mode; the fused backward reads the fp32 transposed pack in every mode
+    mode = _warp_mode(mode)    # the field FORWARD follows the mode; the fused backward picks its pack per pass (_field_wT)
     if beta is None:
         return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), None, *params), mode=mode)
     if len(tables) != 2:
