@@ -485,9 +485,10 @@ SYMBOLS = {
                            "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"],
                            "h2": ["wgrad_regs_h2_kernel<4>", "wgrad_regs_h2_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"]},
     "mh_field_fwd": {"f32": ["field_fwd_kernel"], "b3": ["field_fwd_b3_kernel"], "h2": ["field_fwd_h2_kernel"]},
-    # (the colour + sdf pass -- the one cfg3 issues -- runs the fp32 form in every mode; the sdf-only pass of the b3 mode runs
-    # field_fused_sdf_kernel<false, true>, ops.FIELD_BWD)
-    "mh_field_bwd_fused": {m: ["field_fused_color_kernel<false>", "field_fused_sdf_kernel<true, false>"] for m in ("f32", "b3", "h2")},
+    # (the b3 mode runs the bf16x3 form of the fused kernels, the f32 and h2 modes the fp32-MFMA form; ops.FIELD_BWD)
+    "mh_field_bwd_fused": {"f32": ["field_fused_color_kernel<false>", "field_fused_sdf_kernel<true, false>"],
+                           "h2": ["field_fused_color_kernel<false>", "field_fused_sdf_kernel<true, false>"],
+                           "b3": ["field_fused_color_kernel<true>", "field_fused_sdf_kernel<true, true>"]},
 }
 # bytes per sample point.  "algorithmic" = what the operator must move if everything recomputable stayed on the chip (SURVEY 8d:
 # inputs in, results out); "parked" = what THIS design moves by construction (activations / pre-activation gradients parked
@@ -535,7 +536,8 @@ def _kernel_roofline(name, e, flops_per_call, mode, M, workload, full_size):
     PMC-measured traffic of the committed rocprofv3 passes."""
     secs = e["ms_per_step"] * 1e-3
     per_step_flops = flops_per_call * e["calls_per_step"]
-    fused_fp32 = name == "mh_field_bwd_fused"
+    from morpheus_amd import ops as _ops      # the fused field backward is sliced in the b3 mode only (and only unless switched off)
+    fused_fp32 = name == "mh_field_bwd_fused" and not (mode == "b3" and _ops.FIELD_BWD == "b3")
     kmode = "f32" if fused_fp32 else mode
     prod = PRODUCTS[kmode]
     pipe, unit_peak = PIPE[kmode]
@@ -544,7 +546,7 @@ def _kernel_roofline(name, e, flops_per_call, mode, M, workload, full_size):
     io = IO_BYTES[name]
     parked, algb = io["parked"] * M, io["algorithmic"] * M
     hbm_gbs = parked / secs / 1e9
-    traffic, src, complete = (pmc_step_bytes(SYMBOLS[name][kmode if not fused_fp32 else mode], mode)
+    traffic, src, complete = (pmc_step_bytes(SYMBOLS[name][mode], mode)
                               if (full_size and workload == "cfg3") else (None, None, False))
     return dict(kernel=name, launches_per_step=e["calls_per_step"], ms_per_step=e["ms_per_step"], mode=kmode,
                 bound="mfma", achieved=round(alg_tflops, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(alg_tflops / peak, 4),

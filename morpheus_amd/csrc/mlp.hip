@@ -747,6 +747,7 @@ struct FusedPart {            // where this launch's per-wave partial sums go (f
     int64_t dw[3];            // layer-major: [n_chunks][out_pad * in_pad]
     int64_t db[3];            // [n_chunks][out_pad]
     int64_t gb;               // sdf launch: [n_chunks] partial sums of d(loss)/d(beta)
+    int64_t dw_s2, db_s2;     // colour launch: where the sdf net's last layer keeps its partials (the geo rows' are computed here)
 };
 
 // ---- color_net: Q2 (3 rows) <- g_albedo, Q1, Q0; hands d(geo) to the sdf launch ------------------------------------
@@ -762,6 +763,11 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
     float *scr = reinterpret_cast<float *>(lds_fused + W_F4) + wave * SCR_FLOATS;
     __syncthreads();
     f32x16 w2[2], w1[2][2], w0[2][2];                      // dW of c2 [1 out tile][2 in], c1, c0 [2][2]: 160 registers
+    // + the geo rows of the SDF net's last layer, dW_s2[geo][:] = d(geo) H2^T: d(geo) is produced HERE (this kernel's last
+    // backward-data tile), and the sdf launch -- 160 accumulator registers of its own -- has no room for these 32 in its sliced form
+    f32x16 wg[2];
+    float bg = 0.f;
+    acc_zero<2>(wg);
     acc_zero<2>(w2);
     acc_zero<2>(w1[0]);
     acc_zero<2>(w1[1]);
@@ -858,18 +864,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         }
         fused_wait<2>(B);
         FUSED_SLICE(2, B, Bs);
+        RowFrag Bg[2];                                    // the sdf net's parked S2 rows (160..223): land under the c0 weight gradient
+        row_load_async(Bg[0], atile, 160 + i, h);
+        row_load_async(Bg[1], atile, 192 + i, h);
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
             scr_get(A, scr, 32 * mt + i, h);
             FUSED_DW(2, A, B, Bs, w0[mt], b0[mt]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        {   // dW_s2, geo rows: A = d(geo) rows through the scratch (free now), B = S2 rows
+            float dg[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) dg[r] = acc[1][r];
+            scr_put<1>(scr, dg, pt, h);
+            fused_wait<2>(Bg);
+            FUSED_SLICE(2, Bg, Bs);
+            scr_get(A, scr, i, h);
+            FUSED_DW(2, A, Bg, Bs, wg, bg);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (gmax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) max_c = max(max_c, (uint32_t)__shfl_xor((int)max_c, o));
         if (lane == 0 && max_c) atomicMax(gmax + 1, max_c);
     }
+    bg += __shfl_xor(bg, 32);
     b2 += __shfl_xor(b2, 32);
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
@@ -886,6 +907,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
             q = acc_to_lds<2>(w1[1], q, lane);
             q = acc_to_lds<2>(w0[0], q, lane);
             q = acc_to_lds<2>(w0[1], q, lane);
+            q = acc_to_lds<2>(wg, q, lane);
+            q[5 * 64 + lane] = bg;
             q[0 * 64 + lane] = b2;
             q[1 * 64 + lane] = b1[0];
             q[2 * 64 + lane] = b1[1];
@@ -899,6 +922,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
             q = acc_add_lds<2>(w1[1], q, lane);
             q = acc_add_lds<2>(w0[0], q, lane);
             q = acc_add_lds<2>(w0[1], q, lane);
+            q = acc_add_lds<2>(wg, q, lane);
+            bg += q[5 * 64 + lane];
             b2 += q[0 * 64 + lane];
             b1[0] += q[1 * 64 + lane];
             b1[1] += q[2 * 64 + lane];
@@ -915,8 +940,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         dw_store<2>(ws + part.dw[1] + pchunk * 64 * 64, w1[mt], mt, 64, i, h);
         dw_store<2>(ws + part.dw[0] + pchunk * 64 * 64, w0[mt], mt, 64, i, h);
     }
+    dw_store<2>(ws + part.dw_s2 + pchunk * 64 * 64, wg, 0, 64, i, h);      // out tile 0 (the geo rows) of the sdf net's last layer
     if (h == 0) {
         ws[part.db[2] + pchunk * 32 + i] = b2;
+        ws[part.db_s2 + pchunk * 64 + i] = bg;
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
             ws[part.db[1] + pchunk * 64 + 32 * mt + i] = b1[mt];
@@ -943,16 +970,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     // dP2 = [d geo (32 rows, tile 0; zero on the sdf-only pass) | d sdf (ONE row: tile 1, row 0)].  The sdf row's weight gradient
     // dW2[sdf][in] = sum_pt g[pt] H2[in][pt] is 2 x 16 fused multiply-adds per lane on the rows the lane holds anyway (`wsdf`),
     // not a 32 x 64 matrix tile of which one row is not zero: 32 accumulator registers and 32 (24) MFMAs per tile less
-    constexpr int MT2 = WITH_COLOR ? 1 : 0;
-    f32x16 w2[MT2 ? MT2 : 1][2], w1[2][2], w0[2][3];       // 32 (0) + 64 + 96 = 192 (160) registers
+    // (the geo rows' weight gradient is the colour launch's: it produces d(geo))
+    f32x16 w1[2][2], w0[2][3];                             // 64 + 96 = 160 registers
     float wsdf[2] = {0.f, 0.f}, bsdf = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT2; mt++) acc_zero<2>(w2[mt]);
     acc_zero<2>(w1[0]);
     acc_zero<2>(w1[1]);
     acc_zero<3>(w0[0]);
     acc_zero<3>(w0[1]);
-    float b2[1] = {0.f}, b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
+    float b1[2] = {0.f, 0.f}, b0[2] = {0.f, 0.f};
     uint32_t max_s = 0;
     float gb_acc = 0.f;                                    // d(loss)/d(beta) of this lane's points (lanes h == 0 carry it)
     const float beta = *beta_p;
@@ -1046,13 +1071,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
                         bsdf += g;
                     }
             }
-            if (WITH_COLOR) FUSED_SLICE(2, B, Bs);
             FUSED_STAMP(4);
-#pragma unroll
-            for (int mt = 0; mt < MT2; mt++) {
-                scr_get(A, scr, 32 * mt + i, h);
-                FUSED_DW(2, A, B, Bs, w2[mt], b2[mt]);
-            }
             __builtin_amdgcn_sched_barrier(0);
             FUSED_STAMP(5);
         }
@@ -1159,7 +1178,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         for (int o = 32; o > 0; o >>= 1) max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
         if (lane == 0 && max_s) atomicMax(gmax + 0, max_s);
     }
-    b2[0] += __shfl_xor(b2[0], 32);
     wsdf[0] += __shfl_xor(wsdf[0], 32);
     wsdf[1] += __shfl_xor(wsdf[1], 32);
     bsdf += __shfl_xor(bsdf, 32);
@@ -1174,13 +1192,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         __syncthreads();
         if (wave == src) {
             float *q = red;
-#pragma unroll
-            for (int mt = 0; mt < MT2; mt++) q = acc_to_lds<2>(w2[mt], q, lane);
             q = acc_to_lds<2>(w1[0], q, lane);
             q = acc_to_lds<2>(w1[1], q, lane);
             q = acc_to_lds<3>(w0[0], q, lane);
             q = acc_to_lds<3>(w0[1], q, lane);
-            q[0 * 64 + lane] = b2[0];
             q[1 * 64 + lane] = bsdf;
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
@@ -1193,13 +1208,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         __syncthreads();
         if (wave == 0) {
             const float *q = red;
-#pragma unroll
-            for (int mt = 0; mt < MT2; mt++) q = acc_add_lds<2>(w2[mt], q, lane);
             q = acc_add_lds<2>(w1[0], q, lane);
             q = acc_add_lds<2>(w1[1], q, lane);
             q = acc_add_lds<3>(w0[0], q, lane);
             q = acc_add_lds<3>(w0[1], q, lane);
-            b2[0] += q[0 * 64 + lane];
             bsdf += q[1 * 64 + lane];
 #pragma unroll
             for (int mt = 0; mt < 2; mt++) {
@@ -1224,8 +1236,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
     {
         f32x16 z[2];
         acc_zero<2>(z);
-        if (WITH_COLOR) dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, w2[0], 0, 64, i, h);
-        else dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, z, 0, 64, i, h);
+        if (!WITH_COLOR) dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, z, 0, 64, i, h);      // (with colour: the colour launch's)
         if (h == 0) {                 // tile 1: row 0 = the sdf row (accumulator row r = 0 of the lanes h == 0), the other 31 are zero
             z[0][0] = wsdf[0];
             z[1][0] = wsdf[1];
@@ -1233,7 +1244,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
         dw_store<2>(ws + part.dw[2] + pchunk * 64 * 64, z, 1, 64, i, h);
     }
     if (h == 0) {
-        ws[part.db[2] + pchunk * 64 + i] = WITH_COLOR ? b2[0] : 0.f;
+        if (!WITH_COLOR) ws[part.db[2] + pchunk * 64 + i] = 0.f;
         ws[part.db[2] + pchunk * 64 + 32 + i] = i == 0 ? bsdf : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; mt++) {
@@ -2255,6 +2266,8 @@ static int field_bwd_fused_impl(const float *xc, const float *sdf, const float *
     }
     ps.gb = off;                                    // [chunks] d(beta) partials behind the bias partials
     pc.gb = off;
+    ps.dw_s2 = pc.dw_s2 = dw_off[2];                // the sdf net's last layer: out tile 0 (geo rows) from the colour launch,
+    ps.db_s2 = pc.db_s2 = db_off[2];                // out tile 1 (the sdf row) from the sdf launch
     hipStream_t st = mh_stream(stream);
 #define FUSED_LAUNCH_COLOR(B3_)                                                                                             \
     hipLaunchKernelGGL(field_fused_color_kernel<B3_>, dim3((unsigned)blocks), dim3(FUSED_THREADS), lds_c, st, albedo, g_albedo, wpackT, \

@@ -128,8 +128,8 @@ def _bin_points(lib, x, bound):
 #         weights, per point for activations / gradients, per tensor for the weight-gradient operands), three slice products
 #         per MAC (csrc/mlp_h2.hip).  The fastest and NOT fp32-faithful (operands are narrower than fp32's 24 bits): an
 #         opt-in mode; bench.py reports it beside the headline with its own dtype string.
-# The field nets' fused backward: its colour + sdf pass runs on the native fp32 MFMA in every mode (mh_field_bwd_fused), its sdf-only
-# pass follows the b3 mode (mh_field_bwd_fused_b3); see FIELD_BWD below.
+# The field nets' fused backward follows the b3 mode too (mh_field_bwd_fused_b3); the f32 and h2 modes run it on the native fp32
+# MFMA (mh_field_bwd_fused); see FIELD_BWD below.
 MLP_MODES = ("b3", "f32", "h2")
 MODE_DTYPE = {"f32": "f32", "b3": "f32 (exact 3 x bf16 operand split, 6 slice products per MAC on the bf16 MFMA pipe, fp32 accumulate)",
               "h2": "f32-emulated (2 x fp16 slices, 22-bit block-scaled operands, 3 slice products per MAC, fp32 accumulate)"}
@@ -1019,21 +1019,21 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     return sdf, sigma, albedo, acts
 
 
-# Arithmetic of the fused field backward in the b3 mode, per pass (measured on one box, profiles/r04_ab_field_bwd_b3.txt):
-#   * the sdf-only pass (the finite-difference taps: 4 of a real-view step's 6 field queries, 12 of every 13 points) runs on the
-#     bf16 pipe like every other MLP kernel of the mode (mh_field_bwd_fused_b3): 72 x 72 virtual-view step 2.31 -> 1.99 ms;
-#   * the colour + sdf pass stays on the native fp32 MFMA (mh_field_bwd_fused): its sliced form needs more live registers than the
-#     one wave per SIMD has beside its 192 weight-gradient accumulators, and the spills cost what the shorter MFMAs save
-#     (cfg3 2.13 vs 2.15 ms).
-# MORPHEUS_FIELD_BWD = "b3" forces the sliced form for both passes, "f32" the fp32 form (A/B; the f32 and h2 modes always use it).
-FIELD_BWD = os.environ.get("MORPHEUS_FIELD_BWD", "auto")
-if FIELD_BWD not in ("auto", "b3", "f32"):
-    raise ValueError(f"MORPHEUS_FIELD_BWD={FIELD_BWD!r}: expected 'auto', 'b3' or 'f32'")
+# Arithmetic of the fused field backward in the b3 mode: the bf16 pipe like every other MLP kernel of the mode (mh_field_bwd_fused_b3),
+# both passes -- colour + sdf (cfg3's: 2.13 -> 1.78 ms) and sdf-only (the finite-difference taps, 12 of every 13 points of a
+# training step: virtual-view 72 x 72 2.56 -> 1.88 ms).  Same-box A/Bs: profiles/r04_ab_field_bwd_b3.txt.  The colour + sdf pass
+# only won once the weight gradient of the sdf net's geo rows had moved into the colour launch: before, the sliced sdf launch
+# spilled 91 registers beside its 192 accumulators and measured equal to the fp32 form.
+# MORPHEUS_FIELD_BWD = "f32" keeps the native fp32 MFMA form (mh_field_bwd_fused; what the f32 and h2 modes always use), "sdf" the
+# sliced form for the sdf-only pass alone (A/B).
+FIELD_BWD = os.environ.get("MORPHEUS_FIELD_BWD", "b3")
+if FIELD_BWD not in ("b3", "sdf", "f32"):
+    raise ValueError(f"MORPHEUS_FIELD_BWD={FIELD_BWD!r}: expected 'b3', 'sdf' or 'f32'")
 
 
 def _field_wT(opnd, with_color: bool):
     """-> (transposed weight operand of the fused field backward, is it the bf16x3 pack?)"""
-    sliced = FIELD_BWD == "b3" or (FIELD_BWD == "auto" and not with_color)
+    sliced = FIELD_BWD == "b3" or (FIELD_BWD == "sdf" and not with_color)
     if sliced and opnd.mode == "b3" and opnd.wT3 is not None:
         return opnd.wT3[0], True
     return opnd.wT[0], False
