@@ -779,8 +779,10 @@ def run_one(args):
                    "ranks_share_devices": bool(world > 1 and n_dev < world), "ranks": ranks,
                    "mlp_mode": mode,
                    "mlp_arithmetic": {"b3": "fp32 values everywhere; warp nets (forward, backward-data, weight gradients) and the field "
-                                            "forward: EXACT three-way bf16 split of both operands (all 24 significand bits), six slice "
-                                            "products per MAC on the bf16 matrix pipe, fp32 accumulate; field backward: native fp32 MFMA",
+                                            "nets (forward, fused backward): EXACT three-way bf16 split of both operands (all 24 "
+                                            "significand bits), six slice products per MAC on the bf16 matrix pipe, fp32 accumulate"
+                                            + ("" if ops.FIELD_BWD == "b3" else f"; field backward: MORPHEUS_FIELD_BWD={ops.FIELD_BWD} "
+                                               "(native fp32 MFMA for " + ("the colour + sdf pass" if ops.FIELD_BWD == "sdf" else "both passes") + ")"),
                                       "h2": "NOT fp32-faithful: warp nets and field forward on two fp16 slices per operand at power-of-two "
                                             "scales (22 significand bits, block-scaled per layer / per point / per tensor), three slice "
                                             "products per MAC on the fp16 matrix pipe, fp32 accumulate; 32-row layers' and small batches' "
