@@ -95,6 +95,9 @@ def parse_args(argv=None):
                          "timed in its own process and reported in `modes`, the top-level line is the faster fp32-faithful one "
                          "(b3 / f32); auto elsewhere = MORPHEUS_MLP or the library default (b3)")
     ap.add_argument("--modes", default="b3,f32,h2", help="the modes `--mode auto` times, in this order")
+    ap.add_argument("--detail-out", default=None,
+                    help="where the FULL result object goes (kernel tables, notes, per-mode lines, allocator statistics); default "
+                         "bench_detail.json beside this file.  stdout's LAST line is the compact object (< 6 KB) the driver parses")
     ap.add_argument("--graph", action="store_true",
                     help="capture one whole step (render fwd+bwd, all-reduce excluded, Adam) in a HIP graph and replay it; "
                          "disables the per-kernel event timers")
@@ -727,6 +730,17 @@ def run_one(args):
     n_dev = 0 if stub else torch.cuda.device_count()
     me = dict(rank=rank, device=str(dev), name=(torch.cuda.get_device_name(dev) if not stub else "cpu"), host_pid=os.getpid(),
               ms_per_step=round(own_ms, 3))       # per rank: a scaling run shows its stragglers
+    rccl_version = None
+    if not stub:
+        try:                                      # which physical device each rank ran on, and the RCCL the exchange went through
+            me["uuid"] = str(torch.cuda.get_device_properties(dev).uuid)[-12:]
+        except Exception:      # noqa: BLE001
+            me["uuid"] = None
+        if world > 1 and dist.get_backend() == "nccl":
+            try:
+                rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:      # noqa: BLE001
+                rccl_version = None
     ranks = [me]
     if world > 1:
         gathered = [None] * world
@@ -775,7 +789,9 @@ def run_one(args):
                                                   f" (rays/frames sharded, {bucket.nbytes / 1e6:.2f} MB of gradients all-reduced "
                                                   f"per step" + (", hash-table range early on a side stream" if world > 1 and
                                                                  not args.no_overlap else "") + ")"),
+                   "grad_bucket_MB": None if bucket is None else round(bucket.nbytes / 1e6, 2),
                    "world_size": world, "backend": backend, "devices_visible": n_dev,
+                   "rccl_version": rccl_version, "device_uuids": [r.get("uuid") for r in ranks] if world > 1 and not stub else None,
                    "ranks_share_devices": bool(world > 1 and n_dev < world), "ranks": ranks,
                    "mlp_mode": mode,
                    "mlp_arithmetic": {"b3": "fp32 values everywhere; warp nets (forward, backward-data, weight gradients) and the field "
@@ -826,6 +842,27 @@ def run_one(args):
 
 
 # ------------------------------------------------------------------------------------------------ all three arithmetic modes
+
+def _run_child(flags, mode, timeout):
+    """One bench.py child process (fresh allocator, timers and operand caches); returns (full result object or None, error text).
+    The child writes its FULL object to a temporary --detail-out file; its stdout carries the compact line only."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="morpheus_bench_", suffix=".json")
+    os.close(fd)
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(flags) + ["--detail-out", path]
+        run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env={**os.environ, "MORPHEUS_MLP": mode})
+        if run.returncode != 0 or os.path.getsize(path) == 0:
+            return None, (run.stderr or run.stdout)[-400:]
+        return json.load(open(path)), None
+    except Exception as e:      # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"[:400]
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
 FAITHFUL = ("b3", "f32")      # modes whose operands keep all 24 significand bits of the reference's fp32 (models/decoders.py:59-64)
 
 
@@ -833,20 +870,21 @@ def run_modes(args, argv):
     """N = 1, headline workloads, --mode auto: time every arithmetic mode in its OWN process (fresh allocator, timers and
     operand caches; the same isolation the CPU baseline gets) and report them side by side.  The top-level line is the
     faster of the fp32-faithful modes; h2 rides beside it under its own dtype string."""
-    base = [a for a in argv]
+    base, skip = [], False
+    for a in argv:                   # every child gets its own --detail-out
+        if skip:
+            skip = False
+        elif a == "--detail-out":
+            skip = True
+        elif not a.startswith("--detail-out="):
+            base.append(a)
     results, errors = {}, {}
     for m in args.modes.split(","):
-        cmd = [sys.executable, os.path.abspath(__file__)] + base + ["--mode", m, "--no-cpu-baseline"]
-        try:
-            run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
-                                 env={**os.environ, "MORPHEUS_MLP": m})
-            lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
-            if run.returncode != 0 or not lines:
-                errors[m] = (run.stderr or run.stdout)[-400:]
-                continue
-            results[m] = json.loads(lines[-1])
-        except Exception as e:      # noqa: BLE001
-            errors[m] = f"{type(e).__name__}: {e}"[:400]
+        r, err = _run_child(base + ["--mode", m, "--no-cpu-baseline"], m, 900)
+        if r is None:
+            errors[m] = err
+        else:
+            results[m] = r
     faithful = [m for m in FAITHFUL if m in results]
     if not faithful:
         raise SystemExit("bench.py: no fp32-faithful mode produced a result: " + json.dumps(errors))
@@ -864,20 +902,14 @@ def run_modes(args, argv):
         out["mode_errors"] = errors
     # the same step of the headline mode replayed from ONE captured HIP graph (launch gaps of the eager step removed), reported
     # beside the eager measurement, which stays the headline
-    try:
-        cmd = [sys.executable, os.path.abspath(__file__)] + base + ["--mode", best, "--graph", "--no-cpu-baseline", "--no-kernel-timers"]
-        run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env={**os.environ, "MORPHEUS_MLP": best})
-        lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
-        if run.returncode == 0 and lines:
-            r = json.loads(lines[-1])
-            out["hip_graph_replay"] = {"mode": best, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
-                                       "steps": r["steps"], "loss": r["config"]["loss"],
-                                       "note": "render + loss + backward + Adam captured once and replayed (memset nodes replaced by fill "
-                                               "kernels, csrc/graph.hip); the eager step above is the reported value"}
-        else:
-            out["hip_graph_replay"] = {"error": (run.stderr or run.stdout)[-300:]}
-    except Exception as e:      # noqa: BLE001
-        out["hip_graph_replay"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    r, err = _run_child(base + ["--mode", best, "--graph", "--no-cpu-baseline", "--no-kernel-timers"], best, 600)
+    if r is not None:
+        out["hip_graph_replay"] = {"mode": best, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                   "steps": r["steps"], "loss": r["config"]["loss"],
+                                   "note": "render + loss + backward + Adam captured once and replayed (memset nodes replaced by fill "
+                                           "kernels, csrc/graph.hip); the eager step above is the reported value"}
+    else:
+        out["hip_graph_replay"] = {"error": err}
     if args.workload == "cfg3" and not args.no_extras:
         out.update(run_extras(best))
     if not args.no_cpu_baseline:
@@ -897,23 +929,17 @@ def run_extras(mode):
       train_virtual  its virtual-view step (:1393-1408) at 72 x 72 and 180 x 180 rays, SDS replaced by an injected pred_rgb
                      gradient (the UNet is not part of the hot path and its weights are not available offline)."""
     def sub(flags, timeout=600):
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--mode", mode, "--no-kernel-timers", "--no-cpu-baseline"] + flags
-        try:
-            run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env={**os.environ, "MORPHEUS_MLP": mode})
-            lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
-            if run.returncode != 0 or not lines:
-                return {"error": (run.stderr or run.stdout)[-300:]}
-            r = json.loads(lines[-1])
-            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "iters_per_s", "train_steps_per_s") if k in r}
-            c = r["config"]
-            keep.update(workload=c["workload"], rays_per_gpu=c["rays_per_gpu"], sample_points_per_step=c["sample_points_per_step_per_gpu"],
-                        kernel_timers=c.get("kernel_timers"), loss_mean_of_timed_steps=c.get("loss_mean_of_timed_steps"))
-            for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction", "allocator_in_timed_region", "vram_pretouch_before_warmup"):
-                if k in c:
-                    keep[k] = c[k]
-            return keep
-        except Exception as e:      # noqa: BLE001 -- the extras never fail the headline
-            return {"error": f"{type(e).__name__}: {e}"[:300]}
+        r, err = _run_child(["--gpus", "1", "--mode", mode, "--no-kernel-timers", "--no-cpu-baseline"] + flags, mode, timeout)
+        if r is None:
+            return {"error": err}
+        keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "iters_per_s", "train_steps_per_s") if k in r}
+        c = r["config"]
+        keep.update(workload=c["workload"], rays_per_gpu=c["rays_per_gpu"], sample_points_per_step=c["sample_points_per_step_per_gpu"],
+                    kernel_timers=c.get("kernel_timers"), loss_mean_of_timed_steps=c.get("loss_mean_of_timed_steps"))
+        for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction", "allocator_in_timed_region", "vram_pretouch_before_warmup"):
+            if k in c:
+                keep[k] = c[k]
+        return keep
 
     real = ["--workload", "train_real"]
     return {"train_real": {"eager_fused_glue": sub(real), "hip_graph_replay": sub(real + ["--graph"]),
@@ -929,6 +955,91 @@ def run_extras(mode):
             "train_loop": {"res72": sub(["--workload", "train_loop", "--virtual-res", "72"]),
                            "note": "BASELINE configs[3] (teddy.yaml, end-to-end iterations per second) with the UNet replaced by its interface: "
                                    "iters_per_s of (1 virtual + 10 real) training steps"}}
+
+
+# ------------------------------------------------------------------------------------------------ the driver's line
+COMPACT_LIMIT = 6000          # bytes; the driver reads the LAST stdout line and keeps an 8 KB tail (round 4's 34 KB line came back unparsed)
+SHORT_DTYPE = {"b3": "f32 (exact 3 x bf16 operand split on the bf16 MFMA pipe, fp32 accumulate)",
+               "f32": "f32 (native fp32 MFMA)",
+               "h2": "f32-emulated (2 x fp16 block-scaled slices, 22 bits: NOT fp32-faithful)"}
+
+
+def _num(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(out, detail_path=None):
+    """The object bench.py prints as its LAST stdout line: the contract's keys, `roofline` and `cpu_baseline`, and ONE number per
+    extra.  Everything else (kernel tables, notes, per-mode lines, allocator statistics) is in the detail file."""
+    c = out.get("config", {})
+    mode = c.get("mlp_mode")
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "data")}
+    line["dtype"] = SHORT_DTYPE.get(mode, out.get("dtype"))
+    line["config"] = {"workload": str(c.get("workload", ""))[:160], "rays_per_gpu": c.get("rays_per_gpu"),
+                      "samples_per_ray": c.get("samples_per_ray"), "world_size": c.get("world_size"), "backend": c.get("backend"),
+                      "devices_visible": c.get("devices_visible"), "mlp_mode": mode,
+                      "parallelism": str(c.get("parallelism", "")).split(" (")[0],
+                      "grad_bucket_MB": c.get("grad_bucket_MB"), "kernel_timers": c.get("kernel_timers")}
+    for k in ("rccl_version", "device_uuids", "ranks_share_devices", "glue", "occupied_fraction"):
+        if c.get(k) not in (None, False):
+            line["config"][k] = c[k]
+    if c.get("ranks") and len(c["ranks"]) > 1:
+        line["config"]["rank_ms_per_step"] = [r.get("ms_per_step") for r in c["ranks"]]
+    ro = out.get("roofline")
+    if ro:
+        line["roofline"] = {k: ro.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_step",
+                                                   "algorithmic_bytes", "parked_bytes", "frac_of_sustained")}
+        line["roofline"]["per_kernel"] = {k: {"ms": v.get("ms_per_step"), "frac": v.get("frac")} for k, v in ro.get("per_kernel", {}).items()}
+        line["roofline"]["whole_step_tflops"] = _num(ro, "whole_step", "tflops")
+    else:
+        line["roofline"] = None
+    rh = out.get("roofline_hashgrid")
+    if rh:
+        line["roofline_hashgrid"] = {k: rh.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                            "hbm_measured_gbs", "bwd_achieved", "bwd_frac")}
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:120]}
+    if "speedup_vs_cpu_baseline" in out:
+        line["speedup_vs_cpu_baseline"] = out["speedup_vs_cpu_baseline"]
+    if "modes" in out:
+        line["headline_mode"] = out.get("headline_mode")
+        line["modes_ms_per_step"] = {m: r.get("ms_per_step") for m, r in out["modes"].items()}
+    if "mode_errors" in out:
+        line["mode_errors"] = {m: str(e)[-120:] for m, e in out["mode_errors"].items()}
+    if "hip_graph_replay" in out:
+        line["hip_graph_replay_ms"] = out["hip_graph_replay"].get("ms_per_step", "error")
+    tr = out.get("train_real")
+    if tr:
+        line["train_real_ms"] = {short: _num(tr, key, "ms_per_step") for short, key in
+                                 (("eager", "eager_fused_glue"), ("graph", "hip_graph_replay"), ("reference_glue", "eager_reference_glue"),
+                                  ("reference_scoped", "eager_reference_glue_one_scope"))}
+    tv = out.get("train_virtual")
+    if tv:
+        line["train_virtual_ms"] = {"72": _num(tv, "res72", "ms_per_step"), "180": _num(tv, "res180", "ms_per_step"),
+                                    "180_reserved_GB": _num(tv, "res180", "allocator_in_timed_region", "reserved_GB")}
+    tl = out.get("train_loop")
+    if tl:
+        line["train_loop_iters_per_s"] = _num(tl, "res72", "iters_per_s")
+    for k in ("iters_per_s", "train_steps_per_s", "kernel_sum_ms_per_step"):
+        if k in out:
+            line[k] = out[k]
+    if detail_path:
+        line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:      # never again: drop the optional parts rather than print an unparseable line
+        for k in ("roofline_hashgrid", "train_real_ms", "train_virtual_ms", "modes_ms_per_step", "mode_errors"):
+            line.pop(k, None)
+        if line.get("roofline"):
+            line["roofline"].pop("per_kernel", None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 8192, len(text)
+    return text
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -948,7 +1059,14 @@ def main(argv=None):
             if out["cpu_baseline"]["value"]:
                 out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        detail = args.detail_out or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail, "w") as f:
+                json.dump(out, f)
+        except OSError as e:           # a read-only checkout must not cost the line
+            print(f"bench.py: detail file not written ({e})", file=sys.stderr)
+            detail = None
+        print(compact_line(out, detail), flush=True)
 
 
 if __name__ == "__main__":

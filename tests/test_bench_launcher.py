@@ -18,7 +18,8 @@ def _run(args, extra_env=None):
                          text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    assert len(lines) == 1 and out.stdout.rstrip().splitlines()[-1] == lines[0], out.stdout
+    assert len(lines[0]) < 8192, len(lines[0])            # the driver keeps an 8 KB tail of stdout: the line must fit in it
     return json.loads(lines[0])
 
 
@@ -47,6 +48,35 @@ def test_world_size_mismatch_is_an_error():
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
 
 
+def test_driver_line_is_compact_and_complete(tmp_path):
+    """Round 4's line was 34 KB and came back from the driver unparsed.  The LAST stdout line is a compact object (< 6 KB) carrying
+    the contract's keys plus `roofline` and `cpu_baseline`; the full object goes to --detail-out.  Checked (a) end to end on the stub
+    and (b) by compacting the largest full object ever produced (round 4's committed one)."""
+    import bench
+    detail = tmp_path / "d.json"
+    r = _run(["--steps", "2", "--warmup", "1", "--rays", "32", "--detail-out", str(detail)])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    full = json.load(open(detail))
+    assert full["value"] == r["value"] and "kernels" in full and "kernels" not in r
+    big = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg3.json")))
+    line = bench.compact_line(big, os.path.join(ROOT, "bench_detail.json"))
+    assert len(line) < bench.COMPACT_LIMIT < 8192 and "\n" not in line
+    c = json.loads(line)
+    assert c["value"] == big["value"] and c["ms_per_step"] == big["ms_per_step"] and c["config"]["workload"].endswith("(cfg3)")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert c["roofline"][k] == big["roofline"][k], k
+    assert set(c["roofline"]["per_kernel"]) == set(big["roofline"]["per_kernel"])
+    assert c["cpu_baseline"]["value"] == big["cpu_baseline"]["value"] and c["cpu_baseline"]["cores"] == 32 and c["cpu_baseline"]["kind"] == "port"
+    assert c["train_real_ms"]["reference_glue"] > c["train_real_ms"]["graph"] > 0 and c["train_loop_iters_per_s"] > 0
+    assert set(c["modes_ms_per_step"]) == {"b3", "f32", "h2"}
+    # a pathological object (huge strings everywhere) still yields a parseable line under the tail size
+    big["config"]["workload"] = "x" * 5000
+    big["cpu_baseline"]["sample"] = "y" * 5000
+    assert len(bench.compact_line(big)) < bench.COMPACT_LIMIT
+
+
 def test_committed_bench_line_recomputes_from_committed_profiles():
     """The judged bench line (profiles/r0N_bench_cfg3.json, newest round) must be recomputable from what is committed next to it:
     per mode, `roofline` = the step's largest time item of that mode's kernel table, priced by bench.build_roofline per SURVEY
@@ -59,7 +89,8 @@ def test_committed_bench_line_recomputes_from_committed_profiles():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    path = next(p for p in (os.path.join(root, "profiles", f"{r}_bench_cfg3.json") for r in ("r04", "r03")) if os.path.exists(p))
+    path = next(p for p in (os.path.join(root, "profiles", n) for n in ("r05_bench_cfg3_detail.json", "r04_bench_cfg3.json",
+                                                                      "r03_bench_cfg3.json")) if os.path.exists(p))
     d = json.load(open(path))
     assert set(d["modes"]) == {"b3", "f32", "h2"} and d["headline_mode"] in ("b3", "f32")
     faithful = {m: d["modes"][m]["ms_per_step"] for m in ("b3", "f32")}

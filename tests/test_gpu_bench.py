@@ -12,11 +12,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(*flags):
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "train_real", "--steps", "6", "--warmup", "2",
-                          "--no-kernel-timers", *flags], cwd=ROOT, capture_output=True, text=True, timeout=600)
-    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
-    assert run.returncode == 0 and lines, (run.stderr or run.stdout)[-1500:]
-    return json.loads(lines[-1])
+    """(full object from --detail-out, the compact last stdout line)"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, "detail.json")
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "train_real", "--steps", "6", "--warmup", "2",
+                              "--no-kernel-timers", "--detail-out", detail, *flags], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        lines = run.stdout.rstrip().splitlines()
+        assert run.returncode == 0 and lines and lines[-1].startswith("{"), (run.stderr or run.stdout)[-1500:]
+        assert len(lines[-1]) < 8192
+        line = json.loads(lines[-1])
+        full = json.load(open(detail))
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    return full
 
 
 def test_replayed_training_step_of_the_bench():
