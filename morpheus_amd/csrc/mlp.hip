@@ -1572,7 +1572,7 @@ __device__ __forceinline__ void wgrad_regs_b3_body(const float *__restrict__ act
     do {                                                                                                            \
         if (REAL) { _Pragma("unroll") for (int j = 0; j < 4; j++) bsum += (raw[set].a[j][0] + raw[set].a[j][1]) + (raw[set].a[j][2] + raw[set].a[j][3]); } \
         wg_slice16(raw[set].a, as[par]);                                                                            \
-        if (mt < IT) {                                                                                              \
+        if (IT == 4 || mt < IT) {                                                                                              \
             WgSl bs_;                                                                                               \
             wg_slice16(raw[set].b, bs_);                                                                            \
             f32x4 *dst_ = lds_res + (par) * BUF_F4 + mt * 6 * 64 + lane;                                            \
@@ -1614,13 +1614,57 @@ __device__ __forceinline__ void wgrad_regs_b3_body(const float *__restrict__ act
         WG_SPLIT(((J) + 1) % NS, ((J) + 1) & 1, (k0 + (J) + 1 < n_my));                                             \
         __builtin_amdgcn_sched_barrier(0);                                                  \
     } while (0)
+    // The same step with nothing conditional in it (every tile of the trip is real, so MFMAs and the NEXT tile's slicing sit in one
+    // basic block) and the two streams INTERLEAVED by scheduling groups: one MFMA, then WG_FILL slicing instructions, 12 IT times.
+    // Round 5 (tools/micro/mfma_valu_gap.hip): up to 5-6 single-issue instructions ride free in the 32-cycle shadow of a bf16 MFMA
+    // *of the same wave*; the step used to run its 48 MFMAs and then its ~200 slicing instructions back to back and left the
+    // overlap to whatever the SIMD's other wave happened to be doing.
+#ifndef WG_FILL
+#define WG_FILL 4
+#endif
+#define WG_STEP_FAST(J)                                                                     \
+    do {                                                                                    \
+        __syncthreads();                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        WG_LD((J) % NS, k0 + (J) + NS);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        WG_MMA((J) & 1);                                                                    \
+        WG_SPLIT(((J) + 1) % NS, ((J) + 1) & 1, true);                                      \
+        if (WG_FILL > 0) {                                                                  \
+            _Pragma("unroll") for (int g_ = 0; g_ < 12 * IT; g_++) {                        \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x002, WG_FILL, 0);                    \
+            }                                                                               \
+        }                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
     if (n_my > 0) {
 #pragma unroll
         for (int q = 0; q < NS; q++) WG_LD(q, q);
         __builtin_amdgcn_sched_barrier(0);
         WG_SPLIT(0, 0, true);
         // the set index has period NS, the slice / B-buffer parity period 2: one loop trip = lcm(NS, 2) steps
-        for (int64_t k0 = 0; k0 < n_my; k0 += (NS % 2 ? 2 * NS : NS)) {
+        constexpr int TRIP = (NS % 2 ? 2 * NS : NS);
+        int64_t k0 = 0;
+        if (IT == 4) {           // (4 waves = 4 activation blocks: every wave publishes, `mt < IT` folds away)
+            for (; k0 + TRIP < n_my; k0 += TRIP) {      // every step's tile AND its successor are real
+                WG_STEP_FAST(0);
+                WG_STEP_FAST(1);
+                WG_STEP_FAST(2);
+                WG_STEP_FAST(3);
+                if (TRIP > 4) {
+                    WG_STEP_FAST(4);
+                    WG_STEP_FAST(5);
+                }
+                if (TRIP > 6) {
+                    WG_STEP_FAST(6);
+                    WG_STEP_FAST(7);
+                    WG_STEP_FAST(8);
+                    WG_STEP_FAST(9);
+                }
+            }
+        }
+        for (; k0 < n_my; k0 += TRIP) {
             WG_STEP(0);
             WG_STEP(1);
             WG_STEP(2);
@@ -1638,6 +1682,7 @@ __device__ __forceinline__ void wgrad_regs_b3_body(const float *__restrict__ act
         }
     }
 #undef WG_STEP
+#undef WG_STEP_FAST
 #undef WG_MMA
 #undef WG_SPLIT
 #undef WG_LD

@@ -39,20 +39,30 @@
 #define B3_LDS_BYTES (B3_LH_F4 * 16 + 1024)            // one layer's slices + the layer's bias row (forward)
 
 extern __shared__ f32x4 lds_b3[];
+#ifndef B3_Q4_FILL
+#define B3_Q4_FILL 6
+#endif
+#ifndef B3_KEEP_FWD
+#define B3_KEEP_FWD 33      // VMEM operations a wave issues between a layer's DMA and the wait for it (forward: 32 stores + mask words)
+#endif
+#ifndef B3_KEEP_BWD
+#define B3_KEEP_BWD 32
+#endif
 
 #ifdef MH_PHASE_TRACE
 // phase trace for tools/phase_trace_b3.py (never compiled into the product library): wave 0 of every 32nd workgroup stamps
 // s_memtime at the phase boundaries of warp_fwd_b3_kernel's hidden layers of net 0 (8 slots per layer), s_memrealtime in 62/63
 __device__ long long mh_b3_trace[256 * 64];
+// rows: workgroup blockIdx.x / 64 (every 64th), wave 0 -> even row, wave 4 -> odd row (waves w and w + 4 share SIMD w)
+#define B3_TRACE_ON (((threadIdx.x & 255) == 0) && (blockIdx.x % 64 == 0) && (blockIdx.x / 64 < 128))
+#define B3_TRACE_ROW ((blockIdx.x / 64) * 2 + (threadIdx.x >> 8))
 #define B3_STAMP(slot)                                                                          \
     do {                                                                                        \
-        if ((threadIdx.x == 0) && (blockIdx.x % 32 == 0) && (blockIdx.x / 32 < 256))            \
-            mh_b3_trace[(blockIdx.x / 32) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
+        if (B3_TRACE_ON) mh_b3_trace[B3_TRACE_ROW * 64 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
 #define B3_STAMP_REAL(slot)                                                                     \
     do {                                                                                        \
-        if ((threadIdx.x == 0) && (blockIdx.x % 32 == 0) && (blockIdx.x / 32 < 256))            \
-            mh_b3_trace[(blockIdx.x / 32) * 64 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if (B3_TRACE_ON) mh_b3_trace[B3_TRACE_ROW * 64 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); \
     } while (0)
 extern "C" int mh_b3_trace_read(long long *dst_host) {
     return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(mh_b3_trace), sizeof(long long) * 256 * 64) == hipSuccess ? 0 : 2;
@@ -94,6 +104,18 @@ __device__ __forceinline__ void b3_stage_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
+// The same wait when the wave has issued AT LEAST `YOUNGER` vector-memory operations (parking stores) after the DMA it waits for:
+// vmcnt counts in issue order, so "all but the YOUNGER most recent" covers the DMA and everything older without waiting for the
+// acknowledgement of stores issued a few hundred cycles ago (gfx9 has no separate store counter: vmcnt(0) waits for them too).
+// The caller fences the DMA issue with b3_dma_fence() so that no store can be scheduled ahead of it; anything the compiler adds
+// behind the fence (a spill) only makes the wait cover more.
+template <int YOUNGER>
+__device__ __forceinline__ void b3_stage_wait_keep() {
+    static_assert(YOUNGER >= 0 && YOUNGER <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+    __syncthreads();
+}
+__device__ __forceinline__ void b3_dma_fence() { asm volatile("" ::: "memory"); }
 
 // acc[t] += W[t] . b : six slice products per k16 step, two output tiles in rotation (consecutive MFMAs never chain on one
 // accumulator), small terms first
@@ -178,13 +200,14 @@ __device__ __forceinline__ void b3_quarter(const f32x4 *__restrict__ w, const Fr
 
 // layer epilogue: ReLU in place, park the tile feature-major FIRST (the stores then drain under the ~500 slicing instructions
 // instead of being waited for right after issue), then the sign mask and the next layer's B operand slices
+template <bool PARK>
 __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[4], float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
                                             Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = relu_i(acc[t][r]);
-    if (ht) {
+    if (PARK) {
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -204,7 +227,7 @@ __device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[4], float *__restrict_
                 split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2],
                        bl[2 * t + s2].u[e2]);
     }
-    if (mk) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+    if (PARK) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
 }
 
 // one k16 step of output tiles T0, T0+1 (12 MFMAs)
@@ -235,11 +258,12 @@ __device__ __forceinline__ void b3_quarter_step(const f32x4 *__restrict__ w, con
 }
 
 // registers 8 s2 .. 8 s2 + 7 of output tile t: ReLU in place, park, their 8 mask bits, the slices of k16 step 2t + s2
+template <bool PARK>
 __device__ __forceinline__ void b3_epilogue_eighth(f32x16 (&acc)[4], float *__restrict__ ht, uint32_t (&mt)[4], int pt, int h,
                                                    Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8], int t, int s2) {
 #pragma unroll
     for (int r = 8 * s2; r < 8 * s2 + 8; r++) acc[t][r] = relu_i(acc[t][r]);
-    if (ht) {
+    if (PARK) {
 #pragma unroll
         for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
     }
@@ -252,20 +276,22 @@ __device__ __forceinline__ void b3_epilogue_eighth(f32x16 (&acc)[4], float *__re
         split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
     // pin the slices HERE: they are only used after the layer's barrier, and hipcc otherwise sinks the ~50 slicing instructions
     // down to that use -- out of the MFMA stretch they are meant to fill
+#ifdef B3_Q4_CHUNKS
     Frag &fh = bh[2 * t + s2], &fm = bm[2 * t + s2], &fl = bl[2 * t + s2];
     asm volatile("" : "+v"(fh.u[0]), "+v"(fh.u[1]), "+v"(fh.u[2]), "+v"(fh.u[3]), "+v"(fm.u[0]), "+v"(fm.u[1]), "+v"(fm.u[2]),
                  "+v"(fm.u[3]), "+v"(fl.u[0]), "+v"(fl.u[1]), "+v"(fl.u[2]), "+v"(fl.u[3]), "+v"(mt[t]));
+#endif
 }
 
 // the epilogue of output tiles T0, T0+1 only: ReLU, park, sign-mask halves, slices of k16 steps 2 T0 .. 2 T0 + 3
-template <int T0>
+template <int T0, bool PARK>
 __device__ __forceinline__ void b3_epilogue_half(f32x16 (&acc)[4], float *__restrict__ ht, uint32_t (&mt)[4], int pt, int h,
                                                  Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
 #pragma unroll
     for (int t = T0; t < T0 + 2; t++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = relu_i(acc[t][r]);
-        if (ht) {
+        if (PARK) {
 #pragma unroll
             for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
         }
@@ -282,7 +308,20 @@ __device__ __forceinline__ void b3_epilogue_half(f32x16 (&acc)[4], float *__rest
     }
 }
 
-template <int NW>
+// PARK: the activations / masks are parked (training); a wave beyond the scratch's last tile (tail of the last workgroup: the scratch
+// holds whole 128-point blocks) re-runs that LAST tile and stores the same bytes again -- so that no parking store sits behind a
+// branch: a branch ends the scheduling region, and the epilogue instructions are meant to interleave with the MFMAs around them
+// the slices of k16 steps 0..3 are only USED after the layer's barrier, and hipcc's sinking pass would move the ~270 instructions that
+// make them down to that use, out of the MFMA stretch they are meant to fill: pin them at the END of the quarter (one point, behind
+// every MFMA and LDS read of the layer -- a pin between the chunks would fence the next chunk's LDS reads, asm volatile orders memory)
+__device__ __forceinline__ void b3_pin_slices03(Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        asm volatile("" : "+v"(bh[s].u[0]), "+v"(bh[s].u[1]), "+v"(bh[s].u[2]), "+v"(bh[s].u[3]), "+v"(bm[s].u[0]), "+v"(bm[s].u[1]),
+                     "+v"(bm[s].u[2]), "+v"(bm[s].u[3]), "+v"(bl[s].u[0]), "+v"(bl[s].u[1]), "+v"(bl[s].u[2]), "+v"(bl[s].u[3]));
+}
+
+template <int NW, bool PARK>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     const float *__restrict__ x, const int32_t *__restrict__ slot, const float *__restrict__ bias0_d,
     const float *__restrict__ bias0_t, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
@@ -290,30 +329,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
-    const int64_t tile_id = (int64_t)blockIdx.x * NW + wave;
+    const int64_t tile_raw = (int64_t)blockIdx.x * NW + wave;
+    const int64_t tile_id = tile_raw < n_tiles ? tile_raw : n_tiles - 1;
     const int64_t p = tile_id * TILE + pt;
     const int64_t pc = p < M ? p : M - 1;
     float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
     const int sl = slot ? slot[pc] : 0;
-    // the scratch holds whole 128-point blocks (mh_mlp_tiles); a 256-point workgroup's tail tiles beyond it park nothing
-    float *tile = (acts && tile_id < n_tiles) ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
+    float *tile = PARK ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
 
     b3_stage_issue<B3_L0_F4, NW * 64>(w3_d);
     float bin0[24];
     enc_bin(xv, h, n_bands, bin0);
 #pragma unroll
     for (int k = 20; k < 24; k++) bin0[k] = 0.f;
-    if (tile) {
+    if (PARK) {
 #pragma unroll
         for (int k = 0; k < 32; k++) tile[(2 * k + h) * TILE + pt] = k < 20 ? bin0[k] : 0.f;  // k-step ordered, rows 40..63 pad
     }
-    uint2 *mk = tile ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
+    uint2 *mk = PARK ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
 
     for (int net = 0; net < 2; net++) {
         const f32x4 *wp = net ? w3_t : w3_d;
         const float *bs = net ? bias_t : bias_d;
         const float *b0 = (net ? bias0_t : bias0_d) + (int64_t)sl * 128;
-        float *ht = tile ? tile + (64 + net * 640) * TILE : nullptr;
+        float *ht = PARK ? tile + (64 + net * 640) * TILE : nullptr;
         f32x16 acc[4];
         Frag bh[8], bm[8], bl[8];
         // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot
@@ -328,12 +367,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
         wp += B3_L0_F4;
         b3_stage_issue<B3_LH_F4, NW * 64>(wp);
         b3_stage_bias(bs);
-        b3_epilogue(acc, ht, mk ? mk + (net * 5 + 0) * 64 + lane : nullptr, pt, h, bh, bm, bl);
+        b3_dma_fence();
+        b3_epilogue<PARK>(acc, ht, mk + (net * 5 + 0) * 64 + lane, pt, h, bh, bm, bl);
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
             if (net == 0) B3_STAMP((l - 1) * 8 + 0);
             if (net == 0 && l == 1) B3_STAMP_REAL(62);
-            b3_stage_wait();
+            b3_stage_wait_keep<PARK ? B3_KEEP_FWD : 0>();   // behind the DMA: >= 32 parking stores + the mask words
             acc_bias_lds<4>(acc, h);
             if (net == 0) B3_STAMP((l - 1) * 8 + 1);
             // quarter order: both tile pairs over k16 steps 0..3 first -- those B slices are then dead, and once tiles 0, 1
@@ -347,12 +387,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
             // fourth quarter in four k16-step chunks, each followed by an eighth of the finished tiles' epilogue (8 values:
             // ReLU, park, mask bits, one k16 step of slices); the scheduling fences keep the chunks apart, so that the
             // SIMD's two waves -- not barrier-locked inside a layer -- fill each other's VALU stretches with MFMAs
+#ifdef B3_Q4_CHUNKS
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
-                b3_epilogue_eighth(acc, ht ? ht + l * 128 * TILE : nullptr, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
+                b3_epilogue_eighth<PARK>(acc, ht + l * 128 * TILE, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#else
+            // round 5: the two streams interleaved inside the wave -- one MFMA, then B3_Q4_FILL epilogue instructions, 48 times
+            // (tools/micro/mfma_valu_gap.hip: up to 5-6 single-issue instructions per gap ride free in the shadow of the wave's own MFMA)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
+                b3_epilogue_eighth<PARK>(acc, ht + l * 128 * TILE, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
+            }
+            b3_pin_slices03(bh, bm, bl);
+            asm volatile("" : "+v"(mt[0]), "+v"(mt[1]));
+#pragma unroll
+            for (int g_ = 0; g_ < 48; g_++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, B3_Q4_FILL, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (net == 0) B3_STAMP((l - 1) * 8 + 3);
             __syncthreads();
             if (net == 0) B3_STAMP((l - 1) * 8 + 4);
@@ -362,20 +420,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
             else
                 b3_stage_issue<B3_L5_F4, NW * 64>(wp);
             b3_stage_bias(bs + l * 128, l < 4 ? 32 : 8);   // b5 is one 32-row tile
+            b3_dma_fence();
             if (net == 0) B3_STAMP((l - 1) * 8 + 5);
-            b3_epilogue_half<2>(acc, ht ? ht + l * 128 * TILE : nullptr, mt, pt, h, bh, bm, bl);
-            if (mk) mk[(net * 5 + l) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+            b3_epilogue_half<2, PARK>(acc, ht + l * 128 * TILE, mt, pt, h, bh, bm, bl);
+            if (PARK) mk[(net * 5 + l) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
             if (net == 0) B3_STAMP((l - 1) * 8 + 6);
             if (net == 0 && l == 4) B3_STAMP_REAL(63);
         }
         // layer 5: 128 -> 3 | 2 (one padded tile)
         f32x16 o[1];
-        b3_stage_wait();
+        b3_stage_wait_keep<PARK ? B3_KEEP_FWD : 0>();
         acc_bias_lds<1>(o, h);
         b3_layer<8, 1>(lds_b3, bh, bm, bl, o, lane);
         __syncthreads();
         if (net == 0) b3_stage_issue<B3_L0_F4, NW * 64>(w3_t);
-        if (h == 0 && p < M) {
+        if (h == 0 && p < M && tile_raw < n_tiles) {
             if (net == 0) {
                 out_deform[p * 3 + 0] = o[0][0];
                 out_deform[p * 3 + 1] = o[0][1];
@@ -405,10 +464,8 @@ __device__ __forceinline__ void b3_epilogue_bwd(const f32x16 (&acc)[4], uint2 m,
         float y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) y[r] = mask_bit(mw, r, acc[t][r]);
-        if (dt) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) PARK_STORE(y[r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
-        }
+        for (int r = 0; r < 16; r++) PARK_STORE(y[r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
@@ -423,16 +480,16 @@ __device__ __forceinline__ void b3_epilogue_bwd_eighth(f32x16 (&acc)[4], uint2 m
     const uint32_t mw = (t < 2 ? m.x : m.y) >> (16 * (t & 1));
 #pragma unroll
     for (int r = 8 * s2; r < 8 * s2 + 8; r++) acc[t][r] = mask_bit(mw, r, acc[t][r]);
-    if (dt) {
 #pragma unroll
-        for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
-    }
+    for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
 #pragma unroll
     for (int e2 = 0; e2 < 4; e2++)
         split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
+#ifdef B3_Q4_CHUNKS
     Frag &fh = bh[2 * t + s2], &fm = bm[2 * t + s2], &fl = bl[2 * t + s2];
     asm volatile("" : "+v"(fh.u[0]), "+v"(fh.u[1]), "+v"(fh.u[2]), "+v"(fh.u[3]), "+v"(fm.u[0]), "+v"(fm.u[1]), "+v"(fm.u[2]),
                  "+v"(fm.u[3]), "+v"(fl.u[0]), "+v"(fl.u[1]), "+v"(fl.u[2]), "+v"(fl.u[3]));
+#endif
 }
 
 template <int NW>
@@ -443,14 +500,15 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
                                                                  float *__restrict__ g_x, int64_t M, int64_t n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
-    const int64_t tile_id = (int64_t)blockIdx.x * NW + wave;
+    const int64_t tile_raw = (int64_t)blockIdx.x * NW + wave;
+    // the scratch holds whole 128-point blocks: a wave beyond it (tail of the last 256-point workgroup) re-runs the LAST tile and
+    // stores the same bytes again (no parking store behind a branch: see warp_fwd_b3_kernel)
+    const bool have = tile_raw < n_tiles;
+    const int64_t tile_id = have ? tile_raw : n_tiles - 1;
     const int64_t p = tile_id * TILE + pt;
     const bool live = p < M;
-    // the scratch holds whole 128-point blocks: a wave beyond it (tail of the last 256-point workgroup) runs the chain on
-    // the last real tile's masks and stores nothing
-    const bool have = tile_id < n_tiles;
-    const float *atile = acts + (have ? tile_id : n_tiles - 1) * (int64_t)(WARP_ACT_ROWS * TILE);
-    float *dtile = have ? dpre + tile_id * (int64_t)(WARP_DPRE_ROWS * TILE) : nullptr;
+    const float *atile = acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE);
+    float *dtile = dpre + tile_id * (int64_t)(WARP_DPRE_ROWS * TILE);
     float gx[3] = {0.f, 0.f, 0.f};
 
     b3_stage_issue<B3_T5_F4, NW * 64>(w3T_d);
@@ -458,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
         const f32x4 *wt = net ? w3T_t : w3T_d;
         const float *g = net ? g_topo : g_deform;
         const int nout = net ? 2 : 3;
-        float *dt = dtile ? dtile + net * 672 * TILE : nullptr;
+        float *dt = dtile + net * 672 * TILE;
         const uint2 *mk = reinterpret_cast<const uint2 *>(atile + WARP_HID_ROWS * TILE) + net * 5 * 64 + lane;
         uint2 msk[5];
 #pragma unroll
@@ -472,7 +530,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
             d5[1] = g[p * nout + 1];
             if (nout == 3) d5[2] = g[p * nout + 2];
         }
-        if (dt) store_acc_rows<1>(dt + 640 * TILE, d5, pt, h);
+        store_acc_rows<1>(dt + 640 * TILE, d5, pt, h);
         Frag bh[8], bm[8], bl[8];
 #pragma unroll
         for (int s = 0; s < 2; s++)
@@ -485,23 +543,39 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
         __syncthreads();
         wt += B3_T5_F4;
         b3_stage_issue<B3_LH_F4, NW * 64>(wt);
+        b3_dma_fence();
         // dPre_4 from T5's output (the short first stage: nothing to hide it under)
-        b3_epilogue_bwd(acc, msk[4], dt ? dt + 4 * 128 * TILE : nullptr, pt, h, bh, bm, bl);
+        b3_epilogue_bwd(acc, msk[4], dt + 4 * 128 * TILE, pt, h, bh, bm, bl);
         for (int l = 4; l >= 1; l--) {
             // dH_l = W_l^T dPre_l in quarters (see the forward kernel): tiles 0, 1 are complete after the third quarter and
             // their half of dPre_{l-1} (mask by H_l's ReLU bits, park, slice) runs under the fourth quarter's MFMAs
-            b3_stage_wait();
+            b3_stage_wait_keep<B3_KEEP_BWD>();               // behind the DMA: the 32 parking stores of tiles 2, 3
             acc_zero<4>(acc);
             b3_quarter<0, 0>(lds_b3, bh, bm, bl, acc, lane);
             b3_quarter<2, 0>(lds_b3, bh, bm, bl, acc, lane);
             b3_quarter<0, 4>(lds_b3, bh, bm, bl, acc, lane);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef B3_Q4_CHUNKS
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
-                b3_epilogue_bwd_eighth(acc, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bm, bl, c >> 1, c & 1);
+                b3_epilogue_bwd_eighth(acc, msk[l - 1], dt + (l - 1) * 128 * TILE, pt, h, bh, bm, bl, c >> 1, c & 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#else
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
+                b3_epilogue_bwd_eighth(acc, msk[l - 1], dt + (l - 1) * 128 * TILE, pt, h, bh, bm, bl, c >> 1, c & 1);
+            }
+            b3_pin_slices03(bh, bm, bl);
+#pragma unroll
+            for (int g_ = 0; g_ < 48; g_++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, B3_Q4_FILL, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             __syncthreads();
             wt += B3_LH_F4;
             if (l > 1)
@@ -510,14 +584,15 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
                 b3_stage_issue<B3_T0_F4, NW * 64>(wt);
             else if (net == 0)
                 b3_stage_issue<B3_T5_F4, NW * 64>(w3T_t);
+            b3_dma_fence();
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                b3_epilogue_bwd_eighth(acc, msk[l - 1], dt ? dt + (l - 1) * 128 * TILE : nullptr, pt, h, bh, bm, bl, 2 + (c >> 1), c & 1);
+                b3_epilogue_bwd_eighth(acc, msk[l - 1], dt + (l - 1) * 128 * TILE, pt, h, bh, bm, bl, 2 + (c >> 1), c & 1);
         }
         if (g_x) {
             // d(enc features) = W0^T dPre0; rows ordered (kk = 16t + r, h = lane>>5).  Skipped when nobody asks for d/dx
             f32x16 e[2];
-            b3_stage_wait();
+            b3_stage_wait_keep<B3_KEEP_BWD>();
             b3_layer<8, 2, true>(lds_b3, bh, bm, bl, e, lane);
             __syncthreads();
             if (net == 0) b3_stage_issue<B3_T5_F4, NW * 64>(w3T_t);
@@ -540,7 +615,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
     }
 #pragma unroll
     for (int d = 0; d < 3; d++) gx[d] += __shfl_xor(gx[d], 32);
-    if (g_x && live && h == 0) {
+    if (g_x && live && have && h == 0) {
         g_x[p * 3 + 0] = gx[0];
         g_x[p * 3 + 1] = gx[1];
         g_x[p * 3 + 2] = gx[2];
@@ -808,11 +883,15 @@ static int b3_lds_opt_in() {
     static MhOncePerDevice done;
     const int dev = mh_device();
     if (done.need(dev)) {
-        if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
+        if (hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
-            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
+            hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess)
@@ -887,14 +966,22 @@ extern "C" int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *
     const int64_t blocks = small ? (M + BLOCK_PTS - 1) / BLOCK_PTS : (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
-    if (small)
-        hipLaunchKernelGGL(warp_fwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LDS_BYTES, mh_stream(stream), x, slot,
-                           bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d,
-                           bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
-    else
-        hipLaunchKernelGGL(warp_fwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
-                           slot, bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t),
-                           bias_d, bias_t, (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M));
+#define B3_FWD_LAUNCH(NW_, PARK_, THREADS_)                                                                                          \
+    hipLaunchKernelGGL((warp_fwd_b3_kernel<NW_, PARK_>), dim3((unsigned)blocks), dim3(THREADS_), B3_LDS_BYTES, mh_stream(stream), x, slot, \
+                       bias0_d, bias0_t, reinterpret_cast<const f32x4 *>(w3_d), reinterpret_cast<const f32x4 *>(w3_t), bias_d, bias_t, \
+                       (int)n_bands, out_deform, out_topo, acts, M, mh_mlp_tiles(M))
+    if (small) {
+        if (acts)
+            B3_FWD_LAUNCH(4, true, 256);
+        else
+            B3_FWD_LAUNCH(4, false, 256);
+    } else {
+        if (acts)
+            B3_FWD_LAUNCH(8, true, B3_THREADS);
+        else
+            B3_FWD_LAUNCH(8, false, B3_THREADS);
+    }
+#undef B3_FWD_LAUNCH
     MH_CHECK_LAUNCH();
     return MH_OK;
 }
