@@ -308,17 +308,134 @@ __device__ __forceinline__ void b3_epilogue_half(f32x16 (&acc)[4], float *__rest
     }
 }
 
-// PARK: the activations / masks are parked (training); a wave beyond the scratch's last tile (tail of the last workgroup: the scratch
-// holds whole 128-point blocks) re-runs that LAST tile and stores the same bytes again -- so that no parking store sits behind a
-// branch: a branch ends the scheduling region, and the epilogue instructions are meant to interleave with the MFMAs around them
-// the slices of k16 steps 0..3 are only USED after the layer's barrier, and hipcc's sinking pass would move the ~270 instructions that
-// make them down to that use, out of the MFMA stretch they are meant to fill: pin them at the END of the quarter (one point, behind
-// every MFMA and LDS read of the layer -- a pin between the chunks would fence the next chunk's LDS reads, asm volatile orders memory)
-__device__ __forceinline__ void b3_pin_slices03(Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
+// ---- forward, weight staging pipelined over two k-half slots (round 5) ------------------------------------------------------
+// Round 4's kernel staged ONE layer's slices (96 KB) at a time: the next layer's DMA could only be issued once every wave had left
+// the layer, and the two-wave phase trace (tools/phase_trace_b3_pair.py, profiles/r05_phase_trace_warp_fwd_pair_before.txt) shows
+// what that costs: between the mid-layer barrier and the next layer's first MFMA -- DMA issue, the exposed epilogue of tiles 2, 3,
+// the DMA's flight -- NEITHER wave of a SIMD issues an MFMA for 5.7 k of a layer's 20.2 k ticks (inside the rest the matrix pipe
+// is saturated: 38 ticks per MFMA).  Here the same 96 KB are two 48 KB SLOTS, a slot = one k-half of a 128 x 128 layer (the packs
+// are [k-half][plane][tile][k16 step][lane] already), and a hidden layer is
+//      Q1 (tiles 0,1 x k-half 0) || E23 of the PREVIOUS layer     Q2 (tiles 2,3 x k0)      --M--
+//      Q3 (tiles 0,1 x k-half 1)                                  Q4 (tiles 2,3 x k1) || E01   --E--
+//   * k-half 0 lives in slot 1, k-half 1 in slot 0 (L0 in slot 0, L5 in slot 1).  At M every wave has left slot 1: it takes k0 of
+//     the NEXT layer (L5 after layer 4); at E every wave has left slot 0: it takes k1 of the next layer (the other net's L0 after
+//     layer 4).  A block is read half a layer after it was issued; the wait at M / E is `vmcnt(KEEP)`: all but the wave's KEEP most
+//     recent vector-memory operations -- the parking stores of the quarter just finished -- so it covers the DMA issued at the
+//     previous point without waiting for stores a few hundred cycles old (gfx9 counts both in vmcnt).
+//   * E01 (ReLU, park, mask bits, slices of k16 steps 0..3 -- dead since Q2) runs under Q4 as before; E23, whose slices feed k16
+//     steps 4..7 (first read in Q3), runs under Q1 of the NEXT layer: no epilogue is exposed except layer 0's tiles 0, 1.
+//   * inside Q1 / Q4 the two instruction streams are interleaved by scheduling groups (one MFMA, B3_Q_FILL epilogue instructions):
+//     tools/micro/mfma_valu_gap.hip -- 5-6 single-issue instructions ride free in the shadow of the wave's own bf16 MFMA.
+// Every accumulator sees the same sequence of slice products as before: outputs, parked tiles and mask words are bit-identical.
+// PARK: activations / masks are parked (training).  A wave beyond the scratch's last tile (tail of the last workgroup: the scratch
+// holds whole 128-point blocks) re-runs that LAST tile and stores the same bytes again, so that no parking store sits behind a
+// branch -- a branch ends the scheduling region the epilogue instructions are meant to share with the MFMAs.
+#define B3_SLOT_F4 B3_KH_F4                             // 3072 float4 = 48 KB; L0 (2560) and L5 (1536) fit one slot
+#define B3_BIASROW_F4 (2 * B3_SLOT_F4)                  // two bias rows of 32 float4 behind the slots (row = layer & 1)
+#ifndef B3_Q_FILL
+#define B3_Q_FILL 6
+#endif
+
+// wave-uniform source offset / slot -> LDS-DMA of N_F4 float4.  The offset passes through an empty asm statement: the address
+// arithmetic is loop-invariant for most blocks, and hipcc otherwise hoists it out of the layer loop and spills it
+template <int N_F4, int NTHR>
+__device__ __forceinline__ void b3_slot_issue(const f32x4 *__restrict__ base, int off_f4, int slot) {
+    static_assert(N_F4 % NTHR == 0, "whole rounds of the block");
+    asm volatile("" : "+s"(off_f4));
+    const f32x4 *src = base + off_f4 + threadIdx.x;
+    f32x4 *dst = lds_b3 + slot * B3_SLOT_F4 + (threadIdx.x >> 6) * 64;
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int k = 0; k < N_F4 / NTHR; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * NTHR),
+                                         (__attribute__((address_space(3))) void *)(dst + k * NTHR), 16, 0, 0);
+}
+__device__ __forceinline__ void b3_bias_issue(const float *__restrict__ bias, int off_floats, int n_f4, int row) {
+    asm volatile("" : "+s"(off_floats));
+    if ((int)threadIdx.x < n_f4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const f32x4 *>(bias + off_floats) + threadIdx.x),
+                                         (__attribute__((address_space(3))) void *)(lds_b3 + B3_BIASROW_F4 + row * 32), 16, 0, 0);
+}
+// accumulators of output tiles T0, T0+1 <- the layer's bias row
+template <int T0, int NT, int MT>
+__device__ __forceinline__ void b3_acc_bias_row(f32x16 (&acc)[MT], int h, int row) {
+    const f32x4 *b = lds_b3 + B3_BIASROW_F4 + row * 32;
+#pragma unroll
+    for (int t = T0; t < T0 + NT; t++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 v = b[8 * t + 2 * r4 + h];
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = v[c];
+        }
+}
+// M / E point: this wave's LDS reads have returned, its DMA portions older than its KEEP most recent VMEM operations have landed;
+// then the workgroup barrier.  Not __syncthreads(): with an LDS-DMA in flight its release fence becomes vmcnt(0).
+template <int KEEP>
+__device__ __forceinline__ void b3_point() {
+    static_assert(KEEP >= 0 && KEEP <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// one k16 step `s` (B slices bh[s] ...) of output tiles T0, T0+1 against the k-half block `wk` (12 MFMAs)
+template <int T0>
+__device__ __forceinline__ void b3_step(const f32x4 *__restrict__ wk, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
+                                        f32x16 (&acc)[4], int lane, int s) {
+    constexpr int PLH = 4 * 4 * 64;
+    Frag ah[2], am[2], al[2];
+    const f32x4 *w = wk + (s & 3) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        ah[t].f = w[0 * PLH + (T0 + t) * 256];
+        am[t].f = w[1 * PLH + (T0 + t) * 256];
+        al[t].f = w[2 * PLH + (T0 + t) * 256];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bl[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bm[s].h, acc[T0 + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; t++) acc[T0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh[s].h, acc[T0 + t], 0, 0, 0);
+}
+// one k16 step of the single-tile output layer (pack [plane][k16 step 0..7][lane]); the six products chain on one accumulator in
+// b3_layer<8, 1>'s order
+__device__ __forceinline__ void b3_l5_step(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8], const Frag (&bl)[8],
+                                           f32x16 &o, int lane, int s) {
+    Frag ah, am, al;
+    ah.f = w[0 * 512 + s * 64 + lane];
+    am.f = w[1 * 512 + s * 64 + lane];
+    al.f = w[2 * 512 + s * 64 + lane];
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.h, bh[s].h, o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bm[s].h, o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bl[s].h, o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.h, bh[s].h, o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bm[s].h, o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.h, bh[s].h, o, 0, 0, 0);
+}
+// The slices an epilogue makes are only USED after the next barrier, and hipcc's sinking pass would move the ~270 instructions that
+// make them down to that use, out of the MFMA stretch they are meant to fill: pin them at the END of the quarter (one point, behind
+// every MFMA and LDS read of the quarter -- a pin between the steps would fence the next step's LDS reads: asm volatile orders memory)
+template <int S0>
+__device__ __forceinline__ void b3_pin_slices(Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
+#pragma unroll
+    for (int s = S0; s < S0 + 4; s++)
         asm volatile("" : "+v"(bh[s].u[0]), "+v"(bh[s].u[1]), "+v"(bh[s].u[2]), "+v"(bh[s].u[3]), "+v"(bm[s].u[0]), "+v"(bm[s].u[1]),
                      "+v"(bm[s].u[2]), "+v"(bm[s].u[3]), "+v"(bl[s].u[0]), "+v"(bl[s].u[1]), "+v"(bl[s].u[2]), "+v"(bl[s].u[3]));
+}
+// one MFMA, then FILL other VALU instructions, N times: the order the scheduler is asked for inside a quarter that carries an epilogue
+template <int N, int FILL>
+__device__ __forceinline__ void b3_interleave() {
+#pragma unroll
+    for (int g = 0; g < N; g++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, FILL, 0);
+    }
 }
 
 template <int NW, bool PARK>
@@ -327,6 +444,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     const float *__restrict__ bias0_t, const f32x4 *__restrict__ w3_d, const f32x4 *__restrict__ w3_t,
     const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
     float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
+    constexpr int NT = NW * 64;
+    constexpr int KEEP = PARK ? 32 : 0;      // parking stores a wave issues in a quarter that carries an epilogue
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
     const int64_t tile_raw = (int64_t)blockIdx.x * NW + wave;
@@ -336,8 +455,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     float xv[3] = {x[pc * 3 + 0], x[pc * 3 + 1], x[pc * 3 + 2]};
     const int sl = slot ? slot[pc] : 0;
     float *tile = PARK ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;
+    const f32x4 *const slot0 = lds_b3, *const slot1 = lds_b3 + B3_SLOT_F4;
 
-    b3_stage_issue<B3_L0_F4, NW * 64>(w3_d);
+    // blocks L0d -> slot 0, L1d.k0 -> slot 1, L1d's bias row -> row 1
+    b3_slot_issue<B3_L0_F4, NT>(w3_d, 0, 0);
+    b3_slot_issue<B3_KH_F4, NT>(w3_d, B3_L0_F4, 1);
+    b3_bias_issue(bias_d, 0, 32, 1);
     float bin0[24];
     enc_bin(xv, h, n_bands, bin0);
 #pragma unroll
@@ -349,91 +472,110 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     uint2 *mk = PARK ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
 
     for (int net = 0; net < 2; net++) {
-        const f32x4 *wp = net ? w3_t : w3_d;
+        const f32x4 *wn = net ? w3_t : w3_d;
         const float *bs = net ? bias_t : bias_d;
         const float *b0 = (net ? bias0_t : bias0_d) + (int64_t)sl * 128;
         float *ht = PARK ? tile + (64 + net * 640) * TILE : nullptr;
         f32x16 acc[4];
         Frag bh[8], bm[8], bl[8];
+        uint32_t mt[4] = {0u, 0u, 0u, 0u};
         // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot
 #pragma unroll
         for (int s = 0; s < 3; s++)
 #pragma unroll
             for (int e2 = 0; e2 < 4; e2++) split2(bin0[8 * s + 2 * e2], bin0[8 * s + 2 * e2 + 1], bh[s].u[e2], bm[s].u[e2], bl[s].u[e2]);
         acc_bias<4>(acc, b0, h);
-        b3_stage_wait();
-        b3_layer<3, 4>(lds_b3, bh, bm, bl, acc, lane);
-        __syncthreads();
-        wp += B3_L0_F4;
-        b3_stage_issue<B3_LH_F4, NW * 64>(wp);
-        b3_stage_bias(bs);
+        b3_point<0>();                                     // L0, L1.k0 and L1's bias row have landed (everything has)
+        b3_layer<3, 4>(slot0, bh, bm, bl, acc, lane);
+        b3_point<0>();                                     // every wave has left slot 0
+        b3_slot_issue<B3_KH_F4, NT>(wn, B3_L0_F4 + B3_KH_F4, 0);           // L1.k1 -> slot 0
         b3_dma_fence();
-        b3_epilogue<PARK>(acc, ht, mk + (net * 5 + 0) * 64 + lane, pt, h, bh, bm, bl);
+        // layer 0's tiles 0, 1 here (a 72-MFMA layer has nothing to hide them under); its tiles 2, 3 under layer 1's Q1
+        b3_epilogue_half<0, PARK>(acc, ht, mt, pt, h, bh, bm, bl);
+        __builtin_amdgcn_sched_barrier(0);
         // layers 1..4: 128 -> 128
         for (int l = 1; l <= 4; l++) {
+            const int row = l & 1;
+            float *hp = ht + (l - 1) * 128 * TILE, *hl = ht + l * 128 * TILE;
             if (net == 0) B3_STAMP((l - 1) * 8 + 0);
             if (net == 0 && l == 1) B3_STAMP_REAL(62);
-            b3_stage_wait_keep<PARK ? B3_KEEP_FWD : 0>();   // behind the DMA: >= 32 parking stores + the mask words
-            acc_bias_lds<4>(acc, h);
+            // ---- Q1 (slot 1: k-half 0) under the PREVIOUS layer's tiles 2, 3 epilogue
+            b3_acc_bias_row<0, 2, 4>(acc, h, row);
+            mt[2] = mt[3] = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                b3_step<0>(slot1, bh, bm, bl, acc, lane, c);
+                b3_epilogue_eighth<PARK>(acc, hp, mt, pt, h, bh, bm, bl, 2 + (c >> 1), c & 1);
+            }
+            b3_pin_slices<4>(bh, bm, bl);
+            asm volatile("" : "+v"(mt[2]), "+v"(mt[3]));
+            b3_interleave<48, B3_Q_FILL>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (PARK) mk[(net * 5 + l - 1) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
             if (net == 0) B3_STAMP((l - 1) * 8 + 1);
-            // quarter order: both tile pairs over k16 steps 0..3 first -- those B slices are then dead, and once tiles 0, 1
-            // are complete (third quarter) their epilogue refills exactly these registers UNDER the fourth quarter's MFMAs
-            b3_quarter<0, 0>(lds_b3, bh, bm, bl, acc, lane);
-            b3_quarter<2, 0>(lds_b3, bh, bm, bl, acc, lane);
-            b3_quarter<0, 4>(lds_b3, bh, bm, bl, acc, lane);
+            // ---- Q2
+            b3_acc_bias_row<2, 2, 4>(acc, h, row);
+#pragma unroll
+            for (int c = 0; c < 4; c++) b3_step<2>(slot1, bh, bm, bl, acc, lane, c);
             __builtin_amdgcn_sched_barrier(0);
             if (net == 0) B3_STAMP((l - 1) * 8 + 2);
-            uint32_t mt[4] = {0u, 0u, 0u, 0u};
-            // fourth quarter in four k16-step chunks, each followed by an eighth of the finished tiles' epilogue (8 values:
-            // ReLU, park, mask bits, one k16 step of slices); the scheduling fences keep the chunks apart, so that the
-            // SIMD's two waves -- not barrier-locked inside a layer -- fill each other's VALU stretches with MFMAs
-#ifdef B3_Q4_CHUNKS
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
-                b3_epilogue_eighth<PARK>(acc, ht + l * 128 * TILE, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#else
-            // round 5: the two streams interleaved inside the wave -- one MFMA, then B3_Q4_FILL epilogue instructions, 48 times
-            // (tools/micro/mfma_valu_gap.hip: up to 5-6 single-issue instructions per gap ride free in the shadow of the wave's own MFMA)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
-                b3_epilogue_eighth<PARK>(acc, ht + l * 128 * TILE, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
-            }
-            b3_pin_slices03(bh, bm, bl);
-            asm volatile("" : "+v"(mt[0]), "+v"(mt[1]));
-#pragma unroll
-            for (int g_ = 0; g_ < 48; g_++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, B3_Q4_FILL, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            if (net == 0) B3_STAMP((l - 1) * 8 + 3);
-            __syncthreads();
-            if (net == 0) B3_STAMP((l - 1) * 8 + 4);
-            wp += B3_LH_F4;
+            // ---- M: slot 1 is free; k-half 1 (issued at the previous E / after L0) has landed
+            b3_point<KEEP>();
             if (l < 4)
-                b3_stage_issue<B3_LH_F4, NW * 64>(wp);
+                b3_slot_issue<B3_KH_F4, NT>(wn, B3_L0_F4 + 2 * l * B3_KH_F4, 1);          // k0 of layer l + 1
             else
-                b3_stage_issue<B3_L5_F4, NW * 64>(wp);
-            b3_stage_bias(bs + l * 128, l < 4 ? 32 : 8);   // b5 is one 32-row tile
+                b3_slot_issue<B3_L5_F4, NT>(wn, B3_L0_F4 + 8 * B3_KH_F4, 1);              // L5
+            b3_bias_issue(bs, l * 128, l < 4 ? 32 : 8, (l + 1) & 1);                       // its bias row (b5 is one 32-row tile)
             b3_dma_fence();
+            if (net == 0) B3_STAMP((l - 1) * 8 + 3);
+            // ---- Q3 (slot 0: k-half 1)
+#pragma unroll
+            for (int c = 4; c < 8; c++) b3_step<0>(slot0, bh, bm, bl, acc, lane, c);
+            __builtin_amdgcn_sched_barrier(0);
+            if (net == 0) B3_STAMP((l - 1) * 8 + 4);
+            // ---- Q4 under this layer's tiles 0, 1 epilogue
+            mt[0] = mt[1] = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                b3_step<2>(slot0, bh, bm, bl, acc, lane, 4 + c);
+                b3_epilogue_eighth<PARK>(acc, hl, mt, pt, h, bh, bm, bl, c >> 1, c & 1);
+            }
+            b3_pin_slices<0>(bh, bm, bl);
+            asm volatile("" : "+v"(mt[0]), "+v"(mt[1]));
+            b3_interleave<48, B3_Q_FILL>();
+            __builtin_amdgcn_sched_barrier(0);
             if (net == 0) B3_STAMP((l - 1) * 8 + 5);
-            b3_epilogue_half<2, PARK>(acc, ht + l * 128 * TILE, mt, pt, h, bh, bm, bl);
-            if (PARK) mk[(net * 5 + l) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+            // ---- E: slot 0 is free; the block issued at M has landed
+            b3_point<KEEP>();
+            if (l < 4)
+                b3_slot_issue<B3_KH_F4, NT>(wn, B3_L0_F4 + (2 * l + 1) * B3_KH_F4, 0);    // k1 of layer l + 1
+            else if (net == 0)
+                b3_slot_issue<B3_L0_F4, NT>(w3_t, 0, 0);                                  // the other net's L0
+            b3_dma_fence();
             if (net == 0) B3_STAMP((l - 1) * 8 + 6);
             if (net == 0 && l == 4) B3_STAMP_REAL(63);
         }
-        // layer 5: 128 -> 3 | 2 (one padded tile)
+        // layer 5: 128 -> 3 | 2 (one padded tile, slot 1); k16 steps 0..3 under layer 4's tiles 2, 3 epilogue
         f32x16 o[1];
-        b3_stage_wait_keep<PARK ? B3_KEEP_FWD : 0>();
-        acc_bias_lds<1>(o, h);
-        b3_layer<8, 1>(lds_b3, bh, bm, bl, o, lane);
-        __syncthreads();
-        if (net == 0) b3_stage_issue<B3_L0_F4, NW * 64>(w3_t);
+        b3_acc_bias_row<0, 1, 1>(o, h, 1);
+        mt[2] = mt[3] = 0u;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            b3_l5_step(slot1, bh, bm, bl, o[0], lane, c);
+            b3_epilogue_eighth<PARK>(acc, ht + 4 * 128 * TILE, mt, pt, h, bh, bm, bl, 2 + (c >> 1), c & 1);
+        }
+        b3_pin_slices<4>(bh, bm, bl);
+        asm volatile("" : "+v"(mt[2]), "+v"(mt[3]));
+        b3_interleave<24, 12>();
+        __builtin_amdgcn_sched_barrier(0);
+        if (PARK) mk[(net * 5 + 4) * 64 + lane] = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
+#pragma unroll
+        for (int s = 4; s < 8; s++) b3_l5_step(slot1, bh, bm, bl, o[0], lane, s);
+        b3_point<0>();                                     // slot 1 is free (net 0: the other net's L0 has landed)
+        if (net == 0) {
+            b3_slot_issue<B3_KH_F4, NT>(w3_t, B3_L0_F4, 1);                                // L1t.k0
+            b3_bias_issue(bias_t, 0, 32, 1);
+        }
         if (h == 0 && p < M && tile_raw < n_tiles) {
             if (net == 0) {
                 out_deform[p * 3 + 0] = o[0][0];
@@ -568,7 +710,7 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
                 b3_quarter_step<2>(lds_b3, bh, bm, bl, acc, lane, 4 + c);
                 b3_epilogue_bwd_eighth(acc, msk[l - 1], dt + (l - 1) * 128 * TILE, pt, h, bh, bm, bl, c >> 1, c & 1);
             }
-            b3_pin_slices03(bh, bm, bl);
+            b3_pin_slices<0>(bh, bm, bl);
 #pragma unroll
             for (int g_ = 0; g_ < 48; g_++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """The two waves of ONE SIMD (waves 0 and 4 of a workgroup) through a hidden layer of warp_fwd_b3_kernel, on a common clock: who
 issues MFMAs when, and when does neither?  Needs the trace build (tools/gpu/trace_b3.sh builds it).  Rows: every 64th workgroup,
-even row = wave 0, odd row = wave 4; stamps per layer: 0 before the stage wait, 1 accumulators initialised, 2 quarters 1-3 done,
-3 quarter 4 (+ tiles 0,1 epilogue) done, 4 past the mid barrier, 5 DMA issued, 6 tiles 2,3 epilogue done."""
+even row = wave 0, odd row = wave 4; stamps per layer (the pipelined kernel of round 5): 0 layer start, 1 Q1 (+ previous layer's tiles 2,3
+epilogue) done, 2 Q2 done, 3 past M (barrier + DMA issue), 4 Q3 done, 5 Q4 (+ tiles 0,1 epilogue) done, 6 past E (barrier + DMA issue).
+(profiles/r05_phase_trace_warp_fwd_pair_before.txt is the round-4 kernel under its own stamp set: 0 before the stage wait, 1 accumulators
+ready, 2 quarters 1-3 done, 3 quarter 4 done, 4 past the mid barrier, 5 DMA issued, 6 tiles 2,3 epilogue done.)"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -44,8 +46,7 @@ ok = (t[:, 0, 63] - t[:, 0, 62]) > 0
 t = t[ok]
 span = t[:, 0, 3 * 8 + 6] - t[:, 0, 0]; real = t[:, 0, 63] - t[:, 0, 62]
 print("effective shader clock over the traced layers: %.0f MHz; %d workgroups traced" % (100.0 * (span / real).mean(), ok.sum()))
-names = ["0 enter stage wait", "1 accumulators ready", "2 quarters 1-3 done", "3 quarter 4 done", "4 past mid barrier", "5 DMA issued",
-         "6 tiles 2,3 epilogue done"]
+names = ["0 layer start", "1 Q1 + E23(prev) done", "2 Q2 done", "3 past M + DMA issue", "4 Q3 done", "5 Q4 + E01 done", "6 past E + DMA issue"]
 print("stamps relative to wave 0's stamp 0 of the same layer, mean over layers 2..3 (net 0) and workgroups [ticks]:")
 print("   %-28s %10s %10s" % ("", "wave 0", "wave 4"))
 rel = np.zeros((7, 2))
@@ -58,7 +59,7 @@ for k in range(7):
 nxt = ((t[:, :, 2 * 8] - t[:, 0, 1 * 8][:, None]).mean(axis=0) + (t[:, :, 3 * 8] - t[:, 0, 2 * 8][:, None]).mean(axis=0)) / 2
 print("   %-28s %10.0f %10.0f" % ("next layer's stamp 0", nxt[0], nxt[1]))
 print("per-wave phase durations [ticks] (mean over layers 1..4):")
-dn = ["stage wait", "acc init", "quarters 1-3", "quarter 4 (+E01)", "mid barrier", "DMA issue", "E23 exposed", "to next stamp 0"]
+dn = ["Q1+E23", "-", "Q2", "M", "Q3", "Q4+E01", "E", "to next stamp 0"]
 for w in (0, 1):
     d = np.zeros(8)
     for l in range(4):
@@ -69,8 +70,7 @@ for w in (0, 1):
             if v is not None:
                 d[i] += v.mean() / (4 if i != 7 else 3)
     print("   wave %d: " % (4 * w) + "  ".join(f"{n} {v:.0f}" for n, v in zip(dn, d) if v) + f"   total {d.sum():.0f}")
-# spread of the workgroup: how far apart do waves 0 and 4 reach the mid barrier, and how long after the later of the two is the release
-arr = t[:, :, [l * 8 + 3 for l in range(4)]]
-rel4 = t[:, :, [l * 8 + 4 for l in range(4)]]
-print("mid barrier: |arrival wave 0 - wave 4| mean %.0f ticks; release after the later of the two: mean %.0f ticks (= waiting for the other six waves)" %
-      (np.abs(arr[:, 0] - arr[:, 1]).mean(), (rel4.min(axis=1) - arr.max(axis=1)).mean()))
+# spread of the workgroup at the two points: how far apart do waves 0 and 4 arrive
+for nm, k in (("M", 2), ("E", 5)):
+    arr = t[:, :, [l * 8 + k for l in range(4)]]
+    print("%s: |arrival wave 0 - wave 4| mean %.0f ticks" % (nm, np.abs(arr[:, 0] - arr[:, 1]).mean()))
