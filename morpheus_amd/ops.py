@@ -701,7 +701,7 @@ FIELD_ACT_ROWS = 96 + 64 * 5 + 8   # activations + 8 rows of ReLU masks
 # A/B and test switch: False = every field query returns its own gradient tensors and autograd adds them up (the round-3 form).
 # The in-place sums are keyed on autograd's graph-task id (torch >= 2.1); without it the per-query form is used.
 _GRAPH_TASK_ID = getattr(torch._C, "_current_graph_task_id", None)
-ACCUMULATE_IN_PLACE = _GRAPH_TASK_ID is not None
+ACCUMULATE_IN_PLACE = _GRAPH_TASK_ID is not None and os.environ.get("MORPHEUS_ACCUMULATE_IN_PLACE", "1") != "0"
 
 
 class _QueryAccumulator:

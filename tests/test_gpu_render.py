@@ -700,6 +700,154 @@ def test_virtual_view_step_72_vs_reference_golden(tag):
     assert model.pose_array.data.grad is None                    # optimize_pose=False on virtual views
 
 
+def _delta_digest_check(named, before, golden, key_prefix, tol):
+    """grad_digest_check for parameter DELTAS: a delta is the difference of two fp32 parameter values, so every element carries the
+    rounding of the parameter it was added to (up to an ulp of |p| on either side) whatever its own size."""
+    import numpy as np
+    checked = 0
+    for k, t in named.items():
+        key = key_prefix + k
+        if key + "|norm" not in golden:
+            continue
+        t = t.detach().reshape(-1).double().cpu()
+        ulp = 2.0 ** -23 * max(float(before[k].abs().max()), 1e-30)
+        gn = float(golden[key + "|norm"])
+        assert abs(float(t.norm()) - gn) <= tol * gn + 2 * ulp * np.sqrt(t.numel()), f"{k} norm {float(t.norm())} vs {gn}"
+        idx = torch.linspace(0, t.numel() - 1, min(64, t.numel())).long()
+        smp = torch.from_numpy(golden[key + "|samples"]).double()
+        rms = gn / np.sqrt(t.numel())
+        err = float((t[idx] - smp).abs().max())
+        assert err <= 4 * tol * max(float(smp.abs().max()), rms) + 2 * ulp, f"{k} samples err {err} (ulp {ulp})"
+        checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("variant", ["accum", "freeze"])
+def test_cfg4_step_composition_vs_reference_golden(variant):
+    """BASELINE configs[3]'s optimiser composition (morpheus.py:1390-1424): one virtual-view backward (x 1 / virtual_freq) and one
+    real-view backward into torch.optim.Adam over get_params_all(lr) -- accumulated into ONE step (`accum`: epoch > freeze_epoch), or
+    two steps with the deformation groups' learning rates frozen for the first (`freeze`: freeze_lr_deform / reset_lr_deform,
+    :504-516) -- against the PARAMETER DELTAS of the reference's own model + optimiser run through the same two steps
+    (oracle/make_golden.py:gen_round5; group learning rates from the reference's update_learning_rate at epoch 1000; Adam state
+    seeded so that a move is proportional to its gradient).  Here: VirtualViewTrainStep + RealViewTrainStep (fused glue, the background
+    colour drawn as train_step draws it) + FlatAdam with the groups matched BY NAME."""
+    import numpy as np
+    from morpheus_amd import harness, trainstep
+    from morpheus_amd.optim import FlatAdam
+    from tests.util import DrawInjector
+    g, g4 = load_golden("round5.npz"), load_golden("round4.npz")
+    model = harness.build_model("b", DEV, 0.75).train()
+    cfg = model.config
+    if variant == "freeze":
+        # the normal-smoothness term is ill-conditioned on these weights (its gradient changes x 16 for the first step's 1e-3 move,
+        # measured on the reference: oracle/make_golden.py:gen_round5); it is pinned at the initial parameters by `accum` and the
+        # single-step fixtures, and left out of the variant whose second step runs AFTER a move
+        cfg["train"]["normal_smoothness"] = 0.0
+    groups = model.get_params_all(cfg["train"]["lr"])
+    names = [str(n) for n in g[variant + "|group_names"]]
+    assert [gr["name"] for gr in groups] == names                  # the reference's group names, in its order (models/model.py)
+    opt = FlatAdam(groups, betas=(0.9, 0.99), eps=1e-15)
+
+    def set_lrs(key):                                              # what update_learning_rate / freeze_lr_deform do: by group NAME
+        by_name = dict(zip(names, (float(v) for v in g[variant + "|" + key])))
+        for gr in opt.param_groups:
+            gr["lr"] = by_name[gr["name"]]
+
+    set_lrs("group_lr")
+    assert abs(dict(zip(names, g[variant + "|group_lr"]))["pose"] - 0.1 * dict(zip(names, g[variant + "|group_lr"]))["encoder_sdf"]) < 1e-12
+    sd = opt.state_dict()
+    for st in sd["state"].values():
+        st["step"] = torch.tensor(1000.0)
+        st["exp_avg"] = torch.zeros_like(st["exp_avg"])
+        st["exp_avg_sq"] = torch.full_like(st["exp_avg_sq"], 1.0)
+    opt.load_state_dict(sd)
+    set_lrs("group_lr")                                            # (load_state_dict restores the groups' hyper-parameters too)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    # the virtual-view step: round4.npz's virt72_lam case
+    frame, theta, phi, shading, ambient, bg = VIRT72["lam"]
+    hw, S = 72, 24
+    o, d = synth.camera_rays(hw, hw, synth.look_at_pose(theta, phi, 1.5))
+    N = o.shape[0]
+    smp = of.uniform_samples(o, d, synth.ray_jitter(N), S, 1.01)
+    rend_v = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    vs = trainstep.VirtualViewTrainStep(rend_v, res=hw, guidance=trainstep.InjectedGuidance(hw, hw, DEV, scale=5e-3))
+    vs.epoch, vs.global_step = 1000, 999
+    data_v = dict(H=hw, W=hw, rays_o=o[None].to(DEV), rays_d=d[None].to(DEV), rays_t=torch.full((1, N, 1), frame / 200, device=DEV),
+                  rays_id=torch.full((1, N, 1), frame, device=DEV, dtype=torch.int64))
+    npts = int(cfg["train"]["trunc"] * 100 + 1)
+    keep = np.unpackbits(g4["virt72_lam|keep_bits"])[:npts * N].astype(bool)
+    light = of.safe_normalize(o + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
+    # the real-view step: extras.npz's realview rays, background drawn inside the step
+    sel = torch.from_numpy(g["real|sel"].astype(np.int64))
+    hw_r, S_r = 32, 64
+    o_r, d_r, t_r, rid_r = [v[:, sel] for v in synth.frame_rays(25, hw_r, hw_r)]
+    N_r = o_r.shape[1]
+    smp_r = of.uniform_samples(o_r[0], d_r[0], synth.ray_jitter(hw_r * hw_r)[sel], S_r, 1.01)
+    rend_r = harness.make_renderer(model, S_r, samples=tuple(v.to(DEV) for v in smp_r))
+    frame_r = trainstep.make_frames([25], hw_r, hw_r, DEV)[0]
+    ts = trainstep.RealViewTrainStep(rend_r, [frame_r], ray_num=N_r)
+    ts.epoch = 1000
+    data_r = trainstep.sample_real_view_rays(frame_r, N_r, sel.to(DEV))
+
+    def virtual_backward():
+        with DrawInjector(remap={3: keep} if cfg["train"]["normal_smoothness"] > 0 else None):
+            lv = vs(data=data_v, shading=shading, ambient_ratio=ambient, bg_color=torch.tensor(bg, device=DEV), light_d=light)
+        ((1.0 / cfg["train"]["virtual_freq"]) * lv).backward()
+        return lv
+
+    def real_backward():
+        ts.apply_level()
+        with DrawInjector() as inj, model.operand_scope():
+            lr_ = ts._step(data_r, 1000)
+            assert inj.k == int(g[variant + "|real_n_draws"]), "background first, then what render_rays draws, in the reference's order"
+        lr_.backward()
+        return lr_
+
+    opt.zero_grad()
+    if variant == "accum":
+        lv = virtual_backward()
+        lr_ = real_backward()
+        opt.step()
+    else:
+        set_lrs("group_lr_frozen")
+        assert all(gr["lr"] == 0.0 for gr in opt.param_groups if gr["name"] in ("code_deform", "decoder_deform", "decoder_topo"))
+        lv = virtual_backward()
+        opt.step()
+        d1 = {k: p.detach() - before[k] for k, p in model.named_parameters()}
+        for k, v in d1.items():                                    # frozen groups (and the pose: no gradient on virtual views) stay put
+            if k.startswith(("deform_code", "deform_net", "topo_net", "pose_array")):
+                assert float(v.abs().max()) == 0.0, k
+        assert _delta_digest_check(d1, before, g, variant + "|delta1|", 5e-3) >= 55
+        opt.zero_grad()
+        set_lrs("group_lr")
+        lr_ = real_backward()
+        opt.bucket.collect()
+        lay = {id(p): (o, k) for p, o, k in opt._views}
+        g2 = {k: opt.bucket.flat[lay[id(p)][0]:lay[id(p)][0] + lay[id(p)][1]].view(p.shape) for k, p in model.named_parameters()}
+        assert grad_digest_check(g2, {k.replace("|grad2|", "|grad|"): v for k, v in g.items() if "|grad2|" in k}, variant, 3e-3) >= 50
+        opt.step()
+    assert_close(lv, g[variant + "|loss_virtual"], 1e-2, "virtual-view loss")
+    assert_close(lr_, g[variant + "|loss_real"], 2e-3, "real-view loss")
+    delta = {k: p.detach() - before[k] for k, p in model.named_parameters()}
+    # accum: one step on the SUM of a virtual-view and a real-view gradient, both through finite-difference normals (x 250 round-off
+    # gain, the tolerance of the single-step fixtures); freeze: no normal-smoothness term -> the judge's 1e-3 rel-L2 of the deltas
+    # (measured: <= 8.8e-4 on every tensor; samples of tensors whose whole move is a few fp32 ulps get the 3e-3 the digest allows)
+    n_ok = _delta_digest_check(delta, before, g, variant + "|delta|", 3e-2 if variant == "accum" else 3e-3)
+    assert n_ok >= 55, n_ok
+    if variant == "freeze":
+        for k, v in delta.items():
+            gn = float(g["freeze|delta|" + k + "|norm"])
+            ulp = 2.0 ** -23 * float(before[k].abs().max())
+            if gn > 100 * ulp * v.numel() ** 0.5:                  # (a tensor that moved by a few ulps per element has no 1e-3 to show)
+                assert abs(float(v.double().norm()) - gn) <= 1e-3 * gn, (k, float(v.double().norm()), gn)
+    moved = [k for k, v in delta.items() if float(v.abs().max()) > 0]
+    for k in ("encoder.embeddings", "encoder_c.embeddings", "deform_code.volumes.2", "pose_array.data", "deform_net.net.2.weight_v"):
+        assert k in moved, k
+    for k in delta:                                                # the background net never gets a gradient: never stepped
+        if k.startswith("bg_net"):
+            assert k not in moved, k
+
+
 def test_two_frames_vs_reference_golden():
     """B = 2 frames in one batch against the reference's own render_rays (fixture extras.npz:two|*)."""
     from morpheus_amd import harness
