@@ -821,6 +821,13 @@ def run_one(args):
     if wl.get("pretouch") is not None:
         out["config"]["vram_pretouch_before_warmup"] = wl["pretouch"]
     out["config"]["allocator_in_timed_region"] = alloc
+    if not stub:
+        from morpheus_amd import chunking
+        out["config"]["parked_memory_bound"] = dict(cap_GB=os.environ.get("MORPHEUS_MAX_PARK_GB") or round(chunking.park_cap_bytes(dev) / 1e9, 1),
+                                                   query_calls=chunking.STATS["calls"], chunked_calls=chunking.STATS["chunked_calls"],
+                                                   chunks=chunking.STATS["chunks"], rerun_rows=chunking.STATS["rerun_rows"],
+                                                   note="morpheus_amd/chunking.py: over the cap a query runs in row chunks, all but the "
+                                                        "last re-made in backward (whole process, warm-up included)")
     out["config"]["kernel_timers"] = bool(timers_on)      # per-C-ABI-call HIP events inside the timed region (host cost per call)
     if wl.get("graphed") is not None:
         g = wl["graphed"]
@@ -843,7 +850,7 @@ def run_one(args):
 
 # ------------------------------------------------------------------------------------------------ all three arithmetic modes
 
-def _run_child(flags, mode, timeout):
+def _run_child(flags, mode, timeout, env=None):
     """One bench.py child process (fresh allocator, timers and operand caches); returns (full result object or None, error text).
     The child writes its FULL object to a temporary --detail-out file; its stdout carries the compact line only."""
     import tempfile
@@ -851,7 +858,8 @@ def _run_child(flags, mode, timeout):
     os.close(fd)
     try:
         cmd = [sys.executable, os.path.abspath(__file__)] + list(flags) + ["--detail-out", path]
-        run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env={**os.environ, "MORPHEUS_MLP": mode})
+        run = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                             env={**os.environ, "MORPHEUS_MLP": mode, **(env or {})})
         if run.returncode != 0 or os.path.getsize(path) == 0:
             return None, (run.stderr or run.stdout)[-400:]
         return json.load(open(path)), None
@@ -928,15 +936,16 @@ def run_extras(mode):
                      INTEGRATION.md's three edits alone give);
       train_virtual  its virtual-view step (:1393-1408) at 72 x 72 and 180 x 180 rays, SDS replaced by an injected pred_rgb
                      gradient (the UNet is not part of the hot path and its weights are not available offline)."""
-    def sub(flags, timeout=600):
-        r, err = _run_child(["--gpus", "1", "--mode", mode, "--no-kernel-timers", "--no-cpu-baseline"] + flags, mode, timeout)
+    def sub(flags, timeout=600, env=None):
+        r, err = _run_child(["--gpus", "1", "--mode", mode, "--no-kernel-timers", "--no-cpu-baseline"] + flags, mode, timeout, env)
         if r is None:
             return {"error": err}
         keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "iters_per_s", "train_steps_per_s") if k in r}
         c = r["config"]
         keep.update(workload=c["workload"], rays_per_gpu=c["rays_per_gpu"], sample_points_per_step=c["sample_points_per_step_per_gpu"],
                     kernel_timers=c.get("kernel_timers"), loss_mean_of_timed_steps=c.get("loss_mean_of_timed_steps"))
-        for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction", "allocator_in_timed_region", "vram_pretouch_before_warmup"):
+        for k in ("glue", "hip_graph", "shadings_of_timed_steps", "occupied_fraction", "allocator_in_timed_region", "vram_pretouch_before_warmup",
+                  "parked_memory_bound"):
             if k in c:
                 keep[k] = c[k]
         return keep
@@ -950,6 +959,7 @@ def run_extras(mode):
                                    "model.operand_scope():` line around the step, the other two need this build's caller"},
             "train_virtual": {"res72": sub(["--workload", "train_virtual", "--virtual-res", "72"]),
                               "res180": sub(["--workload", "train_virtual", "--virtual-res", "180"]),
+                              "res180_cap64": sub(["--workload", "train_virtual", "--virtual-res", "180"], env={"MORPHEUS_MAX_PARK_GB": "64"}),
                               "note": "rays/s of the reference's virtual-view training step (render fwd + bwd + Adam under an "
                                       "injected pred_rgb gradient standing for Zero-1-to-3 SDS)"},
             "train_loop": {"res72": sub(["--workload", "train_loop", "--virtual-res", "72"]),
@@ -1022,7 +1032,10 @@ def compact_line(out, detail_path=None):
     tv = out.get("train_virtual")
     if tv:
         line["train_virtual_ms"] = {"72": _num(tv, "res72", "ms_per_step"), "180": _num(tv, "res180", "ms_per_step"),
-                                    "180_reserved_GB": _num(tv, "res180", "allocator_in_timed_region", "reserved_GB")}
+                                    "180_reserved_GB": _num(tv, "res180", "allocator_in_timed_region", "reserved_GB"),
+                                    "180_peak_allocated_GB": _num(tv, "res180", "allocator_in_timed_region", "peak_allocated_GB"),
+                                    "180_cap64": _num(tv, "res180_cap64", "ms_per_step"),
+                                    "180_cap64_reserved_GB": _num(tv, "res180_cap64", "allocator_in_timed_region", "reserved_GB")}
     tl = out.get("train_loop")
     if tl:
         line["train_loop_iters_per_s"] = _num(tl, "res72", "iters_per_s")

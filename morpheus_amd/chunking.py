@@ -1,0 +1,85 @@
+"""A bound on parked memory: per-sample field / warp queries in row chunks whose activations are re-made in backward.
+
+The MLP kernels park what their backward needs in HBM (warp nets: 10.9 KB per sample; every field point query, incl. the six
+finite-difference taps of a normal: ~2 KB).  A whole-view training step (180 x 180 rays of a novel view, finite-difference
+normals, the perturbed-normal regulariser) parks ~45 KB per sample -- 104 GB at its peak on a 288 GB part, and nothing bounded it.
+`chunked_query` splits such a query by rows when the call's estimate exceeds the cap (MORPHEUS_MAX_PARK_GB; unset: 0.4 of the
+device's memory, so that a step which fits comfortably -- the 180 x 180 view: ~106 GB by this estimate -- pays nothing): every
+chunk but the last runs through torch.utils.checkpoint (forward without autograd state, i.e. nothing parked; re-run with parking
+when backward reaches it, one chunk at a time), the last chunk runs as usual -- backward reaches it first, so its parked tiles are
+gone before the first re-run.  The outputs are the concatenation; values and gradients are those of the unchunked call (the
+kernels are batch-size independent: tests/test_gpu_render.py::test_full_size_forward_backward_equals_chunked_renders).
+Cost: one extra forward of the re-run rows, paid only by calls over the cap.  Measured on the 180 x 180 virtual-view step (2.2 M
+samples; profiles/r05_park_cap_180.txt): no bound 48.8 ms with 243 GB reserved by the caching allocator; cap 64 GB: 60.8 ms, 64 GB
+reserved; cap 32 GB: 63.2 ms, 38 GB reserved."""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional, Sequence
+
+import torch
+import torch.utils.checkpoint
+
+WARP_PARK_BYTES = (64 + 2 * 640 + 40 + 2 * 672) * 4      # csrc/mlp_dev.h: WARP_ACT_ROWS + WARP_DPRE_ROWS floats per sample
+FIELD_PARK_BYTES = (96 + 64 * 5 + 8) * 4 + 300           # FIELD_ACT_ROWS floats + hash features / per-point temporaries
+STATS = dict(calls=0, chunked_calls=0, chunks=0, rerun_rows=0)
+
+
+DEFAULT_FRACTION = 0.4       # of the device's memory, when MORPHEUS_MAX_PARK_GB is not set (115 GB on a 288 GB MI355X)
+_total = {}
+
+
+def park_cap_bytes(device=None) -> float:
+    """MORPHEUS_MAX_PARK_GB in GB (<= 0: no bound); unset: DEFAULT_FRACTION of the device's memory.  Read at every call."""
+    env = os.environ.get("MORPHEUS_MAX_PARK_GB")
+    if env is not None and env != "":
+        gb = float(env)
+        return float("inf") if gb <= 0 else gb * 1e9
+    if not torch.cuda.is_available():
+        return float("inf")
+    idx = torch.cuda.current_device() if device is None or getattr(device, "index", None) is None else device.index
+    if idx not in _total:
+        _total[idx] = float(torch.cuda.get_device_properties(idx).total_memory)
+    return DEFAULT_FRACTION * _total[idx]
+
+
+def query_bytes_per_row(warp: bool, field_points: int) -> int:
+    """estimate of what one row of a query parks: the warp nets (if evaluated) + `field_points` field point queries"""
+    return (WARP_PARK_BYTES if warp else 0) + FIELD_PARK_BYTES * int(field_points)
+
+
+def rows_under_cap(bytes_per_row_all_queries: int, cap: Optional[float] = None, device=None) -> int:
+    cap = park_cap_bytes(device) if cap is None else cap
+    if cap == float("inf"):
+        return 1 << 62
+    return max(int(cap // max(bytes_per_row_all_queries, 1)) // 8192 * 8192, 8192)
+
+
+def chunked_query(fn: Callable, sliced: Sequence[Optional[torch.Tensor]], rows: int):
+    """fn(*sliced) -> tuple of per-row tensors (or None entries); `sliced`: tensors with the same leading length (or None),
+    cut by rows.  rows >= the length, or autograd off: one plain call."""
+    M = next(t for t in sliced if t is not None).shape[0]
+    STATS["calls"] += 1
+    if rows >= M or not torch.is_grad_enabled():
+        return fn(*sliced)
+    bounds = list(range(0, M, rows))
+    STATS["chunked_calls"] += 1
+    STATS["chunks"] += len(bounds)
+    # reentrant checkpointing recomputes only if some INPUT requires a gradient (the parameters are reached through the module,
+    # not through the argument list): a one-element carrier that does
+    carrier = torch.ones(1, device=next(t for t in sliced if t is not None).device, requires_grad=True)
+
+    def run(carrier_, *args):
+        return fn(*args)
+
+    outs = []
+    for i, a in enumerate(bounds):
+        b = min(a + rows, M)
+        args = [None if t is None else t[a:b] for t in sliced]
+        if i == len(bounds) - 1:
+            out = fn(*args)
+        else:
+            STATS["rerun_rows"] += b - a
+            out = torch.utils.checkpoint.checkpoint(run, carrier, *args, use_reentrant=True, preserve_rng_state=False)
+        outs.append(tuple(out))
+    return tuple(None if outs[0][j] is None else torch.cat([o[j] for o in outs], 0) for j in range(len(outs[0])))

@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import chunking, ops
 from .model import safe_normalize, scene_representation
 
 
@@ -231,8 +231,22 @@ class HotPathRenderer:
             ray_slots = (rays_t.view(B, n_per)[:, 0].contiguous(), slot_ray)
             frame_slots = (ray_slots[0], slot_ray[ri_long()].contiguous())
         t_light = light_d[ri_long()] if lit else None
-        sdf, sigmas, rgbs, normals, deform, normal_raw = model(xyzs, time_step, t_light, ratio=ambient_ratio,
-                                                               shading=shading, cano=cano, frame_slots=frame_slots)
+        # a bound on what the call parks (chunking.py): the main query and the perturbed-normal query of the regulariser in row
+        # chunks when their estimate passes MORPHEUS_MAX_PARK_GB -- chunks but the last re-made in backward
+        tr_ = cfg["train"]
+        with_normals = shading != "albedo"
+        perturb_query = model.training and tr_["normal_smooth_3d"] > 0 and with_normals
+        row_bytes = chunking.query_bytes_per_row(not cano, 1 + (6 if with_normals else 0)) + \
+            (chunking.query_bytes_per_row((not tr_["topo_none"]) and not cano, 6) if perturb_query else 0)
+        chunk_rows = chunking.rows_under_cap(row_bytes, device=rays_o.device) if torch.is_grad_enabled() else M_samples
+        slot_rows = None if frame_slots is None else frame_slots[1]
+
+        def main_query(x_, t_, l_, s_):
+            return model(x_, t_, l_, ratio=ambient_ratio, shading=shading, cano=cano,
+                         frame_slots=None if s_ is None else (frame_slots[0], s_))
+
+        sdf, sigmas, rgbs, normals, deform, normal_raw = chunking.chunked_query(main_query, (xyzs, time_step, t_light, slot_rows),
+                                                                                 chunk_rows)
 
         weights, opacity, depth, rgb_acc = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), rgbs,
                                                          ray_start, ray_cnt, padded=valid is not None)
@@ -260,11 +274,13 @@ class HotPathRenderer:
                     xyzs_p = ops.ortho_perturb(xyzs, normals, self._ortho_angle(normals), tr["smoothness_std"])
                 else:
                     xyzs_p = xyzs + torch.randn_like(xyzs) * tr["smoothness_std"]
-                if tr["topo_none"]:
-                    normals_p, _ = model.normal(xyzs_p, topo=None, cano=cano)
-                else:
-                    normals_p, _ = model.normal(xyzs_p, topo=model.get_topo(xyzs_p, t=time_step, frame_slots=frame_slots),
-                                                cano=cano)
+                def perturbed_normals(x_, t_, s_):
+                    if tr["topo_none"]:
+                        return model.normal(x_, topo=None, cano=cano)[:1]
+                    fs_ = None if s_ is None else (frame_slots[0], s_)
+                    return model.normal(x_, topo=model.get_topo(x_, t=t_, frame_slots=fs_), cano=cano)[:1]
+
+                normals_p, = chunking.chunked_query(perturbed_normals, (xyzs_p, time_step, slot_rows), chunk_rows)
                 results["loss_normal_perturb"] = l1_mean(normals, normals_p)
                 if tr["normal_smooth_3d_t"] > 0:
                     tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames

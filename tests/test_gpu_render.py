@@ -24,7 +24,7 @@ TOL, FLOOR = 1e-4, 1e-2
 DEPTH_FLOOR = 5e-2   # depth lives on [0, ~2.6]: 2% of its range
 
 
-def _setup(kind, case, max_level=None, train=False):
+def _setup(kind, case, max_level=None, train=False, mlp_mode=None):
     from morpheus_amd import harness
     hw, S, nray = {"cfg1": (32, 64, None), "cfg3head": (128, 128, 256)}[case]
     o, d, t, rid = synth.frame_rays(25, hw, hw)
@@ -33,6 +33,7 @@ def _setup(kind, case, max_level=None, train=False):
     N = o.shape[1]
     jit = synth.ray_jitter(N)
     model = harness.build_model(kind, DEV, max_level)
+    model.mlp_mode = mlp_mode          # None: the process default (b3); "f32": native fp32 MFMA in every MLP kernel
     model.train(train)
     # samples are inputs of the parity runs: the goldens were rendered with the oracle's
     # uniform samples of the UN-corrected rays, so feed exactly those (the HIP sampler is checked
@@ -46,14 +47,16 @@ def _setup(kind, case, max_level=None, train=False):
 MODES = ("eval_albedo_deform", "eval_albedo_cano", "eval_lambertian_deform", "train_albedo_deform_pose")
 
 
-@pytest.mark.parametrize("kind", ["a", "b"])
-@pytest.mark.parametrize("case", ["cfg1", "cfg3head"])
-def test_render_rays_vs_reference_goldens(kind, case):
+# the default arithmetic (b3: exact 3 x bf16 operand split) on every case; the caveat-free native-fp32-MFMA mode ("f32") on cfg1, under
+# the same gates -- both are fp32-faithful, and the driver's GPU run sees both
+@pytest.mark.parametrize("kind,case,mlp_mode", [("a", "cfg1", None), ("b", "cfg1", None), ("a", "cfg3head", None), ("b", "cfg3head", None),
+                                                ("a", "cfg1", "f32"), ("b", "cfg1", "f32")])
+def test_render_rays_vs_reference_goldens(kind, case, mlp_mode):
     g = load_golden("render.npz")
     g4 = load_golden("round4.npz")
     for mode in MODES:
         train = mode.startswith("train")
-        model, rend, rays, light, hw, S, N, jit = _setup(kind, case, train=train)
+        model, rend, rays, light, hw, S, N, jit = _setup(kind, case, train=train, mlp_mode=mlp_mode)
         cfg = rend.config
         cfg["train"]["normal_smooth_3d"] = 0.0     # randomised regularisers are compared statistically elsewhere
         cfg["train"]["normal_smoothness"] = 0.0
@@ -184,7 +187,8 @@ def test_full_size_properties():
     assert_close(f(0.3 * c1 + 0.7 * c2), 0.3 * f(c1) + 0.7 * f(c2), 1e-5, "linearity", floor=1e-3)
 
 
-def test_full_size_forward_backward_equals_chunked_renders():
+@pytest.mark.parametrize("mlp_mode", [None, "f32"])
+def test_full_size_forward_backward_equals_chunked_renders(mlp_mode):
     """BASELINE full size WITH gradients (16 384 rays x 128 samples, deform on, the bench's loss): the one-call render and its
     backward -- the large-batch kernels: per-layer weight-gradient launches, persistent field kernels looping over hundreds
     of tiles, brick-binned hash backward with hot bricks in many chunks -- against the SAME rays rendered as 64 calls of 256
@@ -203,6 +207,7 @@ def test_full_size_forward_backward_equals_chunked_renders():
 
     def run(chunk):
         model = harness.build_model("b", DEV).train()
+        model.mlp_mode = mlp_mode                      # None: the default (b3); "f32": native fp32 MFMA
         for k in ("normal_smoothness", "normal_smooth_3d", "code_reg", "ori_weight"):
             model.config["train"][k] = 0.0
         total, first = 0.0, None
@@ -846,6 +851,55 @@ def test_cfg4_step_composition_vs_reference_golden(variant):
     for k in delta:                                                # the background net never gets a gradient: never stepped
         if k.startswith("bg_net"):
             assert k not in moved, k
+
+
+def test_parked_memory_cap_chunks_the_queries(monkeypatch):
+    """MORPHEUS_MAX_PARK_GB (morpheus_amd/chunking.py): over the cap, the main query and the perturbed-normal query of a training
+    render run in row chunks, all but the last through checkpointing (nothing parked in forward, re-made one chunk at a time in
+    backward).  The 72 x 72 virtual-view step (lambertian shading through FD normals, orientation loss, normal_smooth_3d,
+    normal_smoothness, code_reg; the draws injected) with the cap at 0.4 GB -- 16 chunks per query -- against the same step
+    without a cap: same outputs, same loss, same gradients (different summation orders in the weight-gradient and table sums only)."""
+    import numpy as np
+    from morpheus_amd import chunking, harness, trainstep
+    from tests.util import DrawInjector
+    g4 = load_golden("round4.npz")
+    frame, theta, phi, shading, ambient, bg = VIRT72["lam"]
+    hw, S = 72, 24
+    o, d = synth.camera_rays(hw, hw, synth.look_at_pose(theta, phi, 1.5))
+    N = o.shape[0]
+    smp = of.uniform_samples(o, d, synth.ray_jitter(N), S, 1.01)
+    light = of.safe_normalize(o + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
+    npts = None
+
+    def run(cap_gb):
+        monkeypatch.setenv("MORPHEUS_MAX_PARK_GB", str(cap_gb))
+        model = harness.build_model("b", DEV, 0.75).train()
+        rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+        ts = trainstep.VirtualViewTrainStep(rend, res=hw, guidance=trainstep.InjectedGuidance(hw, hw, DEV, scale=5e-3))
+        ts.epoch, ts.keep_outputs = 1000, True
+        data = dict(H=hw, W=hw, rays_o=o[None].to(DEV), rays_d=d[None].to(DEV), rays_t=torch.full((1, N, 1), frame / 200, device=DEV),
+                    rays_id=torch.full((1, N, 1), frame, device=DEV, dtype=torch.int64))
+        keep = np.unpackbits(g4["virt72_lam|keep_bits"])[:int(model.config["train"]["trunc"] * 100 + 1) * N].astype(bool)
+        before = dict(chunking.STATS)
+        with DrawInjector(remap={3: keep}):
+            loss = ts(data=data, shading=shading, ambient_ratio=ambient, bg_color=torch.tensor(bg, device=DEV), light_d=light)
+        loss.backward()
+        stats = {k: chunking.STATS[k] - before[k] for k in before}
+        res = ts.last_outputs
+        return (float(loss), {k: res[k].detach().clone() for k in ("image", "depth", "sdf", "normal", "weights")},
+                {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}, stats)
+
+    l_ref, out_ref, g_ref, st_ref = run(0)             # no bound
+    l_cap, out_cap, g_cap, st_cap = run(0.4)
+    assert st_ref["chunked_calls"] == 0 and st_cap["chunked_calls"] == 2 and st_cap["chunks"] >= 2 * 8, (st_ref, st_cap)
+    assert st_cap["rerun_rows"] > 1.5 * N * S          # both queries, all chunks but the last
+    for k in out_ref:
+        assert torch.equal(out_ref[k], out_cap[k]), k  # forward values do not depend on how the rows are batched
+    assert abs(l_ref - l_cap) <= 1e-6 * abs(l_ref), (l_ref, l_cap)
+    assert set(g_ref) == set(g_cap) and len(g_ref) >= 50
+    for k, a in g_ref.items():
+        rel = float((a.double() - g_cap[k].double()).norm() / a.double().norm().clamp_min(1e-30))
+        assert rel <= 2e-4, (k, rel)
 
 
 def test_two_frames_vs_reference_golden():
