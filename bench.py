@@ -244,9 +244,10 @@ def build_render_workload(args, rank, world, dev):
 
 
 def build_train_real(args, rank, world, dev):
-    """The reference's real-view training step (morpheus_amd/trainstep.py restates morpheus.py:1147-1236 around render_rays)."""
+    """The reference's real-view training step (bench_support/trainstep.py restates morpheus.py:1147-1236 around render_rays)."""
     import torch
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.optim import FlatAdam
     from morpheus_amd.render import HotPathRenderer
@@ -304,7 +305,7 @@ def build_train_real(args, rank, world, dev):
             f"occupancy-marched ragged samples (step 0.01, {occ * 100:.1f}% of 128^3 cells occupied), albedo_normal, "
             "normal_smooth_3d + normal_smoothness + code_reg, depth/mask/sdf/surface-point losses, pose optimisation, "
             "occupancy refresh every 16 steps, Adam")
-    desc += {"fused": "; caller-side losses: this build's fused glue (morpheus_amd/trainstep.py)",
+    desc += {"fused": "; caller-side losses: this build's fused glue (bench_support/trainstep.py)",
              "reference": "; caller-side losses: the reference's own operator chains + loss.item() per step (INTEGRATION.md's three "
                           "edits only)",
              "reference_scoped": "; caller-side losses: the reference's own operator chains + loss.item() per step, plus ONE line: "
@@ -341,7 +342,8 @@ def build_train_virtual(args, rank, world, dev):
     rates frozen for the virtual step (epochs <= freeze_epoch, :1394-1409) the reference steps the optimiser after it: so does
     this step, with those groups' learning rate at 0."""
     import torch
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.optim import FlatAdam
     from morpheus_amd.render import HotPathRenderer
@@ -400,7 +402,8 @@ def build_train_loop(args, rank, world, dev):
     by `real_freq` = 10 real-view steps of 2048 rays with an optimiser step each, then the reference's loss.item().  Both kinds of
     step share the model, the occupancy grid (refreshed every 16 global steps) and the optimiser."""
     import torch
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.optim import FlatAdam
     from morpheus_amd.render import HotPathRenderer

@@ -29,7 +29,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
-from . import ops, synth
+from morpheus_amd import ops, synth
 
 
 # ------------------------------------------------------------------------------------------ synthetic real-view frames
@@ -592,7 +592,10 @@ class GraphedRealViewStep:
     def level_key(self):
         """what the captured kernels read of model.max_level: (frequency bands, hash-grid levels)"""
         m = self.ts.model
-        return (m._n_bands(), ops.effective_levels(m.max_level, m.encoder.num_levels))
+        key = (m._n_bands(), ops.effective_levels(m.max_level, m.encoder.num_levels))
+        if getattr(m, "encode_topo", False):      # the topology encoding's band count int(max_level * 4) is not implied by the two above
+            key += (None if m.max_level is None else int(m.max_level * 4),)
+        return key
 
     def _body(self, capacity: int):
         # fixed capacity and the static jitter buffer are properties of THIS body, not of the renderer's shared occupancy grid:

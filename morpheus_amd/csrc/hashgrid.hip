@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ g
 #define FX_BITS 40
 #define FX_MAGIC 6755399441055744.0                 // 1.5 * 2^52
 #define FX_MAGIC_BITS 0x4338000000000000ULL
+#define FX_LIMIT 1099511627776.0f                   // 2^40: the fixed-point range a scaled gradient is clamped to
 __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float &from_fx) {
     int e = (int)(maxbits >> 23) + 1;   // biased exponent of the power of two above max|grad|
     e = max(e, 60);                     // gradients below 2^-67 are accumulated with a fixed (coarser) scale
@@ -454,7 +455,11 @@ __global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float
             // fixed point of w * g: a float -> int64 conversion is ~11 VALU instructions and there are 16 per (point, level) -- a
             // quarter of the loop.  In double, w * (g 2^k) + 1.5 * 2^52 has the integer (|q| <= 2^40 < 2^51, round to nearest of
             // the EXACT 48-bit product) in its low bits: q = bits - bits(1.5 * 2^52), one v_fma_f64 and one 32-bit add.
-            const double gxd = (double)(gr.x * to_fx), gyd = (double)(gr.y * to_fx);
+            // (the magic add is exact only below 2^51: a NaN / Inf gradient or a stale maximum word must saturate to ONE bounded
+            //  contribution, not write arbitrary bit patterns into the brick's accumulators -- one v_med3_f32 per value, outside the
+            //  corner loop; v_med3 returns the smallest operand when one is a NaN)
+            const double gxd = (double)__builtin_amdgcn_fmed3f(gr.x * to_fx, -FX_LIMIT, FX_LIMIT),
+                         gyd = (double)__builtin_amdgcn_fmed3f(gr.y * to_fx, -FX_LIMIT, FX_LIMIT);
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const float w = ((c & 1) ? f[0] : 1.f - f[0]) * ((c & 2) ? f[1] : 1.f - f[1]) * ((c & 4) ? f[2] : 1.f - f[2]);

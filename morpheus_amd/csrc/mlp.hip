@@ -897,7 +897,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         b1[mt] += __shfl_xor(b1[mt], 32);
         b0[mt] += __shfl_xor(b0[mt], 32);
     }
-    // the workgroup's partial = the sum of its four waves' (acc_to_lds above): 10 accumulator tiles + 5 bias rows = 41 KB of LDS
+    // the workgroup's partial = the sum of its four waves' (acc_to_lds above): 12 accumulator tiles + 6 bias rows = ~50 KB of LDS
     float *red = reinterpret_cast<float *>(lds_fused);
     for (int src = 1; src < FUSED_THREADS / 64; src++) {
         __syncthreads();

@@ -798,7 +798,7 @@ class _PackOperands(torch.autograd.Function):
             w3 = torch.zeros((jp.fwd2_total_f4 + jp.bwd2_total_f4) * 4, device=flat.device)
             for key, blocks, table, base in (("fwd3", jp.h2_blocks, jp.h2_table, 0),
                                              ("bwd3", jp.h2T_blocks, jp.h2T_table, jp.fwd2_total_f4)):
-                if key == "bwd3" and not jp.sliced_bwd:
+                if key == "bwd3" and not jp.sliced_bwd_for(b3):
                     continue
                 src = flat[m[key]]
                 so, sp = _i32arr([b[0] for b in blocks])
@@ -814,7 +814,7 @@ class _PackOperands(torch.autograd.Function):
             lib = _lib.load()
             w3 = torch.zeros((jp.fwd3_total_f4 + jp.bwd3_total_f4) * 4, device=flat.device)
             for key, layers, base in (("fwd3", jp.b3_layers, 0), ("bwd3", jp.b3T_layers, jp.fwd3_total_f4)):
-                if key == "bwd3" and not jp.sliced_bwd:
+                if key == "bwd3" and not jp.sliced_bwd_for(b3):
                     continue
                 src = flat[m[key]]
                 so, sp = _i32arr([l[0] for l in layers])

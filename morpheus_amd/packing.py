@@ -346,11 +346,18 @@ class JointPacker:
       natural   : [dW net 0 | dW net 1 | ... | db net 0 | db net 1 | ...]
     """
 
+    def sliced_bwd_for(self, mode) -> bool:
+        """are the transposed layers sliced in arithmetic mode `mode` ("b3" / "h2"; the kernels' b3 flag spells b3 as True)?"""
+        mode = "b3" if mode is True else mode
+        return self.sliced_bwd and mode in self.sliced_bwd_modes
+
     def __init__(self, packers: Sequence[NetPacker], skip_first_bias: bool, sliced_bwd: bool = True):
         self.packers = list(packers)
         # sliced_bwd: do the sliced (bf16 x 3 / fp16 x 2) kernels read TRANSPOSED slices of these nets?  The warp nets'
-        # backward-data does; the field nets' fused backward runs on the fp32 MFMA and reads the fp32 transposed pack only
+        # backward-data does in both sliced modes; the field nets' fused backward has a bf16 x 3 form (mode b3) but runs on the fp32
+        # MFMA in the f32 and h2 modes, which read the fp32 transposed pack only (sliced_bwd_for)
         self.sliced_bwd = sliced_bwd
+        self.sliced_bwd_modes = ("b3", "h2")
         nW = sum(p.n_weights for p in self.packers)
         nB = sum(p.n_biases for p in self.packers)
         zero = nW + nB
@@ -522,5 +529,7 @@ def warp_joint_packer() -> JointPacker:
 
 def field_joint_packer() -> JointPacker:
     if "field_joint" not in _PACKERS:
-        _PACKERS["field_joint"] = JointPacker([field_packer()], skip_first_bias=False)
+        jp = JointPacker([field_packer()], skip_first_bias=False)
+        jp.sliced_bwd_modes = ("b3",)          # h2: nothing reads fp16 slices of the transposed field layers (fp32-MFMA fused backward)
+        _PACKERS["field_joint"] = jp
     return _PACKERS["field_joint"]

@@ -408,7 +408,7 @@ def real_view_case(kind="b", hw=32, S=64, n_keep=96):
 def gen_extras():
     import morpheus as ref_morpheus
     from datasets.utils import get_camera_rays
-    from morpheus_amd import trainstep
+    from bench_support import trainstep
     g = {}
     # ---- a1: ray generation = get_camera_rays (datasets/utils.py:28-65) + the c2w application of dataset.py:355-366
     for tag, (H, W) in (("sq", (24, 24)), ("rect", (20, 28))):
@@ -554,7 +554,7 @@ def keep_mask_of_smoothness_points(res_depth, rays_o, rays_d, trunc, offsets_dra
 
 def gen_round4():
     import morpheus as ref_morpheus
-    from morpheus_amd import trainstep
+    from bench_support import trainstep
     g = {}
     # ---- (1) float64 yardstick of the counted gate: the six evaluation renders of the parity table (2 weight states x
     #      {cfg1 deform, cfg1 canonical, cfg3-head deform}) by the imported reference in double
@@ -649,7 +649,7 @@ def gen_round5():
     Adam with eps = 1e-15 moves every touched element by exactly +-lr, which would pin signs only.  Stored: the group learning rates,
     the two losses, and per-tensor digests of the parameter DELTAS."""
     import morpheus as ref_morpheus
-    from morpheus_amd import trainstep
+    from bench_support import trainstep
     g = {}
     hw_v, S_v = 72, 24
     frame_v, theta, phi, shading_v, ambient_v, bg_v = 140, 70.0, 35.0, "lambertian", 0.55, torch.tensor([0.2, 0.5, 0.7])

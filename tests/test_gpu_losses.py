@@ -175,7 +175,8 @@ def test_pose_apply_equals_the_operator_chain(B, n):
 def test_fused_render_loss_equals_the_reference_chain():
     """trainstep.get_gt_from_data + get_real_view_render_loss (the reference's morpheus.py:930-983 as torch operators) against
     ops.real_view_render_loss: the weighted loss, its three terms, the composited target, the valid-depth mask and the gradients."""
-    from morpheus_amd import harness, ops, trainstep
+    from morpheus_amd import harness, ops
+    from bench_support import trainstep
     torch.manual_seed(2)
     N = 3000
     tr = harness.load_config()["train"]

@@ -429,7 +429,8 @@ def test_real_view_step_vs_reference_golden():
     closed-form draws are injected here): numeric values of loss_normal_perturb and normal_reg, not finiteness.
     FD normals amplify round-off x250, so quantities that pass through them are compared at 2e-2."""
     import numpy as np
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from tests.util import DrawInjector
     g = load_golden("extras.npz")
     sel = torch.from_numpy(g["realview|sel"].astype(np.int64))
@@ -659,7 +660,8 @@ def test_virtual_view_step_72_vs_reference_golden(tag):
     smoothness angles on the boolean-indexed points inside the 1.1 sphere; its keep mask rides in the fixture so that the
     same points get the same angles here (tests/util.py: DrawInjector remap)."""
     import numpy as np
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from tests.util import DrawInjector
     g = load_golden("round4.npz")
     frame, theta, phi, shading, ambient, bg = VIRT72[tag]
@@ -737,7 +739,8 @@ def test_cfg4_step_composition_vs_reference_golden(variant):
     seeded so that a move is proportional to its gradient).  Here: VirtualViewTrainStep + RealViewTrainStep (fused glue, the background
     colour drawn as train_step draws it) + FlatAdam with the groups matched BY NAME."""
     import numpy as np
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from morpheus_amd.optim import FlatAdam
     from tests.util import DrawInjector
     g, g4 = load_golden("round5.npz"), load_golden("round4.npz")
@@ -860,7 +863,8 @@ def test_parked_memory_cap_chunks_the_queries(monkeypatch):
     normal_smoothness, code_reg; the draws injected) with the cap at 0.4 GB -- 16 chunks per query -- against the same step
     without a cap: same outputs, same loss, same gradients (different summation orders in the weight-gradient and table sums only)."""
     import numpy as np
-    from morpheus_amd import chunking, harness, trainstep
+    from morpheus_amd import chunking, harness
+    from bench_support import trainstep
     from tests.util import DrawInjector
     g4 = load_golden("round4.npz")
     frame, theta, phi, shading, ambient, bg = VIRT72["lam"]
@@ -886,7 +890,7 @@ def test_parked_memory_cap_chunks_the_queries(monkeypatch):
         loss.backward()
         stats = {k: chunking.STATS[k] - before[k] for k in before}
         res = ts.last_outputs
-        return (float(loss), {k: res[k].detach().clone() for k in ("image", "depth", "sdf", "normal", "weights")},
+        return (float(loss.detach()), {k: res[k].detach().clone() for k in ("image", "depth", "sdf", "normal", "weights")},
                 {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}, stats)
 
     l_ref, out_ref, g_ref, st_ref = run(0)             # no bound
@@ -900,6 +904,66 @@ def test_parked_memory_cap_chunks_the_queries(monkeypatch):
     for k, a in g_ref.items():
         rel = float((a.double() - g_cap[k].double()).norm() / a.double().norm().clamp_min(1e-30))
         assert rel <= 2e-4, (k, rel)
+
+
+def test_in_place_gradient_sums_under_other_autograd_entry_points():
+    """The field queries of a step add their weight / beta / table gradients into shared tensors that the operand pack's backward
+    hands over (ops._QueryAccumulator, keyed on the autograd graph task).  Besides loss.backward() that has to hold for
+    torch.autograd.grad(inputs=...) (the pack node may be pruned: only some leaves asked for), for two backward passes over one
+    retained graph, and for a plain backward AFTER those -- each against the per-query form (ACCUMULATE_IN_PLACE off)."""
+    from morpheus_amd import harness, ops
+    hw, S = 16, 32
+    o, d, t, rid = [v.to(DEV) for v in synth.frame_rays(25, hw, hw)]
+    N = o.shape[1]
+    timg, tdep = [v.to(DEV) for v in synth.targets(N)]
+    light = of.safe_normalize(o[0].cpu() + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
+
+    def build():
+        model = harness.build_model("b", DEV, 0.75).train()
+        for k in ("normal_smoothness", "normal_smooth_3d"):
+            model.config["train"][k] = 0.0
+        rend = harness.make_renderer(model, S, jitter=synth.ray_jitter(N).to(DEV))
+        res = rend.render_rays(o, d, t, rid, hw, hw, ambient_ratio=0.4, light_d=light, shading="lambertian", real_view=False)
+        return model, harness.bench_loss(res, timg, tdep) + res["loss_orient"] + res["loss_code"]
+
+    def named(model, keys):
+        p = dict(model.named_parameters())
+        return [p[k] for k in keys]
+
+    field_keys = ["encoder.embeddings", "encoder_c.embeddings", "sdf2density.beta", "sdf_net.net.1.weight", "color_net.net.0.weight_v"]
+    warp_keys = ["deform_net.net.2.weight_v", "topo_net.net.5.bias", "deform_code.volumes.2"]
+    saved = ops.ACCUMULATE_IN_PLACE
+    try:
+        ops.ACCUMULATE_IN_PLACE = False
+        model, loss = build()
+        loss.backward()
+        want = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        ops.ACCUMULATE_IN_PLACE = saved
+        assert ops.ACCUMULATE_IN_PLACE, "this torch has no graph-task id: nothing to test"
+
+        def close(got, k, scale=1.0):
+            rel = float((got.double() - scale * want[k].double()).norm() / (scale * want[k].double().norm()).clamp_min(1e-30))
+            assert rel <= 2e-5, (k, rel)
+
+        # (a) autograd.grad for the leaves behind the pack (tables, beta, field weights) and for warp-side leaves only (pack pruned)
+        model, loss = build()
+        for keys in (field_keys, warp_keys, field_keys[:1] + warp_keys[:1]):
+            for k, gk in zip(keys, torch.autograd.grad(loss, named(model, keys), retain_graph=True)):
+                close(gk, k)
+        # (b) ... then two plain backward passes over the same retained graph: every gradient exactly twice
+        loss.backward(retain_graph=True)
+        loss.backward()
+        for k, p in model.named_parameters():
+            if p.grad is not None and k in want:
+                close(p.grad, k, 2.0)
+        # (c) a fresh step afterwards is untouched by what the earlier passes left behind
+        model, loss = build()
+        loss.backward()
+        for k, p in model.named_parameters():
+            if p.grad is not None and k in want:
+                close(p.grad, k)
+    finally:
+        ops.ACCUMULATE_IN_PLACE = saved
 
 
 def test_two_frames_vs_reference_golden():
@@ -999,7 +1063,8 @@ def test_graphed_real_view_step_replays_the_eager_step():
     gradient bucket equal the eager step's on the same frame; (ii) un-pinned, three replays give finite, different losses,
     the optimiser moves the parameters, the sample count stays under the capacity (the next batch is drawn and counted on a
     side stream while a replay runs); (iii) a progressive-level change captures a graph of its own."""
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.optim import FlatAdam
     from morpheus_amd.render import HotPathRenderer
@@ -1122,7 +1187,8 @@ def test_reference_glue_equals_fused_glue():
     """bench.py --workload train_real --glue reference: the reference's own caller-side loss code (trainstep.ReferenceGlue: operator
     chains, in-place masks, the boolean index of morpheus.py:1018) around the swapped-in render_rays gives the loss and the
     gradients of this build's fused glue (ops.real_view_render_loss / masked_mean / weighted_sum) on the same batch and draws."""
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.render import HotPathRenderer
     out = {}
@@ -1155,7 +1221,8 @@ def test_field_queries_accumulate_gradients_in_place():
     each inside their kernels (first query returns it to autograd, later ones return None) -- the same gradients as one tensor per
     query summed by autograd, with fewer launches."""
     from torch.utils._python_dispatch import TorchDispatchMode
-    from morpheus_amd import harness, ops, trainstep
+    from morpheus_amd import harness, ops
+    from bench_support import trainstep
     from morpheus_amd.occgrid import OccupancyGrid
     from morpheus_amd.render import HotPathRenderer
 
@@ -1286,7 +1353,8 @@ def test_composed_field_path_equals_fused_path_through_a_training_render():
     and encode_topo=True whose extra first-layer columns are ZERO computes the shipped model's function (same weights otherwise),
     so its real-view training render, loss terms and gradients must equal the fused kernels' -- through rocBLAS instead of the
     MFMA kernels -- and the appearance code gets an exactly-zero gradient."""
-    from morpheus_amd import harness, trainstep
+    from morpheus_amd import harness
+    from bench_support import trainstep
     from morpheus_amd.model import scene_representation
     from tests.util import DrawInjector
     hw, S, N = 16, 32, 96

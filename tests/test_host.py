@@ -440,7 +440,8 @@ def test_virtual_view_step_host_logic():
     gradient, the arithmetic-mode tag bound to a pack."""
     import types
     import torch
-    from morpheus_amd import harness, ops, trainstep
+    from morpheus_amd import harness, ops
+    from bench_support import trainstep
     cfg = harness.load_config()
     fake_model = types.SimpleNamespace(config=cfg)
     vs = trainstep.VirtualViewTrainStep(types.SimpleNamespace(model=fake_model, config=cfg, occupancy_grid=None), res=72, seed=1)
@@ -499,3 +500,16 @@ def test_query_accumulator_joins_by_identity_and_resets_per_backward_pass():
     assert r0 is None and r1 is not None and r2 is None and r3 is not None
     raw, tabs = acc.collect()                        # a different (here: no) pass: nothing stale is handed over
     assert raw is None and tabs == [None, None]
+
+
+def test_sliced_pack_sizes_match_the_kernels_staging_sizes():
+    """The host side lays the bf16 x 3 operand packs out (packing.py), the kernels stage them into LDS by fixed offsets: the two must
+    agree on every total, or a kernel would read past / short of a pack.  Host functions of the library, no GPU."""
+    from morpheus_amd import _lib, packing
+    lib = _lib.load()
+    fj, wj = packing.field_joint_packer(), packing.warp_joint_packer()
+    assert fj.fwd3_total_f4 * 16 == lib.mh_field_w3_bytes() and fj.bwd3_total_f4 * 16 == lib.mh_field_w3T_bytes()
+    assert wj.fwd3_total_f4 * 16 == 2 * lib.mh_warp_w3_bytes() and wj.bwd3_total_f4 * 16 == 2 * lib.mh_warp_w3T_bytes()
+    # the transposed field layers are sliced for the bf16 x 3 fused backward only (h2 and f32 run it on the fp32 MFMA)
+    assert fj.sliced_bwd_for("b3") and fj.sliced_bwd_for(True) and not fj.sliced_bwd_for("h2")
+    assert wj.sliced_bwd_for("b3") and wj.sliced_bwd_for("h2")

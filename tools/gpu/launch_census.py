@@ -9,7 +9,8 @@ import argparse, collections, os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
-from morpheus_amd import harness, trainstep
+from morpheus_amd import harness
+from bench_support import trainstep
 from morpheus_amd.occgrid import OccupancyGrid
 from morpheus_amd.optim import FlatAdam
 from morpheus_amd.render import HotPathRenderer
