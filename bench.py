@@ -485,7 +485,7 @@ PIPE = {"f32": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS),
         "h2": ("fp16 MFMA (v_mfma_f32_32x32x16_f16)", BF16_MFMA_PEAK_TFLOPS)}
 # kernel symbols (rocprofv3 names, profiles/*_pmc_summary.csv) behind each timed C-ABI entry, per arithmetic mode
 SYMBOLS = {
-    "mh_warp_fwd": {"f32": ["warp_fwd_kernel"], "b3": ["warp_fwd_b3_kernel<8>"], "h2": ["warp_fwd_h2_kernel<4>"]},
+    "mh_warp_fwd": {"f32": ["warp_fwd_kernel"], "b3": ["warp_fwd_b3_kernel<8, true>"], "h2": ["warp_fwd_h2_kernel<4>"]},
     "mh_warp_bwd_data": {"f32": ["warp_bwd_kernel"], "b3": ["warp_bwd_b3_kernel<8>"], "h2": ["warp_bwd_h2_kernel<8>"]},
     "mh_mlp_wgrad[warp]": {"f32": ["wgrad_kernel<4, false>", "wgrad_kernel<2, false>", "wgrad_reduce_kernel"],
                            "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"],
@@ -513,8 +513,9 @@ def pmc_step_bytes(symbols, mode):
     same arithmetic mode (profiles/r0N_pmc_summary[_mode].csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB
     units, separate passes).  None when no matching profile is committed."""
     import csv
-    for rnd in ("r04", "r03", "r02"):
-        for name in (f"{rnd}_pmc_summary_{mode}.csv", f"{rnd}_pmc_summary.csv"):
+    for rnd in ("r05", "r04", "r03", "r02"):
+        # the un-suffixed summary is the default mode's (b3); another mode only matches its own passes
+        for name in (f"{rnd}_pmc_summary_{mode}.csv",) + ((f"{rnd}_pmc_summary.csv",) if mode == "b3" else ()):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
@@ -588,7 +589,7 @@ def build_roofline(ktab, mode, M, workload, full_size):
     out["largest_item_of_step"] = True
     out["traffic_note"] = ("HBM bytes per step of this item's kernels from the committed rocprofv3 --pmc passes (profiles/" +
                            str(out.pop("traffic_source")) + ")") if out["traffic"] else \
-        "null: no committed PMC profile matches this workload / mode (tools/gpu/r4_round.sh collects it)"
+        "null: no committed PMC profile matches this workload / mode (tools/gpu/r5_round.sh collects it)"
     out["algorithmic_bytes_note"] = ("SURVEY 8(d): inputs in + results out per point (everything else is recomputable on the chip); "
                                      "traffic far above it is the design's activation parking (DESIGN.md section 3)")
     out["hbm"]["note"] = ("bytes this design moves by construction (parked activation / pre-activation-gradient tiles, each row written "

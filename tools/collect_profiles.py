@@ -3,8 +3,11 @@
 
   python tools/collect_profiles.py [round-tag, default r01]
 
-Inputs (written by tools/gpu/r4_round.sh on the GPU box):
-  gpurun_out/bench.log, bench_cfg2.log, bench_cfg3b.log   -> profiles/<tag>_bench_<workload>.json (the JSON line)
+Inputs (written by tools/gpu/r5_round.sh on the GPU box):
+  gpurun_out/bench.log, bench_cfg2.log, bench_cfg3b.log   -> profiles/<tag>_bench_<workload>.json (bench.py's LAST stdout line: the
+                                                             compact object the driver parses)
+  gpurun_out/bench_detail_<workload>.json                  -> profiles/<tag>_bench_<workload>_detail.json (the full object: kernel
+                                                             tables, per-mode lines, notes, allocator statistics)
   gpurun_out/prof/runc/*_kernel_stats.csv                  -> profiles/<tag>_bench_cfg3_kernel_stats.csv
   gpurun_out/prof_cfg3b/runc/*_kernel_stats.csv            -> profiles/<tag>_bench_cfg3b_kernel_stats.csv
   gpurun_out/parity.log                                    -> profiles/<tag>_parity_report.jsonl
@@ -42,12 +45,14 @@ def latest(pattern):
 
 
 def json_line(path):
+    """the LAST line of the log that is a JSON object (bench.py prints the driver's compact line last)"""
     if not fresh(path):
         return None
+    found = None
     for line in open(path):
         if line.startswith("{"):
-            return line
-    return None
+            found = line
+    return found
 
 
 def short(name):
@@ -93,7 +98,7 @@ def pmc_summary(tag, suffix="", steps_in_run=3):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     os.makedirs(PROF, exist_ok=True)
     for log, wl in (("bench.log", "cfg3"), ("bench_cfg2.log", "cfg2"), ("bench_cfg3b.log", "cfg3b"),
                     ("bench_train_real.log", "train_real"), ("bench_train_real_graph.log", "train_real_hip_graph"),
@@ -103,7 +108,11 @@ def main():
         line = json_line(os.path.join(OUT, log))
         if line:
             open(os.path.join(PROF, f"{tag}_bench_{wl}.json"), "w").write(line)
-            print("bench", wl)
+            print("bench", wl, len(line), "bytes")
+        det = os.path.join(OUT, "bench_detail_" + {"bench.log": "cfg3", "bench_n2.log": "n2", "bench_train_real_graph.log": "train_real_graph",
+                                                   "bench_train_virtual.log": "train_virtual"}.get(log, log[len("bench_"):-len(".log")]) + ".json")
+        if line and fresh(det):
+            shutil.copy(det, os.path.join(PROF, f"{tag}_bench_{wl}_detail.json"))
     for d, wl in (("prof", "cfg3"), ("prof_h2", "cfg3_h2"), ("prof_f32", "cfg3_f32"), ("prof_train_real", "train_real")):
         f = latest(f"{d}/*/*_kernel_stats.csv")
         if f:
@@ -115,11 +124,11 @@ def main():
         if lines:
             open(os.path.join(PROF, f"{tag}_parity_report.jsonl"), "w").writelines(lines)
             print("parity", len(lines), "records")
-    for log, name in (("phase_trace.log", "phase_trace_warp_fwd_fp32_mfma.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd_bf16x3.txt"),
-                      ("phase_trace_h2.log", "phase_trace_warp_fwd.txt"), ("phase_trace_field_bwd.log", "phase_trace_field_bwd.txt"),
+    for log, name in (("phase_trace_field_bwd.log", "phase_trace_field_bwd.txt"),
                       ("census_fused.log", "launch_census_train_real.txt"), ("census_ref.log", "launch_census_train_real_reference_glue.txt"),
                       ("hbm_rates.log", "micro_hbm_rates.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
                       ("mfma_bf16_rate.log", "micro_mfma_bf16_rate.txt"), ("hbm_read.log", "micro_hbm_read.txt"),
+                      ("mfma_valu_gap.log", "micro_mfma_valu_gap.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd_pair.txt"),
                       ("parity_f64.jsonl", "parity_f64.jsonl"),
                       ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt"),
                       ("precision_report.jsonl", "precision_report.jsonl"),
