@@ -44,13 +44,52 @@ __device__ __forceinline__ uint32_t grid_row(uint32_t cx, uint32_t cy, uint32_t 
     return pow2 ? (idx & (T - 1)) : (idx % T);
 }
 
+// the rows of a cell's eight corners (corner c: bit 0 -> x + 1, bit 1 -> y + 1, bit 2 -> z + 1): the per-axis terms of
+// get_grid_index are formed ONCE for the two y and the two z values -- four 32-bit multiplies (v_mul_lo_u32: quarter rate) per cell
+// instead of two or three per corner; the same integers as grid_row() corner by corner
+__device__ __forceinline__ void grid_rows8(const uint32_t (&g)[3], const uint32_t (&g1)[3], uint32_t res, uint32_t T, bool dense,
+                                           bool pow2, uint32_t (&row)[8]) {
+    uint32_t ay[2], az[2];
+    if (dense) {
+        ay[0] = g[1] * res, ay[1] = g1[1] * res;
+        az[0] = g[2] * res * res, az[1] = g1[2] * res * res;
+    } else {
+        ay[0] = g[1] * 2654435761u, ay[1] = g1[1] * 2654435761u;
+        az[0] = g[2] * 805459861u, az[1] = g1[2] * 805459861u;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const uint32_t cx = (c & 1) ? g1[0] : g[0], y = ay[(c >> 1) & 1], z = az[(c >> 2) & 1];
+        if (dense) {
+            row[c] = cx + y + z;
+        } else {
+            const uint32_t idx = cx ^ y ^ z;
+            row[c] = pow2 ? (idx & (T - 1)) : (idx % T);
+        }
+    }
+}
+
+// n / d, correctly rounded (what the reference's fp32 `/` gives), for a divisor that stays the same over many quotients: hipcc
+// expands an IEEE division into ~14 VALU instructions (scale, reciprocal, two refinements, fix-up), and every (point, level) lane
+// of the grid kernels did three of them -- a tenth of the brick backward's instruction stream.  With r = RN(1 / d) (ONE division,
+// hoisted out of the loops: d = 2 bound is a kernel argument) two residual corrections give the correctly rounded quotient
+// (Markstein: q' = RN(q + RN(n - d q) r) is correctly rounded once q is within an ulp and r is the correctly rounded reciprocal);
+// checked against exact rational arithmetic on 2.2e5 numerators for seven divisors (tools/micro/README.md).  No scaling: the
+// operands here are O(1), far from the subnormal / overflow ranges the compiler's fix-up instructions exist for.
+__device__ __forceinline__ float exact_div(float n, float d, float r) {
+    const float q0 = n * r;
+    const float q1 = fmaf(fmaf(-d, q0, n), r, q0);
+    return fmaf(fmaf(-d, q1, n), r, q1);
+}
+
 // position inside level: returns false if the point is outside [0,1]^3
 __device__ __forceinline__ bool grid_locate(const float *__restrict__ x, int64_t p, float bound, float two_bound,
                                             uint32_t res, uint32_t g[3], float f[3]) {
     bool inb = true;
+    const float inv = 1.0f / two_bound;                // loop-invariant in every caller
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        float u = (x[p * 3 + d] + bound) / two_bound;  // grid.py:157, fp32 add then IEEE divide
+        float u = exact_div(x[p * 3 + d] + bound, two_bound, inv);  // grid.py:157, fp32 add then IEEE divide
         inb = inb && !(u < 0.0f || u > 1.0f);
         float pos = fminf(fmaxf(fmaf(u, (float)res, -0.5f), 0.0f), (float)(res - 1));
         float fl = floorf(pos);
@@ -77,13 +116,12 @@ __global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__
         float f[3];
         if (grid_locate(x, p, bound, two_bound, res, g, f)) {
             const float2 *tab = emb + meta.offsets[l];
-            const uint32_t g1x = min(g[0] + 1, res - 1), g1y = min(g[1] + 1, res - 1), g1z = min(g[2] + 1, res - 1);
+            const uint32_t g1[3] = {min(g[0] + 1, res - 1), min(g[1] + 1, res - 1), min(g[2] + 1, res - 1)};
+            uint32_t row[8];
+            grid_rows8(g, g1, res, T, dense, pow2, row);
             float2 v[8];
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                uint32_t cx = (c & 1) ? g1x : g[0], cy = (c & 2) ? g1y : g[1], cz = (c & 4) ? g1z : g[2];
-                v[c] = tab[grid_row(cx, cy, cz, res, T, dense, pow2)];
-            }
+            for (int c = 0; c < 8; c++) v[c] = tab[row[c]];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 float w = ((c & 1) ? f[0] : 1.f - f[0]) * ((c & 2) ? f[1] : 1.f - f[1]) * ((c & 4) ? f[2] : 1.f - f[2]);
@@ -127,12 +165,11 @@ __global__ __launch_bounds__(256) void grid_fwd_grouped_kernel(const float *__re
         float2 r = make_float2(0.f, 0.f);
         if (grid_locate(x, p, bound, two_bound, res, g, f)) {
             if (g[0] != cg[0] || g[1] != cg[1] || g[2] != cg[2]) {
-                const uint32_t g1x = min(g[0] + 1, res - 1), g1y = min(g[1] + 1, res - 1), g1z = min(g[2] + 1, res - 1);
+                const uint32_t g1[3] = {min(g[0] + 1, res - 1), min(g[1] + 1, res - 1), min(g[2] + 1, res - 1)};
+                uint32_t row[8];
+                grid_rows8(g, g1, res, T, dense, pow2, row);
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    uint32_t cx = (c & 1) ? g1x : g[0], cy = (c & 2) ? g1y : g[1], cz = (c & 4) ? g1z : g[2];
-                    v[c] = tab[grid_row(cx, cy, cz, res, T, dense, pow2)];
-                }
+                for (int c = 0; c < 8; c++) v[c] = tab[row[c]];
                 cg[0] = g[0], cg[1] = g[1], cg[2] = g[2];
             }
 #pragma unroll
@@ -250,9 +287,10 @@ struct BrickMeta {
 
 __device__ __forceinline__ int brick_of(const float *__restrict__ x, int64_t p, float bound, float two_bound) {
     int b[3];
+    const float inv = 1.0f / two_bound;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        const float u = (x[p * 3 + d] + bound) / two_bound;
+        const float u = exact_div(x[p * 3 + d] + bound, two_bound, inv);
         if (u < 0.0f || u > 1.0f) return NBRK;  // out of range: no gradient (gridencoder.cu:279-284)
         b[d] = min((int)floorf(u * (float)BRK), BRK - 1);
     }
@@ -395,8 +433,11 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
 // accumulator; two workgroups per CU): 0.66 -> 0.52 ms (1.03 -> 0.87 ms with d/dx).  What is left is the LDS atomic
 // pipe: the 4 points a wave carries share their coarse-level cells, so every ds_add_u64 pays the 4-way same-address rate.
 #define BRK_THREADS 1024
+#ifndef BRK_WAVES_PER_SIMD
+#define BRK_WAVES_PER_SIMD 8   // two 16-wave workgroups per CU: 64 registers per lane (the d/dx forms had grown to 73-80 and ran ONE workgroup per CU)
+#endif
 template <int NEED_DX>      // 0: no d/dx; 1: grad_x = d/dx (pre-zeroed by the host side); 2: grad_x += d/dx
-__global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float2 *__restrict__ grad, const float *__restrict__ x,
+__global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_brick_kernel(const float2 *__restrict__ grad, const float *__restrict__ x,
                                                              const float2 *__restrict__ emb, GridMeta meta, BrickMeta bm,
                                                              const int32_t *__restrict__ perm,
                                                              const int32_t *__restrict__ brick_start,
@@ -463,7 +504,8 @@ __global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const float w = ((c & 1) ? f[0] : 1.f - f[0]) * ((c & 2) ? f[1] : 1.f - f[1]) * ((c & 4) ? f[2] : 1.f - f[2]);
-                const int li = ((c & 1) ? lx1 : lx0) + nn * (((c & 2) ? ly1 : ly0) + nn * ((c & 4) ? lz1 : lz0));
+                // (24-bit multiplies: a brick has < 2^12 vertices per level, v_mul_lo_u32 is a quarter-rate instruction)
+                const int li = ((c & 1) ? lx1 : lx0) + __mul24(nn, ((c & 2) ? ly1 : ly0) + __mul24(nn, (c & 4) ? lz1 : lz0));
                 const double wd = (double)w;
                 const unsigned long long qx = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gxd, FX_MAGIC)) - FX_MAGIC_BITS;
                 const unsigned long long qy = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gyd, FX_MAGIC)) - FX_MAGIC_BITS;
@@ -472,9 +514,10 @@ __global__ __launch_bounds__(BRK_THREADS) void grid_bwd_brick_kernel(const float
             }
             if (NEED_DX) {
                 float2 v[8];
+                uint32_t row[8];
+                grid_rows8(g, g1, res, T, dense, pow2, row);
 #pragma unroll
-                for (int c = 0; c < 8; c++)
-                    v[c] = tab[grid_row((c & 1) ? g1[0] : g[0], (c & 2) ? g1[1] : g[1], (c & 4) ? g1[2] : g[2], res, T, dense, pow2)];
+                for (int c = 0; c < 8; c++) v[c] = tab[row[c]];
                 const float s = (float)res;
 #pragma unroll
                 for (int d = 0; d < 3; d++) {

@@ -616,6 +616,9 @@ __device__ __forceinline__ const float *acc_add_lds(f32x16 (&a)[N], const float 
 }
 
 // ---- the same two primitives with exact fp32 products on the bf16 matrix pipe (mlp_b3.hip's arithmetic) -------------------
+#ifndef FUSED_FILL
+#define FUSED_FILL 0        // measured round 5: 4 fillers per MFMA made the fused backward SLOWER (1.78 -> 1.84-1.93 ms: 6 more spilled registers in the sdf launch)
+#endif
 // weights: [plane hi|mid|lo][out tile][k16 step][lane][8 bf16] (packing.py: bwd3 blocks of the field packer); `bin` holds what
 // the fp32 chain carries per 2-wide k-step, so k16 step s takes bin[8s .. 8s+7]
 template <int KS, int MT>
@@ -649,6 +652,15 @@ __device__ __forceinline__ void mfma_layer_z_b3(const f32x4 *__restrict__ w, con
 #pragma unroll
         for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t].h, bh.h, acc[t], 0, 0, 0);
     }
+    // round 5: step s + 1's slicing (44 VALU) rides in the shadow of step s's 6 MT MFMAs instead of running between them
+    // (tools/micro/mfma_valu_gap.hip: 5-6 single-issue instructions per MFMA gap are free inside a wave; this kernel is one wave per SIMD)
+#if FUSED_FILL > 0
+#pragma unroll
+    for (int g_ = 0; g_ < S * 6 * MT; g_++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, FUSED_FILL, 0);
+    }
+#endif
 }
 
 // ONE k16 step `s` of a layer of S steps, accumulators = that step's products alone (every other step's B operand is zero)
@@ -707,6 +719,13 @@ __device__ __forceinline__ void dw_mma_b3(const RowFrag &a, const RowSl *__restr
 #pragma unroll
         for (int n = 0; n < NI; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as.h[s].h, b[n].h[s].h, acc[n], 0, 0, 0);
     }
+#if FUSED_FILL > 0
+#pragma unroll
+    for (int g_ = 0; g_ < 12 * NI; g_++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, FUSED_FILL, 0);
+    }
+#endif
 }
 // arithmetic selector of the fused kernels (B3 is their template parameter): LAYER(KS, MT, w, bin, acc); SLICE(N, B, Bs) after the
 // parked rows landed; DW(NI, A, B, Bs, acc, bsum)
