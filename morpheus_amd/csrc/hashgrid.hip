@@ -433,6 +433,13 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
 // accumulator; two workgroups per CU): 0.66 -> 0.52 ms (1.03 -> 0.87 ms with d/dx).  What is left is the LDS atomic
 // pipe: the 4 points a wave carries share their coarse-level cells, so every ds_add_u64 pays the 4-way same-address rate.
 #define BRK_THREADS 1024
+#ifdef BRK_AOS          // A/B: the round-4 layout, (x, y) interleaved
+#define BRK_X(v) (2 * (v))
+#define BRK_Y(v) (2 * (v) + 1)
+#else
+#define BRK_X(v) (v)
+#define BRK_Y(v) (BRK_NODES_MAX + (v))
+#endif
 #ifndef BRK_WAVES_PER_SIMD
 #define BRK_WAVES_PER_SIMD 8   // two 16-wave workgroups per CU: 64 registers per lane (the d/dx forms had grown to 73-80 and ran ONE workgroup per CU)
 #endif
@@ -444,7 +451,11 @@ __global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_bric
                                                              float *__restrict__ grad_emb, float *__restrict__ grad_x, int L,
                                                              int n_levels, float bound, float two_bound,
                                                              const uint32_t *__restrict__ gmax_bits) {
-    __shared__ long long acc[2 * BRK_NODES_MAX];  // fixed-point (x, y) per vertex: 73 KB
+    // fixed-point sums per vertex, 73 KB: the x channel of every vertex, then the y channel.  (Round 5 A/B against the round-4
+    // layout of interleaved (x, y) pairs, -DBRK_AOS: the same 1.38 ms -- a channel's 64 ds_add_u64 on an 8-byte instead of a
+    // 16-byte stride did not move the kernel: the replays the counters show are same-VERTEX collisions of the points a wave
+    // carries, which a layout cannot remove.)
+    __shared__ long long acc[2 * BRK_NODES_MAX];
     // work item -> (brick, chunk of <= BRK_CHUNK points): hot bricks (all rays converge near the camera)
     // are split over several workgroups, each with its own LDS accumulation and flush
     const int32_t *work_start = brick_start + NBRK + 2;
@@ -509,8 +520,8 @@ __global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_bric
                 const double wd = (double)w;
                 const unsigned long long qx = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gxd, FX_MAGIC)) - FX_MAGIC_BITS;
                 const unsigned long long qy = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gyd, FX_MAGIC)) - FX_MAGIC_BITS;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[2 * (base + li)]), qx);
-                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[2 * (base + li) + 1]), qy);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BRK_X(base + li)]), qx);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BRK_Y(base + li)]), qy);
             }
             if (NEED_DX) {
                 float2 v[8];
@@ -566,7 +577,7 @@ __global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_bric
             lo2[d] = (int)floorf(fminf(fmaxf(fmaf((float)bxyz[d] / (float)BRK, (float)r, -0.5f), 0.0f), (float)(r - 1)));
         float *ge = grad_emb + (size_t)meta.offsets[lev] * 2;
         for (int j = threadIdx.x; j < n * n * n; j += BRK_THREADS) {
-            const long long qx = acc[2 * (b0 + j)], qy = acc[2 * (b0 + j) + 1];
+            const long long qx = acc[BRK_X(b0 + j)], qy = acc[BRK_Y(b0 + j)];
             if (qx == 0 && qy == 0) continue;
             const float2 v = make_float2((float)qx * from_fx, (float)qy * from_fx);
             const int jx = j % n, jy = (j / n) % n, jz = j / (n * n);
