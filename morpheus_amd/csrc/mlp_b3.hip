@@ -42,9 +42,6 @@ extern __shared__ f32x4 lds_b3[];
 #ifndef B3_Q4_FILL
 #define B3_Q4_FILL 6
 #endif
-#ifndef B3_KEEP_FWD
-#define B3_KEEP_FWD 33      // VMEM operations a wave issues between a layer's DMA and the wait for it (forward: 32 stores + mask words)
-#endif
 #ifndef B3_KEEP_BWD
 #define B3_KEEP_BWD 32
 #endif
@@ -80,25 +77,6 @@ __device__ __forceinline__ void b3_stage_issue(const f32x4 *__restrict__ src) {
     for (int k = 0; k < N_F4 / NTHR; k++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + k * NTHR + threadIdx.x),
                                          (__attribute__((address_space(3))) void *)(lds_b3 + k * NTHR + wave * 64), 16, 0, 0);
-}
-// the layer's bias row (<= 128 floats) rides along: wave 0's lower half fetches 512 bytes into the slot behind the slices,
-// every wave then initialises its accumulators from LDS (broadcast reads, no VMEM latency on the layer's critical path)
-__device__ __forceinline__ void b3_stage_bias(const float *__restrict__ bias, int n_f4 = 32) {
-    if ((int)threadIdx.x < n_f4)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const f32x4 *>(bias) + threadIdx.x),
-                                         (__attribute__((address_space(3))) void *)(lds_b3 + B3_LH_F4 + (threadIdx.x >> 6) * 64), 16, 0, 0);
-}
-template <int MT>
-__device__ __forceinline__ void acc_bias_lds(f32x16 (&acc)[MT], int h) {
-    const f32x4 *b = lds_b3 + B3_LH_F4;
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const f32x4 v = b[8 * t + 2 * r4 + h];
-#pragma unroll
-            for (int c = 0; c < 4; c++) acc[t][4 * r4 + c] = v[c];
-        }
 }
 __device__ __forceinline__ void b3_stage_wait() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -198,38 +176,6 @@ __device__ __forceinline__ void b3_quarter(const f32x4 *__restrict__ w, const Fr
     }
 }
 
-// layer epilogue: ReLU in place, park the tile feature-major FIRST (the stores then drain under the ~500 slicing instructions
-// instead of being waited for right after issue), then the sign mask and the next layer's B operand slices
-template <bool PARK>
-__device__ __forceinline__ void b3_epilogue(f32x16 (&acc)[4], float *__restrict__ ht, uint2 *__restrict__ mk, int pt, int h,
-                                            Frag (&bh)[8], Frag (&bm)[8], Frag (&bl)[8]) {
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = relu_i(acc[t][r]);
-    if (PARK) {
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
-    }
-    uint32_t mt[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        uint32_t m = 0;
-#pragma unroll
-        for (int r = 15; r >= 0; r--) m = push_nz(m, acc[t][r]);
-        mt[t] = m;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-            for (int e2 = 0; e2 < 4; e2++)
-                split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2],
-                       bl[2 * t + s2].u[e2]);
-    }
-    if (PARK) *mk = make_uint2(mt[0] | (mt[1] << 16), mt[2] | (mt[3] << 16));
-}
-
 // one k16 step of output tiles T0, T0+1 (12 MFMAs)
 template <int T0>
 __device__ __forceinline__ void b3_quarter_step(const f32x4 *__restrict__ w, const Frag (&bh)[8], const Frag (&bm)[8],
@@ -274,13 +220,7 @@ __device__ __forceinline__ void b3_epilogue_eighth(f32x16 (&acc)[4], float *__re
 #pragma unroll
     for (int e2 = 0; e2 < 4; e2++)
         split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);
-    // pin the slices HERE: they are only used after the layer's barrier, and hipcc otherwise sinks the ~50 slicing instructions
-    // down to that use -- out of the MFMA stretch they are meant to fill
-#ifdef B3_Q4_CHUNKS
-    Frag &fh = bh[2 * t + s2], &fm = bm[2 * t + s2], &fl = bl[2 * t + s2];
-    asm volatile("" : "+v"(fh.u[0]), "+v"(fh.u[1]), "+v"(fh.u[2]), "+v"(fh.u[3]), "+v"(fm.u[0]), "+v"(fm.u[1]), "+v"(fm.u[2]),
-                 "+v"(fm.u[3]), "+v"(fl.u[0]), "+v"(fl.u[1]), "+v"(fl.u[2]), "+v"(fl.u[3]), "+v"(mt[t]));
-#endif
+    // (the caller pins the slices at the end of its quarter: b3_pin_slices)
 }
 
 // the epilogue of output tiles T0, T0+1 only: ReLU, park, sign-mask halves, slices of k16 steps 2 T0 .. 2 T0 + 3
@@ -479,7 +419,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
         f32x16 acc[4];
         Frag bh[8], bm[8], bl[8];
         uint32_t mt[4] = {0u, 0u, 0u, 0u};
-        // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot
+        // layer 0: 40 (+8 zero) -> 128, bias row chosen by the point's frame slot.  (The encoding's 24 values stay live across the first
+        // net -- the compiler keeps them in scratch, written and read back once per net, outside the layer loop; re-evaluating them for
+        // the second net instead was tried: 45 -> 60 spilled registers, hipcc hoists other things in their place.)
 #pragma unroll
         for (int s = 0; s < 3; s++)
 #pragma unroll
