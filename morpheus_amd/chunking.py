@@ -10,8 +10,8 @@ when backward reaches it, one chunk at a time), the last chunk runs as usual -- 
 gone before the first re-run.  The outputs are the concatenation; values and gradients are those of the unchunked call (the
 kernels are batch-size independent: tests/test_gpu_render.py::test_full_size_forward_backward_equals_chunked_renders).
 Cost: one extra forward of the re-run rows, paid only by calls over the cap.  Measured on the 180 x 180 virtual-view step (2.2 M
-samples; profiles/r05_park_cap_180.txt): no bound 48.8 ms with 243 GB reserved by the caching allocator; cap 64 GB: 60.8 ms, 64 GB
-reserved; cap 32 GB: 63.2 ms, 38 GB reserved."""
+samples; profiles/r05_park_cap_180.txt): no bound 47.8 ms with 243 GB reserved by the caching allocator; cap 64 GB: 58.0 ms, 64 GB
+reserved; cap 32 GB: 61.3 ms, 38 GB reserved."""
 from __future__ import annotations
 
 import os
