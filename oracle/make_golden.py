@@ -774,6 +774,53 @@ def gen_round5():
             g[variant + "|delta|" + kk] = v
         moved = sum(int((v != 0).any()) for v in delta.values())
         print("round5:", variant, "virtual", float(lv), "real", float(lr_), "tensors moved", moved, "of", len(delta))
+    # ---- a virtual-view TRAINING step small enough to run in DOUBLE with its backward (24 x 24 rays x 24 samples; lambertian through
+    #      finite-difference normals, orientation loss, normal_smooth_3d with its draws injected, code_reg; normal_smoothness off: its
+    #      angle draw depends on a boolean index): the reference's fp32 result AND its float64 result on the same inputs, so that the
+    #      HIP path's gradients can be held to "within k x the reference's own fp32 error" instead of a fitted 1-3e-2
+    hw, S = 24, 24
+    o, d = synth.camera_rays(hw, hw, synth.look_at_pose(70.0, 35.0, 1.5))
+    N = o.shape[0]
+    o, d = o[None], d[None]
+    t = torch.full((1, N, 1), 140 / 200)
+    rid = torch.full((1, N, 1), 140, dtype=torch.int64)
+    smp = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
+    light = ofield.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    bg = torch.tensor([0.2, 0.5, 0.7])
+    for prec in ("f32", "f64"):
+        if prec == "f32":
+            m, cfg = build_ref_model(synth.make_state("b"), 0.75)
+        else:
+            m, cfg = build_ref_model_f64(synth.make_state("b"), 0.75)
+            m.encoder.differentiable = m.encoder_c.differentiable = True
+        m.train()
+        cfg["train"]["normal_smoothness"] = 0.0
+        cast = (lambda v: v.double()) if prec == "f64" else (lambda v: v)
+        sampler = _PresetSampler()
+        sampler.samples = (smp[0], cast(smp[1]), cast(smp[2]))
+        fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg, dataset=types.SimpleNamespace(num_frames=200),
+                                     global_step=1000)
+        fake.get_ortho_normal_dir = types.MethodType(ref_morpheus.MorpheuS.get_ortho_normal_dir, fake)
+        with DrawInjector() as inj:
+            res = ref_morpheus.MorpheuS.render_rays(fake, cast(o), cast(d), cast(t), rid, hw, hw, bg_color=cast(bg), ambient_ratio=0.55,
+                                                    light_d=cast(light), shading="lambertian", real_view=False, cano=False)
+            n_draws = inj.k
+        pred_rgb, _, _, pred_normal, _ = ref_morpheus.MorpheuS.get_pred_from_outputs(fake, res, 1, hw, hw)
+        G = trainstep.InjectedGuidance(hw, hw, "cpu", scale=5e-3)
+        l_guid = (pred_rgb * cast(G.grad)).sum()
+        l_reg = ref_morpheus.MorpheuS.get_regularization_loss(fake, res, pred_normal, cano=False)
+        total = l_guid + l_reg
+        m.zero_grad()
+        total.backward()
+        key = "virt24|" + prec
+        g[key + "|n_draws"] = np.int32(n_draws)
+        for lk in ("loss_orient", "loss_normal_perturb", "loss_code"):
+            g[key + "|" + lk] = np.float64(float(res[lk]))
+        g[key + "|loss"] = np.float64(float(total))
+        g[key + "|image"] = res["image"].detach().double().numpy()
+        for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
+            g[key + "|grad|" + kk] = v if not isinstance(v, np.ndarray) else v.astype(np.float64) if prec == "f64" else v
+        print("round5: virt24", prec, "loss", float(total), "draws", n_draws)
     np.savez_compressed(os.path.join(OUT, "round5.npz"), **g)
     print("round5.npz", len(g), "arrays")
 

@@ -966,6 +966,66 @@ def test_in_place_gradient_sums_under_other_autograd_entry_points():
         ops.ACCUMULATE_IN_PLACE = saved
 
 
+def virt24_errors():
+    """-> rows (tensor, |grad|, reference-fp32 error, HIP error), both as max |sample - f64 sample| / max |f64 sample| over the 64
+    strided samples of the fixture's digests, plus (loss_f64, loss_ref32, loss_hip).  The 24 x 24 virtual-view training step of
+    round5.npz: the reference ran it in fp32 AND in double (oracle/make_golden.py:gen_round5)."""
+    import numpy as np
+    from morpheus_amd import harness
+    from bench_support import trainstep
+    from tests.util import DrawInjector
+    g = load_golden("round5.npz")
+    hw, S, frame = 24, 24, 140
+    o, d = synth.camera_rays(hw, hw, synth.look_at_pose(70.0, 35.0, 1.5))
+    N = o.shape[0]
+    smp = of.uniform_samples(o, d, synth.ray_jitter(N), S, 1.01)
+    light = of.safe_normalize(o + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
+    model = harness.build_model("b", DEV, 0.75).train()
+    model.config["train"]["normal_smoothness"] = 0.0
+    rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
+    ts = trainstep.VirtualViewTrainStep(rend, res=hw, guidance=trainstep.InjectedGuidance(hw, hw, DEV, scale=5e-3))
+    ts.epoch, ts.global_step = 1000, 999
+    data = dict(H=hw, W=hw, rays_o=o[None].to(DEV), rays_d=d[None].to(DEV), rays_t=torch.full((1, N, 1), frame / 200, device=DEV),
+                rays_id=torch.full((1, N, 1), frame, device=DEV, dtype=torch.int64))
+    model.zero_grad()
+    with DrawInjector() as inj:
+        loss = ts(data=data, shading="lambertian", ambient_ratio=0.55, bg_color=torch.tensor([0.2, 0.5, 0.7], device=DEV), light_d=light)
+        assert inj.k == int(g["virt24|f32|n_draws"]) == int(g["virt24|f64|n_draws"])
+    loss.backward()
+    rows = []
+    for k, p in model.named_parameters():
+        k64 = "virt24|f64|grad|" + k
+        if p.grad is None or k64 + "|samples" not in g:
+            continue
+        s64 = torch.from_numpy(g[k64 + "|samples"]).double()
+        s32 = torch.from_numpy(g["virt24|f32|grad|" + k + "|samples"]).double()
+        gr = p.grad.detach().reshape(-1).double().cpu()
+        idx = torch.linspace(0, gr.numel() - 1, min(64, gr.numel())).long()
+        scale = float(s64.abs().max())
+        if scale == 0.0:
+            continue
+        rows.append((k, float(g[k64 + "|norm"]), float((s32 - s64).abs().max()) / scale, float((gr[idx] - s64).abs().max()) / scale))
+    return rows, (float(g["virt24|f64|loss"]), float(g["virt24|f32|loss"]), float(loss.detach()))
+
+
+def test_virtual_view_gradients_against_the_reference_in_double():
+    """Round 4's 72 x 72 test holds the virtual-view step's gradients to the reference's fp32 fixture at 3e-2 (finite-difference
+    normals amplify round-off x 250) -- loose enough to miss a 1 % error.  Here the allowance is DERIVED: the reference ran a 24 x 24
+    virtual-view training step (lambertian shading, orientation loss, normal_smooth_3d, code_reg, guidance gradient injected) in fp32
+    and in float64; the HIP path's gradient samples must be as close to the float64 ones as the reference's own fp32 run is, within a
+    factor (3 x, or 2e-4 of the tensor's largest sample where the reference's own error is smaller than that)."""
+    rows, (l64, l32, lhip) = virt24_errors()
+    assert len(rows) >= 45, len(rows)
+    assert abs(lhip - l64) <= max(3 * abs(l32 - l64), 1e-5 * abs(l64)), (l64, l32, lhip)
+    worst = []
+    for k, norm, e_ref, e_hip in rows:
+        if e_hip > max(3 * e_ref, 2e-4):
+            worst.append((k, e_ref, e_hip))
+    assert not worst, worst
+    # and the derived allowance is tight: the median of the reference's own error over the tensors is 1e-3 (worst 1.3e-2)
+    assert sorted(r[2] for r in rows)[len(rows) // 2] < 2e-3
+
+
 def test_two_frames_vs_reference_golden():
     """B = 2 frames in one batch against the reference's own render_rays (fixture extras.npz:two|*)."""
     from morpheus_amd import harness
