@@ -26,6 +26,7 @@ _SIGS = {
     "mh_grid_bin_workspace_ints": (_I64, []),
     "mh_grid_bin_bricks": (_I32, []),
     "mh_grid_bin_index_ints": (_I32, []),
+    "mh_grid_stage_min_points": (ctypes.c_int64, [ctypes.c_int64]),
     "mh_grid_bin_points": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P, _P]),
     "mh_grid_encode_bwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _F, _P, _P]),
     "mh_composite_fwd": (ctypes.c_int, [_P] * 10 + [_I32, _P]),
@@ -120,7 +121,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mh_abi_version() != 5:
+        if lib.mh_abi_version() != 6:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -49,23 +49,24 @@ __device__ __forceinline__ uint32_t grid_row(uint32_t cx, uint32_t cy, uint32_t 
 // instead of two or three per corner; the same integers as grid_row() corner by corner
 __device__ __forceinline__ void grid_rows8(const uint32_t (&g)[3], const uint32_t (&g1)[3], uint32_t res, uint32_t T, bool dense,
                                            bool pow2, uint32_t (&row)[8]) {
-    uint32_t ay[2], az[2];
-    if (dense) {
-        ay[0] = g[1] * res, ay[1] = g1[1] * res;
-        az[0] = g[2] * res * res, az[1] = g1[2] * res * res;
-    } else {
-        ay[0] = g[1] * 2654435761u, ay[1] = g1[1] * 2654435761u;
-        az[0] = g[2] * 805459861u, az[1] = g1[2] * 805459861u;
-    }
+    // branch-free over the lanes of a wave (its 16 level-lanes mix dense and hashed levels, and a divergent branch per corner cost
+    // ~100 scalar instructions and 30 taken branches per point): the axis multipliers are selected once, both combinations are
+    // formed (two adds / two xors per corner pair) and one select keeps the lane's.  A hashed level whose table size is NOT a
+    // power of two (no shipped geometry has one: a hashed level's size is the 2^k cap) takes the modulo in ONE rarely entered
+    // branch for all eight corners.
+    const uint32_t my = dense ? res : 2654435761u, mz = dense ? res * res : 805459861u;
+    const uint32_t ay[2] = {g[1] * my, g1[1] * my}, az[2] = {g[2] * mz, g1[2] * mz};
+    // (the select is a bit merge, v_bfi_b32, on a per-lane all-ones / all-zeros word: written as `dense ? a : b` hipcc turns it
+    //  back into eight divergent branches)
+    const uint32_t mask = pow2 ? T - 1 : 0xffffffffu, sel = dense ? 0xffffffffu : 0u;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const uint32_t cx = (c & 1) ? g1[0] : g[0], y = ay[(c >> 1) & 1], z = az[(c >> 2) & 1];
-        if (dense) {
-            row[c] = cx + y + z;
-        } else {
-            const uint32_t idx = cx ^ y ^ z;
-            row[c] = pow2 ? (idx & (T - 1)) : (idx % T);
-        }
+        row[c] = ((cx + y + z) & sel) | ((cx ^ y ^ z) & mask & ~sel);
+    }
+    if (__builtin_expect(!dense && !pow2, 0)) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) row[c] %= T;
     }
 }
 
@@ -83,13 +84,13 @@ __device__ __forceinline__ float exact_div(float n, float d, float r) {
 }
 
 // position inside level: returns false if the point is outside [0,1]^3
-__device__ __forceinline__ bool grid_locate(const float *__restrict__ x, int64_t p, float bound, float two_bound,
-                                            uint32_t res, uint32_t g[3], float f[3]) {
+__device__ __forceinline__ bool grid_locate(const float (&xv)[3], float bound, float two_bound, uint32_t res, uint32_t g[3],
+                                            float f[3]) {
     bool inb = true;
     const float inv = 1.0f / two_bound;                // loop-invariant in every caller
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        float u = exact_div(x[p * 3 + d] + bound, two_bound, inv);  // grid.py:157, fp32 add then IEEE divide
+        float u = exact_div(xv[d] + bound, two_bound, inv);  // grid.py:157, fp32 add then IEEE divide
         inb = inb && !(u < 0.0f || u > 1.0f);
         float pos = fminf(fmaxf(fmaf(u, (float)res, -0.5f), 0.0f), (float)(res - 1));
         float fl = floorf(pos);
@@ -97,6 +98,12 @@ __device__ __forceinline__ bool grid_locate(const float *__restrict__ x, int64_t
         f[d] = pos - fl;
     }
     return inb;
+}
+
+__device__ __forceinline__ bool grid_locate(const float *__restrict__ x, int64_t p, float bound, float two_bound,
+                                            uint32_t res, uint32_t g[3], float f[3]) {
+    const float xv[3] = {x[p * 3 + 0], x[p * 3 + 1], x[p * 3 + 2]};
+    return grid_locate(xv, bound, two_bound, res, g, f);
 }
 
 __global__ __launch_bounds__(256) void grid_fwd_kernel(const float *__restrict__ x, const float2 *__restrict__ emb, GridMeta meta,
@@ -183,12 +190,44 @@ __global__ __launch_bounds__(256) void grid_fwd_grouped_kernel(const float *__re
     }
 }
 
-// sum over the 16 level-lanes of a point (aligned groups of 16 lanes) -- DPP-free portable form
+// d(loss)/d(pos) of one (point, level): dy_dx (gridencoder.cu:205-247) is res * the sum over the 4 corners of the other two axes
+// of w_other * (table[right] - table[left]) per channel (the border clamp ignored on purpose), and the loss gradient contracts the
+// two channels.  The contraction goes FIRST here -- s_c = gr . table[corner c], eight dot products -- so the three axis sums run on
+// one scalar per corner instead of two channels: 55 VALU instructions instead of 134 for the same sum of the same products
+// (associated differently: fp32 rounding-level differences to the channel-wise form, and to the reference's, which sums the
+// per-level rows in a torch reduction of unspecified order anyway).
+__device__ __forceinline__ void grid_ddx(const float2 (&v)[8], const float (&f)[3], float2 gr, float s, float (&dx)[3]) {
+    float sc[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) sc[c] = fmaf(gr.y, v[c].y, gr.x * v[c].x);
+    const float p[3][2] = {{1.f - f[0], f[0]}, {1.f - f[1], f[1]}, {1.f - f[2], f[2]}};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const int a = (d + 1) % 3, b = (d + 2) % 3;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ba = q & 1, bb = (q >> 1) & 1;
+            const int lo_c = (ba << a) | (bb << b), hi_c = lo_c | (1 << d);
+            const float w = p[a][ba] * p[b][bb], diff = sc[hi_c] - sc[lo_c];
+            acc = q ? fmaf(w, diff, acc) : w * diff;
+        }
+        dx[d] = s * acc;
+    }
+}
+
+// sum over the 16 level-lanes of a point (an aligned group of 16 lanes = one DPP row), every lane gets the total.  The butterfly
+// v += v[lane ^ 1], ^ 2, ^ 4, ^ 8 written as DPP operands of the adds: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then
+// row_half_mirror (lane i <-> 7 - i: after the first two steps a quad's lanes agree, and 7 - i lies in the other quad of the half
+// row -- the value lane i ^ 4 holds) and row_mirror (i <-> 15 - i, the other half row).  The same additions in the same order as the
+// __shfl_xor form, which hipcc turns into twelve ds_bpermute_b32 per point: LDS-pipe instructions with a round trip each, in the
+// middle of the brick backward's dependent chain.
+#define DPP_ADD(v, ctrl) ((v) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, true)))
 __device__ __forceinline__ float sum16(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v = DPP_ADD(v, 0xB1);    // quad_perm:[1,0,3,2]
+    v = DPP_ADD(v, 0x4E);    // quad_perm:[2,3,0,1]
+    v = DPP_ADD(v, 0x141);   // row_half_mirror
+    v = DPP_ADD(v, 0x140);   // row_mirror
     return v;
 }
 
@@ -233,22 +272,7 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const float2 *__restrict_
                 float2 v[8];
 #pragma unroll
                 for (int c = 0; c < 8; c++) v[c] = tab[row[c]];
-                const float s = (float)res;
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const int a = (d + 1) % 3, b = (d + 2) % 3;
-                    float acc_x = 0.f, acc_y = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int ba = q & 1, bb = (q >> 1) & 1;
-                        const float w = s * (ba ? f[a] : 1.f - f[a]) * (bb ? f[b] : 1.f - f[b]);
-                        const int lo = (ba << a) | (bb << b);
-                        const int hi = lo | (1 << d);
-                        acc_x += w * (v[hi].x - v[lo].x);
-                        acc_y += w * (v[hi].y - v[lo].y);
-                    }
-                    dx[d] = gr.x * acc_x + gr.y * acc_y;
-                }
+                grid_ddx(v, f, gr, (float)res, dx);
             }
         }
     }
@@ -428,48 +452,82 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
     from_fx = __uint_as_float((uint32_t)(127 - FX_BITS - 127 + e) << 23);  // 2^((e-127) - 40)
 }
 
-// The main loop is a chain of dependent loads (perm -> x, grad -> LDS atomics) and was latency-bound at 256 lanes: a
-// workgroup is BRK_THREADS = 1024 lanes (64 points x 16 levels in flight per iteration, 16 waves sharing one 73 KB
-// accumulator; two workgroups per CU): 0.66 -> 0.52 ms (1.03 -> 0.87 ms with d/dx).  What is left is the LDS atomic
-// pipe: the 4 points a wave carries share their coarse-level cells, so every ds_add_u64 pays the 4-way same-address rate.
+// Workgroup = BRK_THREADS = 1024 lanes: 64 points x 16 levels in flight per iteration, 16 waves sharing one accumulator.
+//
+// Round-5 timing experiments on the d/dx form (2 tables at cfg3, same box; tools/build_grid_variants.sh, -DBRK_EXP_*):
+//   as shipped in round 4 1.38 ms | VALU stream cut by 40 % (DPP sums, branch-free rows, contracted d/dx) 1.32 | LDS atomics
+//   removed 1.21 | the eight table-row gathers of d/dx sent to ONE row 0.86 | both 0.76.
+// Neither the instruction stream nor the LDS atomic pipe nor load latency (operands requested an iteration ahead: no gain) was
+// the bound: a third of the kernel was the texture-address path working through 8 gathers x 64 distinct cache lines per wave
+// and iteration -- the same 2.1 GB of L2 gathers per table the forward does.  But a brick's points only ever read the brick's own
+// vertices, the very ones the accumulator has a slot for: the d/dx forms now STAGE the brick's table rows in LDS once per work
+// item (4558 rows, against 1024 points x 16 levels x 8 corners = 131 k gathers), one 24-byte slot per vertex {sum x, sum y, row},
+// and the loop reads a corner's row at the address it adds the corner's gradient to.  109 KB per workgroup: ONE workgroup per
+// CU (4 waves per SIMD, 128 registers), which pays for requesting the next point's operands an iteration ahead.
 #define BRK_THREADS 1024
-#ifdef BRK_AOS          // A/B: the round-4 layout, (x, y) interleaved
-#define BRK_X(v) (2 * (v))
-#define BRK_Y(v) (2 * (v) + 1)
-#else
-#define BRK_X(v) (v)
-#define BRK_Y(v) (BRK_NODES_MAX + (v))
+#ifndef BRK_PIPE
+#define BRK_PIPE 2             // A/B: 0 = every operand requested in the iteration that uses it, 1 = the index one iteration ahead, 2 = index two ahead, x / grad one
 #endif
-#ifndef BRK_WAVES_PER_SIMD
-#define BRK_WAVES_PER_SIMD 8   // two 16-wave workgroups per CU: 64 registers per lane (the d/dx forms had grown to 73-80 and ran ONE workgroup per CU)
+#ifndef BRK_STAGE
+#define BRK_STAGE 1            // A/B: 0 = the d/dx forms gather their table rows from global memory (two workgroups per CU)
 #endif
-template <int NEED_DX>      // 0: no d/dx; 1: grad_x = d/dx (pre-zeroed by the host side); 2: grad_x += d/dx
-__global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_brick_kernel(const float2 *__restrict__ grad, const float *__restrict__ x,
-                                                             const float2 *__restrict__ emb, GridMeta meta, BrickMeta bm,
-                                                             const int32_t *__restrict__ perm,
-                                                             const int32_t *__restrict__ brick_start,
-                                                             float *__restrict__ grad_emb, float *__restrict__ grad_x, int L,
-                                                             int n_levels, float bound, float two_bound,
-                                                             const uint32_t *__restrict__ gmax_bits) {
-    // fixed-point sums per vertex, 73 KB: the x channel of every vertex, then the y channel.  (Round 5 A/B against the round-4
-    // layout of interleaved (x, y) pairs, -DBRK_AOS: the same 1.38 ms -- a channel's 64 ds_add_u64 on an 8-byte instead of a
-    // 16-byte stride did not move the kernel: the replays the counters show are same-VERTEX collisions of the points a wave
-    // carries, which a layout cannot remove.)
-    __shared__ long long acc[2 * BRK_NODES_MAX];
+#ifndef BRK_STAGE_UNROLL
+#define BRK_STAGE_UNROLL 8     // staging gathers in flight per lane
+#endif
+#ifndef BRK_STAGE_MIN_POINTS
+#define BRK_STAGE_MIN_POINTS (1 << 20)
+#endif
+#ifndef BRK_STAGE_MIN
+#define BRK_STAGE_MIN 96       // a work item with fewer points gathers its rows directly (staging = 4558 gathers, ~36 points' worth, at half the occupancy)
+#endif
+
+// j / d for 0 <= j < 1800, 1 <= d <= 42 (a brick has <= 16 vertices per axis): one multiply and a shift, m = ceil(2^16 / d)
+__device__ __forceinline__ int brk_div(int j, int m) { return (int)(((uint32_t)j * (uint32_t)m) >> 16); }
+
+// NEED_DX 0: no d/dx; 1: grad_x = d/dx (pre-zeroed by the host side); 2: grad_x += d/dx.
+// STAGED (d/dx forms): rows staged in LDS, one workgroup per CU.  The launcher takes it for calls of >= BRK_STAGE_MIN_POINTS
+// points: the eight ~0.1 ms calls of a real-view training step (139 k - 830 k points, work items of a few hundred points whose
+// zero / stage / flush phases nothing overlaps at one workgroup per CU) are faster in the direct form, 0.75 against 0.81 ms per
+// step; cfg3's two calls of 2.1 M points 1.16 against 1.32 ms.  Inside the staged form a work item of fewer than BRK_STAGE_MIN
+// points still gathers its rows directly (staging is 4558 gathers, 36 points' worth).  (Two launches over the same work-item
+// table -- staged items in one, the others at two workgroups per CU in the second -- measured slower than either.)
+template <int NEED_DX, bool STAGED>
+__global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_kernel(
+    const float2 *__restrict__ grad, const float *__restrict__ x, const float2 *__restrict__ emb, GridMeta meta, BrickMeta bm,
+    const int32_t *__restrict__ perm, const int32_t *__restrict__ brick_start, float *__restrict__ grad_emb,
+    float *__restrict__ grad_x, int L, int n_levels, float bound, float two_bound, const uint32_t *__restrict__ gmax_bits) {
+    // per vertex: fixed-point sum of the x channel, of the y channel, and (d/dx forms) the vertex's table row -- 8-byte words.
+    // (Interleaved or channel-major made no difference in a round-5 A/B: the replays the counters show are same-VERTEX collisions
+    //  of the points a wave carries, which a layout cannot remove.)
+    constexpr int W = STAGED ? 3 : 2;
+    __shared__ long long acc[W * BRK_NODES_MAX];
     // work item -> (brick, chunk of <= BRK_CHUNK points): hot bricks (all rays converge near the camera)
     // are split over several workgroups, each with its own LDS accumulation and flush
     const int32_t *work_start = brick_start + NBRK + 2;
     const int w = blockIdx.x;
-    if (w >= work_start[NBRK]) return;
-    int lo_b = 0, hi_b = NBRK;  // largest b with work_start[b] <= w
-    while (hi_b - lo_b > 1) {
-        const int mid = (lo_b + hi_b) >> 1;
-        if (work_start[mid] <= w) lo_b = mid; else hi_b = mid;
+    // the brick b with work_start[b] <= w < work_start[b + 1] (unique: the table is monotone; none for a surplus workgroup,
+    // w >= work_start[NBRK]).  A binary search is twelve DEPENDENT loads before the workgroup can start; the 1024 lanes look at
+    // four bricks each instead -- one round trip
+    // (and the brick's point range comes with the same round trip)
+    __shared__ int item[3];
+    {
+        constexpr int PER = NBRK / BRK_THREADS;
+        const int b0 = PER * (int)threadIdx.x;
+        int ws[PER + 1], bs[PER + 1];
+#pragma unroll
+        for (int k = 0; k <= PER; k++) ws[k] = work_start[b0 + k], bs[k] = brick_start[b0 + k];
+        bool mine = false;
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (ws[k] <= w && w < ws[k + 1]) {
+                const int first = bs[k] + (w - ws[k]) * BRK_CHUNK;
+                item[0] = b0 + k, item[1] = first, item[2] = min(first + BRK_CHUNK, bs[k + 1]), mine = true;
+            }
+        if (!__syncthreads_or(mine)) return;
     }
-    const int brick = lo_b;
-    const int start = brick_start[brick] + (w - work_start[brick]) * BRK_CHUNK;
-    const int end = min(start + BRK_CHUNK, brick_start[brick + 1]);
-    for (int i = threadIdx.x; i < 2 * BRK_NODES_MAX; i += BRK_THREADS) acc[i] = 0;
+    const int brick = item[0], start = item[1], end = item[2];
+    const bool staged = STAGED && end - start >= BRK_STAGE_MIN;     // uniform over the workgroup
+    for (int i = threadIdx.x; i < BRK_NODES_MAX; i += BRK_THREADS) acc[W * i] = 0, acc[W * i + 1] = 0;
     float to_fx, from_fx;
     fx_scales(*gmax_bits, to_fx, from_fx);
     const int l = threadIdx.x & 15, sub = threadIdx.x >> 4;
@@ -488,19 +546,89 @@ __global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_bric
         const float pos = fminf(fmaxf(fmaf((float)bxyz[d] / (float)BRK, (float)res, -0.5f), 0.0f), (float)(res - 1));
         lo[d] = (int)floorf(pos);
     }
-    __syncthreads();
     const float2 *tab = emb + meta.offsets[l];
+    if (staged && lev_on) {
+        // the lane's level, vertices sub, sub + 64, ...: BRK_STAGE_UNROLL independent gathers in flight.  A slot past the grid's
+        // last vertex (the brick at the upper border) is never read by a point; it gets the border row.
+        const int n3 = nn * nn * nn, m = (65536 + nn - 1) / nn;
+        // (branch-free row index as in grid_rows8: the 16 level-lanes of a wave mix dense and hashed levels)
+        const uint32_t my = dense ? res : 2654435761u, mz = dense ? res * res : 805459861u;
+        const uint32_t mask = pow2 ? T - 1 : 0xffffffffu, sel = dense ? 0xffffffffu : 0u;
+        for (int j0 = sub; j0 < n3; j0 += 64 * BRK_STAGE_UNROLL) {
+            float2 v[BRK_STAGE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BRK_STAGE_UNROLL; u++) {
+                const int j = min(j0 + 64 * u, n3 - 1);
+                const int t = brk_div(j, m), jz = brk_div(t, m);
+                const int jx = j - t * nn, jy = t - jz * nn;
+                const uint32_t cx = min((uint32_t)(lo[0] + jx), res - 1), ym = min((uint32_t)(lo[1] + jy), res - 1) * my,
+                               zm = min((uint32_t)(lo[2] + jz), res - 1) * mz;
+                uint32_t row = ((cx + ym + zm) & sel) | ((cx ^ ym ^ zm) & mask & ~sel);
+                if (__builtin_expect(!dense && !pow2, 0)) row %= T;
+                v[u] = tab[row];
+            }
+#pragma unroll
+            for (int u = 0; u < BRK_STAGE_UNROLL; u++) {
+                const int j = j0 + 64 * u;
+                if (j < n3) *reinterpret_cast<float2 *>(&acc[W * (base + j) + 2]) = v[u];
+            }
+        }
+    }
+    __syncthreads();
     constexpr int PPI = BRK_THREADS / 16;  // points per iteration
     const int end_r = start + ((end - start + PPI - 1) / PPI) * PPI;
+    // (1.5 * 2^52 held in a scalar register pair: as a literal it occupies two vector registers of every lane)
+    int magic_hi, magic_lo;
+    asm("s_mov_b32 %0, 0x43380000" : "=s"(magic_hi));     // FX_MAGIC_BITS >> 32 (opaque to constant folding, which would put it
+    asm("s_mov_b32 %0, 0" : "=s"(magic_lo));              //  back into vector registers)
+    const double magic = __longlong_as_double(((long long)magic_hi << 32) | (unsigned)magic_lo);
+    // Software pipeline: an iteration works on operands requested one iteration earlier (x, grad of the next point) and on an
+    // index requested two iterations earlier; loads past the chunk's end re-read its last point (a valid address, no branch
+    // around a load).  (Two points per lane and iteration, for more independent LDS work per wave, measured slower: 1.19
+    // against 1.16 ms -- and needs the branch around a point's work gone, which costs the sparse work items of the training
+    // steps their skipped waves: 0.75 -> 0.91 ms.)
+    const int last = end - 1;
+    // (the direct-gather d/dx form has no registers for it at two workgroups per CU: 10 spills, and measured no faster)
+    constexpr int PIPE = (NEED_DX && !STAGED) ? 0 : BRK_PIPE;
+    int p_cur = 0, p_nxt = 0;
+    float xv[3] = {0.f, 0.f, 0.f};
+    float2 gr = make_float2(0.f, 0.f);
+    if (PIPE >= 1) p_cur = perm[min(start + sub, last)];
+    if (PIPE == 2) {
+        p_nxt = perm[min(start + sub + PPI, last)];
+#pragma unroll
+        for (int d = 0; d < 3; d++) xv[d] = x[(int64_t)p_cur * 3 + d];
+        gr = grad[(int64_t)p_cur * L + l];
+    }
+    const float inv_2b = 1.0f / two_bound;
     for (int i = start + sub; i < end_r; i += PPI) {
         const bool live = i < end;
-        const int64_t p = perm[live ? i : end - 1];
+        if (PIPE == 0) p_cur = perm[min(i, last)];
+        const int64_t p = p_cur;
+        int p_nn = 0;
+        float xn[3] = {0.f, 0.f, 0.f};
+        float2 grn = make_float2(0.f, 0.f);
+        if (PIPE == 2) {
+            p_nn = perm[min(i + 2 * PPI, last)];
+#pragma unroll
+            for (int d = 0; d < 3; d++) xn[d] = x[(int64_t)p_nxt * 3 + d];
+            grn = grad[(int64_t)p_nxt * L + l];
+        } else {
+            if (PIPE == 1) p_nxt = perm[min(i + PPI, last)];
+#pragma unroll
+            for (int d = 0; d < 3; d++) xv[d] = x[p * 3 + d];
+            gr = grad[p * L + l];
+        }
+        float gx_old[3] = {0.f, 0.f, 0.f};
+        if (NEED_DX == 2 && l == 0) {       // the gradient this point already holds: requested now, added at the iteration's end
+#pragma unroll
+            for (int d = 0; d < 3; d++) gx_old[d] = grad_x[p * 3 + d];
+        }
         float dx[3] = {0.f, 0.f, 0.f};
         if (live && lev_on) {
             uint32_t g[3];
             float f[3];
-            grid_locate(x, p, bound, two_bound, res, g, f);
-            const float2 gr = grad[p * L + l];
+            grid_locate(xv, bound, two_bound, res, g, f);
             const uint32_t g1[3] = {min(g[0] + 1, res - 1), min(g[1] + 1, res - 1), min(g[2] + 1, res - 1)};
             const int lx0 = (int)g[0] - lo[0], ly0 = (int)g[1] - lo[1], lz0 = (int)g[2] - lo[2];
             const int lx1 = (int)g1[0] - lo[0], ly1 = (int)g1[1] - lo[1], lz1 = (int)g1[2] - lo[2];
@@ -512,55 +640,58 @@ __global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_bric
             //  corner loop; v_med3 returns the smallest operand when one is a NaN)
             const double gxd = (double)__builtin_amdgcn_fmed3f(gr.x * to_fx, -FX_LIMIT, FX_LIMIT),
                          gyd = (double)__builtin_amdgcn_fmed3f(gr.y * to_fx, -FX_LIMIT, FX_LIMIT);
+            int slot[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const float w = ((c & 1) ? f[0] : 1.f - f[0]) * ((c & 2) ? f[1] : 1.f - f[1]) * ((c & 4) ? f[2] : 1.f - f[2]);
                 // (24-bit multiplies: a brick has < 2^12 vertices per level, v_mul_lo_u32 is a quarter-rate instruction)
                 const int li = ((c & 1) ? lx1 : lx0) + __mul24(nn, ((c & 2) ? ly1 : ly0) + __mul24(nn, (c & 4) ? lz1 : lz0));
+                slot[c] = W * (base + li);
                 const double wd = (double)w;
-                const unsigned long long qx = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gxd, FX_MAGIC)) - FX_MAGIC_BITS;
-                const unsigned long long qy = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gyd, FX_MAGIC)) - FX_MAGIC_BITS;
-                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BRK_X(base + li)]), qx);
-                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[BRK_Y(base + li)]), qy);
+                const unsigned long long qx = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gxd, magic)) - FX_MAGIC_BITS;
+                const unsigned long long qy = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gyd, magic)) - FX_MAGIC_BITS;
+#ifdef BRK_EXP_NOATOM       // timing experiment only (wrong results): the sums are formed but not added
+                if (li == -12345) {
+#endif
+                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[slot[c]]), qx);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&acc[slot[c] + 1]), qy);
+#ifdef BRK_EXP_NOATOM
+                }
+#endif
             }
             if (NEED_DX) {
                 float2 v[8];
-                uint32_t row[8];
-                grid_rows8(g, g1, res, T, dense, pow2, row);
+                if (staged) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) v[c] = tab[row[c]];
-                const float s = (float)res;
+                    for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float2 *>(&acc[slot[c] + 2]);
+                } else {
+                    // (requesting the rows before the sixteen LDS atomics, to cover their round trip, needs 16 more live registers
+                    //  than the 64 that keep two workgroups on a CU: 18 spills -- the rows are asked for here)
+                    uint32_t row[8];
+                    grid_rows8(g, g1, res, T, dense, pow2, row);
+#ifdef BRK_EXP_SAMEROW      // timing experiment only (wrong results): every lane of a level reads the same eight rows
 #pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const int a = (d + 1) % 3, b = (d + 2) % 3;
-                    float acc_x = 0.f, acc_y = 0.f;
+                    for (int c = 0; c < 8; c++) row[c] = (row[c] & 0) + c;
+#endif
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int ba = q & 1, bb = (q >> 1) & 1;
-                        const float w = s * (ba ? f[a] : 1.f - f[a]) * (bb ? f[b] : 1.f - f[b]);
-                        const int lo_c = (ba << a) | (bb << b);
-                        const int hi_c = lo_c | (1 << d);
-                        acc_x += w * (v[hi_c].x - v[lo_c].x);
-                        acc_y += w * (v[hi_c].y - v[lo_c].y);
-                    }
-                    dx[d] = gr.x * acc_x + gr.y * acc_y;
+                    for (int c = 0; c < 8; c++) v[c] = tab[row[c]];
                 }
+                grid_ddx(v, f, gr, (float)res, dx);
             }
         }
         if (NEED_DX) {
             const float sx = sum16(dx[0]), sy = sum16(dx[1]), sz = sum16(dx[2]);
             if (live && l == 0) {
-                const float inv = 1.0f / two_bound;
-                if (NEED_DX == 2) {
-                    grad_x[p * 3 + 0] += sx * inv;
-                    grad_x[p * 3 + 1] += sy * inv;
-                    grad_x[p * 3 + 2] += sz * inv;
-                } else {
-                    grad_x[p * 3 + 0] = sx * inv;
-                    grad_x[p * 3 + 1] = sy * inv;
-                    grad_x[p * 3 + 2] = sz * inv;
-                }
+                grad_x[p * 3 + 0] = gx_old[0] + sx * inv_2b;       // NEED_DX == 1: gx_old = 0 (grad_x was zero-filled: a point
+                grad_x[p * 3 + 1] = gx_old[1] + sy * inv_2b;       // outside the box is never visited)
+                grad_x[p * 3 + 2] = gx_old[2] + sz * inv_2b;
             }
+        }
+        if (PIPE == 2) {
+            p_cur = p_nxt, p_nxt = p_nn;
+            xv[0] = xn[0], xv[1] = xn[1], xv[2] = xn[2], gr = grn;
+        } else if (PIPE == 1) {
+            p_cur = p_nxt;
         }
     }
     __syncthreads();
@@ -577,7 +708,7 @@ __global__ __launch_bounds__(BRK_THREADS, BRK_WAVES_PER_SIMD) void grid_bwd_bric
             lo2[d] = (int)floorf(fminf(fmaxf(fmaf((float)bxyz[d] / (float)BRK, (float)r, -0.5f), 0.0f), (float)(r - 1)));
         float *ge = grad_emb + (size_t)meta.offsets[lev] * 2;
         for (int j = threadIdx.x; j < n * n * n; j += BRK_THREADS) {
-            const long long qx = acc[BRK_X(b0 + j)], qy = acc[BRK_Y(b0 + j)];
+            const long long qx = acc[W * (b0 + j)], qy = acc[W * (b0 + j) + 1];
             if (qx == 0 && qy == 0) continue;
             const float2 v = make_float2((float)qx * from_fx, (float)qy * from_fx);
             const int jx = j % n, jy = (j / n) % n, jz = j / (n * n);
@@ -678,6 +809,13 @@ extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_
     return MH_OK;
 }
 
+// calls of at least this many points take the staged d/dx form (see grid_bwd_brick_kernel); a process-wide tuning knob
+static int64_t g_stage_min_points = BRK_STAGE_MIN_POINTS;
+extern "C" int64_t mh_grid_stage_min_points(int64_t set) {
+    if (set >= 0) g_stage_min_points = set;
+    return g_stage_min_points;
+}
+
 extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *emb, const int32_t *offsets_host,
                                          const int32_t *res_host, const int32_t *perm, const int32_t *brick_start,
                                          float *grad_emb, float *grad_x, int32_t accumulate_dx, int64_t M, int32_t L,
@@ -709,22 +847,22 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
         hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, mh_stream(stream), grad, M * (int64_t)L * 2, own);
         gmax = own;
     }
+#define BRK_LAUNCH(DXMODE, STG)                                                                                                \
+    hipLaunchKernelGGL((grid_bwd_brick_kernel<DXMODE, STG>), dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),       \
+                       reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,     \
+                       brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax)
+    const bool staged = BRK_STAGE && M >= g_stage_min_points;
     if (grad_x && accumulate_dx) {
         // grad_x already holds a gradient of the same points (the field nets' d/dx): each visited point adds to its own row
-        hipLaunchKernelGGL(grid_bwd_brick_kernel<2>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
-                           reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
-                           brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
+        if (staged) BRK_LAUNCH(2, true); else BRK_LAUNCH(2, false);
     } else if (grad_x) {
         // points outside the box are never visited by a brick: their d/dx is zero
         if (!mh_zero_async(grad_x, sizeof(float) * 3 * (size_t)M, mh_stream(stream))) return MH_ERR_LAUNCH;
-        hipLaunchKernelGGL(grid_bwd_brick_kernel<1>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
-                           reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
-                           brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
+        if (staged) BRK_LAUNCH(1, true); else BRK_LAUNCH(1, false);
     } else {
-        hipLaunchKernelGGL(grid_bwd_brick_kernel<0>, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),
-                           reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,
-                           brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax);
+        BRK_LAUNCH(0, false);
     }
+#undef BRK_LAUNCH
     MH_CHECK_LAUNCH();
     return MH_OK;
 }

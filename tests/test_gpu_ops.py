@@ -29,9 +29,24 @@ def _grid_setup(scale=0.1):
     return emb, offs, level_resolutions(16, s, 16)
 
 
+@pytest.fixture
+def grid_rows_staged():
+    """every brick-binned d/dx backward of the test takes the form that stages a brick's table rows in LDS (the library takes it
+    for calls of >= 2^20 points only); restored at teardown"""
+    from morpheus_amd import _lib
+    lib = _lib.load()
+    before = lib.mh_grid_stage_min_points(-1)
+    assert lib.mh_grid_stage_min_points(0) == 0
+    yield
+    lib.mh_grid_stage_min_points(before)
+
+
+@pytest.mark.parametrize("staged", [False, True])
 @pytest.mark.parametrize("max_level", [None, 0.5])
-def test_grid_encode_forward_backward(max_level):
+def test_grid_encode_forward_backward(max_level, staged, request):
     from morpheus_amd import ops
+    if staged:
+        request.getfixturevalue("grid_rows_staged")
     emb, offs, res = _grid_setup()
     x = synth.hash_tensor((20000, 3), 9002, 1.1)            # ~25% of the points fall outside the +-1.01 box
     w = synth.hash_tensor((20000, 32), 9004, 1.0)
@@ -850,8 +865,18 @@ def test_grid_large_batch_gradients():
         tot.backward()
         return e.grad, xs.grad
 
-    (ge1, gx1), (ge2, gx2) = run(M), run((M + 11) // 12)
+    (ge1, gx1), (ge2, gx2) = run(M), run((M + 11) // 12)     # one call of 1.5 M points: rows staged in LDS; the chunks: gathered
     assert torch.equal(gx1, gx2)
+    from morpheus_amd import _lib
+    lib = _lib.load()
+    before = lib.mh_grid_stage_min_points(1 << 40)             # ... and the single call in the gathering form: the same bits
+    try:
+        ge3, gx3 = run(M)
+    finally:
+        lib.mh_grid_stage_min_points(before)
+    assert torch.equal(gx1, gx3)
+    # (the on-chip fixed-point sums are order-free; the flush of hot bricks' chunks adds floats to one row in arrival order)
+    assert float((ge1 - ge3).abs().max()) / float(ge3.abs().max()) <= 1e-6
     scale = float(ge2.abs().max())
     assert float((ge1 - ge2).abs().max()) / scale <= 1e-5, float((ge1 - ge2).abs().max()) / scale
 
