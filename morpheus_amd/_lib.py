@@ -28,6 +28,7 @@ _SIGS = {
     "mh_grid_bin_index_ints": (_I32, []),
     "mh_grid_stage_min_points": (ctypes.c_int64, [ctypes.c_int64]),
     "mh_grid_bin_points": (ctypes.c_int, [_P, _I64, _F, _P, _P, _P, _P]),
+    "mh_grid_encode_fwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P]),
     "mh_grid_encode_bwd_binned": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I64, _I32, _I32, _F, _P, _P]),
     "mh_composite_fwd": (ctypes.c_int, [_P] * 10 + [_I32, _P]),
     "mh_composite_bwd": (ctypes.c_int, [_P] * 13 + [_I32, _P]),
@@ -123,6 +124,8 @@ def load():
             fn.restype, fn.argtypes = res, args
         if lib.mh_abi_version() != 6:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
+        if os.environ.get("MORPHEUS_GRID_STAGE_MIN_POINTS"):       # tuning knob, see include/morpheus_hip.h
+            lib.mh_grid_stage_min_points(int(os.environ["MORPHEUS_GRID_STAGE_MIN_POINTS"]))
         _lib = lib
     return _lib
 

@@ -484,6 +484,144 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
 // j / d for 0 <= j < 1800, 1 <= d <= 42 (a brick has <= 16 vertices per axis): one multiply and a shift, m = ceil(2^16 / d)
 __device__ __forceinline__ int brk_div(int j, int m) { return (int)(((uint32_t)j * (uint32_t)m) >> 16); }
 
+// work item w -> (brick, first point, end) in item[0..2]; false for a surplus workgroup (w >= work_start[NBRK]).
+// The brick b with work_start[b] <= w < work_start[b + 1] is unique (the table is monotone).  A binary search is twelve DEPENDENT
+// loads before the workgroup can start; the 1024 lanes look at four bricks each instead, and the brick's point range comes with
+// the same round trip.  Ends in a barrier: item[] is visible to every lane on return.
+__device__ __forceinline__ bool brk_find_item(const int32_t *__restrict__ brick_start, int w, int *item) {
+    const int32_t *work_start = brick_start + NBRK + 2;
+    constexpr int PER = NBRK / BRK_THREADS;
+    const int b0 = PER * (int)threadIdx.x;
+    int ws[PER + 1], bs[PER + 1];
+#pragma unroll
+    for (int k = 0; k <= PER; k++) ws[k] = work_start[b0 + k], bs[k] = brick_start[b0 + k];
+    bool mine = false;
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (ws[k] <= w && w < ws[k + 1]) {
+            const int first = bs[k] + (w - ws[k]) * BRK_CHUNK;
+            item[0] = b0 + k, item[1] = first, item[2] = min(first + BRK_CHUNK, bs[k + 1]), mine = true;
+        }
+    return __syncthreads_or(mine) != 0;
+}
+
+// this lane's level of the brick: geometry of the level, of the brick's vertex block inside it, and the row-index terms
+struct BrickLevel {
+    uint32_t res, T, my, mz, mask, sel;     // row = dense ? cx + cy my + cz mz : (cx ^ cy my ^ cz mz) & mask   (sel = dense mask)
+    bool dense, pow2;
+    int nn, base, lo[3];
+    const float2 *tab;
+};
+
+__device__ __forceinline__ BrickLevel brk_level(const GridMeta &meta, const BrickMeta &bm, const float2 *__restrict__ emb, int l,
+                                                int brick) {
+    BrickLevel v;
+    v.res = (uint32_t)meta.res[l];
+    v.T = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
+    v.dense = (uint64_t)v.res * v.res * v.res <= (uint64_t)v.T;
+    v.pow2 = (v.T & (v.T - 1)) == 0;
+    v.my = v.dense ? v.res : 2654435761u, v.mz = v.dense ? v.res * v.res : 805459861u;
+    v.mask = v.pow2 ? v.T - 1 : 0xffffffffu, v.sel = v.dense ? 0xffffffffu : 0u;
+    v.nn = bm.n[l], v.base = bm.lds_off[l];
+    const int bxyz[3] = {brick % BRK, (brick / BRK) % BRK, brick / (BRK * BRK)};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        // smallest cell index a point of this brick can have: same fmaf as grid_locate, monotone in u
+        const float pos = fminf(fmaxf(fmaf((float)bxyz[d] / (float)BRK, (float)v.res, -0.5f), 0.0f), (float)(v.res - 1));
+        v.lo[d] = (int)floorf(pos);
+    }
+    v.tab = emb + meta.offsets[l];
+    return v;
+}
+
+// Stage the table rows of the lane's level of the brick in LDS: vertex j of the level's block goes to the 8-byte word
+// lds8[STRIDE * (base + j) + OFF].  The lane's level, vertices sub, sub + 64, ...: BRK_STAGE_UNROLL independent gathers in flight.
+// A slot past the grid's last vertex (the brick at the upper border) is never read by a point; it gets the border row.
+// (Branch-free row index as in grid_rows8: the 16 level-lanes of a wave mix dense and hashed levels.)
+template <int STRIDE, int OFF>
+__device__ __forceinline__ void brk_stage_rows(const BrickLevel &v, int sub, long long *lds8) {
+    const int n3 = v.nn * v.nn * v.nn, m = (65536 + v.nn - 1) / v.nn;
+    for (int j0 = sub; j0 < n3; j0 += 64 * BRK_STAGE_UNROLL) {
+        float2 r[BRK_STAGE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BRK_STAGE_UNROLL; u++) {
+            const int j = min(j0 + 64 * u, n3 - 1);
+            const int t = brk_div(j, m), jz = brk_div(t, m);
+            const int jx = j - t * v.nn, jy = t - jz * v.nn;
+            const uint32_t cx = min((uint32_t)(v.lo[0] + jx), v.res - 1), ym = min((uint32_t)(v.lo[1] + jy), v.res - 1) * v.my,
+                           zm = min((uint32_t)(v.lo[2] + jz), v.res - 1) * v.mz;
+            uint32_t row = ((cx + ym + zm) & v.sel) | ((cx ^ ym ^ zm) & v.mask & ~v.sel);
+            if (__builtin_expect(!v.dense && !v.pow2, 0)) row %= v.T;
+            r[u] = v.tab[row];
+        }
+#pragma unroll
+        for (int u = 0; u < BRK_STAGE_UNROLL; u++) {
+            const int j = j0 + 64 * u;
+            if (j < n3) *reinterpret_cast<float2 *>(&lds8[STRIDE * (v.base + j) + OFF]) = r[u];
+        }
+    }
+}
+
+// Brick-binned FORWARD.  The ungrouped forward is the texture-address path working through 8 gathers x 64 distinct cache lines
+// per wave (0.46 ms per table at 2.1 M points: one line per clock and CU) -- and the training step bins its points into bricks
+// for the backward anyway.  Binned BEFORE the forward, a work item stages its brick's 4558 rows in LDS (37 KB: two 1024-lane
+// workgroups per CU) and its <= 1024 points read their corners there.  Per-point arithmetic is grid_fwd_kernel's: bit-identical
+// features.  Points outside the box sit behind the last brick in `perm`; the surplus workgroups of the launch (there are at
+// least ceil(#outside / 1024) of them) write their zero rows.
+__global__ __launch_bounds__(BRK_THREADS, 8) void grid_fwd_brick_kernel(const float *__restrict__ x, const float2 *__restrict__ emb,
+                                                                         GridMeta meta, BrickMeta bm,
+                                                                         const int32_t *__restrict__ perm,
+                                                                         const int32_t *__restrict__ brick_start,
+                                                                         float2 *__restrict__ out, int L, int n_levels, float bound,
+                                                                         float two_bound) {
+    __shared__ long long val[BRK_NODES_MAX];    // float2 rows
+    __shared__ int item[3];
+    const int l = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    constexpr int PPI = BRK_THREADS / 16;
+    if (!brk_find_item(brick_start, blockIdx.x, item)) {
+        const int s = (int)blockIdx.x - brick_start[NBRK + 2 + NBRK];                  // surplus workgroup number
+        const int first = brick_start[NBRK] + s * BRK_CHUNK, stop = min(first + BRK_CHUNK, brick_start[NBRK + 1]);
+        for (int i = first + sub; i < stop; i += PPI) out[(int64_t)perm[i] * L + l] = make_float2(0.f, 0.f);
+        return;
+    }
+    const int brick = item[0], start = item[1], end = item[2];
+    const bool lev_on = l < n_levels;
+    const BrickLevel lv = brk_level(meta, bm, emb, l, brick);
+    if (lev_on) brk_stage_rows<1, 0>(lv, sub, val);
+    __syncthreads();
+    const int last = end - 1;
+    // operands of the next point requested an iteration ahead, its index two ahead (as in the backward)
+    int p_cur = perm[min(start + sub, last)], p_nxt = perm[min(start + sub + PPI, last)];
+    float xv[3] = {x[(int64_t)p_cur * 3 + 0], x[(int64_t)p_cur * 3 + 1], x[(int64_t)p_cur * 3 + 2]};
+    for (int i = start + sub; i < end; i += PPI) {
+        const int p_nn = perm[min(i + 2 * PPI, last)];
+        const float xn[3] = {x[(int64_t)p_nxt * 3 + 0], x[(int64_t)p_nxt * 3 + 1], x[(int64_t)p_nxt * 3 + 2]};
+        float2 r = make_float2(0.f, 0.f);
+        if (lev_on) {
+            uint32_t g[3];
+            float f[3];
+            grid_locate(xv, bound, two_bound, lv.res, g, f);     // inside the box: the binning put the point into a brick
+            const uint32_t g1[3] = {min(g[0] + 1, lv.res - 1), min(g[1] + 1, lv.res - 1), min(g[2] + 1, lv.res - 1)};
+            const int lx[2] = {(int)g[0] - lv.lo[0], (int)g1[0] - lv.lo[0]}, ly[2] = {(int)g[1] - lv.lo[1], (int)g1[1] - lv.lo[1]},
+                      lz[2] = {(int)g[2] - lv.lo[2], (int)g1[2] - lv.lo[2]};
+            float2 v[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                v[c] = *reinterpret_cast<const float2 *>(
+                    &val[lv.base + lx[c & 1] + __mul24(lv.nn, ly[(c >> 1) & 1] + __mul24(lv.nn, lz[(c >> 2) & 1]))]);
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float w = ((c & 1) ? f[0] : 1.f - f[0]) * ((c & 2) ? f[1] : 1.f - f[1]) * ((c & 4) ? f[2] : 1.f - f[2]);
+                r.x = fmaf(w, v[c].x, r.x);
+                r.y = fmaf(w, v[c].y, r.y);
+            }
+        }
+        out[(int64_t)p_cur * L + l] = r;
+        p_cur = p_nxt, p_nxt = p_nn;
+        xv[0] = xn[0], xv[1] = xn[1], xv[2] = xn[2];
+    }
+}
+
 // NEED_DX 0: no d/dx; 1: grad_x = d/dx (pre-zeroed by the host side); 2: grad_x += d/dx.
 // STAGED (d/dx forms): rows staged in LDS, one workgroup per CU.  The launcher takes it for calls of >= BRK_STAGE_MIN_POINTS
 // points: the eight ~0.1 ms calls of a real-view training step (139 k - 830 k points, work items of a few hundred points whose
@@ -503,28 +641,8 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
     __shared__ long long acc[W * BRK_NODES_MAX];
     // work item -> (brick, chunk of <= BRK_CHUNK points): hot bricks (all rays converge near the camera)
     // are split over several workgroups, each with its own LDS accumulation and flush
-    const int32_t *work_start = brick_start + NBRK + 2;
-    const int w = blockIdx.x;
-    // the brick b with work_start[b] <= w < work_start[b + 1] (unique: the table is monotone; none for a surplus workgroup,
-    // w >= work_start[NBRK]).  A binary search is twelve DEPENDENT loads before the workgroup can start; the 1024 lanes look at
-    // four bricks each instead -- one round trip
-    // (and the brick's point range comes with the same round trip)
     __shared__ int item[3];
-    {
-        constexpr int PER = NBRK / BRK_THREADS;
-        const int b0 = PER * (int)threadIdx.x;
-        int ws[PER + 1], bs[PER + 1];
-#pragma unroll
-        for (int k = 0; k <= PER; k++) ws[k] = work_start[b0 + k], bs[k] = brick_start[b0 + k];
-        bool mine = false;
-#pragma unroll
-        for (int k = 0; k < PER; k++)
-            if (ws[k] <= w && w < ws[k + 1]) {
-                const int first = bs[k] + (w - ws[k]) * BRK_CHUNK;
-                item[0] = b0 + k, item[1] = first, item[2] = min(first + BRK_CHUNK, bs[k + 1]), mine = true;
-            }
-        if (!__syncthreads_or(mine)) return;
-    }
+    if (!brk_find_item(brick_start, blockIdx.x, item)) return;
     const int brick = item[0], start = item[1], end = item[2];
     const bool staged = STAGED && end - start >= BRK_STAGE_MIN;     // uniform over the workgroup
     for (int i = threadIdx.x; i < BRK_NODES_MAX; i += BRK_THREADS) acc[W * i] = 0, acc[W * i + 1] = 0;
@@ -534,46 +652,13 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
     const int bxyz[3] = {brick % BRK, (brick / BRK) % BRK, brick / (BRK * BRK)};
     // this lane's level
     const bool lev_on = l < n_levels;
-    const uint32_t res = (uint32_t)meta.res[l];
-    const uint32_t T = (uint32_t)(meta.offsets[l + 1] - meta.offsets[l]);
-    const bool dense = (uint64_t)res * res * res <= (uint64_t)T;
-    const bool pow2 = (T & (T - 1)) == 0;
-    const int nn = bm.n[l], base = bm.lds_off[l];
-    int lo[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        // smallest cell index a point of this brick can have: same fmaf as grid_locate, monotone in u
-        const float pos = fminf(fmaxf(fmaf((float)bxyz[d] / (float)BRK, (float)res, -0.5f), 0.0f), (float)(res - 1));
-        lo[d] = (int)floorf(pos);
-    }
-    const float2 *tab = emb + meta.offsets[l];
-    if (staged && lev_on) {
-        // the lane's level, vertices sub, sub + 64, ...: BRK_STAGE_UNROLL independent gathers in flight.  A slot past the grid's
-        // last vertex (the brick at the upper border) is never read by a point; it gets the border row.
-        const int n3 = nn * nn * nn, m = (65536 + nn - 1) / nn;
-        // (branch-free row index as in grid_rows8: the 16 level-lanes of a wave mix dense and hashed levels)
-        const uint32_t my = dense ? res : 2654435761u, mz = dense ? res * res : 805459861u;
-        const uint32_t mask = pow2 ? T - 1 : 0xffffffffu, sel = dense ? 0xffffffffu : 0u;
-        for (int j0 = sub; j0 < n3; j0 += 64 * BRK_STAGE_UNROLL) {
-            float2 v[BRK_STAGE_UNROLL];
-#pragma unroll
-            for (int u = 0; u < BRK_STAGE_UNROLL; u++) {
-                const int j = min(j0 + 64 * u, n3 - 1);
-                const int t = brk_div(j, m), jz = brk_div(t, m);
-                const int jx = j - t * nn, jy = t - jz * nn;
-                const uint32_t cx = min((uint32_t)(lo[0] + jx), res - 1), ym = min((uint32_t)(lo[1] + jy), res - 1) * my,
-                               zm = min((uint32_t)(lo[2] + jz), res - 1) * mz;
-                uint32_t row = ((cx + ym + zm) & sel) | ((cx ^ ym ^ zm) & mask & ~sel);
-                if (__builtin_expect(!dense && !pow2, 0)) row %= T;
-                v[u] = tab[row];
-            }
-#pragma unroll
-            for (int u = 0; u < BRK_STAGE_UNROLL; u++) {
-                const int j = j0 + 64 * u;
-                if (j < n3) *reinterpret_cast<float2 *>(&acc[W * (base + j) + 2]) = v[u];
-            }
-        }
-    }
+    const BrickLevel lv = brk_level(meta, bm, emb, l, brick);
+    const uint32_t res = lv.res, T = lv.T;
+    const bool dense = lv.dense, pow2 = lv.pow2;
+    const int nn = lv.nn, base = lv.base;
+    const int lo[3] = {lv.lo[0], lv.lo[1], lv.lo[2]};
+    const float2 *tab = lv.tab;
+    if (staged && lev_on) brk_stage_rows<W, 2>(lv, sub, acc);
     __syncthreads();
     constexpr int PPI = BRK_THREADS / 16;  // points per iteration
     const int end_r = start + ((end - start + PPI - 1) / PPI) * PPI;
@@ -809,6 +894,38 @@ extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_
     return MH_OK;
 }
 
+static int fill_brick_meta(BrickMeta &bm, const int32_t *res_host, int L) {
+    int off = 0;
+    for (int l = 0; l < L; l++) {
+        const int n = (res_host[l] + BRK - 1) / BRK + 2;
+        bm.n[l] = n;
+        bm.lds_off[l] = off;
+        off += n * n * n;
+    }
+    return off > BRK_NODES_MAX ? MH_ERR_ARG : MH_OK;
+}
+
+extern "C" int mh_grid_encode_fwd_binned(const float *x, const float *emb, const int32_t *offsets_host,
+                                         const int32_t *res_host, const int32_t *perm, const int32_t *brick_start, float *out,
+                                         int64_t M, int32_t L, int32_t n_levels, float bound, void *stream) {
+    if (M == 0) return MH_OK;
+    if (!x || !emb || !out || !perm || !brick_start || M < 0 || M > 0x7fffffffLL || n_levels < 0 || n_levels > L || L != 16 ||
+        !(bound > 0.f))
+        return MH_ERR_ARG;
+    GridMeta meta;
+    int st = fill_meta(meta, offsets_host, res_host, L);
+    if (st) return st;
+    BrickMeta bm;
+    if ((st = fill_brick_meta(bm, res_host, L))) return st;
+    // upper bound on sum_b ceil(cnt_b / BRK_CHUNK) + ceil(#outside / BRK_CHUNK): the surplus workgroups write the zero rows
+    const unsigned work_items = (unsigned)(NBRK + M / BRK_CHUNK + 1);
+    hipLaunchKernelGGL(grid_fwd_brick_kernel, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream), x,
+                       reinterpret_cast<const float2 *>(emb), meta, bm, perm, brick_start, reinterpret_cast<float2 *>(out), (int)L,
+                       (int)n_levels, bound, 2.0f * bound);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+}
+
 // calls of at least this many points take the staged d/dx form (see grid_bwd_brick_kernel); a process-wide tuning knob
 static int64_t g_stage_min_points = BRK_STAGE_MIN_POINTS;
 extern "C" int64_t mh_grid_stage_min_points(int64_t set) {
@@ -828,14 +945,7 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
     int st = fill_meta(meta, offsets_host, res_host, L);
     if (st) return st;
     BrickMeta bm;
-    int off = 0;
-    for (int l = 0; l < L; l++) {
-        const int n = (res_host[l] + BRK - 1) / BRK + 2;
-        bm.n[l] = n;
-        bm.lds_off[l] = off;
-        off += n * n * n;
-    }
-    if (off > BRK_NODES_MAX) return MH_ERR_ARG;
+    if ((st = fill_brick_meta(bm, res_host, L))) return st;
     // upper bound on sum_b ceil(cnt_b / BRK_CHUNK); surplus workgroups exit at once
     const unsigned work_items = (unsigned)(NBRK + M / BRK_CHUNK + 1);
     // max|grad| (float bits): supplied by the producer of `grad` (mh_field_bwd_data computes it on the fly), else

@@ -166,20 +166,30 @@ def _warp_mode(mode: Optional[str] = None) -> str:
 
 
 def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
-    """One forward launch per table at the same points -> list of [M, L*2]."""
+    """One forward launch per table at the same points -> (list of [M, L*2], binning or None).
+    Calls of at least mh_grid_stage_min_points() points (2^20 unless tuned) are binned into bricks FIRST and run the
+    brick-staged forward (rows read from LDS instead of eight gathers per point and level; same bits); the binning is handed
+    back for the caller's backward, which would otherwise make it itself."""
     M = x.shape[0]
     outs = []
+    binned = None
+    if L == 16 and group == 1 and M >= lib.mh_grid_stage_min_points(-1):
+        binned = _bin_points(lib, x, bound)
     for emb in embs:
         out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
         _e = TIMER.start()
-        check(lib.mh_grid_encode_fwd(ptr(x), ptr(emb), o_p, r_p, ptr(out), M, L, n_levels, float(bound), int(group), stream()),
-              "mh_grid_encode_fwd")
+        if binned is not None:
+            check(lib.mh_grid_encode_fwd_binned(ptr(x), ptr(emb), o_p, r_p, ptr(binned[0]), ptr(binned[1]), ptr(out), M, L,
+                                                n_levels, float(bound), stream()), "mh_grid_encode_fwd_binned")
+        else:
+            check(lib.mh_grid_encode_fwd(ptr(x), ptr(emb), o_p, r_p, ptr(out), M, L, n_levels, float(bound), int(group), stream()),
+                  "mh_grid_encode_fwd")
         TIMER.stop("mh_grid_encode_fwd", _e)
         outs.append(out)
-    return outs
+    return outs, binned
 
 
-def _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gmax_ptrs=None, sums=None, g_x_into=None):
+def _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gmax_ptrs=None, sums=None, g_x_into=None, binned=None):
     """Embedding (and position) gradients of several tables evaluated at the same points: ONE brick binning shared by all
     tables.  gmax_ptrs[k]: device address of max|grads[k]| as float bits when its producer reduced it on the fly
     (mh_field_bwd_data), else None -> the kernel reduces it itself.
@@ -188,7 +198,7 @@ def _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gmax_p
     to in the kernel (brick path only), or None.
     -> (g_x or None, [g_emb; None where the gradient went into sums[k]])."""
     M = x.shape[0]
-    g_x_total, g_embs, binned = g_x_into, [], None
+    g_x_total, g_embs = g_x_into, []          # binned: the forward's binning of the same points, when it made one
     brick = M > 0 and L == 16          # the brick kernel's level table is sized for the shipped 16-level geometry
     for k, (emb, grad) in enumerate(zip(embs, grads)):
         if grad is None:
@@ -237,7 +247,7 @@ class _GridEncode(torch.autograd.Function):
         o_np, o_p = _i32arr(offsets_np)
         r_np, r_p = _i32arr(res_np)
         saved = [emb.detach().contiguous() for emb in embs]
-        outs = _grid_fwd(lib, x, saved, o_p, r_p, L, n_levels, bound, group)
+        outs, ctx.binned = _grid_fwd(lib, x, saved, o_p, r_p, L, n_levels, bound, group)
         ctx.save_for_backward(x, *saved)
         ctx.meta = (o_np, r_np, n_levels, float(bound), L)
         return tuple(outs)
@@ -248,7 +258,7 @@ class _GridEncode(torch.autograd.Function):
         x, *embs = ctx.saved_tensors
         o_np, r_np, n_levels, bound, L = ctx.meta
         o_p, r_p = o_np.ctypes.data_as(ctypes.c_void_p), r_np.ctypes.data_as(ctypes.c_void_p)
-        g_x, g_embs = _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, ctx.needs_input_grad[0])
+        g_x, g_embs = _grid_bwd(lib, x, embs, grads, o_p, r_p, L, n_levels, bound, ctx.needs_input_grad[0], binned=ctx.binned)
         return (g_x, None, None, None, None, None, *g_embs)
 
 
@@ -1134,7 +1144,7 @@ class _FieldQuery(torch.autograd.Function):
         o_np, o_p = _i32arr(offsets_np)
         r_np, r_p = _i32arr(res_np)
         embs = [emb_s.detach().contiguous()] + ([emb_c.detach().contiguous()] if with_color else [])
-        feats = _grid_fwd(lib, xc, embs, o_p, r_p, L, n_levels, bound, group)
+        feats, ctx.binned = _grid_fwd(lib, xc, embs, o_p, r_p, L, n_levels, bound, group)
         tp = None if topo is None else topo.detach().contiguous()
         beta_c = beta.detach().reshape(1).contiguous().float()
         sdf, sigma, albedo, acts = _field_fwd(lib, xc, feats[0], feats[1] if with_color else None, tp, beta_c, n_bands,
@@ -1167,7 +1177,8 @@ class _FieldQuery(torch.autograd.Function):
         grads = [g_fs] + ([g_fc] if with_color else [])
         gptrs = [gmax.data_ptr(), gmax.data_ptr() + 4][:len(grads)]
         sums = [acc.tab[k].data_ptr() if acc.tab[k] is not None else None for k in range(len(grads))] if joined else None
-        g_x, g_embs = _grid_bwd(lib, xc, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gptrs, sums=sums, g_x_into=g_xc)
+        g_x, g_embs = _grid_bwd(lib, xc, embs, grads, o_p, r_p, L, n_levels, bound, need_dx, gptrs, sums=sums, g_x_into=g_xc,
+                                binned=ctx.binned)
         if joined:
             if raw is not None:
                 acc.raw = raw

@@ -70,6 +70,54 @@ def test_grid_encode_forward_backward(max_level, staged, request):
         assert (out_g[:, 16:] == 0).all()
 
 
+@pytest.mark.parametrize("n_levels", [16, 9])
+def test_grid_forward_binned_bit_identical(n_levels):
+    """mh_grid_encode_fwd_binned (points binned into bricks first, a brick's rows staged in LDS) against mh_grid_encode_fwd on
+    the same points: the same bits -- rays converging near a camera (hot bricks split into several work items), uniform points,
+    a quarter of them outside the box (zero rows, written by the launch's surplus workgroups), points on the box's faces, and
+    levels switched off (zero columns)."""
+    from morpheus_amd import ops, _lib
+    lib = _lib.load()
+    emb, offs, res = _grid_setup()
+    g = torch.Generator().manual_seed(5)
+    n_r, S = 2048, 96
+    o = torch.tensor([0.0, 0.0, 2.2]) + 0.05 * torch.randn(n_r, 3, generator=g)
+    d = torch.nn.functional.normalize(torch.cat([torch.randn(n_r, 2, generator=g) * 0.35, -torch.ones(n_r, 1)], 1), dim=1)
+    ts = 1.2 + 2.0 * (torch.arange(S).float()[None] + torch.rand(n_r, S, generator=g)) / S
+    rays = (o[:, None] + d[:, None] * ts[..., None]).reshape(-1, 3)
+    faces = torch.rand(4096, 3, generator=g) * 2.02 - 1.01
+    faces[torch.arange(4096), torch.randint(0, 3, (4096,), generator=g)] = 1.01 * (torch.randint(0, 2, (4096,), generator=g) * 2 - 1).float()
+    x = torch.cat([rays, torch.rand(150_000, 3, generator=g) * 2.6 - 1.3, faces]).to(DEV).contiguous()
+    M = x.shape[0]
+    embg = emb.to(DEV)
+    o_np, o_p = ops._i32arr(offs)
+    r_np, r_p = ops._i32arr(res)
+    ref = torch.full((M, 32), 7.0, device=DEV)
+    ops.check(lib.mh_grid_encode_fwd(ops.ptr(x), ops.ptr(embg), o_p, r_p, ops.ptr(ref), M, 16, n_levels, 1.01, 1, ops.stream()), "fwd")
+    perm, bstart = ops._bin_points(lib, x, 1.01)
+    out = torch.full((M, 32), 7.0, device=DEV)                # every row must be written, the outside points' too
+    ops.check(lib.mh_grid_encode_fwd_binned(ops.ptr(x), ops.ptr(embg), o_p, r_p, ops.ptr(perm), ops.ptr(bstart), ops.ptr(out), M, 16,
+                                            n_levels, 1.01, ops.stream()), "fwd_binned")
+    outside = ~(x.abs() <= 1.01).all(-1)
+    assert int(outside.sum()) > 20_000 and bool((out[outside] == 0).all())
+    assert torch.equal(out, ref)
+    # ... and through the autograd op, which takes the binned form by call size and hands its binning to the backward
+    before = lib.mh_grid_stage_min_points(0)
+    try:
+        xs, e = x.clone().requires_grad_(True), embg.clone().requires_grad_(True)
+        feat = ops.grid_encode(xs, e, offs, res, 1.01, max_level=n_levels / 16.0)
+        assert torch.equal(feat.detach(), ref)
+        gw = torch.randn(M, 32, generator=g).to(DEV)
+        (feat * gw).sum().backward()
+        lib.mh_grid_stage_min_points(1 << 40)
+        xs2, e2 = x.clone().requires_grad_(True), embg.clone().requires_grad_(True)
+        (ops.grid_encode(xs2, e2, offs, res, 1.01, max_level=n_levels / 16.0) * gw).sum().backward()
+    finally:
+        lib.mh_grid_stage_min_points(before)
+    assert torch.equal(xs.grad, xs2.grad)
+    assert float((e.grad - e2.grad).abs().max()) / float(e2.grad.abs().max()) <= 1e-6
+
+
 def test_grid_encode_edge_cases():
     from morpheus_amd import ops
     emb, offs, res = _grid_setup()
