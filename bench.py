@@ -604,28 +604,33 @@ def build_roofline(ktab, mode, M, workload, full_size):
 
 
 def build_hash_roofline(ktab, M, workload, full_size, mode):
-    if "mh_grid_encode_fwd" not in ktab:
+    binned = "mh_grid_encode_fwd_binned" in ktab           # calls of >= 2^20 points: binned first, a brick's rows staged in LDS
+    if not binned and "mh_grid_encode_fwd" not in ktab:
         return None
-    # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b)
+    # table-passes per step: 2 tables x M points (+ the 6 FD taps of the SDF table in cfg3b: grouped launches, their own timer key)
     enc_points = (2 * M + (6 * M if workload == "cfg3b" else 0))
-    fwd_key = "mh_grid_encode_fwd"
-    pts_per_launch = enc_points / ktab[fwd_key]["calls_per_step"]
+    fwd_key = "mh_grid_encode_fwd_binned" if binned else "mh_grid_encode_fwd"
+    symbol = "grid_fwd_brick_kernel" if binned else "grid_fwd_kernel"
+    pts_per_launch = (2 * M if binned else enc_points) / ktab[fwd_key]["calls_per_step"]
     secs = ktab[fwd_key]["avg_ms"] * 1e-3
     gb = GRID_FWD_BYTES * pts_per_launch / secs / 1e9
     l2 = GRID_GATHERS_PER_POINT * 64 * pts_per_launch / secs / 1e9
     traffic = None
     if full_size and workload != "cfg3b":
-        t, _, _ = pmc_step_bytes(["grid_fwd_kernel"], mode)
+        t, _, _ = pmc_step_bytes([symbol], mode)
         traffic = None if t is None else round(t / ktab[fwd_key]["calls_per_step"])
-    roof = dict(kernel="grid_fwd_kernel", bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roof = dict(kernel=symbol, bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic, bytes_per_launch=round(GRID_FWD_BYTES * pts_per_launch),
                 launch=fwd_key, hbm_measured_gbs=None if traffic is None else round(traffic / secs / 1e9, 1),
                 gathers_per_s=round(GRID_GATHERS_PER_POINT * pts_per_launch / secs / 1e9, 1),
-                l2_sector_gbs_if_every_gather_missed_l1=round(l2, 1), l2_peak_gbs=L2_PEAK_GBS,
+                l2_sector_gbs_if_every_gather_missed_l1=None if binned else round(l2, 1), l2_peak_gbs=L2_PEAK_GBS,
                 note="achieved = ALGORITHMIC bytes (SURVEY 8d: 1164 B/point) / time -- the yardstick north_star asks for, NOT an "
-                     "HBM utilisation: both 3.2 MB tables are L2/MALL resident, so the gathers are cache-served "
-                     "(hbm_measured_gbs = PMC traffic / time).  What bounds the kernel is the gather rate (gathers_per_s, in G "
-                     "8-byte gathers/s); see DESIGN.md section 3")
+                     "HBM utilisation: both 3.2 MB tables are L2/MALL resident.  " +
+                     ("Brick-binned form: a work item stages its brick's 4558 rows in LDS once and its <= 1024 points read their "
+                      "128 corners each there (gathers_per_s counts those LDS reads); what is left in HBM is x in, features out "
+                      "(hbm_measured_gbs = PMC traffic / time)" if binned else
+                      "The gathers are cache-served (hbm_measured_gbs = PMC traffic / time).  What bounds the kernel is the gather "
+                      "rate (gathers_per_s, in G 8-byte gathers/s)") + "; see DESIGN.md section 3")
     bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
     if bwd_name in ktab:
         gbb = GRID_BWD_BYTES * (enc_points / ktab[bwd_name]["calls_per_step"]) / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9

@@ -184,7 +184,7 @@ def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
         else:
             check(lib.mh_grid_encode_fwd(ptr(x), ptr(emb), o_p, r_p, ptr(out), M, L, n_levels, float(bound), int(group), stream()),
                   "mh_grid_encode_fwd")
-        TIMER.stop("mh_grid_encode_fwd", _e)
+        TIMER.stop("mh_grid_encode_fwd_binned" if binned is not None else "mh_grid_encode_fwd", _e)
         outs.append(out)
     return outs, binned
 

@@ -1,4 +1,5 @@
-"""GPU-box micro-benchmark of the hash-grid kernels (forward, naive backward, brick-binned backward)."""
+"""GPU-box micro-benchmark of the hash-grid kernels (forward: gathered / brick-binned; backward: naive / brick-binned with
+the d/dx rows gathered or staged in LDS)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,15 +34,21 @@ def run(x, tag):
     t_bin = timeit(lambda: lib.mh_grid_bin_points(x.data_ptr(), M, 1.01, ws.data_ptr(), perm.data_ptr(), bs.data_ptr(), st))
     cnt = (bs[1:4098] - bs[:4097]).cpu()
     print(f"[{tag}] M={M} bin {t_bin:.3f} ms; bricks nonempty {(cnt[:4096] > 0).sum().item()}, max {cnt[:4096].max().item()}, mean(nonempty) {cnt[:4096][cnt[:4096] > 0].float().mean().item():.0f}, oob {cnt[4096].item()}")
+    knob = lib.mh_grid_stage_min_points(-1)
     for nl in (16,):
-        for dx in (False, True):
+        for dx, staged in ((False, False), (True, False), (True, True)):
+            lib.mh_grid_stage_min_points(0 if staged else 1 << 40)        # d/dx forms: a brick's rows staged in LDS / gathered
             t = timeit(lambda: lib.mh_grid_encode_bwd_binned(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), perm.data_ptr(), bs.data_ptr(), g_emb.data_ptr(), g_x.data_ptr() if dx else None, 0, M, 16, nl, 1.01, None, st))
-            print(f"   binned n_levels={nl:2d} dx={int(dx)}: {t:.3f} ms")
+            print(f"   binned n_levels={nl:2d} dx={int(dx)}{' rows staged in LDS' if staged else (' rows gathered' if dx else '')}: {t:.3f} ms")
+    lib.mh_grid_stage_min_points(knob)
     t = timeit(lambda: lib.mh_grid_encode_bwd(grad.data_ptr(), x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), g_emb.data_ptr(), None, M, 16, 16, 1.01, st), 2)
     print(f"   naive  n_levels=16 dx=0: {t:.3f} ms")
     out = torch.empty(M, 32, device=dev)
     t = timeit(lambda: lib.mh_grid_encode_fwd(x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), out.data_ptr(), M, 16, 16, 1.01, 1, st))
     print(f"   fwd: {t:.3f} ms")
+    ref = out.clone()
+    t = timeit(lambda: lib.mh_grid_encode_fwd_binned(x.data_ptr(), emb.data_ptr(), P(o_p), P(r_p), perm.data_ptr(), bs.data_ptr(), out.data_ptr(), M, 16, 16, 1.01, st))
+    print(f"   fwd, brick-binned (rows staged in LDS; binning not included): {t:.3f} ms; same bits: {bool(torch.equal(out, ref))}")
     # share of the LDS-sized levels: levels 0..3 are dense tables of 32 / 55 / 85 / 125 KB (level 4 = 176 KB exceeds the
     # 160 KB of LDS); levels >= n_levels are written as zeros by idle lanes, so the launch / store cost is the same in
     # every row and the differences are the gather cost of the added levels
