@@ -359,7 +359,9 @@ __global__ __launch_bounds__(256) void bin_colscan_kernel(int32_t *__restrict__ 
 
 // single block: exclusive scans over the NBRK+1 brick totals -> brick_start[NBRK+2], and over the
 // per-brick work-item counts ceil(cnt/BRK_CHUNK) -> work_start[NBRK+1] (stored behind brick_start)
+#ifndef BRK_CHUNK
 #define BRK_CHUNK 1024
+#endif
 __global__ __launch_bounds__(1024) void bin_rowscan_kernel(const int32_t *__restrict__ brick_cnt,
                                                            int32_t *__restrict__ brick_start) {
     __shared__ int part[1024];
@@ -783,6 +785,9 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
         }
     }
     __syncthreads();
+#ifdef BRK_EXP_NOFLUSH     // timing experiment only (wrong results)
+    if (n_levels > -5) return;
+#endif
     // flush touched vertices: one global atomic per (vertex, channel) instead of one per (point, corner, channel)
     for (int lev = 0; lev < n_levels; lev++) {
         const uint32_t r = (uint32_t)meta.res[lev];
