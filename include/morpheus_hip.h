@@ -74,7 +74,8 @@ int mh_grid_encode_bwd(const float *grad, const float *x, const float *emb,
  * mh_grid_bin_points counting-sorts the points into 16^3 spatial bricks of the box:
  *   workspace: int32[mh_grid_bin_workspace_ints()] scratch; perm: int32[M] point ids grouped by brick
  *   (out-of-box points last); brick_start: int32[mh_grid_bin_index_ints()] = offsets into perm followed
- *   by the work-item table (bricks holding more than 1024 points are split over several workgroups) and a
+ *   by the work-item table (bricks holding more than 1024 points -- 2048 in calls of >= mh_grid_stage_min_points() points -- are
+ *   split over several workgroups) and a
  *   few scratch words used by the backward (max |grad| for its fixed-point on-chip accumulation).
  * One binning serves every encoder evaluated at the same x (sdf and colour tables).
  * mh_grid_encode_bwd_binned: one workgroup per brick accumulates all levels in LDS, then flushes the

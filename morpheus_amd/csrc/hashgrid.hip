@@ -358,12 +358,18 @@ __global__ __launch_bounds__(256) void bin_colscan_kernel(int32_t *__restrict__ 
 }
 
 // single block: exclusive scans over the NBRK+1 brick totals -> brick_start[NBRK+2], and over the
-// per-brick work-item counts ceil(cnt/BRK_CHUNK) -> work_start[NBRK+1] (stored behind brick_start)
-#ifndef BRK_CHUNK
-#define BRK_CHUNK 1024
+// per-brick work-item counts ceil(cnt/chunk) -> work_start[NBRK+1] (stored behind brick_start)
+// points per work item.  Every item flushes its brick's touched vertices -- ~9000 global float atomics whatever its size, a
+// fifth of the staged backward at cfg3 (-DBRK_EXP_NOFLUSH: 1.16 -> 0.94 ms) -- so large calls take larger items (cfg3: 1.16 ->
+// 1.08 ms, the binned forward 0.36 -> 0.34); the small calls of a training step lose balance with them (real-view step 0.78 ->
+// 0.92 ms at 2048, 1.15 at 4096).  The binning writes its choice behind the work-item table; the kernels read it there.
+#define BRK_CHUNK_SMALL 1024
+#ifndef BRK_CHUNK_LARGE
+#define BRK_CHUNK_LARGE 2048
 #endif
+#define BRK_CHUNK_WORD (2 * NBRK + 5)
 __global__ __launch_bounds__(1024) void bin_rowscan_kernel(const int32_t *__restrict__ brick_cnt,
-                                                           int32_t *__restrict__ brick_start) {
+                                                           int32_t *__restrict__ brick_start, int chunk) {
     __shared__ int part[1024];
     __shared__ int partw[1024];
     constexpr int PER = (NBRK + 1 + 1023) / 1024;  // 5
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(1024) void bin_rowscan_kernel(const int32_t *__rest
     for (int k = 0; k < PER; k++) {
         const int i = t * PER + k;
         loc[k] = i <= NBRK ? brick_cnt[i] : 0;
-        locw[k] = i < NBRK ? (loc[k] + BRK_CHUNK - 1) / BRK_CHUNK : 0;  // the out-of-box bucket does no work
+        locw[k] = i < NBRK ? (loc[k] + chunk - 1) / chunk : 0;  // the out-of-box bucket does no work
         s += loc[k];
         sw += locw[k];
     }
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(1024) void bin_rowscan_kernel(const int32_t *__rest
         run += loc[k];
         runw += locw[k];
     }
-    if (t == 1023) brick_start[NBRK + 1] = part[1023];
+    if (t == 1023) brick_start[NBRK + 1] = part[1023], brick_start[BRK_CHUNK_WORD] = chunk;
 }
 
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const float *__restrict__ x, int64_t M, int64_t chunk, float bound,
@@ -436,8 +442,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ g
 
 // LDS float atomics (ds_add_f32) run ~40x slower than integer ones on gfx950 (177 vs 4.6-6.4 cycles per
 // wave instruction, tools/micro/lds_atomics.hip), so vertex gradients are accumulated on-chip in 64-bit
-// fixed point: q = (int64) (v * 2^40 / G),  G = power of two >= max|grad|.  A vertex receives at most 1024
-// terms of magnitude <= 2^40 per chunk (sum < 2^51), every fp32 term is represented to 2^-40 G (i.e.
+// fixed point: q = (int64) (v * 2^40 / G),  G = power of two >= max|grad|.  A vertex receives at most 2048
+// terms of magnitude <= 2^40 per work item (sum < 2^52 in an int64), every fp32 term is represented to 2^-40 G (i.e.
 // exactly, for all practical purposes), and integer addition commutes: the on-chip stage is exact and
 // order-independent -- more accurate than the float atomics it replaces, and ~25x faster.  (ds_add_f64 is also
 // fast, 8.1 cycles, but its same-address rate is 40 vs 26 cycles and the kernel came out 25 % slower with it, even
@@ -495,14 +501,15 @@ __device__ __forceinline__ bool brk_find_item(const int32_t *__restrict__ brick_
     constexpr int PER = NBRK / BRK_THREADS;
     const int b0 = PER * (int)threadIdx.x;
     int ws[PER + 1], bs[PER + 1];
+    const int chunk = brick_start[BRK_CHUNK_WORD];
 #pragma unroll
     for (int k = 0; k <= PER; k++) ws[k] = work_start[b0 + k], bs[k] = brick_start[b0 + k];
     bool mine = false;
 #pragma unroll
     for (int k = 0; k < PER; k++)
         if (ws[k] <= w && w < ws[k + 1]) {
-            const int first = bs[k] + (w - ws[k]) * BRK_CHUNK;
-            item[0] = b0 + k, item[1] = first, item[2] = min(first + BRK_CHUNK, bs[k + 1]), mine = true;
+            const int first = bs[k] + (w - ws[k]) * chunk;
+            item[0] = b0 + k, item[1] = first, item[2] = min(first + chunk, bs[k + 1]), mine = true;
         }
     return __syncthreads_or(mine) != 0;
 }
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(BRK_THREADS, 8) void grid_fwd_brick_kernel(const fl
     constexpr int PPI = BRK_THREADS / 16;
     if (!brk_find_item(brick_start, blockIdx.x, item)) {
         const int s = (int)blockIdx.x - brick_start[NBRK + 2 + NBRK];                  // surplus workgroup number
-        const int first = brick_start[NBRK] + s * BRK_CHUNK, stop = min(first + BRK_CHUNK, brick_start[NBRK + 1]);
+        const int first = brick_start[NBRK] + s * BRK_CHUNK_SMALL, stop = min(first + BRK_CHUNK_SMALL, brick_start[NBRK + 1]);
         for (int i = first + sub; i < stop; i += PPI) out[(int64_t)perm[i] * L + l] = make_float2(0.f, 0.f);
         return;
     }
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
     //  of the points a wave carries, which a layout cannot remove.)
     constexpr int W = STAGED ? 3 : 2;
     __shared__ long long acc[W * BRK_NODES_MAX];
-    // work item -> (brick, chunk of <= BRK_CHUNK points): hot bricks (all rays converge near the camera)
+    // work item -> (brick, chunk of <= 1024 / 2048 points): hot bricks (all rays converge near the camera)
     // are split over several workgroups, each with its own LDS accumulation and flush
     __shared__ int item[3];
     if (!brk_find_item(brick_start, blockIdx.x, item)) return;
@@ -880,6 +887,14 @@ extern "C" int64_t mh_grid_bin_workspace_ints(void) { return (int64_t)BIN_BLOCKS
 extern "C" int32_t mh_grid_bin_bricks(void) { return NBRK; }
 extern "C" int32_t mh_grid_bin_index_ints(void) { return 2 * NBRK + 8; }  // brick_start | work_start | scratch
 
+// calls of at least this many points take the staged forms (grid_fwd_brick_kernel, the d/dx forms of grid_bwd_brick_kernel) and
+// the larger work items; a process-wide tuning knob
+static int64_t g_stage_min_points = BRK_STAGE_MIN_POINTS;
+extern "C" int64_t mh_grid_stage_min_points(int64_t set) {
+    if (set >= 0) g_stage_min_points = set;
+    return g_stage_min_points;
+}
+
 extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_t *workspace, int32_t *perm,
                                   int32_t *brick_start, void *stream) {
     if (M == 0) return MH_OK;
@@ -895,7 +910,8 @@ extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_
                        block_hist);
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((NBRK + 1 + 255) / 256), dim3(256), 0, mh_stream(stream), block_hist,
                        (int)G, brick_cnt);
-    hipLaunchKernelGGL(bin_rowscan_kernel, dim3(1), dim3(1024), 0, mh_stream(stream), brick_cnt, brick_start);
+    hipLaunchKernelGGL(bin_rowscan_kernel, dim3(1), dim3(1024), 0, mh_stream(stream), brick_cnt, brick_start,
+                       M >= g_stage_min_points ? BRK_CHUNK_LARGE : BRK_CHUNK_SMALL);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)G), dim3(256), 0, mh_stream(stream), x, M, chunk, bound,
                        2.0f * bound, block_hist, brick_start, perm);
     MH_CHECK_LAUNCH();
@@ -925,20 +941,14 @@ extern "C" int mh_grid_encode_fwd_binned(const float *x, const float *emb, const
     if (st) return st;
     BrickMeta bm;
     if ((st = fill_brick_meta(bm, res_host, L))) return st;
-    // upper bound on sum_b ceil(cnt_b / BRK_CHUNK) + ceil(#outside / BRK_CHUNK): the surplus workgroups write the zero rows
-    const unsigned work_items = (unsigned)(NBRK + M / BRK_CHUNK + 1);
+    // upper bound on sum_b ceil(cnt_b / chunk) + ceil(#outside / BRK_CHUNK_SMALL) for either chunk size: the surplus
+    // workgroups write the zero rows
+    const unsigned work_items = (unsigned)(NBRK + M / BRK_CHUNK_SMALL + 1);
     hipLaunchKernelGGL(grid_fwd_brick_kernel, dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream), x,
                        reinterpret_cast<const float2 *>(emb), meta, bm, perm, brick_start, reinterpret_cast<float2 *>(out), (int)L,
                        (int)n_levels, bound, 2.0f * bound);
     MH_CHECK_LAUNCH();
     return MH_OK;
-}
-
-// calls of at least this many points take the staged d/dx form (see grid_bwd_brick_kernel); a process-wide tuning knob
-static int64_t g_stage_min_points = BRK_STAGE_MIN_POINTS;
-extern "C" int64_t mh_grid_stage_min_points(int64_t set) {
-    if (set >= 0) g_stage_min_points = set;
-    return g_stage_min_points;
 }
 
 extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *emb, const int32_t *offsets_host,
@@ -954,8 +964,8 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
     if (st) return st;
     BrickMeta bm;
     if ((st = fill_brick_meta(bm, res_host, L))) return st;
-    // upper bound on sum_b ceil(cnt_b / BRK_CHUNK); surplus workgroups exit at once
-    const unsigned work_items = (unsigned)(NBRK + M / BRK_CHUNK + 1);
+    // upper bound on sum_b ceil(cnt_b / chunk) for either chunk size; surplus workgroups exit at once
+    const unsigned work_items = (unsigned)(NBRK + M / BRK_CHUNK_SMALL + 1);
     // max|grad| (float bits): supplied by the producer of `grad` (mh_field_bwd_data computes it on the fly), else
     // reduced here into the scratch word behind the work-item table
     const uint32_t *gmax = gmax_bits;
