@@ -423,6 +423,13 @@ def build_train_loop(args, rank, world, dev):
     occ = float(grid.binaries.float().mean())
     n_virtual, n_real = cfg["train"]["virtual_freq"], cfg["train"]["real_freq"]
     sample_log = []
+    graphed = None
+    if args.graph:
+        # the real-view steps that start from a zeroed gradient (9 of the 10) are replayed from HIP graphs; the first one after a
+        # virtual-view step adds its gradient to the virtual view's and stays eager, as does the virtual-view step itself
+        assert world == 1 and args.glue == "fused", "--graph replays this build's own single-GPU real-view step"
+        graphed = trainstep.GraphedRealViewStep(ts, bucket)
+        graphed.prepare()
 
     def step():
         bucket.zero()
@@ -434,11 +441,14 @@ def build_train_loop(args, rank, world, dev):
             ts.global_step = vs.global_step
             n += vs.last_samples
         for k in range(n_real):
-            if k > 0:
-                bucket.zero()                             # the first real step's update carries the virtual-view gradient
-            loss = ts()
-            loss.backward()
-            bucket.allreduce_mean()
+            if k > 0 and graphed is not None:
+                loss = graphed()                          # zero + render + losses + backward + gradient gather: one replay
+            else:
+                if k > 0:
+                    bucket.zero()                         # the first real step's update carries the virtual-view gradient
+                loss = ts()
+                loss.backward()
+                bucket.allreduce_mean()
             opt.step()
             n += ts.last_samples
         sample_log.append(n)
@@ -450,9 +460,10 @@ def build_train_loop(args, rank, world, dev):
             f"{args.virtual_res} rays, SDS replaced by an injected pred_rgb gradient: the Zero-1-to-3 UNet and its weights are not available "
             f"offline) + {n_real} real-view steps ({args.rays} rays each, Adam step each), occupancy refresh every 16 steps "
             f"({occ * 100:.1f}% of 128^3 cells occupied), loss.item() per iteration; glue: {args.glue}")
-    return dict(step=step, rays_per_step=rays_per_iter, bucket=bucket, desc=desc,
+    return dict(step=step, rays_per_step=rays_per_iter, bucket=bucket,
+                desc=desc + ("; real-view steps 2..%d of an iteration replayed from HIP graphs" % n_real if graphed else ""),
                 samples=lambda: (sum(sample_log[-args.steps:]) / max(len(sample_log[-args.steps:]), 1)), occupied=occ, glue=args.glue,
-                iters=True)
+                iters=True, graphed=graphed)
 
 
 def build_density128(args, rank, world, dev):
@@ -684,7 +695,7 @@ def run_one(args):
     for _ in range(args.warmup):
         step()
     graph = None
-    if args.graph and args.workload != "train_real":     # train_real brings its own graphed step (trainstep.GraphedRealViewStep)
+    if args.graph and args.workload not in ("train_real", "train_loop"):     # those bring their own graphed step (trainstep.GraphedRealViewStep)
         assert world == 1 and args.workload in ("cfg3", "cfg2", "cfg3b"), "--graph captures the single-GPU fixed-shape step"
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
@@ -972,8 +983,10 @@ def run_extras(mode):
                               "note": "rays/s of the reference's virtual-view training step (render fwd + bwd + Adam under an "
                                       "injected pred_rgb gradient standing for Zero-1-to-3 SDS)"},
             "train_loop": {"res72": sub(["--workload", "train_loop", "--virtual-res", "72"]),
+                           "res72_hip_graph": sub(["--workload", "train_loop", "--virtual-res", "72", "--graph"]),
                            "note": "BASELINE configs[3] (teddy.yaml, end-to-end iterations per second) with the UNet replaced by its interface: "
-                                   "iters_per_s of (1 virtual + 10 real) training steps"}}
+                                   "iters_per_s of (1 virtual + 10 real) training steps; res72_hip_graph: the nine real-view steps of an "
+                                   "iteration that start from a zeroed gradient replayed from HIP graphs"}}
 
 
 # ------------------------------------------------------------------------------------------------ the driver's line
@@ -1048,6 +1061,7 @@ def compact_line(out, detail_path=None):
     tl = out.get("train_loop")
     if tl:
         line["train_loop_iters_per_s"] = _num(tl, "res72", "iters_per_s")
+        line["train_loop_hip_graph_iters_per_s"] = _num(tl, "res72_hip_graph", "iters_per_s")
     for k in ("iters_per_s", "train_steps_per_s", "kernel_sum_ms_per_step"):
         if k in out:
             line[k] = out[k]

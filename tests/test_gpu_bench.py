@@ -11,12 +11,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*flags):
+def _bench(*flags, workload="train_real", steps=6):
     """(full object from --detail-out, the compact last stdout line)"""
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         detail = os.path.join(td, "detail.json")
-        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "train_real", "--steps", "6", "--warmup", "2",
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup", "2",
                               "--no-kernel-timers", "--detail-out", detail, *flags], cwd=ROOT, capture_output=True, text=True, timeout=600)
         lines = run.stdout.rstrip().splitlines()
         assert run.returncode == 0 and lines and lines[-1].startswith("{"), (run.stderr or run.stdout)[-1500:]
@@ -36,3 +36,16 @@ def test_replayed_training_step_of_the_bench():
     assert g["unit"] == "rays/s" and g["value"] > 0 and g["vs_baseline"] is None and g["n_gpus"] == 1
     lg, le = g["config"]["loss_mean_of_timed_steps"], e["config"]["loss_mean_of_timed_steps"]
     assert lg == lg and le == le and abs(lg - le) <= 0.1 * abs(le), (lg, le)      # same model, same occupancy, other random batches
+
+
+def test_optimisation_loop_with_replayed_real_view_steps():
+    """`bench.py --workload train_loop --graph`: per iteration one eager virtual-view step, one eager real-view step that adds its
+    gradient to the virtual view's, nine real-view steps replayed from HIP graphs -- nothing captured inside the timed region, a
+    finite loss next to the all-eager loop's."""
+    g = _bench("--graph", workload="train_loop", steps=3)
+    e = _bench(workload="train_loop", steps=3)
+    hg = g["config"]["hip_graph"]
+    assert hg["captures_inside_the_timed_region"] == 0 and hg["overflowed_batches"] == 0
+    assert g["iters_per_s"] > 0 and e["iters_per_s"] > 0 and abs(g["train_steps_per_s"] / g["iters_per_s"] - 11.0) < 0.05
+    lg, le = g["config"]["loss_mean_of_timed_steps"], e["config"]["loss_mean_of_timed_steps"]
+    assert lg == lg and le == le and abs(lg - le) <= 0.3 * abs(le), (lg, le)      # same model and occupancy, other random batches (3 single-step losses each)
