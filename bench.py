@@ -1034,6 +1034,10 @@ def compact_line(out, detail_path=None):
     if rh:
         line["roofline_hashgrid"] = {k: rh.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                                                             "hbm_measured_gbs", "bwd_achieved", "bwd_frac")}
+        if (rh.get("frac") or 0) > 1 or (rh.get("bwd_frac") or 0) > 1:
+            # the yardstick counts the reference's eight 8-byte gathers per (point, level) as memory traffic; the brick forms read a
+            # brick's rows from LDS, so algorithmic bytes / time passes the HBM peak -- a throughput in the reference's units
+            line["roofline_hashgrid"]["note"] = "algorithmic bytes/time; rows served from LDS, so > HBM peak: not a utilisation (see hbm_measured_gbs)"
     cb = out.get("cpu_baseline")
     line["cpu_baseline"] = None if not cb else {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
                                                 "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:120]}
