@@ -472,6 +472,7 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
 // item (4558 rows, against 1024 points x 16 levels x 8 corners = 131 k gathers), one 24-byte slot per vertex {sum x, sum y, row},
 // and the loop reads a corner's row at the address it adds the corner's gradient to.  109 KB per workgroup: ONE workgroup per
 // CU (4 waves per SIMD, 128 registers), which pays for requesting the next point's operands an iteration ahead.
+// (DESIGN.md section 3 "The hash grid" has the whole table; profiles/r05_ab_hashgrid.txt the final kernels' run of it.)
 #define BRK_THREADS 1024
 #ifndef BRK_PIPE
 #define BRK_PIPE 2             // A/B: 0 = every operand requested in the iteration that uses it, 1 = the index one iteration ahead, 2 = index two ahead, x / grad one
@@ -489,7 +490,8 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
 #define BRK_STAGE_MIN 96       // a work item with fewer points gathers its rows directly (staging = 4558 gathers, ~36 points' worth, at half the occupancy)
 #endif
 
-// j / d for 0 <= j < 1800, 1 <= d <= 42 (a brick has <= 16 vertices per axis): one multiply and a shift, m = ceil(2^16 / d)
+// j / d for 0 <= j < 4608, 1 <= d <= 16 (a level's vertex block fits BRK_NODES_MAX: <= 16 vertices per axis): one multiply and a
+// shift, m = ceil(2^16 / d) -- checked exhaustively over that range
 __device__ __forceinline__ int brk_div(int j, int m) { return (int)(((uint32_t)j * (uint32_t)m) >> 16); }
 
 // work item w -> (brick, first point, end) in item[0..2]; false for a surplus workgroup (w >= work_start[NBRK]).
