@@ -96,7 +96,8 @@ int mh_grid_encode_bwd_binned(const float *grad, const float *x, const float *em
 /* Brick-binned forward: mh_grid_encode_fwd's features (bit-identical), for points binned by mh_grid_bin_points BEFORE the
  * forward: a workgroup stages its brick's table rows in LDS once and its <= 1024 points read their corners there instead of
  * gathering 8 rows per (point, level) through the texture-address path (0.46 -> 0.2x ms per table at 2.1 M points).  The
- * same perm / brick_start then serve mh_grid_encode_bwd_binned.  L must be 16.  Points outside the box get zero rows. */
+ * same perm / brick_start then serve mh_grid_encode_bwd_binned.  L must be 16.  Points outside the box get zero rows.
+ * (The host side takes it for every call of >= mh_grid_stage_min_points() points, the grouped finite-difference-tap calls included.) */
 int mh_grid_encode_fwd_binned(const float *x, const float *emb, const int32_t *offsets_host, const int32_t *res_host,
                               const int32_t *perm, const int32_t *brick_start, float *out, int64_t M, int32_t L,
                               int32_t n_levels, float bound, void *stream);

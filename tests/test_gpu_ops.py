@@ -107,6 +107,8 @@ def test_grid_forward_binned_bit_identical(n_levels):
         xs, e = x.clone().requires_grad_(True), embg.clone().requires_grad_(True)
         feat = ops.grid_encode(xs, e, offs, res, 1.01, max_level=n_levels / 16.0)
         assert torch.equal(feat.detach(), ref)
+        n6 = M // 6 * 6                                        # a large call with the finite-difference-tap hint is binned as well
+        assert torch.equal(ops.grid_encode(x[:n6], embg, offs, res, 1.01, max_level=n_levels / 16.0, group=6), ref[:n6])
         gw = torch.randn(M, 32, generator=g).to(DEV)
         (feat * gw).sum().backward()
         lib.mh_grid_stage_min_points(1 << 40)
