@@ -43,6 +43,13 @@ def test_argument_validation_without_gpu(lib):
     """status codes, never exceptions or launches, for bad arguments"""
     assert lib.mh_grid_encode_fwd(None, None, None, None, None, 10, 16, 16, 1.01, 1, None) == 1
     assert lib.mh_grid_encode_fwd(None, None, None, None, None, 0, 16, 16, 1.01, 1, None) == 0      # empty input is fine
+    assert lib.mh_grid_encode_fwd_binned(None, None, None, None, None, None, None, 10, 16, 16, 1.01, None) == 1
+    assert lib.mh_grid_encode_fwd_binned(None, None, None, None, None, None, None, 0, 16, 16, 1.01, None) == 0
+    # the call-size knob of the brick-staged hash-grid forms: a process-wide host value, set / queried without a device
+    before = lib.mh_grid_stage_min_points(-1)
+    assert before == 1 << 20 or "MORPHEUS_GRID_STAGE_MIN_POINTS" in os.environ
+    assert lib.mh_grid_stage_min_points(12345) == 12345 and lib.mh_grid_stage_min_points(-1) == 12345
+    assert lib.mh_grid_stage_min_points(before) == before
     assert lib.mh_composite_fwd(*([None] * 10), 0, None) == 0
     assert lib.mh_composite_fwd(*([None] * 10), 5, None) == 1
     assert lib.mh_warp_fwd(*([None] * 8), 6, None, None, None, 128, None) == 1
