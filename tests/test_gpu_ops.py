@@ -120,6 +120,37 @@ def test_grid_forward_binned_bit_identical(n_levels):
     assert float((e.grad - e2.grad).abs().max()) / float(e2.grad.abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("M", [1, 5, 63, 1025, 2049])
+def test_grid_staged_forms_on_tiny_and_ragged_calls(M, grid_rows_staged):
+    """the brick-staged forward and d/dx backward forced onto calls far below their size class -- one point, a handful, one short of
+    a wave, one past a work item, one past a large work item; some points outside the box, all of them outside in a second pass --
+    against the gathering forms: the same features and d/dx bits, table gradients to the fixed-point resolution."""
+    from morpheus_amd import ops, _lib
+    lib = _lib.load()
+    emb, offs, res = _grid_setup()
+    g = torch.Generator().manual_seed(100 + M)
+    for spread in (1.2, 0.0):
+        x = (torch.rand(M, 3, generator=g) * 2 - 1) * spread if spread else torch.full((M, 3), 1.5)
+        x, gw, embg = x.to(DEV), torch.randn(M, 32, generator=g).to(DEV), emb.to(DEV)
+
+        def run():
+            xs, e = x.clone().requires_grad_(True), embg.clone().requires_grad_(True)
+            f = ops.grid_encode(xs, e, offs, res, 1.01)
+            (f * gw).sum().backward()
+            return f.detach(), xs.grad, e.grad
+
+        f1, gx1, ge1 = run()                                   # staged (the fixture set the knob to 0)
+        lib.mh_grid_stage_min_points(1 << 40)
+        try:
+            f2, gx2, ge2 = run()
+        finally:
+            lib.mh_grid_stage_min_points(0)
+        assert torch.equal(f1, f2) and torch.equal(gx1, gx2)
+        assert float((ge1 - ge2).abs().max()) <= 1e-6 * float(ge2.abs().max()) + 1e-30
+        if not spread:
+            assert not f1.any() and not gx1.any() and not ge1.any()
+
+
 def test_grid_encode_edge_cases():
     from morpheus_amd import ops
     emb, offs, res = _grid_setup()
