@@ -438,6 +438,7 @@ def build_train_loop(args, rank, world, dev):
             vs.global_step = ts.global_step
             loss = vs() * (1.0 / n_virtual)               # morpheus.py:1401
             loss.backward()                               # epoch > freeze_epoch: no optimiser step of its own (:1403-1409)
+            loss = loss.detach()                          # (see below)
             ts.global_step = vs.global_step
             n += vs.last_samples
         for k in range(n_real):
@@ -448,6 +449,10 @@ def build_train_loop(args, rank, world, dev):
                     bucket.zero()                         # the first real step's update carries the virtual-view gradient
                 loss = ts()
                 loss.backward()
+                # keep the VALUE only: a loss that still holds its (freed) autograd graph keeps the parameters' AccumulateGrad
+                # nodes alive on this stream, and a graph captured later in the run (a new capacity bucket) would run its
+                # backward's accumulation on them -- outside the capturing stream (a 100-iteration soak crashed on exactly that)
+                loss = loss.detach()
                 bucket.allreduce_mean()
             opt.step()
             n += ts.last_samples

@@ -9,6 +9,8 @@ PY
 }
 run cfg3_200 --mode b3 --steps 200 --warmup 5 --no-kernel-timers
 run train_loop_100 --workload train_loop --steps 100 --warmup 2 --no-kernel-timers
+run train_loop_graph_100 --workload train_loop --graph --steps 100 --warmup 2
+run train_virtual_72_200 --workload train_virtual --steps 200 --warmup 3 --no-kernel-timers
 run train_real_400 --workload train_real --steps 400 --warmup 5 --no-kernel-timers
 run train_real_graph_400 --workload train_real --graph --steps 400 --warmup 5
 MORPHEUS_MAX_PARK_GB=64 run train_virtual_180_cap64_40 --workload train_virtual --virtual-res 180 --steps 40 --warmup 3 --no-kernel-timers
