@@ -527,7 +527,13 @@ class GraphedRealViewStep:
     learning-rate schedule.  Graphs are keyed by (capacity bucket, frequency bands, hash-grid levels) -- what the kernels read of
     the progressive level -- each with its own memory pool, least recently used evicted beyond `max_graphs`.
 
-    Usage:  gs = GraphedRealViewStep(ts, opt.bucket);  loss = gs();  opt.step()        (loss: a 0-dim device tensor)"""
+    Usage:  gs = GraphedRealViewStep(ts, opt.bucket);  loss = gs();  opt.step()        (loss: a 0-dim device tensor)
+
+    Mixed with EAGER training steps on the same parameters (the loop's virtual-view step, a real-view step that must add to an
+    existing gradient): keep only the VALUE of an eager loss once its backward has run (`loss = loss.detach()`).  A loss tensor
+    that still holds its freed autograd graph keeps the parameters' AccumulateGrad nodes alive on the eager stream; a bucket captured
+    later in the run would run its backward's accumulation on them, outside the capturing stream (bench.py --workload train_loop
+    --graph crashed on that in a 100-iteration soak, profiles/r05_soak.txt)."""
 
     def __init__(self, step: RealViewTrainStep, bucket, bucket_step: int = 8192, margin: float = 0.02, lookahead: bool = True,
                  max_graphs: int = 24):
