@@ -1117,6 +1117,44 @@ def test_fixed_capacity_sampling_equals_ragged_sampling(monkeypatch):
     assert int(grid.overflow) == 1 and int(grid.n_valid) == 4096 and res["sdf"].shape[0] == 4096
 
 
+def test_graph_captured_after_eager_steps_on_the_same_parameters():
+    """the optimisation loop's mix (bench.py --workload train_loop --graph): an eager real-view step whose loss keeps only its
+    value, then a replayed step whose capacity bucket has NOT been captured yet -- the capture happens in the middle of the run,
+    after eager backward passes on the same parameters (a loss that still held its graph made exactly this capture crash in a
+    100-iteration soak).  The captured step must produce a finite loss and a gradient, and the optimiser must move on it."""
+    from morpheus_amd import harness
+    from bench_support import trainstep
+    from morpheus_amd.occgrid import OccupancyGrid
+    from morpheus_amd.optim import FlatAdam
+    from morpheus_amd.render import HotPathRenderer
+    model = harness.build_model("b", DEV).train()
+    grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(DEV)
+    rend = HotPathRenderer(model, model.config, grid, 200)
+    ts = trainstep.RealViewTrainStep(rend, trainstep.make_frames([25, 33], 64, 64, DEV), ray_num=512)
+    ts.epoch = 1000
+    opt = FlatAdam(model.get_params_all(model.config["train"]["lr"]), betas=(0.9, 0.99), eps=1e-15)
+    with torch.no_grad():
+        trainstep.warm_up_occupancy(ts)
+    ts.global_step = 4096 + 3
+    gs = trainstep.GraphedRealViewStep(ts, opt.bucket)            # no prepare(): nothing captured yet
+    for _ in range(2):                                             # eager steps first, as the loop's virtual / first real step
+        opt.bucket.zero()
+        loss = ts()
+        loss.backward()
+        loss = loss.detach()
+        opt.bucket.allreduce_mean()
+        opt.step()
+    p0 = opt.flat_p.clone()
+    assert gs.n_captures == 0
+    lg = gs()                                                      # captures its bucket here, then replays it
+    assert gs.n_captures == 1 and bool(torch.isfinite(lg)) and float(opt.bucket.flat.abs().max()) > 0
+    opt.step()
+    loss = ts()                                                    # and an eager step after it still works on the same renderer
+    loss.backward()
+    assert bool(torch.isfinite(loss.detach())) and not torch.equal(opt.flat_p, p0)
+    gs.release()
+
+
 def test_graphed_real_view_step_replays_the_eager_step():
     """trainstep.GraphedRealViewStep: the real-view step captured in a HIP graph.  Draw-for-draw equality with the eager step is
     not available (the graph owns its Philox offsets), so: (i) with every random draw pinned the replayed graph's loss and
