@@ -29,8 +29,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   beside it the HBM view (parked bytes, algorithmic bytes, PMC traffic) and `per_kernel` with the same numbers
                   for every MLP entry of the step
   cpu_baseline -- the CPU oracle ("port") timed on a bounded sample of the same workload
-  modes        -- N=1: the three arithmetic modes (b3 / f32 / h2), each timed in its own process; the top-level numbers are
-                  the faster fp32-faithful one's
+  modes        -- N=1: the two arithmetic modes (b3 / f32, both fp32-faithful), each timed in its own process; the top-level
+                  numbers are the faster one's
 plus roofline_hashgrid (HBM-bound hash-grid stage, as north_star asks) and a per-kernel time table.
 """
 from __future__ import annotations
@@ -90,11 +90,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one all-reduce after backward instead of the early "
                                                               "side-stream exchange of the hash-table gradients")
-    ap.add_argument("--mode", default="auto", choices=["auto", "b3", "f32", "h2"],
+    ap.add_argument("--mode", default="auto", choices=["auto", "b3", "f32"],
                     help="arithmetic of the MLP kernels (morpheus_amd.ops).  auto at N=1 on a headline workload: every mode is "
-                         "timed in its own process and reported in `modes`, the top-level line is the faster fp32-faithful one "
+                         "timed in its own process and reported in `modes`, the top-level line is the faster one "
                          "(b3 / f32); auto elsewhere = MORPHEUS_MLP or the library default (b3)")
-    ap.add_argument("--modes", default="b3,f32,h2", help="the modes `--mode auto` times, in this order")
+    ap.add_argument("--modes", default="b3,f32", help="the modes `--mode auto` times, in this order")
     ap.add_argument("--detail-out", default=None,
                     help="where the FULL result object goes (kernel tables, notes, per-mode lines, allocator statistics); default "
                          "bench_detail.json beside this file.  stdout's LAST line is the compact object (< 6 KB) the driver parses")
@@ -141,7 +141,18 @@ def launch_ranks(args, argv) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(workload: str, n_rays: int, S: int, reps: int = 2):
+def _cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(workload: str, n_rays: int, S: int, reps: int = 3):
     """Oracle (CPU restatement, kind 'port') fwd+bwd on a bounded sample of the same workload, in a
     subprocess per thread count (all-core runs of these small GEMMs are slower than 16-64 threads,
     so a few settings are tried and the best is reported with the thread count actually used)."""
@@ -161,11 +172,11 @@ def cpu_baseline(workload: str, n_rays: int, S: int, reps: int = 2):
         if best is None or r["rays_per_s"] > best["rays_per_s"]:
             best = r
     if best is None:
-        return dict(value=None, unit="rays/s", cores=0, kind="port", sample="failed", tried=tried)
+        return dict(value=None, unit="rays/s", cores=0, kind="port", sample="failed", tried=tried, cpu=_cpu_model())
     return dict(value=round(best["rays_per_s"], 1), unit="rays/s", cores=best["threads"], kind="port",
                 sample=f"{n_rays} rays x {S} samples of the same frame/weights ({wl} render fwd+bwd), min of {reps} after 1 "
                        f"warm-up (oracle/field.py + oracle/hashgrid.c, OpenMP + torch CPU); host has {ncpu} logical CPUs",
-                tried=tried)
+                tried=tried, cpu=_cpu_model())
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -495,21 +506,18 @@ def build_density128(args, rank, world, dev):
 
 
 # ------------------------------------------------------------------------------------------------ roofline
-PRODUCTS = {"f32": 1.0, "b3": 6.0, "h2": 3.0}     # matrix-pipe slice products issued per fp32 MAC
+PRODUCTS = {"f32": 1.0, "b3": 6.0}     # matrix-pipe slice products issued per fp32 MAC
 PIPE = {"f32": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS),
-        "b3": ("bf16 MFMA (v_mfma_f32_32x32x16_bf16)", BF16_MFMA_PEAK_TFLOPS),
-        "h2": ("fp16 MFMA (v_mfma_f32_32x32x16_f16)", BF16_MFMA_PEAK_TFLOPS)}
+        "b3": ("bf16 MFMA (v_mfma_f32_32x32x16_bf16)", BF16_MFMA_PEAK_TFLOPS)}
 # kernel symbols (rocprofv3 names, profiles/*_pmc_summary.csv) behind each timed C-ABI entry, per arithmetic mode
 SYMBOLS = {
-    "mh_warp_fwd": {"f32": ["warp_fwd_kernel"], "b3": ["warp_fwd_b3_kernel<8, true>"], "h2": ["warp_fwd_h2_kernel<4>"]},
-    "mh_warp_bwd_data": {"f32": ["warp_bwd_kernel"], "b3": ["warp_bwd_b3_kernel<8>"], "h2": ["warp_bwd_h2_kernel<8>"]},
+    "mh_warp_fwd": {"f32": ["warp_fwd_kernel"], "b3": ["warp_fwd_b3_kernel<8, true>"]},
+    "mh_warp_bwd_data": {"f32": ["warp_bwd_kernel"], "b3": ["warp_bwd_b3_kernel<8>"]},
     "mh_mlp_wgrad[warp]": {"f32": ["wgrad_kernel<4, false>", "wgrad_kernel<2, false>", "wgrad_reduce_kernel"],
-                           "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"],
-                           "h2": ["wgrad_regs_h2_kernel<4>", "wgrad_regs_h2_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"]},
-    "mh_field_fwd": {"f32": ["field_fwd_kernel"], "b3": ["field_fwd_b3_kernel"], "h2": ["field_fwd_h2_kernel"]},
-    # (the b3 mode runs the bf16x3 form of the fused kernels, the f32 and h2 modes the fp32-MFMA form; ops.FIELD_BWD)
+                           "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"]},
+    "mh_field_fwd": {"f32": ["field_fwd_kernel"], "b3": ["field_fwd_b3_kernel"]},
+    # (the b3 mode runs the bf16x3 form of the fused kernels, the f32 mode the fp32-MFMA form; ops.FIELD_BWD)
     "mh_field_bwd_fused": {"f32": ["field_fused_color_kernel<false>", "field_fused_sdf_kernel<true, false>"],
-                           "h2": ["field_fused_color_kernel<false>", "field_fused_sdf_kernel<true, false>"],
                            "b3": ["field_fused_color_kernel<true>", "field_fused_sdf_kernel<true, true>"]},
 }
 # bytes per sample point.  "algorithmic" = what the operator must move if everything recomputable stayed on the chip (SURVEY 8d:
@@ -529,7 +537,7 @@ def pmc_step_bytes(symbols, mode):
     same arithmetic mode (profiles/r0N_pmc_summary[_mode].csv: FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE, KB
     units, separate passes).  None when no matching profile is committed."""
     import csv
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         # the un-suffixed summary is the default mode's (b3); another mode only matches its own passes
         for name in (f"{rnd}_pmc_summary_{mode}.csv",) + ((f"{rnd}_pmc_summary.csv",) if mode == "b3" else ()):
             path = os.path.join(ROOT, "profiles", name)
@@ -603,9 +611,10 @@ def build_roofline(ktab, mode, M, workload, full_size):
     name = max(per, key=lambda k: per[k]["ms_per_step"])
     out = dict(per[name])
     out["largest_item_of_step"] = True
-    out["traffic_note"] = ("HBM bytes per step of this item's kernels from the committed rocprofv3 --pmc passes (profiles/" +
-                           str(out.pop("traffic_source")) + ")") if out["traffic"] else \
-        "null: no committed PMC profile matches this workload / mode (tools/gpu/r5_round.sh collects it)"
+    out["traffic_source"] = ("profiles/" + str(out["traffic_source"]) + " (committed rocprofv3 --pmc passes of this command; NOT measured in this run)") \
+        if out["traffic"] else None
+    out["traffic_note"] = "HBM bytes per step of this item's kernels, read from traffic_source" if out["traffic"] else \
+        "null: no committed PMC profile matches this workload / mode (tools/gpu/r6_round.sh collects it)"
     out["algorithmic_bytes_note"] = ("SURVEY 8(d): inputs in + results out per point (everything else is recomputable on the chip); "
                                      "traffic far above it is the design's activation parking (DESIGN.md section 3)")
     out["hbm"]["note"] = ("bytes this design moves by construction (parked activation / pre-activation-gradient tiles, each row written "
@@ -619,7 +628,15 @@ def build_roofline(ktab, mode, M, workload, full_size):
     return out
 
 
+GRID_FWD_COMPULSORY, GRID_BWD_COMPULSORY = 12 + 128, 12 + 128 + 12     # x in + features out; grad in + x in + d/dx out (tables stay in L2)
+
+
 def build_hash_roofline(ktab, M, workload, full_size, mode):
+    """HBM roofline of the hash-grid stage (north_star).  `achieved` / `frac` = HBM bytes / time against 8 TB/s, where the bytes are
+    the PMC-measured traffic of the committed rocprofv3 passes when this is the profiled workload (traffic_source names the file)
+    and the COMPULSORY bytes otherwise (x in, features out: 140 B per point and table; a lower bound of the traffic) -- so `frac` is a
+    utilisation and never passes 1.  SURVEY 8(d)'s yardstick (1164 / 2188 algorithmic bytes per point, which count the reference's
+    eight gathers per level as memory traffic) rides beside it as `algorithmic_gbs`, a throughput in the reference's units."""
     binned = "mh_grid_encode_fwd_binned" in ktab           # calls of >= 2^20 points: binned first, a brick's rows staged in LDS
     if not binned and "mh_grid_encode_fwd" not in ktab:
         return None
@@ -629,31 +646,39 @@ def build_hash_roofline(ktab, M, workload, full_size, mode):
     symbol = "grid_fwd_brick_kernel" if binned else "grid_fwd_kernel"
     pts_per_launch = (2 * M if binned else enc_points) / ktab[fwd_key]["calls_per_step"]
     secs = ktab[fwd_key]["avg_ms"] * 1e-3
-    gb = GRID_FWD_BYTES * pts_per_launch / secs / 1e9
-    l2 = GRID_GATHERS_PER_POINT * 64 * pts_per_launch / secs / 1e9
-    traffic = None
+    alg_gbs = GRID_FWD_BYTES * pts_per_launch / secs / 1e9
+    compulsory = GRID_FWD_COMPULSORY * pts_per_launch
+    traffic, src = None, None
     if full_size and workload != "cfg3b":
-        t, _, _ = pmc_step_bytes([symbol], mode)
+        t, src, _ = pmc_step_bytes([symbol], mode)
         traffic = None if t is None else round(t / ktab[fwd_key]["calls_per_step"])
+    hbm_bytes = traffic if traffic is not None else compulsory
+    gb = hbm_bytes / secs / 1e9
     roof = dict(kernel=symbol, bound="hbm", achieved=round(gb, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic, bytes_per_launch=round(GRID_FWD_BYTES * pts_per_launch),
-                launch=fwd_key, hbm_measured_gbs=None if traffic is None else round(traffic / secs / 1e9, 1),
+                frac=round(gb / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_source=("profiles/" + src) if traffic is not None else "none: achieved = compulsory bytes / time",
+                compulsory_bytes=round(compulsory), algorithmic_bytes=round(GRID_FWD_BYTES * pts_per_launch),
+                algorithmic_gbs=round(alg_gbs, 1), launch=fwd_key, ms_per_launch=ktab[fwd_key]["avg_ms"],
                 gathers_per_s=round(GRID_GATHERS_PER_POINT * pts_per_launch / secs / 1e9, 1),
-                l2_sector_gbs_if_every_gather_missed_l1=None if binned else round(l2, 1), l2_peak_gbs=L2_PEAK_GBS,
-                note="achieved = ALGORITHMIC bytes (SURVEY 8d: 1164 B/point) / time -- the yardstick north_star asks for, NOT an "
-                     "HBM utilisation: both 3.2 MB tables are L2/MALL resident.  " +
-                     ("Brick-binned form: a work item stages its brick's 4558 rows in LDS once and its <= 1024 points read their "
-                      "128 corners each there (gathers_per_s counts those LDS reads); what is left in HBM is x in, features out "
-                      "(hbm_measured_gbs = PMC traffic / time)" if binned else
-                      "The gathers are cache-served (hbm_measured_gbs = PMC traffic / time).  What bounds the kernel is the gather "
-                      "rate (gathers_per_s, in G 8-byte gathers/s)") + "; see DESIGN.md section 3")
+                note="frac = HBM bytes (PMC traffic of the committed profile, else the compulsory x-in + features-out bytes) / time / "
+                     "8 TB/s.  algorithmic_gbs = SURVEY 8d's 1164 B/point / time: a throughput in the reference's units (its gathers "
+                     "counted as memory traffic), not a utilisation -- both 3.2 MB tables are L2 resident and " +
+                     ("the brick-binned form stages a brick's 4558 rows in LDS once (gathers_per_s counts LDS reads)" if binned else
+                      "the gathers are cache-served (gathers_per_s, in G 8-byte gathers/s, is what bounds the kernel)") +
+                     "; DESIGN.md section 3")
     bwd_name = "mh_grid_encode_bwd_binned" if "mh_grid_encode_bwd_binned" in ktab else "mh_grid_encode_bwd"
     if bwd_name in ktab:
-        gbb = GRID_BWD_BYTES * (enc_points / ktab[bwd_name]["calls_per_step"]) / (ktab[bwd_name]["avg_ms"] * 1e-3) / 1e9
-        roof.update(bwd_kernel=bwd_name, bwd_achieved=round(gbb, 1), bwd_frac=round(gbb / HBM_PEAK_GBS, 4),
-                    bwd_note="algorithmic bytes of the reference's formulation (2188 B per point incl. the atomics' "
-                             "read-modify-write); the brick kernel accumulates on-chip, so this is a throughput in the "
-                             "reference's units, not an HBM utilisation")
+        bsecs = ktab[bwd_name]["avg_ms"] * 1e-3
+        bpts = enc_points / ktab[bwd_name]["calls_per_step"]
+        btraffic = None
+        if full_size and workload != "cfg3b" and bwd_name == "mh_grid_encode_bwd_binned":
+            t, _, _ = pmc_step_bytes(["grid_bwd_brick_kernel<2, true>"], mode)
+            btraffic = None if t is None else round(t / ktab[bwd_name]["calls_per_step"])
+        bbytes = btraffic if btraffic is not None else GRID_BWD_COMPULSORY * bpts
+        roof.update(bwd_kernel=bwd_name, bwd_achieved=round(bbytes / bsecs / 1e9, 1), bwd_frac=round(bbytes / bsecs / 1e9 / HBM_PEAK_GBS, 4),
+                    bwd_traffic=btraffic, bwd_algorithmic_gbs=round(GRID_BWD_BYTES * bpts / bsecs / 1e9, 1), bwd_ms_per_launch=ktab[bwd_name]["avg_ms"],
+                    bwd_note="bwd_frac as frac (measured or compulsory HBM bytes); bwd_algorithmic_gbs = the reference formulation's 2188 B "
+                             "per point incl. the atomics' read-modify-write / time: the brick kernel accumulates on-chip")
     return roof
 
 
@@ -824,10 +849,6 @@ def run_one(args):
                                             "significand bits), six slice products per MAC on the bf16 matrix pipe, fp32 accumulate"
                                             + ("" if ops.FIELD_BWD == "b3" else f"; field backward: MORPHEUS_FIELD_BWD={ops.FIELD_BWD} "
                                                "(native fp32 MFMA for " + ("the colour + sdf pass" if ops.FIELD_BWD == "sdf" else "both passes") + ")"),
-                                      "h2": "NOT fp32-faithful: warp nets and field forward on two fp16 slices per operand at power-of-two "
-                                            "scales (22 significand bits, block-scaled per layer / per point / per tensor), three slice "
-                                            "products per MAC on the fp16 matrix pipe, fp32 accumulate; 32-row layers' and small batches' "
-                                            "weight gradients bf16 x 3; field backward native fp32 MFMA",
                                       "f32": "native fp32 MFMA (v_mfma_f32_32x32x2_f32) in every MLP kernel"}[mode],
                    "weights": "closed-form state b", "loss": float(loss.item()) if hasattr(loss, "item") else float(loss),
                    "loss_mean_of_timed_steps": None if loss_acc is None else float(loss_acc.item()) / args.steps},
@@ -873,7 +894,7 @@ def run_one(args):
     return out
 
 
-# ------------------------------------------------------------------------------------------------ all three arithmetic modes
+# ------------------------------------------------------------------------------------------------ both arithmetic modes
 
 def _run_child(flags, mode, timeout, env=None):
     """One bench.py child process (fresh allocator, timers and operand caches); returns (full result object or None, error text).
@@ -902,7 +923,7 @@ FAITHFUL = ("b3", "f32")      # modes whose operands keep all 24 significand bit
 def run_modes(args, argv):
     """N = 1, headline workloads, --mode auto: time every arithmetic mode in its OWN process (fresh allocator, timers and
     operand caches; the same isolation the CPU baseline gets) and report them side by side.  The top-level line is the
-    faster of the fp32-faithful modes; h2 rides beside it under its own dtype string."""
+    faster of the two (both keep all 24 operand bits; `modes_ms_per_step` carries both)."""
     base, skip = [], False
     for a in argv:                   # every child gets its own --detail-out
         if skip:
@@ -925,8 +946,8 @@ def run_modes(args, argv):
     out = dict(results[best])
     out["headline_mode"] = best
     out["headline_rule"] = ("value / ms_per_step / dtype / roofline / kernels are those of the faster fp32-faithful mode (b3: exact "
-                            "3 x bf16 operand split; f32: native fp32 MFMA); h2 (22-bit block-scaled operands) is reported in "
-                            "`modes` only")
+                            "3 x bf16 operand split -- a deviation from SURVEY section 7's 'no split-precision tricks', DESIGN.md section 3; "
+                            "f32: native fp32 MFMA, the caveat-free number, in `modes`)")
     out["modes"] = {m: {k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "kernels",
                                           "kernel_sum_ms_per_step")} | {"loss": r["config"]["loss"],
                                                                         "fp32_faithful": m in FAITHFUL}
@@ -997,8 +1018,7 @@ def run_extras(mode):
 # ------------------------------------------------------------------------------------------------ the driver's line
 COMPACT_LIMIT = 6000          # bytes; the driver reads the LAST stdout line and keeps an 8 KB tail (round 4's 34 KB line came back unparsed)
 SHORT_DTYPE = {"b3": "f32 (exact 3 x bf16 operand split on the bf16 MFMA pipe, fp32 accumulate)",
-               "f32": "f32 (native fp32 MFMA)",
-               "h2": "f32-emulated (2 x fp16 block-scaled slices, 22 bits: NOT fp32-faithful)"}
+               "f32": "f32 (native fp32 MFMA)"}
 
 
 def _num(d, *path):
@@ -1029,23 +1049,20 @@ def compact_line(out, detail_path=None):
         line["config"]["rank_ms_per_step"] = [r.get("ms_per_step") for r in c["ranks"]]
     ro = out.get("roofline")
     if ro:
-        line["roofline"] = {k: ro.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_step",
-                                                   "algorithmic_bytes", "parked_bytes", "frac_of_sustained")}
+        line["roofline"] = {k: ro.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                   "ms_per_step", "algorithmic_bytes", "parked_bytes", "frac_of_sustained")}
         line["roofline"]["per_kernel"] = {k: {"ms": v.get("ms_per_step"), "frac": v.get("frac")} for k, v in ro.get("per_kernel", {}).items()}
         line["roofline"]["whole_step_tflops"] = _num(ro, "whole_step", "tflops")
     else:
         line["roofline"] = None
     rh = out.get("roofline_hashgrid")
     if rh:
-        line["roofline_hashgrid"] = {k: rh.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                            "hbm_measured_gbs", "bwd_achieved", "bwd_frac")}
-        if (rh.get("frac") or 0) > 1 or (rh.get("bwd_frac") or 0) > 1:
-            # the yardstick counts the reference's eight 8-byte gathers per (point, level) as memory traffic; the brick forms read a
-            # brick's rows from LDS, so algorithmic bytes / time passes the HBM peak -- a throughput in the reference's units
-            line["roofline_hashgrid"]["note"] = "algorithmic bytes/time; rows served from LDS, so > HBM peak: not a utilisation (see hbm_measured_gbs)"
+        line["roofline_hashgrid"] = {k: rh.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                            "compulsory_bytes", "algorithmic_gbs", "bwd_achieved", "bwd_frac",
+                                                            "bwd_algorithmic_gbs")}
     cb = out.get("cpu_baseline")
     line["cpu_baseline"] = None if not cb else {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
-                                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:120]}
+                                                "kind": cb.get("kind"), "cpu": cb.get("cpu"), "sample": str(cb.get("sample", ""))[:120]}
     if "speedup_vs_cpu_baseline" in out:
         line["speedup_vs_cpu_baseline"] = out["speedup_vs_cpu_baseline"]
     if "modes" in out:

@@ -26,10 +26,9 @@
  *                               models/decoders.py:59-64, models/encodings.py:35-57,
  *                               models/density.py:22-31 -- plain PyTorch in the reference
  *   mh_mlp_wgrad                the weight-gradient GEMMs autograd ran for those MLPs
- * The warp / field entries exist in three arithmetic forms of the SAME interface -- fp32 in, fp32 out, same parked tiles:
- * native fp32 MFMA (no suffix), exact three-way bf16 splits (_b3: fp32-faithful, what the Python side calls by default --
- * morpheus_amd/ops.py, MORPHEUS_MLP), two fp16 slices at power-of-two scales (_h2: opt-in, 22-bit operands); mh_b3_slice /
- * mh_h2_slice cut their weight operands, mh_h2_amax_words sizes the table the _h2 kernels record the parked tensors' maxima in.
+ * The warp / field entries exist in two arithmetic forms of the SAME interface -- fp32 in, fp32 out, same parked tiles:
+ * native fp32 MFMA (no suffix) and exact three-way bf16 splits (_b3: fp32-faithful, what the Python side calls by default --
+ * morpheus_amd/ops.py, MORPHEUS_MLP); mh_b3_slice cuts the weight operands of the latter.
  */
 #ifndef MORPHEUS_HIP_H
 #define MORPHEUS_HIP_H
@@ -44,7 +43,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 6   /* 6: mh_grid_stage_min_points, mh_grid_encode_fwd_binned; 5: accumulate flags of mh_grid_encode_bwd_binned (d/dx) and mh_field_bwd_fused (raw; d(beta) is raw[24 928]); 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*, mh_render_loss_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
+#define MH_ABI_VERSION 7   /* 7: the fp16 x 2 (_h2) entry points removed (not fp32-faithful; round-5 verdict item 8); 6: mh_grid_stage_min_points, mh_grid_encode_fwd_binned; 5: accumulate flags of mh_grid_encode_bwd_binned (d/dx) and mh_field_bwd_fused (raw; d(beta) is raw[24 928]); 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*, mh_render_loss_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -244,47 +243,6 @@ int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const float *g_to
 int mh_warp_fwd_b3(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w3_d,
                    const void *w3_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
                    float *out_topo, float *acts, int64_t M, void *stream);
-/* ---- the same with two fp16 slices per operand (csrc/mlp_h2.hip) -------------------------------------------------
- * x . 2^k = h + l (fp16 each, 22 significand bits together), three slice products Wh.xh + Wh.xl + Wl.xh per fp32 product
- * through v_mfma_f32_32x32x16_f16 with fp32 accumulation: half the matrix work of the bf16x3 form at fp32-grade error
- * (tests/test_gpu_ops.py::test_warp_sliced_arithmetic_is_fp32_grade).  Power-of-two scales keep the slices inside fp16's
- * exponent range: one per layer for the weights, one per point for activations and gradients (computed in the kernels).
- *
- * mh_h2_slice: fp32 fragments in the 32x32x16 order (the gathers of mh_b3_slice), block after block -> per block two fp16
- *   planes [h | l] at the layer's scale; first the layers' largest |w| go (fp32 bits) into dst word table_word[layer] -- the
- *   table the kernels read their weight exponents from.  layer[b] = layer of block b (blocks of a layer consecutive in
- *   src); src_off / n in floats (n % 8 == 0), dst_off in 16-byte units; host arrays (<= 32 blocks).
- * mh_warp_fwd_h2 / mh_warp_bwd_data_h2: mh_warp_fwd / mh_warp_bwd_data with one net's sliced pack (mh_warp_w2_bytes() /
- *   mh_warp_w2T_bytes() bytes: blocks in whole 512 x 16-byte DMA rounds, then one round holding the scale table).  Same
- *   outputs, same parked tiles and dPre tiles (fp32; mh_mlp_wgrad_b3 consumes them). */
-int mh_h2_slice(const float *src, void *dst, int32_t n_blocks, const int32_t *src_off_host, const int32_t *n_host,
-                const int32_t *dst_off_f4_host, const int32_t *layer_host, int32_t n_layers, const int32_t *table_word_host,
-                void *stream);
-int64_t mh_warp_w2_bytes(void);
-int64_t mh_warp_w2T_bytes(void);
-int mh_warp_fwd_h2(const float *x, const int32_t *slot, const float *bias0_d, const float *bias0_t, const void *w2_d,
-                   const void *w2_t, const float *bias_d, const float *bias_t, int32_t n_bands, float *out_deform,
-                   float *out_topo, float *acts, uint32_t *amax, int64_t M, void *stream);
-int mh_warp_bwd_data_h2(const float *x, const float *g_deform, const float *g_topo, const void *w2T_d, const void *w2T_t,
-                        int32_t n_bands, const float *acts, float *dpre, float *g_x, uint32_t *amax, int64_t M, void *stream);
-/* amax (NULL = not recorded): mh_h2_amax_words() device words (64 copies of a 32-word table, one per workgroup residue, against
- * atomic contention), zeroed by the caller before the forward; the kernels atomicMax the largest magnitude (fp32 bits) of
- * every row block they park into it -- word 0: the encoding rows, 1 + 5 net + j: the output of layer j (0..4),
- * 16 + 6 net + l: dPre_l.  mh_mlp_wgrad_h2 takes its per-tensor scales from it (maximum over the copies):
- * mh_mlp_wgrad_b3 whose 128-row layers run, from 16 384 tiles on, on two fp16 slices per operand; a_slot[l] / b_slot[l] = the table
- * words of layer l's dPre and of its input activations (negative: the layer stays on the bf16 x 3 kernel). */
-int64_t mh_h2_amax_words(void);
-int mh_mlp_wgrad_h2(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
-                    int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                    const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
-                    float *db_raw, int64_t n_tiles, const uint32_t *amax, const int32_t *a_slot_host,
-                    const int32_t *b_slot_host, void *stream);
-/* mh_field_fwd_h2: mh_field_fwd with the fp16x2 pack of the six field layers and their two scale tables (mh_field_w2_bytes()
- *   bytes, resident in LDS; packing.py field_joint_packer().h2_blocks).  Same outputs, same parked tiles. */
-int64_t mh_field_w2_bytes(void);
-int mh_field_fwd_h2(const float *xc, const float *feat_s, const float *feat_c, const float *topo, const void *w2,
-                    const float *bias, const float *beta, int32_t n_bands, int32_t with_color, float *sdf, float *sigma,
-                    float *albedo, float *acts, int64_t M, void *stream);
 /* backward-data: consumes g_deform [M,3], g_topo [M,2] (either may be NULL = zero), acts from the
  * forward and the TRANSPOSED packs; writes g_x [M,3] (d/dx through the frequency encoding; pass NULL when the
  * sample positions carry no gradient and the first-layer transposed GEMM is skipped) and

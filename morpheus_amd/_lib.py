@@ -61,15 +61,6 @@ _SIGS = {
     "mh_warp_bwd_data": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_b3_slice": (ctypes.c_int, [_P, _P, _I32, _P, _P, _P, _P]),
     "mh_warp_w3_bytes": (_I64, []),
-    "mh_h2_slice": (ctypes.c_int, [_P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P]),
-    "mh_warp_w2_bytes": (_I64, []),
-    "mh_h2_amax_words": (_I64, []),
-    "mh_field_w2_bytes": (_I64, []),
-    "mh_field_fwd_h2": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
-    "mh_warp_w2T_bytes": (_I64, []),
-    "mh_warp_fwd_h2": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _P, _I64, _P]),
-    "mh_warp_bwd_data_h2": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _P, _I64, _P]),
-    "mh_mlp_wgrad_h2": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "mh_field_w3_bytes": (_I64, []),
     "mh_field_fwd_b3": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_warp_w3T_bytes": (_I64, []),
@@ -122,7 +113,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mh_abi_version() != 6:
+        if lib.mh_abi_version() != 7:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
         if os.environ.get("MORPHEUS_GRID_STAGE_MIN_POINTS"):       # tuning knob, see include/morpheus_hip.h
             lib.mh_grid_stage_min_points(int(os.environ["MORPHEUS_GRID_STAGE_MIN_POINTS"]))

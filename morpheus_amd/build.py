@@ -15,13 +15,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 SO = os.path.join(OUT_DIR, "libmorpheus_hip.so")
-SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_b3.hip", "mlp_h2.hip", "optim.hip", "wnorm.hip", "normal.hip", "graph.hip", "losses.hip"]
+SOURCES = ["hashgrid.hip", "composite.hip", "sampler.hip", "mlp.hip", "mlp_b3.hip", "optim.hip", "wnorm.hip", "normal.hip", "graph.hip", "losses.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "morpheus_hip.h")]
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent scalar fp32 adds / muls of the epilogues into v_pk_* instructions, which
 # cost more than two plain ones beside MFMAs (MI355X_MICROARCH.md); measured on one box, whole library, cfg3: 15.61 -> 15.38
 # ms/step (fused field backward 2.27 -> 2.17 ms, warp forward / backward-data -0.045 / -0.04, hash-grid backward -0.05).  Same
 # IEEE results instruction for instruction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"] + os.environ.get("MH_EXTRA_FLAGS", "").split()
+# macros of timing experiments that compute WRONG results on purpose (tools/micro/hashgrid_brk_exp.patch, built by
+# tools/build_grid_variants.sh into side libraries only) must never reach the product library
+if any("BRK_EXP" in f for f in FLAGS):
+    raise RuntimeError("MH_EXTRA_FLAGS carries a -DBRK_EXP_* timing-experiment macro: refused for libmorpheus_hip.so "
+                       "(tools/build_grid_variants.sh builds those variants)")
 # losses.hip restates chains of rounded fp32 operators (the pose correction: R from six sin / cos, then R d): with hipcc's default
 # -ffp-contract=fast the compiler fuses its products and sums into FMAs and R moves by an ulp -- enough to move SDF values next to
 # zero past the counted parity gate (tests/test_gpu_losses.py compares with the operator chain bit for bit)

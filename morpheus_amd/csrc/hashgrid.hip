@@ -91,7 +91,9 @@ __device__ __forceinline__ bool grid_locate(const float (&xv)[3], float bound, f
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         float u = exact_div(xv[d] + bound, two_bound, inv);  // grid.py:157, fp32 add then IEEE divide
-        inb = inb && !(u < 0.0f || u > 1.0f);
+        // (an infinite coordinate makes exact_div's residual inf - inf = NaN where the IEEE quotient is +-inf: the ordered
+        //  comparison sends both -- and a NaN coordinate -- out of the box, as `u < 0 || u > 1` does for the reference's +-inf)
+        inb = inb && (u >= 0.0f && u <= 1.0f);
         float pos = fminf(fmaxf(fmaf(u, (float)res, -0.5f), 0.0f), (float)(res - 1));
         float fl = floorf(pos);
         g[d] = (uint32_t)fl;
@@ -315,7 +317,7 @@ __device__ __forceinline__ int brick_of(const float *__restrict__ x, int64_t p, 
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         const float u = exact_div(x[p * 3 + d] + bound, two_bound, inv);
-        if (u < 0.0f || u > 1.0f) return NBRK;  // out of range: no gradient (gridencoder.cu:279-284)
+        if (!(u >= 0.0f && u <= 1.0f)) return NBRK;  // out of range (or not finite): no gradient (gridencoder.cu:279-284)
         b[d] = min((int)floorf(u * (float)BRK), BRK - 1);
     }
     return (b[2] * BRK + b[1]) * BRK + b[0];
@@ -462,7 +464,8 @@ __device__ __forceinline__ void fx_scales(uint32_t maxbits, float &to_fx, float 
 
 // Workgroup = BRK_THREADS = 1024 lanes: 64 points x 16 levels in flight per iteration, 16 waves sharing one accumulator.
 //
-// Round-5 timing experiments on the d/dx form (2 tables at cfg3, same box; tools/build_grid_variants.sh, -DBRK_EXP_*):
+// Round-5 timing experiments on the d/dx form (2 tables at cfg3, same box; the wrong-result variants live in
+// tools/micro/hashgrid_brk_exp.patch, applied to a copy by tools/build_grid_variants.sh exp:NAME -- never in this file):
 //   as shipped in round 4 1.38 ms | VALU stream cut by 40 % (DPP sums, branch-free rows, contracted d/dx) 1.32 | LDS atomics
 //   removed 1.21 | the eight table-row gathers of d/dx sent to ONE row 0.86 | both 0.76.
 // Neither the instruction stream nor the LDS atomic pipe nor load latency (operands requested an iteration ahead: no gain) was
@@ -646,8 +649,10 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
     const int32_t *__restrict__ perm, const int32_t *__restrict__ brick_start, float *__restrict__ grad_emb,
     float *__restrict__ grad_x, int L, int n_levels, float bound, float two_bound, const uint32_t *__restrict__ gmax_bits) {
     // per vertex: fixed-point sum of the x channel, of the y channel, and (d/dx forms) the vertex's table row -- 8-byte words.
-    // (Interleaved or channel-major made no difference in a round-5 A/B: the replays the counters show are same-VERTEX collisions
-    //  of the points a wave carries, which a layout cannot remove.)
+    // (Interleaved or channel-major made no difference in a round-5 A/B.  The bank-conflict replays the counters show are NOT
+    //  same-vertex collisions of the points a wave carries -- SQ_LDS_ADDR_CONFLICT is ~0, and walking the corners in a different
+    //  order per point measured the same time (comment at the atomics below): they are the 64-bit atomics of the 16 levels' regions
+    //  landing on random banks.)
     constexpr int W = STAGED ? 3 : 2;
     __shared__ long long acc[W * BRK_NODES_MAX];
     // work item -> (brick, chunk of <= 1024 / 2048 points): hot bricks (all rays converge near the camera)
@@ -749,14 +754,8 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
                 const double wd = (double)w;
                 const unsigned long long qx = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gxd, magic)) - FX_MAGIC_BITS;
                 const unsigned long long qy = (unsigned long long)__double_as_longlong(__builtin_fma(wd, gyd, magic)) - FX_MAGIC_BITS;
-#ifdef BRK_EXP_NOATOM       // timing experiment only (wrong results): the sums are formed but not added
-                if (li == -12345) {
-#endif
                 atomicAdd(reinterpret_cast<unsigned long long *>(&acc[slot[c]]), qx);
                 atomicAdd(reinterpret_cast<unsigned long long *>(&acc[slot[c] + 1]), qy);
-#ifdef BRK_EXP_NOATOM
-                }
-#endif
             }
             if (NEED_DX) {
                 float2 v[8];
@@ -768,10 +767,6 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
                     //  than the 64 that keep two workgroups on a CU: 18 spills -- the rows are asked for here)
                     uint32_t row[8];
                     grid_rows8(g, g1, res, T, dense, pow2, row);
-#ifdef BRK_EXP_SAMEROW      // timing experiment only (wrong results): every lane of a level reads the same eight rows
-#pragma unroll
-                    for (int c = 0; c < 8; c++) row[c] = (row[c] & 0) + c;
-#endif
 #pragma unroll
                     for (int c = 0; c < 8; c++) v[c] = tab[row[c]];
                 }
@@ -794,9 +789,6 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
         }
     }
     __syncthreads();
-#ifdef BRK_EXP_NOFLUSH     // timing experiment only (wrong results)
-    if (n_levels > -5) return;
-#endif
     // flush touched vertices: one global atomic per (vertex, channel) instead of one per (point, corner, channel)
     for (int lev = 0; lev < n_levels; lev++) {
         const uint32_t r = (uint32_t)meta.res[lev];

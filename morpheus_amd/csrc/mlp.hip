@@ -1725,133 +1725,6 @@ __global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_regs_b3_kernel(const 
                            (int)blockIdx.x);
 }
 
-// ---- the same kernel on two fp16 slices per operand (mlp_dev.h: split_h) ---------------------------------------------------
-// wgrad_regs_b3_kernel spends as much issue time as HBM time (48 MFMAs + ~180 slicing instructions per wave and tile against
-// 4 us of traffic at the 6 TB/s a streaming read reaches on this box: tools/micro/hbm_read.hip); with two fp16 slices it is 24
-// MFMAs and ~110.  The contraction runs over POINTS, so per-point scales do not factor out: each operand tensor (a layer's dPre,
-// the layer's input activations) gets ONE power-of-two scale, from the largest magnitude the forward / backward kernels of
-// mlp_h2.hip recorded while parking it (amax table; mlp_h2.hip: H2_AMAX_*).  An element within 2^-17 of its tensor's maximum
-// keeps 22 bits; below, the absolute error is 2^-39 of that maximum.  The accumulators hold 2^(ka + kb) dW; the epilogue
-// scales back.  The bias gradient is summed from the raw fp32 rows as before.
-struct WgSlH {
-    FragH h[2], l[2];
-};
-__device__ __forceinline__ void wg_slice16_h2(const f32x4 (&v)[4], int k, WgSlH &o) {
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int e2 = 0; e2 < 4; e2++)
-            split_h(__builtin_ldexpf(v[2 * s + (e2 >> 1)][2 * (e2 & 1)], k), __builtin_ldexpf(v[2 * s + (e2 >> 1)][2 * (e2 & 1) + 1], k),
-                    o.h[s].u[e2], o.l[s].u[e2]);
-}
-
-template <int IT>
-__global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_regs_h2_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
-                                                                int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
-                                                                int dpre_off, float *__restrict__ dw_part,
-                                                                float *__restrict__ db_part, int64_t n_tiles, int n_chunks,
-                                                                const uint32_t *__restrict__ amax, int a_slot, int b_slot) {
-    // B slices: [buffer 2][in tile IT][plane 2][step 2][lane 64] float4
-    constexpr int BUF_F4 = IT * 4 * 64;
-    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
-    const int i = lane & 31, g = lane >> 5;
-    const int chunk = blockIdx.x;
-    const int64_t st = n_chunks;
-    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
-    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
-    const int bt = mt & (IT - 1);            // activation block this wave loads (waves >= IT reload one, publish nothing)
-    const float *a0 = dpre + dpre_off + (int64_t)(32 * mt + i) * TILE + 16 * g;
-    const float *b0 = acts + act_off + (int64_t)(32 * bt + i) * TILE + 16 * g;
-    const int ka = h2_gexp(h2_read_amax(amax, a_slot)), kb = h2_gexp(h2_read_amax(amax, b_slot));
-    f32x16 acc[IT];
-    acc_zero<IT>(acc);
-    float bsum = 0.f;
-    constexpr int NS = WG_REG_SETS;
-    WgRaw raw[NS];
-    WgSlH as[2];
-#define WG_T(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
-#define WG_LD(set, k)                                                                \
-    do {                                                                             \
-        const int64_t t_ = WG_T(k);                                                  \
-        wg_raw_load(raw[set], a0 + t_ * dpre_tile_floats, b0 + t_ * acts_tile_floats); \
-    } while (0)
-#define WG_SPLIT(set, par, REAL)                                                                                          \
-    do {                                                                                                            \
-        if (REAL) { _Pragma("unroll") for (int j = 0; j < 4; j++) bsum += (raw[set].a[j][0] + raw[set].a[j][1]) + (raw[set].a[j][2] + raw[set].a[j][3]); } \
-        wg_slice16_h2(raw[set].a, ka, as[par]);                                                                     \
-        if (mt < IT) {                                                                                              \
-            WgSlH bs_;                                                                                              \
-            wg_slice16_h2(raw[set].b, kb, bs_);                                                                     \
-            f32x4 *dst_ = lds_res + (par) * BUF_F4 + mt * 4 * 64 + lane;                                            \
-            _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                         \
-                dst_[(0 * 2 + s) * 64] = bs_.h[s].f;                                                                \
-                dst_[(1 * 2 + s) * 64] = bs_.l[s].f;                                                                \
-            }                                                                                                       \
-        }                                                                                                           \
-    } while (0)
-#define WG_MMA(par)                                                                                                 \
-    do {                                                                                                            \
-        const f32x4 *src_ = lds_res + (par) * BUF_F4 + lane;                                                        \
-        _Pragma("unroll") for (int np = 0; np < IT; np += 2) {                                                      \
-            FragH bh_[2][2], bl_[2][2];                                                                             \
-            _Pragma("unroll") for (int t = 0; t < 2; t++) _Pragma("unroll") for (int s = 0; s < 2; s++) {           \
-                bh_[t][s].f = src_[((np + t) * 4 + 0 * 2 + s) * 64];                                                \
-                bl_[t][s].f = src_[((np + t) * 4 + 1 * 2 + s) * 64];                                                \
-            }                                                                                                       \
-            _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                         \
-                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[par].l[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
-                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[par].h[s].h, bl_[t][s].h, acc[np + t], 0, 0, 0); \
-                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as[par].h[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
-            }                                                                                                       \
-        }                                                                                                           \
-    } while (0)
-#define WG_STEP(J)                                                                          \
-    do {                                                                                    \
-        __syncthreads();                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        WG_LD((J) % NS, k0 + (J) + NS);                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-        if (k0 + (J) < n_my) WG_MMA((J) & 1);                                               \
-        WG_SPLIT(((J) + 1) % NS, ((J) + 1) & 1, (k0 + (J) + 1 < n_my));                     \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-    } while (0)
-    if (n_my > 0) {
-#pragma unroll
-        for (int q = 0; q < NS; q++) WG_LD(q, q);
-        __builtin_amdgcn_sched_barrier(0);
-        WG_SPLIT(0, 0, true);
-        for (int64_t k0 = 0; k0 < n_my; k0 += (NS % 2 ? 2 * NS : NS)) {
-            WG_STEP(0);
-            WG_STEP(1);
-            WG_STEP(2);
-            WG_STEP(3);
-            if ((NS % 2 ? 2 * NS : NS) > 4) {
-                WG_STEP(4);
-                WG_STEP(5);
-            }
-            if ((NS % 2 ? 2 * NS : NS) > 6) {
-                WG_STEP(6);
-                WG_STEP(7);
-                WG_STEP(8);
-                WG_STEP(9);
-            }
-        }
-    }
-#undef WG_STEP
-#undef WG_MMA
-#undef WG_SPLIT
-#undef WG_LD
-#undef WG_T
-    const int in_pad = 32 * IT;
-    float *dw = dw_part + (int64_t)chunk * 128 * in_pad;
-#pragma unroll
-    for (int n = 0; n < IT; n++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, g)) * in_pad + 32 * n + i] = __builtin_ldexpf(acc[n][r], -(ka + kb));
-    bsum += __shfl_xor(bsum, 32);
-    if (g == 0) db_part[(int64_t)chunk * 128 + 32 * mt + i] = bsum;
-}
-
 template <int IT, bool B3 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                        int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
@@ -2087,8 +1960,7 @@ extern "C" int64_t mh_mlp_wgrad_workspace_floats(int32_t n_layers, const int32_t
 static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
                       int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
                       const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
-                      float *db_raw, int64_t n_tiles, void *stream, bool b3, const uint32_t *amax = nullptr,
-                      const int32_t *a_slot_host = nullptr, const int32_t *b_slot_host = nullptr) {
+                      float *db_raw, int64_t n_tiles, void *stream, bool b3) {
     if (n_tiles == 0 || n_layers == 0) return MH_OK;
     if (!acts || !dpre || !act_off_host || !dpre_off_host || !in_feats_host || !out_feats_host || !workspace || !dw_raw ||
         !db_raw || n_layers < 0 || n_layers > WG_MAX_LAYERS || n_tiles < 0)
@@ -2135,19 +2007,7 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
         all.db_off[l] = db_poff[l];
         all.first_block[l + 1] = all.first_block[l] + chunks;
         if (per_layer && b3 && out == 128 && (in == 128 || in == 64)) {
-            if (amax && a_slot_host && b_slot_host && a_slot_host[l] >= 0 && b_slot_host[l] >= 0) {
-                // fp16 x 2 slices at the tensors' recorded scales (LDS: two planes per B tile)
-                if (in == 128)
-                    hipLaunchKernelGGL(wgrad_regs_h2_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 4 * 1024, mh_stream(stream),
-                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks, amax, (int)a_slot_host[l],
-                                       (int)b_slot_host[l]);
-                else
-                    hipLaunchKernelGGL(wgrad_regs_h2_kernel<2>, dim3((unsigned)chunks), dim3(256), 2 * 2 * 4 * 1024, mh_stream(stream),
-                                       acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                       workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks, amax, (int)a_slot_host[l],
-                                       (int)b_slot_host[l]);
-            } else if (in == 128)
+            if (in == 128)
                 hipLaunchKernelGGL(wgrad_regs_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
                                    acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
                                    workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
@@ -2189,7 +2049,7 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
         rd.out_off[n_layers + l] = dw_total + db_out;
         db_out += out;
     }
-    if (!per_layer && b3 && !amax && n_tiles >= WG_MERGED_REGS_TILES) {
+    if (!per_layer && b3 && n_tiles >= WG_MERGED_REGS_TILES) {
         // two merged launches: the 128-row layers on the slice-once body, the rest (the narrow output layers) as before
         WgAll wide, rest;
         wide.n = rest.n = 0;
@@ -2247,21 +2107,6 @@ extern "C" int mh_mlp_wgrad_b3(const float *acts, const float *dpre, int64_t act
                                float *db_raw, int64_t n_tiles, void *stream) {
     return wgrad_impl(acts, dpre, acts_tile_floats, dpre_tile_floats, n_layers, act_off_host, dpre_off_host, in_feats_host,
                       out_feats_host, workspace, dw_raw, db_raw, n_tiles, stream, true);
-}
-
-// mh_mlp_wgrad_b3 whose large-batch 128-row layers run on two fp16 slices: amax = the table the mlp_h2.hip kernels filled while
-// parking (device, mh_h2_amax_words() words), a_slot[l] / b_slot[l] = the entries of layer l's dPre and input activations (negative: the layer
-// stays on the bf16 x 3 kernel, as do small batches and 32-row layers)
-extern "C" int mh_mlp_wgrad_h2(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
-                               int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                               const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
-                               float *db_raw, int64_t n_tiles, const uint32_t *amax, const int32_t *a_slot_host,
-                               const int32_t *b_slot_host, void *stream) {
-    if (!amax || !a_slot_host || !b_slot_host) return MH_ERR_ARG;
-    for (int l = 0; l < n_layers && l < WG_MAX_LAYERS; l++)
-        if (a_slot_host[l] >= 32 || b_slot_host[l] >= 32) return MH_ERR_ARG;
-    return wgrad_impl(acts, dpre, acts_tile_floats, dpre_tile_floats, n_layers, act_off_host, dpre_off_host, in_feats_host,
-                      out_feats_host, workspace, dw_raw, db_raw, n_tiles, stream, true, amax, a_slot_host, b_slot_host);
 }
 
 // ---- fused field backward (backward-data + weight gradients, see field_fused_*_kernel) ---------------------------------

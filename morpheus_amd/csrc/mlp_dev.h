@@ -219,66 +219,3 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_
     mid = m.u;
     lo = l.u;
 }
-
-// ---- fp16 x 2 slices (mlp_h2.hip; the large-batch weight-gradient kernel of mlp.hip) -----------------------------------------
-// x . 2^k = h + l + r with h = fp16(x . 2^k), l = fp16(x . 2^k - h), |r| <= 2^-22 |x . 2^k|: the power-of-two scale 2^k puts the
-// largest magnitude of the operand's scale group (a layer's weights; a point's feature vector; a whole parked tensor for the
-// weight gradients) in [2^14, 2^15), inside fp16's five exponent bits.
-#define H2_TOP 141                                       // 127 + 14: biased exponent e -> shift H2_TOP - e puts 2^(e-127) at 2^14
-#define H2_W_CLAMP 60
-#define H2_FWD_CLAMP 40                                  // per-point shifts, forward: 2^-(60 + 40) must stay a normal float
-#define H2_BWD_CLAMP 100                                 // backward: loss gradients down to ~1e-26 reach full scale
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-union FragH {
-    f32x4 f;
-    f16x8 h;
-    uint32_t u[4];
-};
-
-__device__ __forceinline__ int h2_wexp(uint32_t amax_bits) { return min(H2_TOP - (int)(amax_bits >> 23), H2_W_CLAMP); }
-__device__ __forceinline__ int h2_gexp(uint32_t amax_bits) { return min(H2_TOP - (int)(amax_bits >> 23), H2_BWD_CLAMP); }
-
-// two ALREADY SCALED fp32 values -> their packed fp16 slices (round to nearest: v_cvt_pk_f16_f32; x - h is exact in fp32)
-__device__ __forceinline__ void split_h(float x0, float x1, uint32_t &hi, uint32_t &lo) {
-    const f32x2_t v = {x0, x1};
-    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
-    const f32x2_t r = v - __builtin_convertvector(h, f32x2_t);
-    const f16x2_t l = __builtin_convertvector(r, f16x2_t);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-
-// the point's shift from the largest magnitude (fp32 bits, sign cleared) among this lane's values: the partner lane (other
-// half of the point's column) holds the rest.  Shift so that the maximum lands in [2^14, 2^15), at most `cap`.
-__device__ __forceinline__ int h2_point_shift(int amax_bits, int cap) {
-    amax_bits = max(amax_bits, __shfl_xor(amax_bits, 32));
-    return min(H2_TOP - (amax_bits >> 23), cap);
-}
-
-// largest magnitude of a parked row block over the whole launch -> the amax table (fp32 bits, monotonic as unsigned): the
-// weight-gradient kernel contracts over POINTS, so its operands need one scale per tensor, not per point.  Every wave raises
-// its block's word once per layer -- ~10^6 atomics per launch; on 32 addresses they serialise in L2 (measured: forward 2.6 ->
-// 8.4 ms), so the table is kept in H2_AMAX_COPIES copies (one 128-byte line each), a workgroup uses copy blockIdx % copies, and
-// the reader takes the maximum over the copies.  No read-back in the writers: a peek at the word first costs its latency or,
-// placed behind the parking stores, their drain.
-#define H2_AMAX_COPIES 64
-__device__ __forceinline__ void h2_note_amax(uint32_t *__restrict__ table, int slot, int amax_bits) {
-    // wave maximum of non-negative ints on the DPP network (row shifts, then the row broadcasts); valid in lane 63
-    int v = amax_bits;
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));   // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));   // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));   // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));   // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
-    if ((threadIdx.x & 63) == 63) atomicMax(table + (blockIdx.x & (H2_AMAX_COPIES - 1)) * 32 + slot, (uint32_t)v);
-}
-// the reader's side: lane c fetches copy c, the wave maximum is the tensor's
-__device__ __forceinline__ uint32_t h2_read_amax(const uint32_t *__restrict__ table, int slot) {
-    int v = (int)table[(threadIdx.x & (H2_AMAX_COPIES - 1)) * 32 + slot];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return (uint32_t)v;
-}

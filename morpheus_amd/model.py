@@ -251,7 +251,7 @@ class scene_representation(nn.Module):
             self.bg_net = MLP(self.in_dim_bg + self.in_dim_bg_t, 3, hidden_dim_bg, num_layers_bg)
         self.sdf2density = LaplaceDensity(0.1)
         self._opcache = None        # operand cache of the current operand_scope() (None outside a scope)
-        # arithmetic of this model's MLP kernels: "b3" / "f32" / "h2", or None = the process default (ops.mlp_mode()); bound to
+        # arithmetic of this model's MLP kernels: "b3" / "f32", or None = the process default (ops.mlp_mode()); bound to
         # the operand packs when they are prepared, so two models of one process may run different forms
         self.mlp_mode: Optional[str] = None
 

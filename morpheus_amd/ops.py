@@ -124,15 +124,12 @@ def _bin_points(lib, x, bound):
 #         product, less than the rounding of an fp32 multiply-add.
 #   "f32" the native fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere (csrc/mlp.hip): the reference's arithmetic instruction for
 #         instruction, and the slowest (the fp32 MFMA runs at the vector-ALU rate on gfx950).
-#   "h2"  fp16 x 2: two fp16 slices per operand at power-of-two scales (22 significand bits, block-scaled: per layer for
-#         weights, per point for activations / gradients, per tensor for the weight-gradient operands), three slice products
-#         per MAC (csrc/mlp_h2.hip).  The fastest and NOT fp32-faithful (operands are narrower than fp32's 24 bits): an
-#         opt-in mode; bench.py reports it beside the headline with its own dtype string.
-# The field nets' fused backward follows the b3 mode too (mh_field_bwd_fused_b3); the f32 and h2 modes run it on the native fp32
+# (A third form, two fp16 slices at power-of-two scales -- 22-bit operands, NOT fp32-faithful -- existed in rounds 3-5 and was
+# deleted in round 6: git history, csrc/mlp_h2.hip.)
+# The field nets' fused backward follows the b3 mode too (mh_field_bwd_fused_b3); the f32 mode runs it on the native fp32
 # MFMA (mh_field_bwd_fused); see FIELD_BWD below.
-MLP_MODES = ("b3", "f32", "h2")
-MODE_DTYPE = {"f32": "f32", "b3": "f32 (exact 3 x bf16 operand split, 6 slice products per MAC on the bf16 MFMA pipe, fp32 accumulate)",
-              "h2": "f32-emulated (2 x fp16 slices, 22-bit block-scaled operands, 3 slice products per MAC, fp32 accumulate)"}
+MLP_MODES = ("b3", "f32")
+MODE_DTYPE = {"f32": "f32", "b3": "f32 (exact 3 x bf16 operand split, 6 slice products per MAC on the bf16 MFMA pipe, fp32 accumulate)"}
 _mode = os.environ.get("MORPHEUS_MLP", "b3")
 if _mode not in MLP_MODES:
     raise ValueError(f"MORPHEUS_MLP={_mode!r}: expected one of {MLP_MODES}")
@@ -155,7 +152,7 @@ def set_mlp_mode(mode: str) -> str:
 
 
 def _warp_mode(mode: Optional[str] = None) -> str:
-    """operand-pack tag of the MLP nets: "h2" / "b3" / "" (native fp32 MFMA).  `mode`: an explicit choice (a model's own
+    """operand-pack tag of the MLP nets: "b3" / "" (native fp32 MFMA).  `mode`: an explicit choice (a model's own
     `mlp_mode`); None = the process default (MORPHEUS_MLP / set_mlp_mode).  The tag is fixed when a pack is prepared and travels
     with it (MLPOperands.mode -> every forward's ctx): a forward and its backward always use the same arithmetic, and two models
     of one process may differ."""
@@ -677,8 +674,7 @@ def sample_positions(rays_o, rays_d, ray_idx, t_starts, t_ends, ray_start, ray_c
 
 
 # ------------------------------------------------------------------------------------ fused MLPs
-def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False, amax=None,
-           slots=None):
+def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False):
     n_layers = len(act_off)
     dw_len = int(sum(i * o for i, o in zip(in_pad, out_pad)))
     db_len = int(sum(out_pad))
@@ -691,17 +687,9 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     raw = torch.empty(dw_len + db_len, device=dev) if n_tiles > 0 else torch.zeros(dw_len + db_len, device=dev)
     dw_raw, db_raw = raw[:dw_len], raw[dw_len:]
     _e = TIMER.start()
-    if amax is not None:
-        # fp16 x 2 slices at the per-tensor scales the h2 forward / backward recorded (large-batch 128-row layers; the C side
-        # keeps the rest on the bf16 x 3 kernels)
-        sa_np, sa_p = _i32arr(slots[0])
-        sb_np, sb_p = _i32arr(slots[1])
-        check(lib.mh_mlp_wgrad_h2(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw),
-                                  ptr(db_raw), n_tiles, ptr(amax), sa_p, sb_p, stream()), "mh_mlp_wgrad_h2")
-    else:
-        fn = lib.mh_mlp_wgrad_b3 if b3 else lib.mh_mlp_wgrad
-        check(fn(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw), ptr(db_raw), n_tiles,
-                 stream()), "mh_mlp_wgrad")
+    fn = lib.mh_mlp_wgrad_b3 if b3 else lib.mh_mlp_wgrad
+    check(fn(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw), ptr(db_raw), n_tiles,
+             stream()), "mh_mlp_wgrad")
     TIMER.stop("mh_mlp_wgrad[" + tag + "]", _e)
     return raw          # dw_raw | db_raw, tile-row order (packing.JointPacker.unpack_grads maps it back)
 
@@ -804,23 +792,7 @@ class _PackOperands(torch.autograd.Function):
         flat = jp.flat(weights, biases)
         m = jp.on(flat.device)
         fpack, bpack = flat[m["fwd"]], flat[m["bwd"]]
-        if b3 == "h2":
-            # fp16x2 slices (csrc/mlp_h2.hip): same gathers, [h | l] planes per block at the layer's scale + the scale tables
-            lib = _lib.load()
-            w3 = torch.zeros((jp.fwd2_total_f4 + jp.bwd2_total_f4) * 4, device=flat.device)
-            for key, blocks, table, base in (("fwd3", jp.h2_blocks, jp.h2_table, 0),
-                                             ("bwd3", jp.h2T_blocks, jp.h2T_table, jp.fwd2_total_f4)):
-                if key == "bwd3" and not jp.sliced_bwd_for(b3):
-                    continue
-                src = flat[m[key]]
-                so, sp = _i32arr([b[0] for b in blocks])
-                no, np_ = _i32arr([b[1] for b in blocks])
-                do, dp = _i32arr([b[2] for b in blocks])
-                lo, lp = _i32arr([b[3] for b in blocks])
-                to, tp = _i32arr(table)
-                check(lib.mh_h2_slice(ptr(src), ptr(w3[4 * base:]), len(blocks), sp, np_, dp, lp, len(table), tp, stream()),
-                      "mh_h2_slice")
-        elif b3:
+        if b3:
             # bf16x3 forward fragments (csrc/mlp_b3.hip): the same weights gathered in the 32x32x16 fragment order, then cut
             # into [hi | mid | lo] bf16 planes per layer by one launch
             lib = _lib.load()
@@ -861,14 +833,10 @@ class MLPOperands:
     def __init__(self, jp, fpack, bpack, w3, token, mode="", acc=None):
         self.jp, self.fpack, self.bpack, self.token = jp, fpack, bpack, token
         self.acc = acc                                     # running gradient sums of the queries that share these operands
-        self.mode = mode if w3.numel() else ""             # "b3" / "h2": which sliced kernels the operands are cut for
+        self.mode = mode if w3.numel() else ""             # "b3": the sliced kernels the operands are cut for
         # slices per net (float32 storage, 4 floats per float4 unit), or None when the fp32-MFMA kernels serve
-        if self.mode == "h2":
-            self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w2]
-            self.wT3 = [w3[4 * (jp.fwd2_total_f4 + o):4 * (jp.fwd2_total_f4 + o + n)] for o, n in jp.wT2]
-        else:
-            self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w3] if w3.numel() else None
-            self.wT3 = [w3[4 * (jp.fwd3_total_f4 + o):4 * (jp.fwd3_total_f4 + o + n)] for o, n in jp.wT3] if w3.numel() else None
+        self.w3 = [w3[4 * o:4 * (o + n)] for o, n in jp.w3] if w3.numel() else None
+        self.wT3 = [w3[4 * (jp.fwd3_total_f4 + o):4 * (jp.fwd3_total_f4 + o + n)] for o, n in jp.wT3] if w3.numel() else None
         self.w = [jp.take(fpack, sl) for sl in jp.w]
         self.b = [jp.take(fpack, sl) for sl in jp.b]
         self.wT = [jp.take(bpack, sl) for sl in jp.wT]
@@ -876,7 +844,7 @@ class MLPOperands:
 
 def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[torch.Tensor], mode: Optional[str] = None) -> MLPOperands:
     """params_{d,t}: W0x [128,39], W1..W4 [128,128], W5 [n_out,128], b0 (its gradient travels through bias0), b1..b5.
-    mode: the arithmetic the pack is cut for ("b3" / "f32" / "h2"; None = the process default)."""
+    mode: the arithmetic the pack is cut for ("b3" / "f32"; None = the process default)."""
     jp = warp_joint_packer()
     flat = list(params_d[:6]) + list(params_t[:6]) + list(params_d[6:]) + list(params_t[6:])
     mode = _warp_mode(mode)
@@ -918,14 +886,7 @@ class _WarpMLP(torch.autograd.Function):
         b0d, b0t = bias0_d.detach().contiguous(), bias0_t.detach().contiguous()
         slot_c = None if slot is None else slot.contiguous()
         _e = TIMER.start()
-        amax = None
-        if opnd.mode == "h2":
-            # the kernels record the largest magnitude of every parked block: per-tensor scales of the weight-gradient kernel
-            if need_grad and WGRAD_H2:
-                amax = torch.zeros(lib.mh_h2_amax_words(), dtype=torch.int32, device=dev) if AMAX_SEED is None else AMAX_SEED.clone()
-            check(lib.mh_warp_fwd_h2(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
-                                     n_bands, ptr(deform), ptr(topo), ptr(acts), ptr(amax), M, stream()), "mh_warp_fwd_h2")
-        elif opnd.w3 is not None:
+        if opnd.w3 is not None:
             check(lib.mh_warp_fwd_b3(ptr(x), ptr(slot_c), ptr(b0d), ptr(b0t), ptr(opnd.w3[0]), ptr(opnd.w3[1]), ptr(bd), ptr(bt),
                                      n_bands, ptr(deform), ptr(topo), ptr(acts), M, stream()), "mh_warp_fwd_b3")
         else:
@@ -935,7 +896,7 @@ class _WarpMLP(torch.autograd.Function):
         ctx.b3, ctx.mode = opnd.wT3 is not None, opnd.mode
         if ctx.b3:
             wdT, wtT = opnd.wT3
-        ctx.save_for_backward(x, slot_c, wdT, wtT, acts, amax)
+        ctx.save_for_backward(x, slot_c, wdT, wtT, acts)
         ctx.n_bands, ctx.n_slots, ctx.jp = n_bands, bias0_d.shape[0], opnd.jp
         # the caller SAYS when slot[i] == i (model._slots' one-slot-per-sample case); n_slots == M alone does not imply it
         # (B frames == M samples, or torch.unique's sorted inverse)
@@ -945,25 +906,19 @@ class _WarpMLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_deform, g_topo):
         lib = _lib.load()
-        x, slot, wdT, wtT, acts, amax = ctx.saved_tensors
+        x, slot, wdT, wtT, acts = ctx.saved_tensors
         M, dev = x.shape[0], x.device
         n_tiles = lib.mh_mlp_tiles(M)
         dpre = torch.empty(lib.mh_warp_dpre_floats(M), device=dev)
         g_x = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL -> the kernel skips the W0^T stage
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
-        if ctx.mode == "h2":
-            check(lib.mh_warp_bwd_data_h2(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre),
-                                          ptr(g_x), ptr(amax), M, stream()), "mh_warp_bwd_data_h2")
-        else:
-            bwd_data = lib.mh_warp_bwd_data_b3 if ctx.b3 else lib.mh_warp_bwd_data
-            check(bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
-                           stream()), "mh_warp_bwd_data")
+        bwd_data = lib.mh_warp_bwd_data_b3 if ctx.b3 else lib.mh_warp_bwd_data
+        check(bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
+                       stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)
         raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
-                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3, amax=amax, slots=_WARP_WG_SLOTS)
-        if AMAX_CAPTURE is not None and amax is not None:
-            AMAX_CAPTURE.append(amax.clone())
+                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3)
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
             (od, ot) = ctx.jp.bias0_raw
@@ -993,18 +948,6 @@ def _warp_wg_geometry():
 
 
 _WARP_WG = _warp_wg_geometry()
-# amax-table words (csrc/mlp_h2.hip: H2_AMAX_*) of the warp layers' dPre and input activations; the 32-row last layers stay bf16 x 3
-_WARP_WG_SLOTS = ([(16 + 6 * net + l) if l < 5 else -1 for net in range(2) for l in range(6)],
-                  [(0 if l == 0 else 1 + 5 * net + (l - 1)) if l < 5 else -1 for net in range(2) for l in range(6)])
-
-
-# Test hooks of the h2 mode (tests/test_gpu_ops.py; never set by the product path): WGRAD_H2 = False keeps the h2 mode's weight
-# gradients on the bf16 x 3 kernel (the two are compared on the same parked tensors); AMAX_SEED pre-loads the table of parked
-# maxima (the kernels only ever raise it), so a run can be given ANOTHER run's per-tensor scales.
-WGRAD_H2 = True
-AMAX_SEED = None
-AMAX_CAPTURE = None      # a list: every h2 backward appends its table of parked maxima (after the weight gradients ran)
-
 
 def warp_mlp(x, slot, bias0_d, bias0_t, n_bands, opnd: MLPOperands, slots_are_identity: bool = False):
     """slots_are_identity: slot[i] == i for every sample (bias0 rows are per sample): the first-layer bias gradient is then
@@ -1021,9 +964,8 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     albedo = torch.empty(M, 3, device=dev) if with_color else None
     _e = TIMER.start()
     if opnd.w3 is not None:
-        fwd = lib.mh_field_fwd_h2 if opnd.mode == "h2" else lib.mh_field_fwd_b3
-        check(fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(opnd.w3[0]), ptr(b), ptr(beta_c), n_bands,
-                  int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd_" + opnd.mode)
+        check(lib.mh_field_fwd_b3(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(opnd.w3[0]), ptr(b), ptr(beta_c), n_bands,
+                  int(bool(with_color)), ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd_b3")
     else:
         check(lib.mh_field_fwd(ptr(xc), ptr(fs), ptr(fc), ptr(tp), ptr(w), ptr(b), ptr(beta_c), n_bands, int(bool(with_color)),
                                ptr(sdf), ptr(sigma), ptr(albedo), ptr(acts), M, stream()), "mh_field_fwd")
@@ -1036,7 +978,7 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
 # training step: virtual-view 72 x 72 2.56 -> 1.88 ms).  Same-box A/Bs: profiles/r04_ab_field_bwd_b3.txt.  The colour + sdf pass
 # only won once the weight gradient of the sdf net's geo rows had moved into the colour launch: before, the sliced sdf launch
 # spilled 91 registers beside its 192 accumulators and measured equal to the fp32 form.
-# MORPHEUS_FIELD_BWD = "f32" keeps the native fp32 MFMA form (mh_field_bwd_fused; what the f32 and h2 modes always use), "sdf" the
+# MORPHEUS_FIELD_BWD = "f32" keeps the native fp32 MFMA form (mh_field_bwd_fused; what the f32 mode always uses), "sdf" the
 # sliced form for the sdf-only pass alone (A/B).
 FIELD_BWD = os.environ.get("MORPHEUS_FIELD_BWD", "b3")
 if FIELD_BWD not in ("b3", "sdf", "f32"):

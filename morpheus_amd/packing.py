@@ -108,15 +108,6 @@ def _b3_blocks(idx: np.ndarray, MT: int, KS16: int):
     return [idx]
 
 
-def _h2_offsets(block_floats):
-    """float4 offsets of the blocks' [h | l] fp16 planes (whole DMA rounds each), of the scale table behind them, and the total."""
-    offs, f4 = [], 0
-    for n in block_floats:
-        offs.append(f4)
-        f4 += -(-(2 * n // 8) // B3_DMA_F4) * B3_DMA_F4
-    return offs, f4, f4 + B3_DMA_F4
-
-
 B3_DMA_F4 = 512      # a layer's slices are staged by whole rounds of the 512-thread block (16 bytes per thread and round)
 
 
@@ -257,10 +248,6 @@ class NetPacker:
             self.bwd3_f4.append(f4)
             f4 += -(-(3 * n // 8) // B3_DMA_F4) * B3_DMA_F4
         self.bwd3_total_f4 = f4
-        # fp16x2 slices (csrc/mlp_h2.hip): the same gathers, two planes per block, and behind the net's blocks one DMA round
-        # that holds the per-layer scale table (largest |w| of layer i in 32-bit word i)
-        self.fwd2_f4, self.fwd2_tab_f4, self.fwd2_total_f4 = _h2_offsets(self.fwd3_n)
-        self.bwd2_f4, self.bwd2_tab_f4, self.bwd2_total_f4 = _h2_offsets(self.bwd3_n)
         # bias vector (accumulator-row order, padded to 32*MT) : gather from [b_0 | b_1 | ... | 0]
         b_offs, nb = [], 0
         for s in self.specs:
@@ -347,17 +334,15 @@ class JointPacker:
     """
 
     def sliced_bwd_for(self, mode) -> bool:
-        """are the transposed layers sliced in arithmetic mode `mode` ("b3" / "h2"; the kernels' b3 flag spells b3 as True)?"""
+        """are the transposed layers sliced in arithmetic mode `mode` ("b3"; the kernels' b3 flag spells it as True)?"""
         mode = "b3" if mode is True else mode
-        return self.sliced_bwd and mode in self.sliced_bwd_modes
+        return self.sliced_bwd and mode == "b3"
 
     def __init__(self, packers: Sequence[NetPacker], skip_first_bias: bool, sliced_bwd: bool = True):
         self.packers = list(packers)
-        # sliced_bwd: do the sliced (bf16 x 3 / fp16 x 2) kernels read TRANSPOSED slices of these nets?  The warp nets'
-        # backward-data does in both sliced modes; the field nets' fused backward has a bf16 x 3 form (mode b3) but runs on the fp32
-        # MFMA in the f32 and h2 modes, which read the fp32 transposed pack only (sliced_bwd_for)
+        # sliced_bwd: do the sliced (bf16 x 3) kernels read TRANSPOSED slices of these nets?  (The f32 mode reads the fp32
+        # transposed pack only: sliced_bwd_for)
         self.sliced_bwd = sliced_bwd
-        self.sliced_bwd_modes = ("b3", "h2")
         nW = sum(p.n_weights for p in self.packers)
         nB = sum(p.n_biases for p in self.packers)
         zero = nW + nB
@@ -406,10 +391,6 @@ class JointPacker:
             wo += p.n_weights
         self.bwd3_index = np.concatenate(t3)
         self.bwd3_total_f4 = f4
-        # fp16x2 slices of all nets (mh_h2_slice): blocks (src float offset, floats, dst float4, layer id) and the table word of
-        # every layer, for the forward and the transposed chains; w2 / wT2 = (float4 offset, float4 count) per net
-        self.w2, self.h2_blocks, self.h2_table, self.fwd2_total_f4 = self._h2_plan("fwd")
-        self.wT2, self.h2T_blocks, self.h2T_table, self.bwd2_total_f4 = self._h2_plan("bwd")
         # gradients
         raw_dw = sum(p.raw_dw for p in self.packers)
         g, dwo, dbo = [], 0, raw_dw
@@ -435,21 +416,6 @@ class JointPacker:
             pos += p.n_biases
         self.grad_index_nob0 = gz
         self._dev: Dict[Tuple[str, int], Dict[str, torch.Tensor]] = {}
-
-    def _h2_plan(self, which: str):
-        nets, blocks, table, src, f4, layer0 = [], [], [], 0, 0, 0
-        for p in self.packers:
-            ns, o4s, lys = getattr(p, which + "3_n"), getattr(p, which + "2_f4"), getattr(p, which + "3_layer")
-            tab_f4, total = getattr(p, which + "2_tab_f4"), getattr(p, which + "2_total_f4")
-            nets.append((f4, total))
-            for n, o4, ly in zip(ns, o4s, lys):
-                blocks.append((src, n, f4 + o4, layer0 + ly))
-                src += n
-            n_layers = max(lys) + 1
-            table += [4 * (f4 + tab_f4) + i for i in range(n_layers)]
-            layer0 += n_layers
-            f4 += total
-        return nets, blocks, table, f4
 
     def on(self, device: torch.device) -> Dict[str, torch.Tensor]:
         key = (device.type, device.index or 0)
@@ -529,7 +495,5 @@ def warp_joint_packer() -> JointPacker:
 
 def field_joint_packer() -> JointPacker:
     if "field_joint" not in _PACKERS:
-        jp = JointPacker([field_packer()], skip_first_bias=False)
-        jp.sliced_bwd_modes = ("b3",)          # h2: nothing reads fp16 slices of the transposed field layers (fp32-MFMA fused backward)
-        _PACKERS["field_joint"] = jp
+        _PACKERS["field_joint"] = JointPacker([field_packer()], skip_first_bias=False)
     return _PACKERS["field_joint"]

@@ -17,7 +17,7 @@ DEV = "cuda"
 
 
 def _set_mlp(monkeypatch, ops, mode):
-    """arithmetic of the MLP kernels for this test: "b3" (bf16 x 3 slices, the fp32-faithful default), "h2" (fp16 x 2 slices)
+    """arithmetic of the MLP kernels for this test: "b3" (bf16 x 3 slices, the fp32-faithful default)
     or "f32" (native fp32 MFMA); restored by monkeypatch at teardown"""
     monkeypatch.setattr(ops, "_mode", ops.mlp_mode())      # registers the restore
     ops.set_mlp_mode(mode)
@@ -253,10 +253,9 @@ def _wn(p, pre, l):
 
 @pytest.mark.parametrize("kind", ["a", "b"])
 @pytest.mark.parametrize("max_level", [None, 0.5])
-@pytest.mark.parametrize("mlp", ["b3", "h2", "f32"])
+@pytest.mark.parametrize("mlp", ["b3", "f32"])
 def test_warp_mlp(kind, max_level, mlp, monkeypatch):
-    """deform_net + topo_net (fused MFMA kernels: sliced operands on the 16-bit matrix pipe -- bf16 x 3 and fp16 x 2 -- and
-    native fp32 MFMA) vs the oracle, values and every gradient."""
+    """deform_net + topo_net (fused MFMA kernels: bf16 x 3 sliced operands on the bf16 matrix pipe, and native fp32 MFMA) vs the oracle, values and every gradient."""
     from morpheus_amd import ops
     _set_mlp(monkeypatch, ops, mlp)
     M = 1000                                              # not a multiple of 128: exercises the ragged tail
@@ -299,10 +298,10 @@ def test_warp_mlp(kind, max_level, mlp, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["a", "b"])
 @pytest.mark.parametrize("with_color", [True, False])
-@pytest.mark.parametrize("fwd", ["h2", "b3", "f32"])
+@pytest.mark.parametrize("fwd", ["b3", "f32"])
 def test_field_mlp(kind, with_color, fwd, monkeypatch):
-    """sdf_net + Laplace density + color_net (fused MFMA kernels; forward with bf16 x 3 slices = the default, fp16 x 2 slices,
-    native fp32 MFMA; backward = the fused fp32-MFMA kernels in every mode) vs the oracle, given identical hash features (the
+    """sdf_net + Laplace density + color_net (fused MFMA kernels; bf16 x 3 slices = the default, forward and fused backward; native fp32 MFMA in
+    the f32 mode) vs the oracle, given identical hash features (the
     hash grid itself is checked above)."""
     from morpheus_amd import ops
     _set_mlp(monkeypatch, ops, fwd)
@@ -780,15 +779,13 @@ def _warp_float64(nets, x, slot, b0, kink_rel=1e-4):
 
 @pytest.mark.parametrize("data", ["gauss", "geometric", "heavy", "dominant", "large", "small"])
 def test_warp_sliced_arithmetic_against_float64(data, monkeypatch):
-    """All three arithmetic forms of the warp kernels against a float64 evaluation of the same networks -- forward values,
+    """Both arithmetic forms of the warp kernels against a float64 evaluation of the same networks -- forward values,
     d/dx and every weight gradient -- on ordinary AND adversarial operand distributions (see _precision_case).
     What is asserted, per form, relative to the native fp32-MFMA kernels' own error on the same data:
       b3 (exact three-way bf16 split, the fp32-faithful default): forward values within 3x, d/dx within 6x, weight gradients
          within 12x (measured 3-8x, worst 7.8e-6 against 9.8e-7 rel-L2 on the "dominant" data: the OPERANDS are exact, but six
          slice products per MAC go through the bf16 pipe's internal adder, which does not round to nearest, and a weight
-         gradient is a 10^3..10^6-term sum per entry) -- or below the absolute floors 4e-7 / 5e-6 rel-L2;
-      h2 (two fp16 slices at block scales, NOT fp32-faithful, opt-in): forward within 8x or 2e-6 of the output scale, gradients
-         within 30x or 5e-5 rel-L2 -- its documented envelope, two orders below the 1e-4 contract.
+         gradient is a 10^3..10^6-term sum per entry) -- or below the absolute floors 4e-7 / 5e-6 rel-L2.
     Every measured ratio goes to the precision report (profiles/r03_precision_report.jsonl)."""
     from morpheus_amd import ops
     torch.manual_seed(7)
@@ -814,7 +811,7 @@ def test_warp_sliced_arithmetic_against_float64(data, monkeypatch):
     def rl2(a, b):
         return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
 
-    res = {m: run(m) for m in ("f32", "b3", "h2")}
+    res = {m: run(m) for m in ("f32", "b3")}
     g64 = [[p.grad for p in net] for net in ps64]
     meas = {}
     for m, r in res.items():
@@ -826,14 +823,13 @@ def test_warp_sliced_arithmetic_against_float64(data, monkeypatch):
     _report(dict(test="warp_sliced_arithmetic_against_float64", data=data, points=M, safe_points=int(safe.sum()), **{
         m: {k: (round(v, 12) if isinstance(v, float) else v) for k, v in meas[m].items()} for m in meas}))
     f32 = meas["f32"]
-    lim = {"b3": dict(fwd=(3.0, 4e-7), dx=(6.0, 5e-6), wgrad=(12.0, 5e-6), bias0=(12.0, 5e-6)),
-           "h2": dict(fwd=(8.0, 2e-6), dx=(30.0, 5e-5), wgrad=(30.0, 5e-5), bias0=(30.0, 5e-5))}
-    for m in ("b3", "h2"):
+    lim = {"b3": dict(fwd=(3.0, 4e-7), dx=(6.0, 5e-6), wgrad=(12.0, 5e-6), bias0=(12.0, 5e-6))}
+    for m in ("b3",):
         for q, (ratio, floor) in lim[m].items():
             assert meas[m][q] <= max(ratio * f32[q], floor), (data, m, q, meas[m][q], f32[q])
 
 
-@pytest.mark.parametrize("mlp", ["b3", "h2", "f32"])
+@pytest.mark.parametrize("mlp", ["b3", "f32"])
 def test_warp_large_batch_weight_gradients(mlp, monkeypatch):
     """The large-batch kernels of the warp path (from 16 384 tiles on mh_mlp_wgrad(_b3) launches one kernel per layer: the
     slice-once-per-workgroup b3 kernel / the three-register-set fp32 kernel; the 8-wave forward / backward run hundreds of
@@ -962,49 +958,6 @@ def test_grid_large_batch_gradients():
     assert float((ge1 - ge2).abs().max()) / scale <= 1e-5, float((ge1 - ge2).abs().max()) / scale
 
 
-def test_warp_weight_gradient_kernel_on_fp16_slices(monkeypatch):
-    """wgrad_regs_h2_kernel (large batches of the h2 mode: two fp16 slices per operand at ONE power-of-two scale per parked tensor,
-    taken from the amax table the forward / backward kernels fill) against the bf16 x 3 kernel on the very same parked
-    tensors: every weight gradient within 5e-6 rel-L2 -- the distance the bf16 x 3 kernel itself keeps from float64 -- with
-    loss gradients spread over eight decades (a per-tensor scale must not lose the small ones), bias gradients identical
-    (both sum the raw fp32 rows), and the amax table must hold the tensors' true maxima."""
-    from morpheus_amd import ops, _lib
-    _set_mlp(monkeypatch, ops, "h2")
-    torch.manual_seed(11)
-    M = 600_000                                             # 18 750 tiles: the per-layer large-batch launches
-    nets = []
-    for nout in (3, 2):
-        W = [torch.randn(128, 39, device=DEV) * 0.15] + [torch.randn(128, 128, device=DEV) * 0.1 for _ in range(4)] + \
-            [torch.randn(nout, 128, device=DEV) * 0.15]
-        b = [torch.randn(128, device=DEV) * 0.1 for _ in range(5)] + [torch.randn(nout, device=DEV) * 0.1]
-        nets.append(W + b)
-    x = torch.rand(M, 3, device=DEV) * 2 - 1
-    b0 = [torch.randn(1, 128, device=DEV) * 0.3 for _ in range(2)]
-    decades = 10.0 ** (-8.0 * torch.rand(M, 1, device=DEV))
-    g = (torch.randn(M, 3, device=DEV) * decades, torch.randn(M, 2, device=DEV) * decades)
-
-    def run(wgrad_h2):
-        monkeypatch.setattr(ops, "WGRAD_H2", wgrad_h2)
-        ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
-        d, t = ops.warp_mlp(x, None, b0[0], b0[1], 6, ops.prepare_warp_operands(ps[0], ps[1]))
-        torch.autograd.backward([d, t], [g[0], g[1]])
-        return d.detach(), [p.grad for net in ps for p in net]
-
-    (d_h, g_h), (d_b, g_b) = run(True), run(False)
-    assert torch.equal(d_h, d_b)                            # recording the maxima does not touch the values
-    n = 0
-    for k, (a, b) in enumerate(zip(g_h, g_b)):
-        if b is None:
-            continue
-        if a.dim() == 1 or a.shape[0] < 128:                # biases, and the 32-row last layers (bf16 x 3 in both runs)
-            assert torch.equal(a, b), k
-        else:
-            rel = float((a - b).norm() / b.norm())
-            assert rel <= 5e-6, (k, tuple(b.shape), rel)
-            n += 1
-    assert n == 10
-
-
 def test_background_net_on_the_gpu_vs_reference():
     """a13 (models/model.py:400-410) on cuda: colour and gradients against the reference-generated fixture the CPU test uses
     (tests/test_reference_extras.py); the background net is plain torch in the product (dead in the reference's own loop)."""
@@ -1026,59 +979,3 @@ def test_background_net_on_the_gpu_vs_reference():
             gw, gb = g[f"bg_{kind}_{ml_tag}|grad_w0"], g[f"bg_{kind}_{ml_tag}|grad_b1"]
             assert_close(model.bg_net.net[0].weight_v.grad, gw, 1e-4, "bg dW0", floor=1e-2 * float(abs(gw).max()))
             assert_close(model.bg_net.net[1].bias.grad, gb, 1e-4, "bg db1", floor=1e-2 * float(abs(gb).max()))
-
-
-def test_h2_weight_gradients_keep_the_small_gradient_points():
-    """The h2 weight-gradient kernel slices each parked tensor at ONE power-of-two scale taken from the tensor's maximum, so a
-    point whose loss gradient is decades below the batch's largest sits low in the fp16 slices.  Whole-tensor rel-L2 cannot
-    see what happens to such points (the large ones dominate it), so this test isolates them: the loss gradients span eight
-    decades; the gradient of ONLY the bottom four decades' points is computed (i) in float64, (ii) by the h2 kernel WITH THE
-    SCALES OF THE FULL BATCH (the table of parked maxima of the full run is pre-loaded, ops.AMAX_SEED -- exactly the
-    situation of those points inside the full batch) and (iii) by the bf16 x 3 kernel (no scales).  Asserted: the h2 result
-    stays within 1e-3 rel-L2 of float64 on every weight gradient -- small members are kept to the precision the scale
-    leaves them (absolute error 2^-39 of the tensor's maximum per element), not flushed -- and the measured ratios are
-    recorded next to the bf16 x 3 kernel's."""
-    from morpheus_amd import ops
-    torch.manual_seed(13)
-    M = 600_000                                             # 18 750 tiles: the per-layer large-batch h2 kernel
-    nets, x, b0 = _precision_case("gauss", M)
-    b0 = [t[:1].contiguous() for t in b0]
-    u = torch.rand(M, 1, device=DEV)
-    decades = 10.0 ** (-8.0 * u)
-    g_full = (torch.randn(M, 3, device=DEV) * decades, torch.randn(M, 2, device=DEV) * decades)
-    small = (u > 0.5)                                       # the bottom four decades: factors 1e-4 .. 1e-8
-    outs, (ps64, x64, b64), safe = _warp_float64(nets, x, None, b0)
-    keep = (small[:, 0] & safe)[:, None]
-    g_small = (g_full[0] * keep, g_full[1] * keep)
-    torch.autograd.backward(outs, [g_small[0].double(), g_small[1].double()])
-    g64 = [p.grad for net in ps64 for p in net]
-
-    def run(g, mode, seed=None, wgrad_h2=True, capture=None):
-        prev = ops.set_mlp_mode(mode)
-        ops.AMAX_SEED, ops.WGRAD_H2, ops.AMAX_CAPTURE = seed, wgrad_h2, capture
-        try:
-            ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
-            d, t = ops.warp_mlp(x, None, b0[0], b0[1], 6, ops.prepare_warp_operands(ps[0], ps[1]))
-            torch.autograd.backward([d, t], [g[0], g[1]])
-            return [p.grad for net in ps for p in net]
-        finally:
-            ops.set_mlp_mode(prev)
-            ops.AMAX_SEED, ops.WGRAD_H2, ops.AMAX_CAPTURE = None, True, None
-
-    cap = []
-    run((g_full[0] * safe[:, None], g_full[1] * safe[:, None]), "h2", capture=cap)     # the full batch: records its maxima
-    assert len(cap) == 1
-    g_h2 = run(g_small, "h2", seed=cap[0])
-    g_b3 = run(g_small, "h2", wgrad_h2=False)
-
-    def rl2(a, b):
-        return float((a.double() - b).norm() / b.norm().clamp_min(1e-300))
-    rows, n = [], 0
-    for k, (a, b, r) in enumerate(zip(g_h2, g_b3, g64)):
-        if r is None or a.dim() == 1 or a.shape[0] < 128:   # biases and the 32-row last layers stay on bf16 x 3 in both runs
-            continue
-        rows.append(dict(tensor=k, shape=list(a.shape), h2_vs_f64=rl2(a, r), b3_vs_f64=rl2(b, r)))
-        assert rl2(a, r) <= 1e-3, rows[-1]
-        n += 1
-    assert n == 10
-    _report(dict(test="h2_weight_gradients_small_gradient_points", points=M, small_points=int(keep.sum()), rows=rows))

@@ -1381,13 +1381,13 @@ def test_two_models_with_their_own_arithmetic_in_one_process():
         model.mlp_mode = m
     rends = {m: harness.make_renderer(model, S, jitter=synth.ray_jitter(N).to(DEV)) for m, model in models.items()}
     outs = {m: rends[m].render_rays(o, d, t, rid, hw, hw, ambient_ratio=1.0, shading="albedo") for m in models}   # both graphs alive
-    prev = ops.set_mlp_mode("h2")                        # a changed default must not reach the packs already prepared
-    try:
-        for m, model in models.items():
+    for m, model in models.items():                      # a changed default must not reach the packs already prepared
+        prev = ops.set_mlp_mode("f32" if m == "b3" else "b3")
+        try:
             harness.bench_loss(outs[m], timg, tdep).backward()
             grads[m] = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-    finally:
-        ops.set_mlp_mode(prev)
+        finally:
+            ops.set_mlp_mode(prev)
     assert not torch.equal(outs["b3"]["sdf"], outs["f32"]["sdf"])          # two arithmetic forms really ran ...
     assert_close(outs["b3"]["image"], outs["f32"]["image"], 1e-5, "image b3 vs f32", floor=FLOOR)   # ... and agree to fp32 round-off
     for k in grads["f32"]:

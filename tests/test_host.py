@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/morpheus_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.mh_abi_version() == 6
+    assert lib.mh_abi_version() == 7
     assert lib.mh_status_string(1).decode().startswith("invalid argument")
     # size queries are pure host functions
     assert lib.mh_mlp_tiles(1) == 4 and lib.mh_mlp_tiles(129) == 8
@@ -307,69 +307,6 @@ def test_b3_fragment_index_matches_the_mfma_layout():
     assert jp.w3 == [(0, 28672), (28672, 28672)] and jp.wT3 == [(0, 29184), (29184, 29184)]
 
 
-def test_h2_pack_geometry_matches_the_kernels(lib):
-    """The fp16x2 packs (csrc/mlp_h2.hip) reuse the bf16x3 gathers; what the kernels hard-wire is the block geometry: two planes
-    per block in whole 512-float4 DMA rounds, one round with the layers' scale table behind every net, both k-halves of a
-    128 x 128 layer in ONE scale group, and the byte sizes the C-ABI reports."""
-    from morpheus_amd.packing import field_joint_packer, warp_joint_packer
-    jp = warp_joint_packer()
-    assert jp.w2 == [(0, 19456), (19456, 19456)] and jp.wT2 == [(0, 19968), (19968, 19968)]
-    assert lib.mh_warp_w2_bytes() == 19456 * 16 and lib.mh_warp_w2T_bytes() == 19968 * 16
-    # forward net 0: L0 (1536 float4), four layers of two 2048-float4 k-half blocks, L5 (1024), then the table
-    assert [b[2] for b in jp.h2_blocks[:10]] == [0, 1536, 3584, 5632, 7680, 9728, 11776, 13824, 15872, 17920]
-    assert [b[3] for b in jp.h2_blocks[:10]] == [0, 1, 1, 2, 2, 3, 3, 4, 4, 5]
-    assert jp.h2_table[:6] == [4 * 18944 + i for i in range(6)] and jp.h2_table[6:] == [4 * (19456 + 18944) + i for i in range(6)]
-    # transposed chain: T5 (1024), T4..T1, T0 (2048), table at 19456
-    assert [b[2] for b in jp.h2T_blocks[:10]] == [0, 1024, 3072, 5120, 7168, 9216, 11264, 13312, 15360, 17408]
-    assert jp.h2T_table[:6] == [4 * 19456 + i for i in range(6)]
-    for blocks in (jp.h2_blocks, jp.h2T_blocks):
-        src = 0
-        for so, n, d4, ly in blocks:                      # the gathered source is consumed block after block
-            assert so == src and n % 8 == 0 and d4 % 512 == 0
-            src += n
-    fp = field_joint_packer()
-    assert fp.w2 == [(0, 6656)] and lib.mh_field_w2_bytes() == 6656 * 16
-    assert [b[2] for b in fp.h2_blocks] == [0, 1536, 2560, 3584, 4608, 5632] and fp.h2_table == [4 * 6144 + i for i in range(6)]
-
-
-def test_fp16_slice_arithmetic_model():
-    """The arithmetic claim behind csrc/mlp_h2.hip, on the CPU (numpy float16 rounds to nearest like v_cvt_pk_f16_f32): at a
-    power-of-two scale that puts a vector's maximum in [2^14, 2^15), x = (h + l) / 2^k to 2^-22 |x| for elements within 2^-17 of
-    the maximum and to 2^-39 of the maximum below; and on layer-shaped data the three-slice-product GEMM is closer to the
-    float64 result than a plain fp32 GEMM is."""
-    import numpy as np
-    rng = np.random.default_rng(3)
-    x = (rng.standard_normal(4096) * 10.0 ** rng.uniform(-9, 1, 4096)).astype(np.float32)
-    amax = np.abs(x).max()
-    k = 141 - ((np.float32(amax).view(np.uint32) >> 23) & 0xFF)          # H2_TOP - biased exponent
-    xs = np.ldexp(x, int(k)).astype(np.float32)
-    assert 2.0 ** 14 <= np.abs(xs).max() < 2.0 ** 15
-    h = xs.astype(np.float16)
-    l = (xs - h.astype(np.float32)).astype(np.float16)
-    err = np.abs((h.astype(np.float64) + l.astype(np.float64)) / 2.0 ** int(k) - x.astype(np.float64))
-    bound = np.maximum(2.0 ** -22 * np.abs(x.astype(np.float64)), 2.0 ** -39 * float(amax))
-    assert (err <= bound).all()
-    K, M, N = 128, 128, 2048
-    W = (rng.standard_normal((M, K)) * np.sqrt(2.0 / K)).astype(np.float32)
-    X = np.maximum(rng.standard_normal((K, N)), 0).astype(np.float32) * np.float32(0.3)
-    ref = W.astype(np.float64) @ X.astype(np.float64)
-
-    def slices(a, axis):
-        m = np.abs(a).max(axis=axis, keepdims=True)
-        s = 2.0 ** (14 - np.floor(np.log2(np.maximum(m, 1e-30))))
-        a_s = (a * s).astype(np.float32)
-        hh = a_s.astype(np.float16)
-        ll = (a_s - hh.astype(np.float32)).astype(np.float16)
-        return hh.astype(np.float64) / s, ll.astype(np.float64) / s
-
-    Wh, Wl = slices(W, None)                                            # one scale per layer
-    Xh, Xl = slices(X, 0)                                               # one scale per point (column)
-    sliced = Wh @ Xh + Wh @ Xl + Wl @ Xh
-    rel = lambda a: float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
-    e_h2, e_f32 = rel(sliced), rel((W @ X).astype(np.float64))
-    assert e_h2 < 1.5e-7 and e_h2 < e_f32, (e_h2, e_f32)
-
-
 def test_model_switches_shapes_and_refusals():
     """scene_representation's constructor switches (models/model.py:36-53) build the reference's state_dict shapes (the fixtures'
     states load strictly) and parameter groups; use_t / use_joint stay on the fused kernels, use_app / encode_topo /
@@ -517,6 +454,6 @@ def test_sliced_pack_sizes_match_the_kernels_staging_sizes():
     fj, wj = packing.field_joint_packer(), packing.warp_joint_packer()
     assert fj.fwd3_total_f4 * 16 == lib.mh_field_w3_bytes() and fj.bwd3_total_f4 * 16 == lib.mh_field_w3T_bytes()
     assert wj.fwd3_total_f4 * 16 == 2 * lib.mh_warp_w3_bytes() and wj.bwd3_total_f4 * 16 == 2 * lib.mh_warp_w3T_bytes()
-    # the transposed field layers are sliced for the bf16 x 3 fused backward only (h2 and f32 run it on the fp32 MFMA)
-    assert fj.sliced_bwd_for("b3") and fj.sliced_bwd_for(True) and not fj.sliced_bwd_for("h2")
-    assert wj.sliced_bwd_for("b3") and wj.sliced_bwd_for("h2")
+    # the transposed layers are sliced for the bf16 x 3 kernels only (f32 reads the fp32 transposed pack)
+    assert fj.sliced_bwd_for("b3") and fj.sliced_bwd_for(True) and not fj.sliced_bwd_for("f32")
+    assert wj.sliced_bwd_for("b3") and not wj.sliced_bwd_for("")

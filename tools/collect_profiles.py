@@ -61,7 +61,7 @@ def short(name):
 
 
 def pmc_summary(tag, suffix="", steps_in_run=3):
-    """suffix: "" for the default (b3) passes in gpurun_out/pmc_{sq,fetch,write}, "_h2" / "_f32" for the per-mode passes in
+    """suffix: "" for the default (b3) passes in gpurun_out/pmc_{sq,fetch,write}, "_f32" for the per-mode passes in
     gpurun_out/pmc_{sq,fetch,write}_<mode>.  steps_in_run: warm-up + timed steps of the profiled bench command (its
     launches / steps_in_run = launches per step)."""
     per = defaultdict(lambda: defaultdict(list))
@@ -113,7 +113,7 @@ def main():
                                                    "bench_train_virtual.log": "train_virtual"}.get(log, log[len("bench_"):-len(".log")]) + ".json")
         if line and fresh(det):
             shutil.copy(det, os.path.join(PROF, f"{tag}_bench_{wl}_detail.json"))
-    for d, wl in (("prof", "cfg3"), ("prof_h2", "cfg3_h2"), ("prof_f32", "cfg3_f32"), ("prof_train_real", "train_real")):
+    for d, wl in (("prof", "cfg3"), ("prof_f32", "cfg3_f32"), ("prof_train_real", "train_real")):
         f = latest(f"{d}/*/*_kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(PROF, f"{tag}_bench_{wl}_kernel_stats.csv"))
@@ -138,7 +138,7 @@ def main():
         if fresh(src):
             shutil.copy(src, os.path.join(PROF, f"{tag}_{name}"))
             print("copied", name)
-    print("pmc summary", pmc_summary(tag), [pmc_summary(tag, "_" + m) for m in ("h2", "f32")])
+    print("pmc summary", pmc_summary(tag), [pmc_summary(tag, "_" + m) for m in ("f32",)])
 
 
 if __name__ == "__main__":
