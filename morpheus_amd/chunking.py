@@ -7,8 +7,11 @@ normals, the perturbed-normal regulariser) parks ~45 KB per sample -- 104 GB at 
 device's memory, so that a step which fits comfortably -- the 180 x 180 view: ~106 GB by this estimate -- pays nothing): every
 chunk but the last runs through torch.utils.checkpoint (forward without autograd state, i.e. nothing parked; re-run with parking
 when backward reaches it, one chunk at a time), the last chunk runs as usual -- backward reaches it first, so its parked tiles are
-gone before the first re-run.  The outputs are the concatenation; values and gradients are those of the unchunked call (the
-kernels are batch-size independent: tests/test_gpu_render.py::test_full_size_forward_backward_equals_chunked_renders).
+gone before the first re-run.  The outputs are the concatenation; values and gradients are those of the unchunked call
+(tests/test_gpu_render.py::test_parked_memory_cap_chunks_the_queries, backward outside and INSIDE an open operand_scope).
+Reentrant checkpointing means: a chunked call's gradients are reached by `loss.backward()` only -- `torch.autograd.grad(...)` and
+`backward(inputs=...)` raise torch's own "Checkpointing is not compatible with .grad()" error; and a
+chunk's re-run prepares weight operands of its own (model.fresh_operand_scope), never the enclosing step's.
 Cost: one extra forward of the re-run rows, paid only by calls over the cap.  Measured on the 180 x 180 virtual-view step (2.2 M
 samples; profiles/r05_park_cap_180.txt): no bound 47.8 ms with 243 GB reserved by the caching allocator; cap 64 GB: 58.0 ms, 64 GB
 reserved; cap 32 GB: 61.3 ms, 38 GB reserved."""
@@ -55,9 +58,10 @@ def rows_under_cap(bytes_per_row_all_queries: int, cap: Optional[float] = None, 
     return max(int(cap // max(bytes_per_row_all_queries, 1)) // 8192 * 8192, 8192)
 
 
-def chunked_query(fn: Callable, sliced: Sequence[Optional[torch.Tensor]], rows: int):
+def chunked_query(fn: Callable, sliced: Sequence[Optional[torch.Tensor]], rows: int, model=None):
     """fn(*sliced) -> tuple of per-row tensors (or None entries); `sliced`: tensors with the same leading length (or None),
-    cut by rows.  rows >= the length, or autograd off: one plain call."""
+    cut by rows.  rows >= the length, or autograd off: one plain call.  model: the scene_representation fn queries -- a chunk's
+    re-run in backward gets an operand scope of its own (see model.fresh_operand_scope for why it must)."""
     M = next(t for t in sliced if t is not None).shape[0]
     STATS["calls"] += 1
     if rows >= M or not torch.is_grad_enabled():
@@ -70,6 +74,9 @@ def chunked_query(fn: Callable, sliced: Sequence[Optional[torch.Tensor]], rows: 
     carrier = torch.ones(1, device=next(t for t in sliced if t is not None).device, requires_grad=True)
 
     def run(carrier_, *args):
+        if model is not None and torch.is_grad_enabled():      # the re-run inside backward (the first pass runs under no_grad)
+            with model.fresh_operand_scope():
+                return fn(*args)
         return fn(*args)
 
     outs = []

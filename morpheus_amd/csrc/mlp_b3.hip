@@ -42,9 +42,14 @@ extern __shared__ f32x4 lds_b3[];
 #ifndef B3_Q4_FILL
 #define B3_Q4_FILL 6
 #endif
-#ifndef B3_KEEP_BWD
-#define B3_KEEP_BWD 32
-#endif
+// Parking stores a wave issues per epilogue EIGHTH (8 accumulator registers of one tile: one global_store_dword each) and per
+// epilogue HALF (two tiles = four eighths).  The vmcnt(KEEP) waits below are only right if at least KEEP such stores sit between
+// the LDS-DMA they wait for and the wait itself: KEEP is DERIVED from these counts, never chosen (round-5 advisor finding: a -D
+// override could exceed the store count and the kernel would read stale weight slices).
+#define B3_PARK_STORES_EIGHTH 8
+#define B3_PARK_STORES_HALF (4 * B3_PARK_STORES_EIGHTH)
+#define B3_KEEP_BWD B3_PARK_STORES_HALF
+static_assert(B3_KEEP_BWD <= B3_PARK_STORES_HALF && B3_PARK_STORES_HALF <= 63, "vmcnt(KEEP) must not exceed the stores behind the DMA");
 
 #ifdef MH_PHASE_TRACE
 // phase trace for tools/phase_trace_b3.py (never compiled into the product library): wave 0 of every 32nd workgroup stamps
@@ -211,7 +216,7 @@ __device__ __forceinline__ void b3_epilogue_eighth(f32x16 (&acc)[4], float *__re
     for (int r = 8 * s2; r < 8 * s2 + 8; r++) acc[t][r] = relu_i(acc[t][r]);
     if (PARK) {
 #pragma unroll
-        for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
+        for (int r = 8 * s2; r < 8 * s2 + B3_PARK_STORES_EIGHTH; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);
     }
     uint32_t m = 0;
 #pragma unroll
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
     const float *__restrict__ bias_d, const float *__restrict__ bias_t, int n_bands, float *__restrict__ out_deform,
     float *__restrict__ out_topo, float *__restrict__ acts, int64_t M, int64_t n_tiles) {
     constexpr int NT = NW * 64;
-    constexpr int KEEP = PARK ? 32 : 0;      // parking stores a wave issues in a quarter that carries an epilogue
+    constexpr int KEEP = PARK ? B3_PARK_STORES_HALF : 0;      // parking stores a wave issues in a quarter that carries an epilogue (4 eighths)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = lane & 31, h = lane >> 5;
     const int64_t tile_raw = (int64_t)blockIdx.x * NW + wave;
@@ -565,7 +570,7 @@ __device__ __forceinline__ void b3_epilogue_bwd_eighth(f32x16 (&acc)[4], uint2 m
 #pragma unroll
     for (int r = 8 * s2; r < 8 * s2 + 8; r++) acc[t][r] = mask_bit(mw, r, acc[t][r]);
 #pragma unroll
-    for (int r = 8 * s2; r < 8 * s2 + 8; r++) PARK_STORE(acc[t][r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
+    for (int r = 8 * s2; r < 8 * s2 + B3_PARK_STORES_EIGHTH; r++) PARK_STORE(acc[t][r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
 #pragma unroll
     for (int e2 = 0; e2 < 4; e2++)
         split2(acc[t][8 * s2 + 2 * e2], acc[t][8 * s2 + 2 * e2 + 1], bh[2 * t + s2].u[e2], bm[2 * t + s2].u[e2], bl[2 * t + s2].u[e2]);

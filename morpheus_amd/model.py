@@ -304,6 +304,20 @@ class scene_representation(nn.Module):
             if outer is None:
                 self._opcache = None
 
+    @contextlib.contextmanager
+    def fresh_operand_scope(self):
+        """A scope of its own, whatever scope is open around it: chunking.chunked_query re-runs a chunk's forward INSIDE backward
+        (reentrant checkpointing: a nested autograd pass with its own graph-task id).  Operands cached by the step's scope carry
+        the step's raw-gradient token and in-place gradient sums (ops._QueryAccumulator, keyed on the graph task): a re-run that
+        picked them up would reset the outer pass's sums and run the step's _PackOperands node early.  With operands of its own the
+        nested pass is self-contained: its sums are collected by its own pack node and reach the parameters' .grad directly."""
+        outer = self._opcache
+        self._opcache = {}
+        try:
+            yield self
+        finally:
+            self._opcache = outer
+
     def _cached(self, key, build):
         c = self._opcache
         if c is None:

@@ -246,7 +246,7 @@ class HotPathRenderer:
                          frame_slots=None if s_ is None else (frame_slots[0], s_))
 
         sdf, sigmas, rgbs, normals, deform, normal_raw = chunking.chunked_query(main_query, (xyzs, time_step, t_light, slot_rows),
-                                                                                 chunk_rows)
+                                                                                 chunk_rows, model=model)
 
         weights, opacity, depth, rgb_acc = ops.composite(sigmas, t_starts_.contiguous(), t_ends_.contiguous(), rgbs,
                                                          ray_start, ray_cnt, padded=valid is not None)
@@ -280,7 +280,7 @@ class HotPathRenderer:
                     fs_ = None if s_ is None else (frame_slots[0], s_)
                     return model.normal(x_, topo=model.get_topo(x_, t=t_, frame_slots=fs_), cano=cano)[:1]
 
-                normals_p, = chunking.chunked_query(perturbed_normals, (xyzs_p, time_step, slot_rows), chunk_rows)
+                normals_p, = chunking.chunked_query(perturbed_normals, (xyzs_p, time_step, slot_rows), chunk_rows, model=model)
                 results["loss_normal_perturb"] = l1_mean(normals, normals_p)
                 if tr["normal_smooth_3d_t"] > 0:
                     tt = time_step + torch.rand_like(time_step) * 1 / self.num_frames

@@ -861,7 +861,11 @@ def test_parked_memory_cap_chunks_the_queries(monkeypatch):
     render run in row chunks, all but the last through checkpointing (nothing parked in forward, re-made one chunk at a time in
     backward).  The 72 x 72 virtual-view step (lambertian shading through FD normals, orientation loss, normal_smooth_3d,
     normal_smoothness, code_reg; the draws injected) with the cap at 0.4 GB -- 16 chunks per query -- against the same step
-    without a cap: same outputs, same loss, same gradients (different summation orders in the weight-gradient and table sums only)."""
+    without a cap: same outputs, same loss, same gradients (different summation orders in the weight-gradient and table sums only).
+    Third run (round-5 advisor finding): the capped step with backward called INSIDE an open `model.operand_scope()` -- what
+    INTEGRATION.md invites ("wrap a step") -- where a chunk's re-run used to pick up the step's cached operands and, being a nested
+    autograd pass, reset the outer pass's in-place gradient sums; the re-run now takes a scope of its own (fresh_operand_scope)."""
+    import contextlib
     import numpy as np
     from morpheus_amd import chunking, harness
     from bench_support import trainstep
@@ -875,7 +879,7 @@ def test_parked_memory_cap_chunks_the_queries(monkeypatch):
     light = of.safe_normalize(o + torch.tensor([0.3, -0.2, 0.5])).to(DEV)
     npts = None
 
-    def run(cap_gb):
+    def run(cap_gb, backward_inside_scope=False):
         monkeypatch.setenv("MORPHEUS_MAX_PARK_GB", str(cap_gb))
         model = harness.build_model("b", DEV, 0.75).train()
         rend = harness.make_renderer(model, S, samples=tuple(v.to(DEV) for v in smp))
@@ -885,9 +889,10 @@ def test_parked_memory_cap_chunks_the_queries(monkeypatch):
                     rays_id=torch.full((1, N, 1), frame, device=DEV, dtype=torch.int64))
         keep = np.unpackbits(g4["virt72_lam|keep_bits"])[:int(model.config["train"]["trunc"] * 100 + 1) * N].astype(bool)
         before = dict(chunking.STATS)
-        with DrawInjector(remap={3: keep}):
-            loss = ts(data=data, shading=shading, ambient_ratio=ambient, bg_color=torch.tensor(bg, device=DEV), light_d=light)
-        loss.backward()
+        with (model.operand_scope() if backward_inside_scope else contextlib.nullcontext()):
+            with DrawInjector(remap={3: keep}):
+                loss = ts(data=data, shading=shading, ambient_ratio=ambient, bg_color=torch.tensor(bg, device=DEV), light_d=light)
+            loss.backward()
         stats = {k: chunking.STATS[k] - before[k] for k in before}
         res = ts.last_outputs
         return (float(loss.detach()), {k: res[k].detach().clone() for k in ("image", "depth", "sdf", "normal", "weights")},
@@ -904,6 +909,12 @@ def test_parked_memory_cap_chunks_the_queries(monkeypatch):
     for k, a in g_ref.items():
         rel = float((a.double() - g_cap[k].double()).norm() / a.double().norm().clamp_min(1e-30))
         assert rel <= 2e-4, (k, rel)
+    l_in, out_in, g_in, st_in = run(0.4, backward_inside_scope=True)
+    assert st_in["chunked_calls"] == 2 and abs(l_ref - l_in) <= 1e-6 * abs(l_ref)
+    assert set(g_in) == set(g_ref)
+    for k, a in g_ref.items():
+        rel = float((a.double() - g_in[k].double()).norm() / a.double().norm().clamp_min(1e-30))
+        assert rel <= 2e-4, ("backward inside the scope", k, rel)
 
 
 def test_in_place_gradient_sums_under_other_autograd_entry_points():
