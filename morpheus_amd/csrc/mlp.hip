@@ -621,13 +621,16 @@ __device__ __forceinline__ const float *acc_add_lds(f32x16 (&a)[N], const float 
 #endif
 // weights: [plane hi|mid|lo][out tile][k16 step][lane][8 bf16] (packing.py: bwd3 blocks of the field packer); `bin` holds what
 // the fp32 chain carries per 2-wide k-step, so k16 step s takes bin[8s .. 8s+7]
-template <int KS, int MT>
+// S_RUN < KS / 8: the caller knows that bin[8 S_RUN ..] is all zeros (the short last layers: dP2 = [d geo | d sdf | zeros], dQ2 = three
+// rows): those k16 steps are not multiplied -- 12 MFMAs and 44 slicing instructions per skipped step (round 6; the sums are the same
+// numbers: a step of zeros adds +0 to every accumulator)
+template <int KS, int MT, int S_RUN = KS / 8>
 __device__ __forceinline__ void mfma_layer_z_b3(const f32x4 *__restrict__ w, const float (&bin)[KS], f32x16 (&acc)[MT], int lane) {
-    static_assert(KS % 8 == 0, "k16 steps");
+    static_assert(KS % 8 == 0 && S_RUN >= 1 && S_RUN <= KS / 8, "k16 steps");
     constexpr int S = KS / 8, PL = MT * S * 64;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < S; s++) {
+    for (int s = 0; s < S_RUN; s++) {
         Frag bh, bm, bl;
 #pragma unroll
         for (int e2 = 0; e2 < 4; e2++) split2(bin[8 * s + 2 * e2], bin[8 * s + 2 * e2 + 1], bh.u[e2], bm.u[e2], bl.u[e2]);
@@ -656,7 +659,7 @@ __device__ __forceinline__ void mfma_layer_z_b3(const f32x4 *__restrict__ w, con
     // (tools/micro/mfma_valu_gap.hip: 5-6 single-issue instructions per MFMA gap are free inside a wave; this kernel is one wave per SIMD)
 #if FUSED_FILL > 0
 #pragma unroll
-    for (int g_ = 0; g_ < S * 6 * MT; g_++) {
+    for (int g_ = 0; g_ < S_RUN * 6 * MT; g_++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, FUSED_FILL, 0);
     }
@@ -822,7 +825,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_color_kernel(
         row_load_async(B[0], atile, 352 + i, h);
         row_load_async(B[1], atile, 384 + i, h);
         scr_put<1>(scr, d2, pt, h);
-        FUSED_LAYER(16, 2, wt, d2, acc);
+        if (B3) mfma_layer_z_b3<16, 2, 1>(wt, d2, acc, lane);      // (rows 8.. of dQ2 are zeros: k16 step 0 only)
+        else mfma_layer_z<16, 2>(wt, d2, acc, lane);
         wt += FUSED_TC2(B3);
 #pragma unroll
         for (int j = 0; j < 32; j++) dbin[j] = mask_bit(mw3, j, acc[j >> 4][j & 15]);   // mask C2 -> dQ1
@@ -1058,7 +1062,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             FUSED_STAMP(1);
             scr_put<2>(scr, d2, pt, h);
             if (WITH_COLOR) {
-                FUSED_LAYER(32, 2, wt, d2, acc);
+                if (B3) mfma_layer_z_b3<32, 2, 3>(wt, d2, acc, lane);      // (dP2 rows 24.. are zeros: k16 steps 0, 1, 2)
+                else mfma_layer_z<32, 2>(wt, d2, acc, lane);
             } else if (B3) {
                 // d2 is zero but for g_sdf = d2[16]: the k16 step 2 of the layer's 4 (12 MFMAs instead of 48)
                 mfma_kstep_z_b3<4, 2>(wt, 2, &d2[16], acc, lane);
