@@ -634,6 +634,7 @@ class GraphedRealViewStep:
                 self._body(capacity)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.ts.model.end_step()               # nothing an eager forward prepared (and its autograd graph) outlives into the capture
         graph = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.cuda.graph(graph):          # its own memory pool (~35 KB per sample point: a few GB of the 288 per bucket)
             loss = self._body(capacity)

@@ -43,7 +43,7 @@ extern "C" {
 #define MH_ERR_ARG 1     /* bad size / null pointer / unsupported configuration */
 #define MH_ERR_LAUNCH 2  /* hipGetLastError() != hipSuccess after the launch */
 
-#define MH_ABI_VERSION 7   /* 7: the fp16 x 2 (_h2) entry points removed (not fp32-faithful; round-5 verdict item 8); 6: mh_grid_stage_min_points, mh_grid_encode_fwd_binned; 5: accumulate flags of mh_grid_encode_bwd_binned (d/dx) and mh_field_bwd_fused (raw; d(beta) is raw[24 928]); 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*, mh_render_loss_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
+#define MH_ABI_VERSION 8   /* 8: mh_smooth_points_*, mh_bg_blend_* (the last operator chains inside render_rays); 7: the fp16 x 2 (_h2) entry points removed (not fp32-faithful; round-5 verdict item 8); 6: mh_grid_stage_min_points, mh_grid_encode_fwd_binned; 5: accumulate flags of mh_grid_encode_bwd_binned (d/dx) and mh_field_bwd_fused (raw; d(beta) is raw[24 928]); 4: mh_graph_*, mh_masked_mean_*, mh_ortho_perturb_*, mh_pose_apply_*, mh_render_loss_*; 3: round-3 prune (measured-loser entry points removed), n_valid in mh_sdf_losses_* */
 #define MH_MAX_LEVELS 32
 #define MH_TILE 32       /* sample points per wavefront tile in the MLP kernels */
 
@@ -358,6 +358,20 @@ int mh_masked_mean_bwd(int32_t kind, const float *a, const float *b, const float
  * x, n, out [M,3], phi [M] (the caller's uniform draw times 2 pi).  Backward: g_x = g_out (no launch), g_n from *_bwd. */
 int mh_ortho_perturb_fwd(const float *x, const float *n, const float *phi, float scale, int64_t M, float *out, void *stream);
 int mh_ortho_perturb_bwd(const float *n, const float *phi, const float *g_out, float scale, int64_t M, float *g_n, void *stream);
+/* The points of get_normal_smoothness_loss (morpheus.py:530-547): pts[k, n, :] = (depth[n] + off[k]) * rays_d[n, :] + rays_o[n, :],
+ * keep[k, n] = |pts| < 1.1 as 0 / 1 (the reference drops the others with a boolean index, :546-547; here they leave the mean
+ * through this weight).  depth [N], off [K], rays_o / rays_d [N,3], pts [K*N,3], keep [K*N].  Every product and sum rounded on
+ * its own, in the operator chain's order: the same bits.  Backward: g_depth [N], g_o, g_d [N,3] (any may be NULL), the K points
+ * of a ray added in index order.  One launch each way (12 / 8 as torch operators). */
+int mh_smooth_points_fwd(const float *depth, const float *off, const float *rays_o, const float *rays_d, int64_t N, int32_t K,
+                         float *pts, float *keep, void *stream);
+int mh_smooth_points_bwd(const float *g_pts, const float *depth, const float *off, const float *rays_d, int64_t N, int32_t K,
+                         float *g_depth, float *g_o, float *g_d, void *stream);
+/* image = color + (1 - opacity) * bg with a per-ray background (morpheus.py:686-694; bg from get_bg_color, :887-903): color, bg,
+ * image [N,3], opacity [N].  Backward: g_color = g_image (nothing to launch), g_opacity [N] = -sum_c g_image bg, g_bg [N,3] =
+ * (1 - opacity) g_image (NULL: not wanted).  One launch each way (3 / 4 as torch operators), the chain's rounding. */
+int mh_bg_blend_fwd(const float *color, const float *opacity, const float *bg, int64_t N, float *image, void *stream);
+int mh_bg_blend_bwd(const float *g_image, const float *opacity, const float *bg, int64_t N, float *g_opacity, float *g_bg, void *stream);
 
 /* Per-frame pose correction of a ray batch made of B rows of n_per_row rays, ONE frame per row (models/pose.py:4-64 PoseArray,
  * models/model.py:335-346 pose_optimisation): o' = o + t_f, d' = R(a, b, g)_f d with pose [n_frames, 6] = (a, b, g, t) per frame

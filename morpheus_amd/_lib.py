@@ -84,6 +84,10 @@ _SIGS = {
     "mh_masked_mean_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "mh_ortho_perturb_fwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
     "mh_ortho_perturb_bwd": (ctypes.c_int, [_P, _P, _P, _F, _I64, _P, _P]),
+    "mh_smooth_points_fwd": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "mh_smooth_points_bwd": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "mh_bg_blend_fwd": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P]),
+    "mh_bg_blend_bwd": (ctypes.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "mh_pose_bwd_workspace_floats": (_I64, [_I64, _I64]),
     "mh_pose_apply_fwd": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "mh_pose_apply_bwd": (ctypes.c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P]),
@@ -113,7 +117,7 @@ def load():
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mh_abi_version() != 7:
+        if lib.mh_abi_version() != 8:
             raise MorpheusHipError("libmorpheus_hip.so ABI version mismatch")
         if os.environ.get("MORPHEUS_GRID_STAGE_MIN_POINTS"):       # tuning knob, see include/morpheus_hip.h
             lib.mh_grid_stage_min_points(int(os.environ["MORPHEUS_GRID_STAGE_MIN_POINTS"]))

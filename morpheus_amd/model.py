@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
+import weakref
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -176,6 +178,11 @@ class GridEncoder(nn.Module):
         return ops.grid_encode(inputs, self.embeddings, self._offsets_np, self._res_np, float(bound), max_level, group)
 
 
+# LaplaceDensity object -> the scene_representation whose step cache its get_beta() may use (registered by the model's training
+# forward; kept outside the modules so that copies and pickles of a model carry no reference to another one)
+_DENSITY_OWNER: "weakref.WeakValueDictionary" = weakref.WeakValueDictionary()
+
+
 class LaplaceDensity(nn.Module):
     """VolSDF density, learnable beta (models/density.py:17-31)."""
 
@@ -185,6 +192,14 @@ class LaplaceDensity(nn.Module):
         self.beta_min = beta_min
 
     def get_beta(self):
+        # inside a training forward of the owning scene_representation the value is prepared once (its step cache): the field
+        # kernels and the caller's beta regulariser (morpheus.py:1121-1122) then share ONE tensor and one abs / add each way
+        owner = _DENSITY_OWNER.get(id(self))
+        if owner is not None and owner.sdf2density is self:
+            return owner._cached("beta", self._beta)
+        return self._beta()
+
+    def _beta(self):
         return self.beta.abs() + self.beta_min
 
     def forward(self, sdf, beta=None):
@@ -204,6 +219,38 @@ def _freq_encode_torch(x, n_freqs=6, max_level=None):
 
 
 # ------------------------------------------------------------------------------------ the model
+IMPLICIT_OPERANDS = os.environ.get("MORPHEUS_IMPLICIT_OPERANDS", "1") != "0"
+
+
+class _StepCache:
+    """Prepared operands of ONE training forward (scene_representation._step_cache)."""
+    __slots__ = ("sig", "entries", "stale")
+
+    def __init__(self, sig):
+        self.sig, self.entries, self.stale = sig, {}, False
+
+    def _spent(self, *_):
+        # the graph behind the entries is being run: drop them now -- nothing spent lingers in the model (a HIP-graph capture later
+        # in the run crashed on autograd nodes an earlier eager step had left alive: profiles/r05_soak.txt)
+        self.stale = True
+        self.entries.clear()
+
+    def watch(self, value):
+        """the backward pass reaching any graph-bearing member of a cached value ends the step"""
+        if isinstance(value, (tuple, list)):
+            for v in value:
+                self.watch(v)
+        elif isinstance(value, ops.MLPOperands):
+            if value.notify is not None:
+                value.notify.append(self._spent)
+        elif torch.is_tensor(value) and value.requires_grad and value.grad_fn is not None:
+            value.register_hook(self._mark)
+
+    def _mark(self, grad):
+        self._spent()
+        return None
+
+
 class scene_representation(nn.Module):
     def __init__(self, config, bound, max_level=None, num_layers=3, num_layers_t=6, hidden_dim=64, hidden_dim_t=128,
                  hidden_dim_tpo=128, num_layers_bg=2, geo_dim=32, deform_dim=16, hidden_dim_bg=32, amb_dim=2,
@@ -251,6 +298,9 @@ class scene_representation(nn.Module):
             self.bg_net = MLP(self.in_dim_bg + self.in_dim_bg_t, 3, hidden_dim_bg, num_layers_bg)
         self.sdf2density = LaplaceDensity(0.1)
         self._opcache = None        # operand cache of the current operand_scope() (None outside a scope)
+        self._scope_step = None     # the step cache that scope stands on (None: a scope of its own)
+        self._stepcache = None      # prepared operands of the running training forward (_step_cache)
+        self._step_params = None    # the parameters whose version counters say "same step"
         # arithmetic of this model's MLP kernels: "b3" / "f32", or None = the process default (ops.mlp_mode()); bound to
         # the operand packs when they are prepared, so two models of one process may run different forms
         self.mlp_mode: Optional[str] = None
@@ -294,15 +344,19 @@ class scene_representation(nn.Module):
         depends only on the parameters -- effective (weight-normed) weights, the MFMA operand packs, the per-frame code
         bias, beta -- is prepared ONCE and shared by all warp / field calls: a real-view step evaluates the warp nets 4x and
         the field nets 6x, and the weight gradients of all those calls meet in one raw-gradient token per net group
-        (ops._PackOperands) instead of one accumulation per parameter per call.  Parameters must not change inside a scope."""
+        (ops._PackOperands) instead of one accumulation per parameter per call.  Parameters must not change inside a scope.
+        In a training forward the scope IS the model's step cache (below): what a later call of the same step needs is there."""
         outer = self._opcache
         if outer is None:
-            self._opcache = {}
+            sc = self._step_cache()
+            self._opcache = {} if sc is None else sc.entries
+            self._scope_step = sc
         try:
             yield self
         finally:
             if outer is None:
                 self._opcache = None
+                self._scope_step = None
 
     @contextlib.contextmanager
     def fresh_operand_scope(self):
@@ -311,20 +365,69 @@ class scene_representation(nn.Module):
         the step's raw-gradient token and in-place gradient sums (ops._QueryAccumulator, keyed on the graph task): a re-run that
         picked them up would reset the outer pass's sums and run the step's _PackOperands node early.  With operands of its own the
         nested pass is self-contained: its sums are collected by its own pack node and reach the parameters' .grad directly."""
-        outer = self._opcache
-        self._opcache = {}
+        outer, outer_step = self._opcache, self._scope_step
+        self._opcache, self._scope_step = {}, None
         try:
             yield self
         finally:
-            self._opcache = outer
+            self._opcache, self._scope_step = outer, outer_step
+
+    # The step cache: the scope nobody had to open (round 6).  The reference's train_step (morpheus.py:1147-1236) calls the model
+    # from three places -- render_rays, the surface-point query of get_real_view_point_loss, get_regularization_loss -- and knows
+    # nothing of operand scopes: with a scope per call the weight norm, the operand packs and their slices were made twice per
+    # step and every parameter received two gradients for autograd to add (reference-glue step: 333 torch launches, 90 of them
+    # this).  So a TRAINING forward (module in train mode, gradients enabled, not inside a stream capture) keeps its prepared
+    # operands in the model, and the next call finds them -- until one of these ends the step:
+    #   * the backward pass reached an operand pack (ops._PackOperands.backward -> `stale`): the graph behind the cached tensors
+    #     is spent; gradient accumulation over several forward / backward pairs re-prepares per pair, as it must;
+    #   * a parameter changed in place (optimizer.step: `_version`; FlatAdam bumps the counters itself, its kernel writes through
+    #     raw pointers), the module was switched with train() / eval(), moved or re-typed (_apply), the arithmetic mode or the
+    #     progressive level changed.
+    # Forwards under no_grad (evaluation, the occupancy refresh) are never kept across calls: code that swaps weights through
+    # `param.data` -- torch_ema's copy_to / restore around the reference's evaluation -- moves no version counter.
+    # Two forwards whose backward passes are run separately, later and out of order, share the pack's graph: the second
+    # backward then fails with torch's "backward through the graph a second time"; MORPHEUS_IMPLICIT_OPERANDS=0 (or an explicit
+    # scope per forward) restores one set of operands per call.
+    def _step_cache(self):
+        """-> the live _StepCache of this training forward (created if the last one has ended), or None when nothing may be kept"""
+        if not (IMPLICIT_OPERANDS and self.training and torch.is_grad_enabled()):
+            return None
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return None           # operands prepared inside a capture belong to the graph; operands from outside would freeze in it
+        ps = self._step_params
+        if ps is None:
+            ps = self._step_params = list(self.parameters())
+            _DENSITY_OWNER[id(self.sdf2density)] = self
+        sig = (tuple([p._version for p in ps]), self.mlp_mode, ops.mlp_mode() if self.mlp_mode is None else None, self.max_level)
+        sc = self._stepcache
+        if sc is None or sc.stale or sc.sig != sig or len(sc.entries) > 64:
+            sc = self._stepcache = _StepCache(sig)
+        return sc
+
+    def end_step(self):
+        """Drop what the running training forward has prepared (a forward that will never be run backward; before a capture)."""
+        self._stepcache = None
+
+    def train(self, mode: bool = True):
+        self._stepcache = self._step_params = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self._stepcache = self._step_params = None
+        return super()._apply(fn, *a, **kw)
 
     def _cached(self, key, build):
-        c = self._opcache
+        c, sc = self._opcache, self._scope_step
         if c is None:
-            return build()
+            sc = self._step_cache()
+            if sc is None:
+                return build()
+            c = sc.entries
         key = (key, torch.is_grad_enabled())
         if key not in c:
-            c[key] = build()
+            c[key] = v = build()
+            if sc is not None and key[1]:
+                sc.watch(v)
         return c[key]
 
     def _warp_operands(self):

@@ -775,8 +775,9 @@ class _PackOperands(torch.autograd.Function):
     bias0 (model.warp), so its slot in the raw gradient is dropped here."""
 
     @staticmethod
-    def forward(ctx, jp, zero_bias0, b3, n_w, acc, *params):
+    def forward(ctx, jp, zero_bias0, b3, n_w, acc, notify, *params):
         ctx.set_materialize_grads(False)      # unused outputs hand backward None, not a zero-filled tensor (one launch each)
+        ctx.notify = notify                   # callables run when this node's backward runs (model: the step cache went stale)
         # behind the n_w weights / biases: the tensors whose gradients the queries sum in `acc` (field nets: beta, the hash tables)
         params, extras = params[:n_w], params[n_w:]
         ctx.acc, ctx.n_extra = acc, len(extras)
@@ -791,7 +792,13 @@ class _PackOperands(torch.autograd.Function):
         assert o == len(params) == n_w
         flat = jp.flat(weights, biases)
         m = jp.on(flat.device)
-        fpack, bpack = flat[m["fwd"]], flat[m["bwd"]]
+        if b3:       # the four operand gathers as one (packing.JointPacker.all_index): sections are views of one buffer
+            sect = jp.all_index()[1]
+            gathered = flat[m["all"]]
+            take = lambda k: gathered[sect[k][0]:sect[k][0] + sect[k][1]]
+            fpack, bpack = take("fwd"), take("bwd")
+        else:
+            fpack, bpack = flat[m["fwd"]], flat[m["bwd"]]
         if b3:
             # bf16x3 forward fragments (csrc/mlp_b3.hip): the same weights gathered in the 32x32x16 fragment order, then cut
             # into [hi | mid | lo] bf16 planes per layer by one launch
@@ -800,7 +807,7 @@ class _PackOperands(torch.autograd.Function):
             for key, layers, base in (("fwd3", jp.b3_layers, 0), ("bwd3", jp.b3T_layers, jp.fwd3_total_f4)):
                 if key == "bwd3" and not jp.sliced_bwd_for(b3):
                     continue
-                src = flat[m[key]]
+                src = take(key)
                 so, sp = _i32arr([l[0] for l in layers])
                 no, np_ = _i32arr([l[1] for l in layers])
                 do, dp = _i32arr([l[2] + base for l in layers])
@@ -814,6 +821,8 @@ class _PackOperands(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _gf, _gb, _g3, g_token):
+        for f in ctx.notify:
+            f()
         n = ctx.jp.raw_len
         raw, tabs = ctx.acc.collect() if ctx.acc is not None else (None, [])
         g_extra = [None] * ctx.n_extra
@@ -821,17 +830,18 @@ class _PackOperands(torch.autograd.Function):
             g_token = raw[:n] if g_token is None else g_token + raw[:n]
             g_extra = [raw[n].reshape(())] + list(tabs)
         if g_token is None:
-            return (None,) * (5 + sum(2 * len(pk.specs) for pk in ctx.jp.packers)) + tuple(g_extra)
+            return (None,) * (6 + sum(2 * len(pk.specs) for pk in ctx.jp.packers)) + tuple(g_extra)
         nat_w, nat_b = ctx.jp.unpack_grads(g_token, zero_bias0=ctx.zero_bias0)
         flat = [g for net in nat_w for g in net] + [g for net in nat_b for g in net]
-        return (None, None, None, None, None, *flat, *g_extra)
+        return (None, None, None, None, None, None, *flat, *g_extra)
 
 
 class MLPOperands:
     """Prepared operands of the warp nets (deform_net + topo_net) or of the field nets (sdf_net + color_net)."""
 
-    def __init__(self, jp, fpack, bpack, w3, token, mode="", acc=None):
+    def __init__(self, jp, fpack, bpack, w3, token, mode="", acc=None, notify=None):
         self.jp, self.fpack, self.bpack, self.token = jp, fpack, bpack, token
+        self.notify = notify                               # list the pack node calls through when its backward runs
         self.acc = acc                                     # running gradient sums of the queries that share these operands
         self.mode = mode if w3.numel() else ""             # "b3": the sliced kernels the operands are cut for
         # slices per net (float32 storage, 4 floats per float4 unit), or None when the fp32-MFMA kernels serve
@@ -848,7 +858,8 @@ def prepare_warp_operands(params_d: Sequence[torch.Tensor], params_t: Sequence[t
     jp = warp_joint_packer()
     flat = list(params_d[:6]) + list(params_t[:6]) + list(params_d[6:]) + list(params_t[6:])
     mode = _warp_mode(mode)
-    return MLPOperands(jp, *_PackOperands.apply(jp, True, mode, len(flat), None, *flat), mode=mode)
+    notify = []
+    return MLPOperands(jp, *_PackOperands.apply(jp, True, mode, len(flat), None, notify, *flat), mode=mode, notify=notify)
 
 
 def prepare_field_operands(params: Sequence[torch.Tensor], mode: Optional[str] = None, beta=None, tables=()) -> MLPOperands:
@@ -857,12 +868,14 @@ def prepare_field_operands(params: Sequence[torch.Tensor], mode: Optional[str] =
     their beta / table / weight gradients in place and the pack hands the sums over once (_QueryAccumulator)."""
     jp = field_joint_packer()
     mode = _warp_mode(mode)    # the field FORWARD follows the mode; the fused backward picks its pack per pass (_field_wT)
+    notify = []
     if beta is None:
-        return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), None, *params), mode=mode)
+        return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), None, notify, *params), mode=mode, notify=notify)
     if len(tables) != 2:
         raise ValueError("prepare_field_operands: tables = (sdf table, colour table)")
     acc = _QueryAccumulator(beta, tables)
-    return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), acc, *params, beta, *tables), mode=mode, acc=acc)
+    return MLPOperands(jp, *_PackOperands.apply(jp, False, mode, len(params), acc, notify, *params, beta, *tables), mode=mode, acc=acc,
+                       notify=notify)
 
 
 class _WarpMLP(torch.autograd.Function):
@@ -1050,7 +1063,7 @@ class _FieldMLP(torch.autograd.Function):
         ctx.cfg = (n_bands, bool(with_color), topo is not None, feat_c is not None)
         ctx.jp = opnd.jp
         if albedo is None:
-            albedo = torch.zeros(0, device=xc.device)
+            albedo = torch.empty(0, device=xc.device)        # (an empty allocation: no fill is dispatched)
             ctx.mark_non_differentiable(albedo)
         return sdf, sigma, albedo
 
@@ -1099,7 +1112,7 @@ class _FieldQuery(torch.autograd.Function):
         ctx.jp, ctx.acc = opnd.jp, opnd.acc
         ctx.ids = (id(beta), id(emb_s), id(emb_c))       # identities of the shared inputs (see _QueryAccumulator.joins)
         if albedo is None:
-            albedo = torch.zeros(0, device=xc.device)
+            albedo = torch.empty(0, device=xc.device)        # (an empty allocation: no fill is dispatched)
             ctx.mark_non_differentiable(albedo)
         return sdf, sigma, albedo
 
@@ -1268,6 +1281,79 @@ def ortho_perturb(x, normals, phi, scale: float):
     """x + scale * get_ortho_normal_dir(normals)  (morpheus.py:518-528 applied at :549 / :766) in one launch; phi [M] or [M,1] is the
     caller's uniform draw times 2 pi.  Gradients reach x (identity) and the normals."""
     return _OrthoPerturb.apply(x, normals, phi, scale)
+
+
+class _SmoothPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, off, rays_o, rays_d):
+        ctx.set_materialize_grads(False)
+        require_gpu(depth, off, rays_o, rays_d)
+        lib = _lib.load()
+        d_c, f_c = depth.detach().reshape(-1).contiguous().float(), off.detach().reshape(-1).contiguous().float()
+        o_c, r_c = rays_o.detach().contiguous().float(), rays_d.detach().contiguous().float()
+        N, K = d_c.shape[0], f_c.shape[0]
+        assert o_c.shape == (N, 3) and r_c.shape == (N, 3)
+        pts, keep = torch.empty(K * N, 3, device=d_c.device), torch.empty(K * N, device=d_c.device)
+        check(lib.mh_smooth_points_fwd(ptr(d_c), ptr(f_c), ptr(o_c), ptr(r_c), N, K, ptr(pts), ptr(keep), stream()), "mh_smooth_points_fwd")
+        ctx.save_for_backward(d_c, f_c, r_c)
+        ctx.depth_shape = depth.shape
+        ctx.mark_non_differentiable(keep)
+        return pts, keep
+
+    @staticmethod
+    def backward(ctx, g, _gk):
+        if g is None:
+            return None, None, None, None
+        d_c, f_c, r_c = ctx.saved_tensors
+        N, K = d_c.shape[0], f_c.shape[0]
+        need_depth, _, need_o, need_d = ctx.needs_input_grad
+        g_depth = torch.empty(N, device=g.device) if need_depth else None
+        g_o = torch.empty(N, 3, device=g.device) if need_o else None
+        g_d = torch.empty(N, 3, device=g.device) if need_d else None
+        if need_depth or need_o or need_d:
+            check(_lib.load().mh_smooth_points_bwd(ptr(g.contiguous().float()), ptr(d_c), ptr(f_c), ptr(r_c), N, K, ptr(g_depth), ptr(g_o),
+                                                   ptr(g_d), stream()), "mh_smooth_points_bwd")
+        return (None if g_depth is None else g_depth.view(ctx.depth_shape)), None, g_o, g_d
+
+
+def smooth_points(depth, off, rays_o, rays_d):
+    """-> pts [K*N,3] = (depth[n] + off[k]) * rays_d[n] + rays_o[n] (point k*N + n), keep [K*N] = (|pts| < 1.1) as 0 / 1: the points
+    of get_normal_smoothness_loss (morpheus.py:530-547) in one launch each way; gradients to depth, rays_o, rays_d."""
+    return _SmoothPoints.apply(depth, off, rays_o, rays_d)
+
+
+class _BgBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, opacity, bg):
+        ctx.set_materialize_grads(False)
+        require_gpu(color, opacity, bg)
+        c_c, o_c, b_c = color.detach().contiguous().float(), opacity.detach().reshape(-1).contiguous().float(), bg.detach().contiguous().float()
+        N = c_c.shape[0]
+        assert c_c.shape == (N, 3) and b_c.shape == (N, 3) and o_c.shape[0] == N
+        image = torch.empty_like(c_c)
+        check(_lib.load().mh_bg_blend_fwd(ptr(c_c), ptr(o_c), ptr(b_c), N, ptr(image), stream()), "mh_bg_blend_fwd")
+        ctx.save_for_backward(o_c, b_c)
+        ctx.opacity_shape = opacity.shape
+        return image
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        o_c, b_c = ctx.saved_tensors
+        N = o_c.shape[0]
+        need_c, need_o, need_b = ctx.needs_input_grad
+        g_c = g.contiguous().float()
+        g_o = torch.empty(N, device=g.device) if need_o else None
+        g_b = torch.empty(N, 3, device=g.device) if need_b else None
+        if need_o or need_b:
+            check(_lib.load().mh_bg_blend_bwd(ptr(g_c), ptr(o_c), ptr(b_c), N, ptr(g_o), ptr(g_b), stream()), "mh_bg_blend_bwd")
+        return (g_c if need_c else None), (None if g_o is None else g_o.view(ctx.opacity_shape)), g_b
+
+
+def bg_blend(color, opacity, bg):
+    """color + (1 - opacity) * bg for a per-ray background [N,3] (morpheus.py:686-694) in one launch each way, the chain's rounding."""
+    return _BgBlend.apply(color, opacity, bg)
 
 
 class _PoseApply(torch.autograd.Function):

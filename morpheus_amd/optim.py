@@ -75,6 +75,7 @@ class FlatAdam(torch.optim.Optimizer):
             for p, o, k in self._views:
                 self.flat_p[o:o + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[o:o + k].view(p.shape)
+        self._plist = [p for p, _, _ in self._views]
         self.bucket = GradBucket.from_layout(self._views, self.n, dev)
         self._steps = [0] * len(self._views)      # per-parameter step counts (torch.optim.Adam's state['step'])
         self._kseg_end_c = (ctypes.c_int64 * len(self._kseg_end))(*self._kseg_end)
@@ -132,6 +133,9 @@ class FlatAdam(torch.optim.Optimizer):
             raise MorpheusHipError("FlatAdam steps on an MI355X only; there is no CPU path")
         lib = _lib.load()
         self.bucket.collect()       # no-op when allreduce_mean() already gathered the gradients
+        # the kernels below write the parameters through raw pointers: move their version counters as an in-place torch update
+        # would (the model's step cache -- model.scene_representation._step_cache -- reads them to see that a step has ended)
+        torch.autograd.graph.increment_version(self._plist)
         g0 = self.param_groups[0]
         ns = len(self._kseg_end)
         lrs = (ctypes.c_float * ns)(*[float(self.param_groups[gi]["lr"]) for gi in self._kseg_group])
@@ -212,12 +216,14 @@ class FlatEMA:
     @torch.no_grad()
     def copy_to(self):
         self.opt.flat_p.copy_(self.shadow)
+        torch.autograd.graph.increment_version(self.opt._plist)     # (the parameters are views of flat_p with counters of their own)
 
     @torch.no_grad()
     def restore(self):
         if self.collected is None:
             raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
         self.opt.flat_p.copy_(self.collected)
+        torch.autograd.graph.increment_version(self.opt._plist)
         self.collected = None
 
     def state_dict(self):

@@ -422,8 +422,24 @@ class JointPacker:
         if key not in self._dev:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
             self._dev[key] = dict(fwd=t(self.fwd_index), bwd=t(self.bwd_index), grad=t(self.grad_index),
-                                  grad_nob0=t(self.grad_index_nob0), fwd3=t(self.fwd3_index), bwd3=t(self.bwd3_index))
+                                  grad_nob0=t(self.grad_index_nob0), fwd3=t(self.fwd3_index), bwd3=t(self.bwd3_index),
+                                  all=t(self.all_index()[0]))
         return self._dev[key]
+
+    def all_index(self):
+        """-> (index, {section: (offset, length)}): the four operand gathers (fwd | bwd | fwd3 | bwd3) as ONE gather of the flat
+        parameter vector, every section padded with the zero sentinel to a whole float4 (the kernels read their operands as
+        float4, mh_b3_slice takes 16-byte aligned sources)"""
+        if getattr(self, "_all", None) is None:
+            zero = self.n_flat - 1
+            parts, sect, off = [], {}, 0
+            for name, idx in (("fwd", self.fwd_index), ("bwd", self.bwd_index), ("fwd3", self.fwd3_index), ("bwd3", self.bwd3_index)):
+                pad = (-len(idx)) % 4
+                parts.append(np.concatenate([idx, np.full(pad, zero, dtype=idx.dtype)]))
+                sect[name] = (off, len(idx))
+                off += len(idx) + pad
+            self._all = (np.concatenate(parts), sect)
+        return self._all
 
     def pack(self, weights: Sequence[Sequence[torch.Tensor]], biases: Sequence[Sequence[torch.Tensor]]):
         """weights[k] / biases[k]: the layers of net k (natural).  -> (fwd pack, bwd pack); slice with self.w/b/wT."""

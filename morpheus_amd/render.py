@@ -88,7 +88,8 @@ class HotPathRenderer:
     @staticmethod
     def _ortho_angle(normals):
         """the random angle of get_ortho_normal_dir (morpheus.py:525): one uniform draw per normal, times 2 pi"""
-        return torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * 2.0 * np.pi
+        # (fp32(2 pi) == 2 fp32(pi): one product gives the bits of the reference's `rand() * 2.0 * np.pi`)
+        return torch.rand(list(normals.shape[:-1]) + [1], device=normals.device) * (2.0 * np.pi)
 
     def get_normal_smoothness_loss(self, rays_o, rays_d, rays_t, depth, offsets=None, phi=None, ray_slots=None,
                                    single_frame=None):
@@ -103,11 +104,11 @@ class HotPathRenderer:
         npts = int(trunc * 100 + 1)
         if offsets is None:
             off = self._const(("smooth_offsets", trunc, npts), lambda: torch.linspace(-0.5 * trunc, 0.5 * trunc, npts), depth.device)
-            off = off + 0.01 * torch.rand_like(off)
+            off = torch.add(off, torch.rand_like(off), alpha=0.01)
         else:
             off = offsets
-        pts = (depth + off[:, None].to(depth))[..., None] * rays_d[None] + rays_o[None]
-        pts = pts.view(-1, 3)
+        # pts = (depth + off[:, None])[..., None] * rays_d[None] + rays_o[None] and the 1.1-sphere test in one launch each way
+        pts, keep = ops.smooth_points(depth, off.to(depth), rays_o, rays_d)
         n_rays = rays_t.shape[0]
         if ray_slots is not None:
             tt, fs = rays_t[None].repeat(npts, 1, 1).view(-1, 1), (ray_slots[0], ray_slots[1].repeat(npts))
@@ -115,7 +116,6 @@ class HotPathRenderer:
             tt, fs = rays_t[:1].expand(npts * n_rays, 1), None
         else:                      # rays of several times without a row structure: per-sample times (model._slots)
             tt, fs = rays_t[None].repeat(npts, 1, 1).view(-1, 1), None
-        keep = (torch.linalg.norm(pts, ord=2, dim=-1) < 1.1).float()
         n1, _ = self.model.normal(pts, t=tt, frame_slots=fs)
         # pts + get_ortho_normal_dir(n1) * smoothness_std, then sum(square(n1 - n2) * keep) / max(3 sum(keep), 1): one launch each
         pts_p = ops.ortho_perturb(pts, n1, self._ortho_angle(n1) if phi is None else phi, self.config["train"]["smoothness_std"])
@@ -256,7 +256,10 @@ class HotPathRenderer:
                 bg_color = model.background(rays_d, rays_t)
             else:
                 bg_color = 1
-        image = (rgb_acc + (1 - opacity) * bg_color).view(*prefix, 3)
+        if torch.is_tensor(bg_color) and bg_color.shape == rgb_acc.shape and bg_color.is_cuda:
+            image = ops.bg_blend(rgb_acc, opacity, bg_color).view(*prefix, 3)       # the same three rounded operations, one launch
+        else:
+            image = (rgb_acc + (1 - opacity) * bg_color).view(*prefix, 3)
         depth = depth.view(*prefix)
         results.update(image=image, depth=depth, sdf=sdf, weights=weights, weights_sum=opacity, normal=normals,
                        deform=deform, normal_raw=normal_raw)
@@ -273,7 +276,7 @@ class HotPathRenderer:
                 if tr["normal_dir"]:
                     xyzs_p = ops.ortho_perturb(xyzs, normals, self._ortho_angle(normals), tr["smoothness_std"])
                 else:
-                    xyzs_p = xyzs + torch.randn_like(xyzs) * tr["smoothness_std"]
+                    xyzs_p = torch.add(xyzs, torch.randn_like(xyzs), alpha=tr["smoothness_std"])
                 def perturbed_normals(x_, t_, s_):
                     if tr["topo_none"]:
                         return model.normal(x_, topo=None, cano=cano)[:1]
@@ -301,7 +304,8 @@ class HotPathRenderer:
                 d = 1.0 / self.num_frames
                 offs = self._const(("code_reg_offsets", d), lambda: torch.tensor([[0.0], [-d], [d]]), time_step.device)
                 code, cp, cn = model.get_deform_code(time_step[:1] + offs).unbind(0)
-                results["loss_code"] = torch.square(2 * code - cp - cn).mean()
+                # square(2 code - cp - cn).mean() with the chain's rounding ((2 code - cp) - cn): the difference and the mean in one launch
+                results["loss_code"] = ops.masked_mean("sqdiff", (2 * code - cp)[None], cn[None])
             if tr["normal_smooth_2d"] > 0 and normals is not None and (not real_view):
                 # accumulate_along_rays(weights, (normals+1)/2) with the LIVE weights (morpheus.py:775): the density
                 # gradient of the normal image is part of the normal_smooth_2d loss

@@ -211,3 +211,51 @@ def test_fused_render_loss_equals_the_reference_chain():
     for a, b, name in ((i2.grad, i1.grad, "image"), (d2.grad, d1.grad, "depth"), (o2.grad, o1.grad, "opacity")):
         assert _rel(a, b) <= 3e-6, (name, _rel(a, b))
     assert float(o2.grad[0, :40].abs().max()) == 0.0
+
+
+def test_smooth_points_equals_the_torch_chain():
+    """ops.smooth_points (mh_smooth_points_*): the points of get_normal_smoothness_loss (morpheus.py:530-547) -- values bit for bit
+    the operator chain (csrc/losses.hip is compiled without FMA contraction), the 0 / 1 sphere weight, gradients to depth and rays."""
+    from morpheus_amd import ops
+    torch.manual_seed(9)
+    N, K = 2048, 11
+    depth = (torch.rand(1, N, device=DEV) * 2.0 + 0.2).requires_grad_()
+    off = torch.linspace(-0.05, 0.05, K, device=DEV) + 0.01 * torch.rand(K, device=DEV)
+    o = (torch.randn(N, 3, device=DEV) * 0.1 + torch.tensor([0.0, 0.0, 1.5], device=DEV)).requires_grad_()
+    d = torch.randn(N, 3, device=DEV).mul(0.5).requires_grad_()
+    pts_t = ((depth + off[:, None])[..., None] * d[None] + o[None]).view(-1, 3)
+    keep_t = (torch.linalg.norm(pts_t, ord=2, dim=-1) < 1.1).float()
+    pts, keep = ops.smooth_points(depth, off, o, d)
+    assert torch.equal(pts, pts_t)
+    near = (torch.linalg.norm(pts_t.double(), dim=-1) - 1.1).abs() < 1e-6        # the comparison may fall either way within an ulp
+    assert torch.equal(keep[~near], keep_t[~near]) and 0 < float(keep.mean()) < 1
+    g = torch.randn_like(pts_t)
+    gt = torch.autograd.grad(pts_t, [depth, o, d], g)
+    gh = torch.autograd.grad(pts, [depth, o, d], g)
+    for a, b in zip(gh, gt):
+        assert a.shape == b.shape and _rel(a, b) < 2e-6
+    # a subset of the gradients only (rays without a gradient of their own: no pose optimisation)
+    pts2, _ = ops.smooth_points(depth, off, o.detach(), d.detach())
+    (g2,) = torch.autograd.grad(pts2, [depth], g)
+    assert torch.equal(g2, gh[0])
+
+
+def test_bg_blend_equals_the_torch_chain():
+    """ops.bg_blend (mh_bg_blend_*): image = color + (1 - opacity) * bg (morpheus.py:686-694) -- the chain's bits forward, its
+    gradients to colour, opacity and a background that has one (the background net of a virtual view)."""
+    from morpheus_amd import ops
+    torch.manual_seed(10)
+    N = 5000
+    color = torch.rand(N, 3, device=DEV).requires_grad_()
+    opacity = torch.rand(N, 1, device=DEV).requires_grad_()
+    bg = torch.rand(N, 3, device=DEV).requires_grad_()
+    ref = color + (1 - opacity) * bg
+    out = ops.bg_blend(color, opacity, bg)
+    assert torch.equal(out, ref)
+    g = torch.randn_like(ref)
+    gt = torch.autograd.grad(ref, [color, opacity, bg], g)
+    gh = torch.autograd.grad(out, [color, opacity, bg], g)
+    assert torch.equal(gh[0], gt[0]) and torch.equal(gh[2], gt[2]) and gh[1].shape == gt[1].shape and _rel(gh[1], gt[1]) < 1e-6
+    out2 = ops.bg_blend(color, opacity, bg.detach())
+    g2 = torch.autograd.grad(out2, [color, opacity], g)
+    assert torch.equal(g2[0], gh[0]) and torch.equal(g2[1], gh[1])

@@ -1325,6 +1325,106 @@ def test_reference_glue_equals_fused_glue():
             assert rel <= 2e-3, (other, k, rel)          # same terms, other summation orders; FD-normal terms amplify round-off
 
 
+def test_step_cache_lifecycle():
+    """model._step_cache (round 6): a training forward keeps its prepared operands in the model, so that the reference's train_step
+    -- render_rays, then model.density for the surface points, no operand scope anywhere -- prepares them once.  Checked here:
+    (i) two model calls of one training forward share ONE operand pack, and the gradients equal those of a scope per call;
+    (ii) the backward pass ends the step: forward / backward pairs accumulated before one optimiser step re-prepare and add up;
+    (iii) an optimiser step (torch's Adam through the version counters, FlatAdam through its own bump) ends the step;
+    (iv) nothing is kept under no_grad or in eval mode -- a weight swap through `param.data` (torch_ema's copy_to around the
+    reference's evaluation, morpheus.py:1297-1301) moves no version counter and must still be seen;
+    (v) a new parameter set through train() / eval() ends the step."""
+    from morpheus_amd import harness, model as mm
+    from morpheus_amd.optim import FlatAdam
+    torch.manual_seed(5)
+    x = (torch.rand(3000, 3, device=DEV) - 0.5) * 1.6
+    t = torch.full((1, 1), 0.125, device=DEV).expand(3000, 1)
+
+    def two_calls(model):
+        a = model.density(x[:2000], t[:2000])
+        b = model.density(x[1000:], t[1000:])
+        return (a["sdf"].square().mean() + a["albedo"].mean() + b["sigma"].mean() * 1e-3 + b["sdf"].mean())
+
+    def grads(model):
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    model = harness.build_model("b", DEV).train()
+    assert mm.IMPLICIT_OPERANDS
+    # (i)
+    loss = two_calls(model)
+    sc = model._stepcache
+    assert sc is not None and not sc.stale and ("warp", True) in sc.entries and ("field", True) in sc.entries
+    opnd = sc.entries[("field", True)][0]
+    model.zero_grad()
+    loss.backward()
+    assert sc.stale and not sc.entries                # (ii) the backward pass reached the packs: the step is over, its operands dropped
+    g_shared = grads(model)
+    mm.IMPLICIT_OPERANDS = False
+    try:
+        model.zero_grad()
+        loss2 = two_calls(model)
+        assert model._stepcache is sc                 # untouched: nothing was kept
+        loss2.backward()
+        g_per_call = grads(model)
+    finally:
+        mm.IMPLICIT_OPERANDS = True
+    assert float(loss) == float(loss2) and set(g_shared) == set(g_per_call)
+    for k in g_shared:
+        rel = float((g_shared[k] - g_per_call[k]).norm() / g_per_call[k].norm().clamp_min(1e-30))
+        assert rel <= 2e-5, (k, rel)                   # the same terms; the shared pack sums the two calls' raw gradients first
+    # (ii) two forward / backward pairs before one step: the second forward re-prepares (its own pack), the gradients add up
+    model.zero_grad()
+    two_calls(model).backward()
+    l_again = two_calls(model)
+    assert model._stepcache is not sc and model._stepcache.entries[("field", True)][0] is not opnd
+    l_again.backward()
+    assert model._stepcache.stale and not model._stepcache.entries       # nothing spent lingers in the model
+    for k, g in grads(model).items():
+        rel = float((g - 2 * g_shared[k]).norm() / g_shared[k].norm().clamp_min(1e-30))
+        assert rel <= 2e-5, (k, rel)
+    # (iii) optimiser steps
+    for make in (lambda: torch.optim.Adam(model.parameters(), lr=1e-3), lambda: FlatAdam(model.get_params_all(1e-3), betas=(0.9, 0.99), eps=1e-15)):
+        opt = make()
+        opt.zero_grad()
+        l0 = two_calls(model)
+        l0.backward()
+        opt.step()
+        l1 = two_calls(model)                          # a forward that is never run backward: its operands stay in the model ...
+        before = model._stepcache
+        assert not before.stale
+        mm.IMPLICIT_OPERANDS = False
+        try:
+            opt.zero_grad()
+            two_calls(model).backward()                # (gradients from a graph of its own)
+        finally:
+            mm.IMPLICIT_OPERANDS = True
+        assert model._stepcache is before and not before.stale
+        opt.step()                                    # ... until the parameters move under them
+        l2 = two_calls(model)
+        assert model._stepcache is not before and float(l2) != float(l1) and float(l1) != float(l0)
+        model.zero_grad()
+    # (iv) no_grad / eval: nothing kept across calls; a `.data` swap is seen
+    model.eval()
+    assert model._stepcache is None
+    with torch.no_grad():
+        s0 = model.density(x, t)["sdf"].clone()
+        assert model._stepcache is None
+        saved = [p.data.clone() for p in model.sdf_net.parameters()]
+        for p in model.sdf_net.parameters():
+            p.data.copy_(p.data * 1.01)
+        s1 = model.density(x, t)["sdf"].clone()
+        for p, q in zip(model.sdf_net.parameters(), saved):
+            p.data.copy_(q)
+        s2 = model.density(x, t)["sdf"]
+    assert float((s1 - s0).abs().max()) > 1e-4 and torch.equal(s2, s0)
+    # (v)
+    model.train()
+    two_calls(model)
+    assert model._stepcache is not None
+    model.eval()
+    assert model._stepcache is None
+
+
 def test_field_queries_accumulate_gradients_in_place():
     """ops._QueryAccumulator: the six field queries of a real-view step add their weight / beta / table gradients into ONE tensor
     each inside their kernels (first query returns it to autograd, later ones return None) -- the same gradients as one tensor per

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/morpheus_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.mh_abi_version() == 7
+    assert lib.mh_abi_version() == 8
     assert lib.mh_status_string(1).decode().startswith("invalid argument")
     # size queries are pure host functions
     assert lib.mh_mlp_tiles(1) == 4 and lib.mh_mlp_tiles(129) == 8
