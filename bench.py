@@ -360,6 +360,12 @@ def build_train_virtual(args, rank, world, dev):
     from morpheus_amd.render import HotPathRenderer
     res = args.virtual_res
     touched = pretouch_vram(dev) if res * res > 20000 else None      # whole-view steps at the final resolution: ~100 GB per step
+    # what the caching allocator may RESERVE: whole-view steps allocate ~105 GB and left 245 GB reserved after a dozen views
+    # (morpheus_amd/chunking.py, profiles/r06_park_alloc.txt); 0.6 of the device bounds it at no cost.  The line INTEGRATION.md
+    # section 5 recommends to the reference's trainer; MORPHEUS_BENCH_MEM_FRACTION=0 measures without it.
+    mem_fraction = float(os.environ.get("MORPHEUS_BENCH_MEM_FRACTION", "0.6") or 0.6)
+    if touched is not None and 0.0 < mem_fraction < 1.0:
+        torch.cuda.memory.set_per_process_memory_fraction(mem_fraction, dev)
     model = harness.build_model("b", dev).train()
     cfg = model.config
     grid = OccupancyGrid([-model.bound] * 3 + [model.bound] * 3, 128).to(dev)
@@ -745,6 +751,8 @@ def run_one(args):
             return loss_g
     ops.TIMER.reset(enabled=timers_on)
     captures0 = wl["graphed"].n_captures if wl.get("graphed") is not None else 0
+    if not stub:
+        torch.cuda.reset_peak_memory_stats(dev)       # `peak_allocated_GB` below is the timed steps' own (not the VRAM pre-touch's)
     mem0 = None if stub else torch.cuda.memory_stats(dev)
     if world > 1:
         dist.barrier()

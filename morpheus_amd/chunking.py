@@ -46,13 +46,40 @@ def park_cap_bytes(device=None) -> float:
     return DEFAULT_FRACTION * _total[idx]
 
 
+# What the caching allocator keeps RESERVED is a second quantity, and not this module's to bound (round 6, profiles/r06_park_alloc.txt).
+# The 180 x 180 virtual-view step allocates 104-108 GB at its peak; after a dozen steps the allocator holds 245-250 GB of the
+# device's 288 -- the packed sample count changes from view to view, a cached block can be split but never grown, and every step
+# opens new segments beside the chopped ones.  Measured: size classes for the large buffers, the allocator's own
+# roundup_power2_divisions and garbage_collection_threshold change nothing; handing the unused blocks back before a step
+# (empty_cache) costs 0.4 s per driver allocation on this platform (480-720 ms per step instead of 48) -- the sporadic 350-600 ms
+# runs of the capped configuration were exactly that; `torch.cuda.memory.set_per_process_memory_fraction(0.6)` in the CALLER bounds
+# it for nothing: 112 GB reserved, 48.5 ms (its frees happen once, in the first steps).  INTEGRATION.md section 5 recommends that
+# line for whole-view steps; bench.py's train_virtual workload sets it.  What this module does about the rest of the device: the
+# default cap also looks at what is actually free when the call is made (`available_bytes`).
+BIG_CALL = 8e9
+
+
+def available_bytes(device=None) -> float:
+    """device memory a call could still get: free on the device + cached by this process's allocator and not in use"""
+    idx = torch.cuda.current_device() if device is None or getattr(device, "index", None) is None else device.index
+    free, _ = torch.cuda.mem_get_info(idx)
+    return float(free) + float(torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx))
+
+
 def query_bytes_per_row(warp: bool, field_points: int) -> int:
     """estimate of what one row of a query parks: the warp nets (if evaluated) + `field_points` field point queries"""
     return (WARP_PARK_BYTES if warp else 0) + FIELD_PARK_BYTES * int(field_points)
 
 
-def rows_under_cap(bytes_per_row_all_queries: int, cap: Optional[float] = None, device=None) -> int:
+def rows_under_cap(bytes_per_row_all_queries: int, cap: Optional[float] = None, device=None, rows: Optional[int] = None) -> int:
+    """rows per chunk under the cap.  rows: the call's row count -- a call whose estimate is large (>= 8 GB) is also held to 0.85 of
+    the memory that is free when it is made (another tenant of the device -- the reference's guidance UNet, a second process --
+    is not in DEFAULT_FRACTION); an explicit MORPHEUS_MAX_PARK_GB is taken as given."""
+    explicit = cap is not None or bool(os.environ.get("MORPHEUS_MAX_PARK_GB"))
     cap = park_cap_bytes(device) if cap is None else cap
+    if not explicit and rows is not None and torch.cuda.is_available() and float(bytes_per_row_all_queries) * rows >= BIG_CALL \
+            and not torch.cuda.is_current_stream_capturing():
+        cap = min(cap, 0.85 * available_bytes(device))
     if cap == float("inf"):
         return 1 << 62
     return max(int(cap // max(bytes_per_row_all_queries, 1)) // 8192 * 8192, 8192)

@@ -91,6 +91,20 @@ def _i32arr(a):
 
 
 # ------------------------------------------------------------------------------------ hash grid
+def _scratch(n: int, device, dtype=torch.float32) -> torch.Tensor:
+    """An uninitialised 1-D scratch buffer of n elements for the kernels' parked tiles / per-point rows, allocated in SIZE CLASSES
+    (eight per octave: n rounded up by at most 12.5 %).  The packed sample count of a training step changes from step to step, and
+    so did the byte counts of its ~40 large allocations: the caching allocator can split a cached block but cannot grow one, so
+    every step whose batch was a little larger than any before it opened new segments beside the cached ones -- the 180 x 180
+    virtual-view step allocates 104 GB at its peak and had 245 GB RESERVED (profiles/r06_park_alloc.txt).  With size classes a
+    step's requests find the previous step's blocks."""
+    n = int(n)
+    if n >= (1 << 18):
+        q = 1 << (n.bit_length() - 4)
+        return torch.empty((n + q - 1) // q * q, dtype=dtype, device=device)[:n]
+    return torch.empty(n, dtype=dtype, device=device)
+
+
 def level_resolutions(L: int, per_level_scale: float, base: int) -> np.ndarray:
     """res_l = (uint32)ceil(exp2f(l*S)*H) in float32, S = (float)log2(per_level_scale)
     (gridencoder.cu:133, grid.py:39).  Host-computed so no device libm is involved."""
@@ -108,7 +122,7 @@ def _bin_points(lib, x, bound):
     """Counting-sort the points into 16^3 bricks (shared by every table evaluated at x)."""
     M, dev = x.shape[0], x.device
     ws = torch.empty(lib.mh_grid_bin_workspace_ints(), dtype=torch.int32, device=dev)
-    perm = torch.empty(M, dtype=torch.int32, device=dev)
+    perm = _scratch(M, dev, torch.int32)
     bstart = torch.empty(lib.mh_grid_bin_index_ints(), dtype=torch.int32, device=dev)
     _e = TIMER.start()
     check(lib.mh_grid_bin_points(ptr(x), M, bound, ptr(ws), ptr(perm), ptr(bstart), stream()), "mh_grid_bin_points")
@@ -175,7 +189,7 @@ def _grid_fwd(lib, x, embs, o_p, r_p, L, n_levels, bound, group):
     if L == 16 and M >= lib.mh_grid_stage_min_points(-1):     # (whatever `group`: a staged brick shares a cell's rows among all its points)
         binned = _bin_points(lib, x, bound)
     for emb in embs:
-        out = torch.empty(M, L * 2, device=x.device, dtype=torch.float32)
+        out = _scratch(M * L * 2, x.device).view(M, L * 2)
         _e = TIMER.start()
         if binned is not None:
             check(lib.mh_grid_encode_fwd_binned(ptr(x), ptr(emb), o_p, r_p, ptr(binned[0]), ptr(binned[1]), ptr(out), M, L,
@@ -505,7 +519,7 @@ class _FdTaps(torch.autograd.Function):
         M, dev = xc.shape[0], xc.device
         tc = None if topo is None else topo.detach().contiguous().float()
         C = 0 if tc is None else tc.shape[1]
-        taps = torch.empty(6 * M, 3, device=dev)
+        taps = _scratch(6 * M * 3, dev).view(6 * M, 3)
         topo6 = torch.empty(6 * M, C, device=dev) if tc is not None else torch.empty(0, device=dev)
         check(lib.mh_fd_taps(ptr(xc), ptr(tc), C, float(eps), float(bound), M, ptr(taps), ptr(topo6 if tc is not None else None),
                              stream()), "mh_fd_taps")
@@ -894,7 +908,7 @@ class _WarpMLP(torch.autograd.Function):
         x = x.detach().contiguous().float()
         M, dev = x.shape[0], x.device
         need_grad = any(ctx.needs_input_grad)
-        acts = torch.empty(lib.mh_warp_acts_floats(M), device=dev) if need_grad else None
+        acts = _scratch(lib.mh_warp_acts_floats(M), dev) if need_grad else None
         deform, topo = torch.empty(M, 3, device=dev), torch.empty(M, 2, device=dev)
         b0d, b0t = bias0_d.detach().contiguous(), bias0_t.detach().contiguous()
         slot_c = None if slot is None else slot.contiguous()
@@ -922,7 +936,7 @@ class _WarpMLP(torch.autograd.Function):
         x, slot, wdT, wtT, acts = ctx.saved_tensors
         M, dev = x.shape[0], x.device
         n_tiles = lib.mh_mlp_tiles(M)
-        dpre = torch.empty(lib.mh_warp_dpre_floats(M), device=dev)
+        dpre = _scratch(lib.mh_warp_dpre_floats(M), dev)
         g_x = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL -> the kernel skips the W0^T stage
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
@@ -972,7 +986,7 @@ def _field_fwd(lib, xc, fs, fc, tp, beta_c, n_bands, with_color, opnd, need_grad
     """-> sdf, sigma, albedo|None, acts|None (parked activations for backward)."""
     w, b = opnd.w[0], opnd.b[0]
     M, dev = xc.shape[0], xc.device
-    acts = torch.empty(lib.mh_field_acts_floats(M), device=dev) if need_grad else None
+    acts = _scratch(lib.mh_field_acts_floats(M), dev) if need_grad else None
     sdf, sigma = torch.empty(M, device=dev), torch.empty(M, device=dev)
     albedo = torch.empty(M, 3, device=dev) if with_color else None
     _e = TIMER.start()
@@ -1018,12 +1032,12 @@ def _field_bwd(lib, xc, wT, beta_c, acts, sdf, albedo, g_sdf, g_sigma, g_albedo,
     if not with_color:
         g_albedo = None
     g_xc = torch.empty(M, 3, device=dev) if need_dx else None
-    g_fs = torch.empty(M, 32, device=dev)
-    g_fc = torch.empty(M, 32, device=dev) if (with_color and has_fc) else None
+    g_fs = _scratch(M * 32, dev).view(M, 32)
+    g_fc = _scratch(M * 32, dev).view(M, 32) if (with_color and has_fc) else None
     g_tp = torch.empty(M, 2, device=dev) if has_topo else None
     if gmax is None:
         gmax = torch.zeros(2, dtype=torch.int32, device=dev)
-    dgeo = torch.empty(lib.mh_field_dgeo_floats(M), device=dev) if with_color else None
+    dgeo = _scratch(lib.mh_field_dgeo_floats(M), dev) if with_color else None
     ws = torch.empty(lib.mh_field_bwd_fused_workspace_floats(M), device=dev)
     raw = None
     if raw_into is None:      # an empty query returns MH_OK without writing: the gradient must then be zeros, not heap contents

@@ -238,7 +238,7 @@ class HotPathRenderer:
         perturb_query = model.training and tr_["normal_smooth_3d"] > 0 and with_normals
         row_bytes = chunking.query_bytes_per_row(not cano, 1 + (6 if with_normals else 0)) + \
             (chunking.query_bytes_per_row((not tr_["topo_none"]) and not cano, 6) if perturb_query else 0)
-        chunk_rows = chunking.rows_under_cap(row_bytes, device=rays_o.device) if torch.is_grad_enabled() else M_samples
+        chunk_rows = chunking.rows_under_cap(row_bytes, device=rays_o.device, rows=M_samples) if torch.is_grad_enabled() else M_samples
         slot_rows = None if frame_slots is None else frame_slots[1]
 
         def main_query(x_, t_, l_, s_):
