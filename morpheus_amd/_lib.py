@@ -73,8 +73,8 @@ _SIGS = {
     "mh_field_bwd_fused_b3": (ctypes.c_int, [_P] * 8 + [_I32, _I32] + [_P] * 4 + [_I32] + [_P] * 5 + [_I64, _P]),
     "mh_field_w3T_bytes": (_I64, []),
     "mh_mlp_wgrad_workspace_floats": (_I64, [_I32, _P, _P, _I64]),
-    "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
-    "mh_mlp_wgrad_b3": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mh_mlp_wgrad": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mh_mlp_wgrad_b3": (ctypes.c_int, [_P, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mh_weight_norm_fwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
     "mh_weight_norm_bwd": (ctypes.c_int, [_I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mh_adam_step": (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _P]),

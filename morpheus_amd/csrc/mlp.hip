@@ -1290,16 +1290,22 @@ struct WgFrag {
     f32x4 b[IT][4];
 };
 
+// Pad rows are neither written nor read (round 6): the first layer's input tile has 64 rows for 40 encoding values, the last
+// layer's dPre tile 32 rows for 3 | 2 outputs -- 1.4 GB of a cfg3 step's parked traffic.  A lane whose row lies behind the layer's
+// live rows re-reads the LAST live row (the line is being fetched for its owner anyway: no extra traffic, the same number of load
+// instructions, so the counted waits stand): its values only reach dW rows / columns of pad features, which nobody gathers.
+__device__ __forceinline__ int wg_row(int row, int live) { return row < live ? row : live - 1; }
+
 template <int IT>
 __device__ __forceinline__ void wg_load(WgFrag<IT> &f, const float *__restrict__ acts, const float *__restrict__ dpre,
                                         int64_t t, int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
-                                        int dpre_off, int mt, int i, int h) {
-    const f32x4 *a = reinterpret_cast<const f32x4 *>(dpre + t * dpre_tile_floats + dpre_off + (int64_t)(32 * mt + i) * TILE + 16 * h);
+                                        int dpre_off, int mt, int i, int h, int in_live, int out_live) {
+    const f32x4 *a = reinterpret_cast<const f32x4 *>(dpre + t * dpre_tile_floats + dpre_off + (int64_t)wg_row(32 * mt + i, out_live) * TILE + 16 * h);
 #pragma unroll
     for (int j = 0; j < 4; j++) f.a[j] = a[j];
 #pragma unroll
     for (int n = 0; n < IT; n++) {
-        const f32x4 *b = reinterpret_cast<const f32x4 *>(acts + t * acts_tile_floats + act_off + (int64_t)(32 * n + i) * TILE + 16 * h);
+        const f32x4 *b = reinterpret_cast<const f32x4 *>(acts + t * acts_tile_floats + act_off + (int64_t)wg_row(32 * n + i, in_live) * TILE + 16 * h);
 #pragma unroll
         for (int j = 0; j < 4; j++) f.b[n][j] = b[j];
     }
@@ -1310,15 +1316,15 @@ __device__ __forceinline__ void wg_load(WgFrag<IT> &f, const float *__restrict__
 template <int IT>
 __device__ __forceinline__ void wg_load_async(WgFrag<IT> &f, const float *__restrict__ acts, const float *__restrict__ dpre,
                                               int64_t t, int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
-                                              int dpre_off, int mt, int i, int h) {
-    const float *a = dpre + t * dpre_tile_floats + dpre_off + (int64_t)(32 * mt + i) * TILE + 16 * h;
+                                              int dpre_off, int mt, int i, int h, int in_live, int out_live) {
+    const float *a = dpre + t * dpre_tile_floats + dpre_off + (int64_t)wg_row(32 * mt + i, out_live) * TILE + 16 * h;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.a[0]) : "v"(a) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.a[1]) : "v"(a) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.a[2]) : "v"(a) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(f.a[3]) : "v"(a) : "memory");
 #pragma unroll
     for (int n = 0; n < IT; n++) {
-        const float *b = acts + t * acts_tile_floats + act_off + (int64_t)(32 * n + i) * TILE + 16 * h;
+        const float *b = acts + t * acts_tile_floats + act_off + (int64_t)wg_row(32 * n + i, in_live) * TILE + 16 * h;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.b[n][0]) : "v"(b) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(f.b[n][1]) : "v"(b) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(f.b[n][2]) : "v"(b) : "memory");
@@ -1361,7 +1367,7 @@ template <int IT>
 __device__ __forceinline__ void wgrad_body(const float *__restrict__ acts, const float *__restrict__ dpre,
                                            int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off, int dpre_off,
                                            int out_pad, float *__restrict__ dw_part, float *__restrict__ db_part,
-                                           int64_t n_tiles, int n_chunks, int chunk) {
+                                           int64_t n_tiles, int n_chunks, int chunk, int in_live, int out_live) {
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     // tiles are dealt round-robin: at any instant the resident workgroups read NEIGHBOURING tiles (172 KB apart,
@@ -1383,7 +1389,7 @@ __device__ __forceinline__ void wgrad_body(const float *__restrict__ acts, const
     const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
     const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
 #define WG_TILE(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
-#define WG_LOAD(f, k) wg_load_async<IT>(f, acts, dpre, WG_TILE(k), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h)
+#define WG_LOAD(f, k) wg_load_async<IT>(f, acts, dpre, WG_TILE(k), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h, in_live, out_live)
     if (n_my > 0) {
         WgFrag<IT> f1, f2;
         WG_LOAD(f0, 0);
@@ -1470,7 +1476,7 @@ template <int IT>
 __device__ __forceinline__ void wgrad_body_b3(const float *__restrict__ acts, const float *__restrict__ dpre,
                                               int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off, int dpre_off,
                                               int out_pad, float *__restrict__ dw_part, float *__restrict__ db_part,
-                                              int64_t n_tiles, int n_chunks, int chunk) {
+                                              int64_t n_tiles, int n_chunks, int chunk, int in_live, int out_live) {
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int64_t st = n_chunks;
@@ -1483,7 +1489,7 @@ __device__ __forceinline__ void wgrad_body_b3(const float *__restrict__ acts, co
     const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
     const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
 #define WG_TILE(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
-#define WG_LOAD(f, k) wg_load_async<IT>(f, acts, dpre, WG_TILE(k), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h)
+#define WG_LOAD(f, k) wg_load_async<IT>(f, acts, dpre, WG_TILE(k), acts_tile_floats, dpre_tile_floats, act_off, dpre_off, mt, i, h, in_live, out_live)
     if (n_my > 0) {
         WgFrag<IT> f0, f1;
         WG_LOAD(f0, 0);
@@ -1568,7 +1574,7 @@ template <int IT>
 __device__ __forceinline__ void wgrad_regs_b3_body(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                    int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off, int dpre_off,
                                                    float *__restrict__ dw_part, float *__restrict__ db_part, int64_t n_tiles,
-                                                   int n_chunks, int chunk) {
+                                                   int n_chunks, int chunk, int in_live) {
     // B slices: [buffer 2][in tile IT][plane 3][step 2][lane 64] float4
     constexpr int BUF_F4 = IT * 6 * 64;
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
@@ -1578,7 +1584,7 @@ __device__ __forceinline__ void wgrad_regs_b3_body(const float *__restrict__ act
     const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
     const int bt = mt & (IT - 1);            // activation block this wave loads (waves >= IT reload one, publish nothing)
     const float *a0 = dpre + dpre_off + (int64_t)(32 * mt + i) * TILE + 16 * g;
-    const float *b0 = acts + act_off + (int64_t)(32 * bt + i) * TILE + 16 * g;
+    const float *b0 = acts + act_off + (int64_t)wg_row(32 * bt + i, in_live) * TILE + 16 * g;      // (the 128 dPre rows of these layers are all live)
     f32x16 acc[IT];
     acc_zero<IT>(acc);
     float bsum = 0.f;
@@ -1725,22 +1731,23 @@ template <int IT>
 __global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_regs_b3_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                                 int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
                                                                 int dpre_off, float *__restrict__ dw_part,
-                                                                float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
+                                                                float *__restrict__ db_part, int64_t n_tiles, int n_chunks, int in_live) {
     wgrad_regs_b3_body<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, dw_part, db_part, n_tiles, n_chunks,
-                           (int)blockIdx.x);
+                           (int)blockIdx.x, in_live);
 }
 
 template <int IT, bool B3 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                        int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
                                                        int dpre_off, int out_pad, float *__restrict__ dw_part,
-                                                       float *__restrict__ db_part, int64_t n_tiles, int n_chunks) {
+                                                       float *__restrict__ db_part, int64_t n_tiles, int n_chunks, int in_live,
+                                                       int out_live) {
     if (B3)
         wgrad_body_b3<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, out_pad, dw_part, db_part, n_tiles,
-                          n_chunks, (int)blockIdx.x);
+                          n_chunks, (int)blockIdx.x, in_live, out_live);
     else
         wgrad_body<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, act_off, dpre_off, out_pad, dw_part, db_part, n_tiles,
-                       n_chunks, (int)blockIdx.x);
+                       n_chunks, (int)blockIdx.x, in_live, out_live);
 }
 
 // All layers of a net group in ONE launch: block b belongs to the layer whose block range holds it.  Used for small
@@ -1751,6 +1758,7 @@ struct WgAll {
     int32_t n;
     int32_t first_block[WG_MAX_LAYERS + 1];
     int32_t act_off[WG_MAX_LAYERS], dpre_off[WG_MAX_LAYERS], out_pad[WG_MAX_LAYERS], in_tiles[WG_MAX_LAYERS];
+    int32_t in_live[WG_MAX_LAYERS], out_live[WG_MAX_LAYERS];      // rows of the input / dPre tile that carry values (wg_row)
     int32_t chunks[WG_MAX_LAYERS];
     int64_t dw_off[WG_MAX_LAYERS], db_off[WG_MAX_LAYERS];
 };
@@ -1767,10 +1775,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_all_kernel(const float *__restri
 #define WG_CASE(IT)                                                                                                          \
     if (B3)                                                                                                                  \
         wgrad_body_b3<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db,    \
-                          n_tiles, d.chunks[l], chunk);                                                                      \
+                          n_tiles, d.chunks[l], chunk, d.in_live[l], d.out_live[l]);                                         \
     else                                                                                                                     \
         wgrad_body<IT>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], d.out_pad[l], dw, db,       \
-                       n_tiles, d.chunks[l], chunk)
+                       n_tiles, d.chunks[l], chunk, d.in_live[l], d.out_live[l])
     switch (d.in_tiles[l]) {
         case 1: WG_CASE(1); break;
         case 2: WG_CASE(2); break;
@@ -1793,9 +1801,9 @@ __global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_all_regs_b3_kernel(co
     const int chunk = (int)blockIdx.x - d.first_block[l];
     float *dw = ws + d.dw_off[l], *db = ws + d.db_off[l];
     if (d.in_tiles[l] == 4)
-        wgrad_regs_b3_body<4>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], dw, db, n_tiles, d.chunks[l], chunk);
+        wgrad_regs_b3_body<4>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], dw, db, n_tiles, d.chunks[l], chunk, d.in_live[l]);
     else
-        wgrad_regs_b3_body<2>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], dw, db, n_tiles, d.chunks[l], chunk);
+        wgrad_regs_b3_body<2>(acts, dpre, acts_tile_floats, dpre_tile_floats, d.act_off[l], d.dpre_off[l], dw, db, n_tiles, d.chunks[l], chunk, d.in_live[l]);
 }
 
 // sum the per-chunk partials of every layer in one launch
@@ -1964,8 +1972,9 @@ extern "C" int64_t mh_mlp_wgrad_workspace_floats(int32_t n_layers, const int32_t
 
 static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
                       int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                      const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
-                      float *db_raw, int64_t n_tiles, void *stream, bool b3) {
+                      const int32_t *in_feats_host, const int32_t *out_feats_host, const int32_t *in_live_host,
+                      const int32_t *out_live_host, float *workspace, float *dw_raw, float *db_raw, int64_t n_tiles, void *stream,
+                      bool b3) {
     if (n_tiles == 0 || n_layers == 0) return MH_OK;
     if (!acts || !dpre || !act_off_host || !dpre_off_host || !in_feats_host || !out_feats_host || !workspace || !dw_raw ||
         !db_raw || n_layers < 0 || n_layers > WG_MAX_LAYERS || n_tiles < 0)
@@ -1973,6 +1982,10 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
     for (int l = 0; l < n_layers; l++) {
         const int in = in_feats_host[l], out = out_feats_host[l];
         if (in <= 0 || out <= 0 || (in % 32) || (out % 32) || in > 128 || out > 128) return MH_ERR_ARG;
+        if (in_live_host && (in_live_host[l] < 1 || in_live_host[l] > in)) return MH_ERR_ARG;
+        if (out_live_host && (out_live_host[l] < 1 || out_live_host[l] > out)) return MH_ERR_ARG;
+        // the slice-once kernels take every dPre row of their 128-row layers
+        if (out_live_host && out == 128 && out_live_host[l] != 128) return MH_ERR_ARG;
     }
     // workspace: [dW partials of layer 0 | 1 | ...][db partials of layer 0 | 1 | ...]; outputs: dw_raw | db_raw
     WgReduce rd;
@@ -2007,6 +2020,9 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
         all.dpre_off[l] = dpre_off_host[l];
         all.out_pad[l] = out;
         all.in_tiles[l] = in / 32;
+        const int in_live = in_live_host ? in_live_host[l] : in, out_live = out_live_host ? out_live_host[l] : out;
+        all.in_live[l] = in_live;
+        all.out_live[l] = out_live;
         all.chunks[l] = chunks;
         all.dw_off[l] = dw_poff[l];
         all.db_off[l] = db_poff[l];
@@ -2015,11 +2031,11 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
             if (in == 128)
                 hipLaunchKernelGGL(wgrad_regs_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
                                    acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                   workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+                                   workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks, in_live);
             else
                 hipLaunchKernelGGL(wgrad_regs_b3_kernel<2>, dim3((unsigned)chunks), dim3(256), 2 * 2 * 6 * 1024, mh_stream(stream),
                                    acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
-                                   workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+                                   workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks, in_live);
             MH_CHECK_LAUNCH();
         } else if (per_layer) {
             const dim3 grid((unsigned)chunks), block((unsigned)(out / 32) * 64);
@@ -2027,11 +2043,11 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
     if (b3)                                                                                                   \
         hipLaunchKernelGGL((wgrad_kernel<IT, true>), grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats, \
                            dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, workspace + dw_poff[l], \
-                           workspace + db_poff[l], n_tiles, chunks);                                          \
+                           workspace + db_poff[l], n_tiles, chunks, in_live, out_live);                       \
     else                                                                                                      \
         hipLaunchKernelGGL((wgrad_kernel<IT, false>), grid, block, 0, mh_stream(stream), acts, dpre, acts_tile_floats, \
                            dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l], out, workspace + dw_poff[l], \
-                           workspace + db_poff[l], n_tiles, chunks)
+                           workspace + db_poff[l], n_tiles, chunks, in_live, out_live)
             switch (in / 32) {
                 case 1: WG_LAUNCH(1); break;
                 case 2: WG_LAUNCH(2); break;
@@ -2066,6 +2082,8 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
             t.dpre_off[k] = all.dpre_off[l];
             t.out_pad[k] = all.out_pad[l];
             t.in_tiles[k] = all.in_tiles[l];
+            t.in_live[k] = all.in_live[l];
+            t.out_live[k] = all.out_live[l];
             t.chunks[k] = all.chunks[l];
             t.dw_off[k] = all.dw_off[l];
             t.db_off[k] = all.db_off[l];
@@ -2100,18 +2118,20 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
 
 extern "C" int mh_mlp_wgrad(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
                             int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                            const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
-                            float *db_raw, int64_t n_tiles, void *stream) {
+                            const int32_t *in_feats_host, const int32_t *out_feats_host, const int32_t *in_live_host,
+                            const int32_t *out_live_host, float *workspace, float *dw_raw, float *db_raw, int64_t n_tiles,
+                            void *stream) {
     return wgrad_impl(acts, dpre, acts_tile_floats, dpre_tile_floats, n_layers, act_off_host, dpre_off_host, in_feats_host,
-                      out_feats_host, workspace, dw_raw, db_raw, n_tiles, stream, false);
+                      out_feats_host, in_live_host, out_live_host, workspace, dw_raw, db_raw, n_tiles, stream, false);
 }
 
 extern "C" int mh_mlp_wgrad_b3(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
                                int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
-                               const int32_t *in_feats_host, const int32_t *out_feats_host, float *workspace, float *dw_raw,
-                               float *db_raw, int64_t n_tiles, void *stream) {
+                               const int32_t *in_feats_host, const int32_t *out_feats_host, const int32_t *in_live_host,
+                               const int32_t *out_live_host, float *workspace, float *dw_raw, float *db_raw, int64_t n_tiles,
+                               void *stream) {
     return wgrad_impl(acts, dpre, acts_tile_floats, dpre_tile_floats, n_layers, act_off_host, dpre_off_host, in_feats_host,
-                      out_feats_host, workspace, dw_raw, db_raw, n_tiles, stream, true);
+                      out_feats_host, in_live_host, out_live_host, workspace, dw_raw, db_raw, n_tiles, stream, true);
 }
 
 // ---- fused field backward (backward-data + weight gradients, see field_fused_*_kernel) ---------------------------------

@@ -411,8 +411,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
 #pragma unroll
     for (int k = 20; k < 24; k++) bin0[k] = 0.f;
     if (PARK) {
+#if defined(MH_PARK_PAD_ROWS) || defined(MH_PARK_H0_PAD)   // A/B (tools/gpu/r6_pad_ab.sh): the round-5 form, pad rows written (and, with MORPHEUS_WGRAD_LIVE=0, read)
 #pragma unroll
-        for (int k = 0; k < 32; k++) tile[(2 * k + h) * TILE + pt] = k < 20 ? bin0[k] : 0.f;  // k-step ordered, rows 40..63 pad
+        for (int k = 0; k < 32; k++) tile[(2 * k + h) * TILE + pt] = k < 20 ? bin0[k] : 0.f;
+#else
+#pragma unroll
+        for (int k = 0; k < 20; k++) tile[(2 * k + h) * TILE + pt] = bin0[k];  // k-step ordered; the pad rows 40..63 are never read (wg_row)
+#endif
     }
     uint2 *mk = PARK ? reinterpret_cast<uint2 *>(tile + WARP_HID_ROWS * TILE) : nullptr;
 
@@ -619,7 +624,15 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
             d5[1] = g[p * nout + 1];
             if (nout == 3) d5[2] = g[p * nout + 2];
         }
+        // dPre5's live rows only (0..nout-1 <= 3: registers 0..3 of the lower half; mh_mlp_wgrad reads no row behind them, wg_row)
+#ifdef MH_PARK_PAD_ROWS
         store_acc_rows<1>(dt + 640 * TILE, d5, pt, h);
+#else
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) dt[(640 + r) * TILE + pt] = d5[r];
+        }
+#endif
         Frag bh[8], bm[8], bl[8];
 #pragma unroll
         for (int s = 0; s < 2; s++)

@@ -688,8 +688,19 @@ def sample_positions(rays_o, rays_d, ray_idx, t_starts, t_ends, ray_start, ray_c
 
 
 # ------------------------------------------------------------------------------------ fused MLPs
-def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False):
+# A/B switch (tools/gpu/r6_pad_ab.sh): 0 = the weight-gradient kernels read every row of the padded tiles (needs a library built with
+# -DMH_PARK_PAD_ROWS, whose forward / backward-data kernels write them)
+WGRAD_LIVE_ROWS = os.environ.get("MORPHEUS_WGRAD_LIVE", "1") != "0"
+
+
+def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False, in_live=None,
+           out_live=None):
+    """in_live / out_live: rows of each layer's input / dPre tile that carry values (None: all; include/morpheus_hip.h)"""
     n_layers = len(act_off)
+    if not WGRAD_LIVE_ROWS:
+        in_live = out_live = None
+    il_p = None if in_live is None else _i32arr(in_live)[1]
+    ol_p = None if out_live is None else _i32arr(out_live)[1]
     dw_len = int(sum(i * o for i, o in zip(in_pad, out_pad)))
     db_len = int(sum(out_pad))
     a_np, a_p = _i32arr(act_off)
@@ -702,8 +713,8 @@ def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out
     dw_raw, db_raw = raw[:dw_len], raw[dw_len:]
     _e = TIMER.start()
     fn = lib.mh_mlp_wgrad_b3 if b3 else lib.mh_mlp_wgrad
-    check(fn(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, ptr(ws), ptr(dw_raw), ptr(db_raw), n_tiles,
-             stream()), "mh_mlp_wgrad")
+    check(fn(ptr(acts), ptr(dpre), acts_tile, dpre_tile, n_layers, a_p, d_p, i_p, o_p, il_p, ol_p, ptr(ws), ptr(dw_raw), ptr(db_raw),
+             n_tiles, stream()), "mh_mlp_wgrad")
     TIMER.stop("mh_mlp_wgrad[" + tag + "]", _e)
     return raw          # dw_raw | db_raw, tile-row order (packing.JointPacker.unpack_grads maps it back)
 
@@ -945,7 +956,7 @@ class _WarpMLP(torch.autograd.Function):
                        stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)
         raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
-                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3)
+                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3, in_live=_WARP_WG[4], out_live=_WARP_WG[5])
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
             (od, ot) = ctx.jp.bias0_raw
@@ -964,14 +975,18 @@ class _WarpMLP(torch.autograd.Function):
 
 
 def _warp_wg_geometry():
-    act_off, dpre_off, in_pad, out_pad = [], [], [], []
+    act_off, dpre_off, in_pad, out_pad, in_live, out_live = [], [], [], [], [], []
     for net in range(2):
         for l in range(6):
             act_off.append(0 if l == 0 else (64 + net * 640 + (l - 1) * 128) * 32)
             dpre_off.append((net * 672 + l * 128) * 32)
             in_pad.append(64 if l == 0 else 128)
             out_pad.append(32 if l == 5 else 128)
-    return act_off, dpre_off, in_pad, out_pad
+            # rows that carry values: 40 of H0's 64 (20 encoding k-steps x 2 halves), 3 | 2 of dPre5's 32 -- the b3 kernels write,
+            # and every weight-gradient kernel reads, only those (csrc/mlp.hip: wg_row)
+            in_live.append(40 if l == 0 else 128)
+            out_live.append((3, 2)[net] if l == 5 else 128)
+    return act_off, dpre_off, in_pad, out_pad, in_live, out_live
 
 
 _WARP_WG = _warp_wg_geometry()

@@ -457,3 +457,58 @@ def test_sliced_pack_sizes_match_the_kernels_staging_sizes():
     # the transposed layers are sliced for the bf16 x 3 kernels only (f32 reads the fp32 transposed pack)
     assert fj.sliced_bwd_for("b3") and fj.sliced_bwd_for(True) and not fj.sliced_bwd_for("f32")
     assert wj.sliced_bwd_for("b3") and not wj.sliced_bwd_for("")
+
+
+def test_step_cache_host_logic():
+    """model._step_cache (round 6), the parts that need no GPU: nothing is kept outside a training forward (eval mode, no_grad, the
+    switch off), a parameter's version counter or a train() / eval() call ends the step, an explicit operand_scope of a training
+    forward stands on the step cache and leaves it in the model for the next call, a fresh scope never does, and the merged
+    operand gather of a pack addresses the four section layouts the separate gathers had."""
+    import torch
+    from morpheus_amd import harness, model as mm, packing
+    m = harness.build_model("b", "cpu")
+    m.eval()
+    assert m._step_cache() is None
+    m.train()
+    with torch.no_grad():
+        assert m._step_cache() is None
+    sc = m._step_cache()
+    assert sc is not None and m._step_cache() is sc and not sc.stale
+    with m.operand_scope():
+        assert m._opcache is sc.entries and m._scope_step is sc
+        with m.fresh_operand_scope():
+            assert m._opcache is not sc.entries and m._scope_step is None
+        assert m._opcache is sc.entries
+    assert m._opcache is None and m._stepcache is sc
+    with torch.no_grad():
+        next(iter(m.sdf_net.parameters())).add_(0.0)           # an in-place update, as an optimiser step makes it
+    sc2 = m._step_cache()
+    assert sc2 is not sc
+    sc2._spent()
+    assert sc2.stale and m._step_cache() is not sc2             # the backward pass reached a pack: the next forward re-prepares
+    m.eval()
+    assert m._stepcache is None
+    m.train()
+    saved = mm.IMPLICIT_OPERANDS
+    try:
+        mm.IMPLICIT_OPERANDS = False
+        assert m._step_cache() is None
+        with m.operand_scope():
+            assert m._opcache == {} and m._scope_step is None
+    finally:
+        mm.IMPLICIT_OPERANDS = saved
+    for jp in (packing.warp_joint_packer(), packing.field_joint_packer()):
+        idx, sect = jp.all_index()
+        for name, part in (("fwd", jp.fwd_index), ("bwd", jp.bwd_index), ("fwd3", jp.fwd3_index), ("bwd3", jp.bwd3_index)):
+            o, n = sect[name]
+            assert o % 4 == 0 and n == len(part) and (idx[o:o + n] == part).all()
+        assert (idx < jp.n_flat).all()
+
+
+def test_nerfacc_check_tool_says_what_it_needs():
+    """tools/check_against_nerfacc.py cannot run here -- nerfacc is not in the image -- and says so: exit code 2 and
+    its own message, not a traceback."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_against_nerfacc.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "nerfacc is not installed" in r.stderr and "Traceback" not in r.stderr
