@@ -64,7 +64,10 @@ _SIGS = {
     "mh_field_w3_bytes": (_I64, []),
     "mh_field_fwd_b3": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_warp_w3T_bytes": (_I64, []),
-    "mh_warp_bwd_data_b3": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _P]),
+    "mh_warp_bwd_data_b3": (ctypes.c_int, [_P] * 5 + [_I32, _P, _P, _P, _I64, _I32, _P]),
+    "mh_warp_regen_dpre4": (_I32, [_I64]),
+    "mh_warp_wgrad_workspace_floats": (_I64, [_I64]),
+    "mh_warp_wgrad_b3": (ctypes.c_int, [_P] * 6 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_warp_fwd_b3": (ctypes.c_int, [_P] * 8 + [_I32, _P, _P, _P, _I64, _P]),
     "mh_field_fwd": (ctypes.c_int, [_P] * 7 + [_I32, _I32, _P, _P, _P, _P, _I64, _P]),
     "mh_field_bwd_fused_workspace_floats": (_I64, [_I64]),

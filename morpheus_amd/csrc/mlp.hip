@@ -1736,6 +1736,167 @@ __global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_regs_b3_kernel(const 
                            (int)blockIdx.x, in_live);
 }
 
+// ---- layer 4 of a warp net with dPre4 REGENERATED instead of read (round 6) ------------------------------------
+// dPre4 = relu'(H5) (W5^T dPre5), and dPre5 is the incoming gradient itself: three (two) numbers per point.  The backward-data kernel
+// wrote those 128 rows per tile and net (16 KB of its 172) for this kernel alone to read them back: 4.3 GB of a cfg3 step's 57.  Here
+// wave mt makes ITS 32 rows of dPre4 from the gradient (12 B per point), the ReLU sign words the forward parked (8 B per point and
+// layer) and the T5 slices (loop-invariant registers), with the backward-data kernel's own instruction sequence -- so that what
+// reaches the weight-gradient MFMAs is bit for bit what that kernel would have parked:
+//   * chain (mlp_b3.hip, b3_layer<2, 4, true> on T5):  D[row = feature][col = point] = sum of six slice products A = W5^T slices,
+//     B = dPre5 slices, k16 step 0 (step 1 is all zeros).  Here the SAME registers in swapped roles: A' = the lane's dPre5 slices
+//     (lane (i, g) = point i, k = 8g .. 8g + 7: the gradient in lanes g = 0, e = 0..2), B' = the T5 fragment of tile mt (lane (i, g) =
+//     feature i, the same k) give D'[row = point][col = feature] = D^T: the same products summed over the same k positions.
+//   * D' leaves lane (i, g) with points acc_row(r, g); the weight-gradient MFMAs want points 16 g .. 16 g + 15 (the order in which the
+//     parked rows were read): eight v_permlane32_swap exchange the two halves' register groups.
+//   * the sign words are parked per chain lane (point, half): 16 ballots hand every feature lane the 32-point word of its row.
+struct WgRegenRaw {
+    f32x4 b[4];        // the activation row block (H4 rows 32 bt + i, points 16 g ..)
+    uint2 m;           // H5's ReLU sign words of chain lane `lane` (point lane & 31, half lane >> 5)
+    float gv[3];       // the incoming gradient of point lane & 31 (lanes g = 0)
+};
+
+__global__ __launch_bounds__(256, WG_REG_WAVES) void wgrad_regen_b3_kernel(
+    const float *__restrict__ acts, const float *__restrict__ g5, int nout, int64_t M, const f32x4 *__restrict__ w3T,
+    int64_t acts_tile_floats, int act_off, int mask_off, float *__restrict__ dw_part, float *__restrict__ db_part, int64_t n_tiles,
+    int n_chunks) {
+    constexpr int IT = 4, NS = 3, BUF_F4 = IT * 6 * 64;
+    const int chunk = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const int64_t st = n_chunks;
+    const int64_t n_my = chunk < n_tiles ? (n_tiles - chunk + st - 1) / st : 0;
+    const int64_t last = chunk + (n_my > 0 ? n_my - 1 : 0) * st;
+    const float *b0 = acts + act_off + (int64_t)(32 * mt + i) * TILE + 16 * g;
+    const uint2 *m0 = reinterpret_cast<const uint2 *>(acts + mask_off) + lane;
+    // T5 fragments of output tile mt, k16 step 0: [plane][tile][step][lane] (packing.py; mlp_b3.hip: b3_layer<2, 4>)
+    Frag wh, wm, wl;
+    wh.f = w3T[0 * 512 + (mt * 2) * 64 + lane];
+    wm.f = w3T[1 * 512 + (mt * 2) * 64 + lane];
+    wl.f = w3T[2 * 512 + (mt * 2) * 64 + lane];
+    // which ballot carries this lane's row: feature i = acc_row(r', h') of tile mt
+    const int my_r = (i & 3) + 4 * (i >> 3), my_h = (i >> 2) & 1;
+    f32x16 acc[IT];
+    acc_zero<IT>(acc);
+    float bsum = 0.f;
+    WgRegenRaw raw[NS];
+    WgSl as[2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define RG_T(k) ((chunk + (k) * st) <= last ? (chunk + (k) * st) : last)
+#define RG_LD(set, k)                                                                                   \
+    do {                                                                                                \
+        const int64_t t_ = RG_T(k);                                                                     \
+        const f32x4 *b4_ = reinterpret_cast<const f32x4 *>(b0 + t_ * acts_tile_floats);                 \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) raw[set].b[j] = b4_[j];                           \
+        raw[set].m = m0[t_ * (acts_tile_floats / 2)];                                                   \
+        const int64_t p_ = t_ * TILE + i;                                                               \
+        const bool on_ = g5 && g == 0 && p_ < M;                                                        \
+        raw[set].gv[0] = on_ ? g5[p_ * nout + 0] : 0.f;                                                 \
+        raw[set].gv[1] = on_ ? g5[p_ * nout + 1] : 0.f;                                                 \
+        raw[set].gv[2] = (on_ && nout == 3) ? g5[p_ * nout + 2] : 0.f;                                  \
+    } while (0)
+    // raw set -> dPre4 rows (regenerated) -> slices as[par]; activation rows -> slices in LDS buffer par
+#define RG_SPLIT(set, par, REAL)                                                                                              \
+    do {                                                                                                                      \
+        Frag dh_, dm_, dl_;                                                                                                   \
+        split2(raw[set].gv[0], raw[set].gv[1], dh_.u[0], dm_.u[0], dl_.u[0]);                                                 \
+        split2(raw[set].gv[2], 0.f, dh_.u[1], dm_.u[1], dl_.u[1]);                                                            \
+        dh_.u[2] = dh_.u[3] = dm_.u[2] = dm_.u[3] = dl_.u[2] = dl_.u[3] = 0u;                                                 \
+        f32x16 D_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh_.h, wl.h, zero16, 0, 0, 0);                                   \
+        D_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dm_.h, wm.h, D_, 0, 0, 0);                                               \
+        D_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl_.h, wh.h, D_, 0, 0, 0);                                               \
+        D_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh_.h, wm.h, D_, 0, 0, 0);                                               \
+        D_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dm_.h, wh.h, D_, 0, 0, 0);                                               \
+        D_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh_.h, wh.h, D_, 0, 0, 0);                                               \
+        /* the 32-point sign word of this lane's row: ballot r carries rows acc_row(r, 0) (low half) and acc_row(r, 1) (high) */ \
+        const uint32_t w16_ = ((mt < 2 ? raw[set].m.x : raw[set].m.y) >> (16 * (mt & 1))) & 0xffffu;                          \
+        uint32_t rowm_ = 0u;                                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                                      \
+            const uint64_t bal_ = __builtin_amdgcn_ballot_w64(((w16_ >> r) & 1u) != 0u);                                      \
+            const uint32_t v_ = my_h ? (uint32_t)(bal_ >> 32) : (uint32_t)bal_;                                               \
+            rowm_ = my_r == r ? v_ : rowm_;                                                                                   \
+        }                                                                                                                     \
+        rowm_ >>= 16 * g;                                                                                                     \
+        /* points acc_row(r, g) -> points 16 g + 0..15 */                                                                     \
+        f32x4 a_[4];                                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                                       \
+            const auto s0_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(D_[c]), __float_as_uint(D_[8 + c]), false, false);      \
+            const auto s1_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(D_[4 + c]), __float_as_uint(D_[12 + c]), false, false); \
+            a_[0][c] = mask_bit(rowm_, 0 + c, __uint_as_float(s0_[0]));                                                       \
+            a_[1][c] = mask_bit(rowm_, 4 + c, __uint_as_float(s0_[1]));                                                       \
+            a_[2][c] = mask_bit(rowm_, 8 + c, __uint_as_float(s1_[0]));                                                       \
+            a_[3][c] = mask_bit(rowm_, 12 + c, __uint_as_float(s1_[1]));                                                      \
+        }                                                                                                                     \
+        if (REAL) { _Pragma("unroll") for (int j = 0; j < 4; j++) bsum += (a_[j][0] + a_[j][1]) + (a_[j][2] + a_[j][3]); }    \
+        wg_slice16(a_, as[par]);                                                                                              \
+        WgSl bs_;                                                                                                             \
+        wg_slice16(raw[set].b, bs_);                                                                                          \
+        f32x4 *dst_ = lds_res + (par) * BUF_F4 + mt * 6 * 64 + lane;                                                          \
+        _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                                       \
+            dst_[(0 * 2 + s) * 64] = bs_.h[s].f;                                                                              \
+            dst_[(1 * 2 + s) * 64] = bs_.m[s].f;                                                                              \
+            dst_[(2 * 2 + s) * 64] = bs_.l[s].f;                                                                              \
+        }                                                                                                                     \
+    } while (0)
+#define RG_MMA(par)                                                                                                 \
+    do {                                                                                                            \
+        const f32x4 *src_ = lds_res + (par) * BUF_F4 + lane;                                                        \
+        _Pragma("unroll") for (int np = 0; np < IT; np += 2) {                                                      \
+            Frag bh_[2][2], bm_[2][2], bl_[2][2];                                                                   \
+            _Pragma("unroll") for (int t = 0; t < 2; t++) _Pragma("unroll") for (int s = 0; s < 2; s++) {           \
+                bh_[t][s].f = src_[((np + t) * 6 + 0 * 2 + s) * 64];                                                \
+                bm_[t][s].f = src_[((np + t) * 6 + 1 * 2 + s) * 64];                                                \
+                bl_[t][s].f = src_[((np + t) * 6 + 2 * 2 + s) * 64];                                                \
+            }                                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < 2; s++) {                                                         \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].l[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].m[s].h, bm_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].h[s].h, bl_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].m[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].h[s].h, bm_[t][s].h, acc[np + t], 0, 0, 0); \
+                _Pragma("unroll") for (int t = 0; t < 2; t++) acc[np + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[par].h[s].h, bh_[t][s].h, acc[np + t], 0, 0, 0); \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+#define RG_STEP(J)                                                                          \
+    do {                                                                                    \
+        __syncthreads();                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        RG_LD((J) % NS, k0 + (J) + NS);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        if (k0 + (J) < n_my) RG_MMA((J) & 1);                                               \
+        RG_SPLIT(((J) + 1) % NS, ((J) + 1) & 1, (k0 + (J) + 1 < n_my));                     \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+    if (n_my > 0) {
+#pragma unroll
+        for (int q = 0; q < NS; q++) RG_LD(q, q);
+        __builtin_amdgcn_sched_barrier(0);
+        RG_SPLIT(0, 0, true);
+        // (the guarded step only.  Measured and dropped, same box: an unguarded main loop as in wgrad_regs_b3_kernel -- 73 spilled
+        // registers; the same with the MFMA block fenced from the slicing and the T5 fragments in LDS -- 6 spills, +0.05 ms per launch)
+        for (int64_t k0 = 0; k0 < n_my; k0 += 6) {        // lcm(NS, 2) steps per trip
+            RG_STEP(0);
+            RG_STEP(1);
+            RG_STEP(2);
+            RG_STEP(3);
+            RG_STEP(4);
+            RG_STEP(5);
+        }
+    }
+#undef RG_STEP
+#undef RG_MMA
+#undef RG_SPLIT
+#undef RG_LD
+#undef RG_T
+    float *dw = dw_part + (int64_t)chunk * 128 * 128;
+#pragma unroll
+    for (int n = 0; n < IT; n++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) dw[(int64_t)(32 * mt + acc_row(r, g)) * 128 + 32 * n + i] = acc[n][r];
+    bsum += __shfl_xor(bsum, 32);
+    if (g == 0) db_part[(int64_t)chunk * 128 + 32 * mt + i] = bsum;
+}
+
 template <int IT, bool B3 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_kernel(const float *__restrict__ acts, const float *__restrict__ dpre,
                                                        int64_t acts_tile_floats, int64_t dpre_tile_floats, int act_off,
@@ -1970,11 +2131,21 @@ extern "C" int64_t mh_mlp_wgrad_workspace_floats(int32_t n_layers, const int32_t
     return tot;
 }
 
+// layers whose dPre rows the launch regenerates instead of reading (wgrad_regen_b3_kernel): the warp nets' layer 4
+struct WgRegenHost {
+    bool on[WG_MAX_LAYERS];
+    const float *g5[WG_MAX_LAYERS];       // the net's incoming gradient [M, nout] (NULL: none, dPre4 = 0)
+    int nout[WG_MAX_LAYERS];
+    const f32x4 *w3T[WG_MAX_LAYERS];      // the net's transposed slices (T5 first)
+    int mask_off[WG_MAX_LAYERS];          // floats from the tile's start to H5's ReLU sign words of the net
+    int64_t M;
+};
+
 static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_floats, int64_t dpre_tile_floats,
                       int32_t n_layers, const int32_t *act_off_host, const int32_t *dpre_off_host,
                       const int32_t *in_feats_host, const int32_t *out_feats_host, const int32_t *in_live_host,
                       const int32_t *out_live_host, float *workspace, float *dw_raw, float *db_raw, int64_t n_tiles, void *stream,
-                      bool b3) {
+                      bool b3, const WgRegenHost *regen = nullptr) {
     if (n_tiles == 0 || n_layers == 0) return MH_OK;
     if (!acts || !dpre || !act_off_host || !dpre_off_host || !in_feats_host || !out_feats_host || !workspace || !dw_raw ||
         !db_raw || n_layers < 0 || n_layers > WG_MAX_LAYERS || n_tiles < 0)
@@ -2027,7 +2198,12 @@ static int wgrad_impl(const float *acts, const float *dpre, int64_t acts_tile_fl
         all.dw_off[l] = dw_poff[l];
         all.db_off[l] = db_poff[l];
         all.first_block[l + 1] = all.first_block[l] + chunks;
-        if (per_layer && b3 && out == 128 && (in == 128 || in == 64)) {
+        if (per_layer && b3 && out == 128 && in == 128 && regen && regen->on[l]) {
+            hipLaunchKernelGGL(wgrad_regen_b3_kernel, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream), acts,
+                               regen->g5[l], regen->nout[l], regen->M, regen->w3T[l], acts_tile_floats, (int)act_off_host[l],
+                               regen->mask_off[l], workspace + dw_poff[l], workspace + db_poff[l], n_tiles, chunks);
+            MH_CHECK_LAUNCH();
+        } else if (per_layer && b3 && out == 128 && (in == 128 || in == 64)) {
             if (in == 128)
                 hipLaunchKernelGGL(wgrad_regs_b3_kernel<4>, dim3((unsigned)chunks), dim3(256), 2 * 4 * 6 * 1024, mh_stream(stream),
                                    acts, dpre, acts_tile_floats, dpre_tile_floats, (int)act_off_host[l], (int)dpre_off_host[l],
@@ -2132,6 +2308,58 @@ extern "C" int mh_mlp_wgrad_b3(const float *acts, const float *dpre, int64_t act
                                void *stream) {
     return wgrad_impl(acts, dpre, acts_tile_floats, dpre_tile_floats, n_layers, act_off_host, dpre_off_host, in_feats_host,
                       out_feats_host, in_live_host, out_live_host, workspace, dw_raw, db_raw, n_tiles, stream, true);
+}
+
+// ---- the warp nets' weight gradients with their geometry on this side of the ABI ----------------------------------------------------
+// (the 12 layers of deform_net + topo_net in the tiles of mh_warp_fwd / mh_warp_bwd_data; morpheus_amd/ops.py used to spell the
+// offsets out).  regen_dpre4: the two layer-4 launches regenerate dPre4 (wgrad_regen_b3_kernel) -- the caller ran
+// mh_warp_bwd_data_b3 with skip_dpre4 = 1, and both decisions come from mh_warp_regen_dpre4(M).
+struct WarpWg {
+    int32_t act_off[12], dpre_off[12], in[12], out[12], in_live[12], out_live[12];
+};
+static WarpWg warp_wg_geometry() {
+    WarpWg w;
+    for (int net = 0; net < 2; net++)
+        for (int l = 0; l < 6; l++) {
+            const int k = net * 6 + l;
+            w.act_off[k] = l == 0 ? 0 : (64 + net * 640 + (l - 1) * 128) * TILE;
+            w.dpre_off[k] = (net * 672 + l * 128) * TILE;
+            w.in[k] = l == 0 ? 64 : 128;
+            w.out[k] = l == 5 ? 32 : 128;
+            w.in_live[k] = l == 0 ? 40 : 128;
+            w.out_live[k] = l == 5 ? (net ? 2 : 3) : 128;
+        }
+    return w;
+}
+
+// dPre4 is regenerated by the large-batch (one launch per layer) weight-gradient path only
+extern "C" int32_t mh_warp_regen_dpre4(int64_t M) { return M > 0 && n_tiles_for(M) >= WG_PER_LAYER_TILES ? 1 : 0; }
+
+extern "C" int64_t mh_warp_wgrad_workspace_floats(int64_t M) {
+    const WarpWg w = warp_wg_geometry();
+    return mh_mlp_wgrad_workspace_floats(12, w.in, w.out, n_tiles_for(M));
+}
+
+extern "C" int mh_warp_wgrad_b3(const float *acts, const float *dpre, const float *g_deform, const float *g_topo, const void *w3T_d,
+                                const void *w3T_t, int32_t regen_dpre4, float *workspace, float *dw_raw, float *db_raw, int64_t M,
+                                void *stream) {
+    if (M == 0) return MH_OK;
+    if (M < 0 || !w3T_d || !w3T_t) return MH_ERR_ARG;
+    if (regen_dpre4 && !mh_warp_regen_dpre4(M)) return MH_ERR_ARG;      // (the small-batch launches read dPre4)
+    const WarpWg w = warp_wg_geometry();
+    WgRegenHost rg;
+    for (int k = 0; k < WG_MAX_LAYERS; k++) rg.on[k] = false;
+    rg.M = M;
+    for (int net = 0; net < 2; net++) {
+        const int k = net * 6 + 4;
+        rg.on[k] = regen_dpre4 != 0;
+        rg.g5[k] = net ? g_topo : g_deform;
+        rg.nout[k] = net ? 2 : 3;
+        rg.w3T[k] = reinterpret_cast<const f32x4 *>(net ? w3T_t : w3T_d);
+        rg.mask_off[k] = WARP_HID_ROWS * TILE + (net * 5 + 4) * 64 * 2;
+    }
+    return wgrad_impl(acts, dpre, (int64_t)WARP_ACT_ROWS * TILE, (int64_t)WARP_DPRE_ROWS * TILE, 12, w.act_off, w.dpre_off, w.in, w.out,
+                      w.in_live, w.out_live, workspace, dw_raw, db_raw, n_tiles_for(M), stream, true, regen_dpre4 ? &rg : nullptr);
 }
 
 // ---- fused field backward (backward-data + weight gradients, see field_fused_*_kernel) ---------------------------------

@@ -548,7 +548,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 1 : 2) void warp_fwd_b3_kernel(
 #define B3_T0_F4 3072                                   // 3 planes x 2 tiles x 8 k16 steps x 64 lanes
 #define B3_NETT_F4 (B3_T5_F4 + 4 * B3_LH_F4 + B3_T0_F4)  // 29 184 float4 per net
 
-// masked accumulators -> parked dPre tile + the next transposed layer's B operands
+// masked accumulators -> parked dPre tile (PARK) + the next transposed layer's B operands
+template <bool PARK = true>
 __device__ __forceinline__ void b3_epilogue_bwd(const f32x16 (&acc)[4], uint2 m, float *__restrict__ dt, int pt, int h, Frag (&bh)[8],
                                                 Frag (&bm)[8], Frag (&bl)[8]) {
     mfma_results_settle();
@@ -558,8 +559,10 @@ __device__ __forceinline__ void b3_epilogue_bwd(const f32x16 (&acc)[4], uint2 m,
         float y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) y[r] = mask_bit(mw, r, acc[t][r]);
+        if (PARK) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) PARK_STORE(y[r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
+            for (int r = 0; r < 16; r++) PARK_STORE(y[r], &dt[(32 * t + acc_row(r, h)) * TILE + pt]);
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
@@ -586,7 +589,8 @@ __device__ __forceinline__ void b3_epilogue_bwd_eighth(f32x16 (&acc)[4], uint2 m
 #endif
 }
 
-template <int NW>
+// PARK4 = false (round 6): dPre4 is not parked -- the layer-4 weight-gradient launch regenerates it (mlp.hip: wgrad_regen_b3_kernel)
+template <int NW, bool PARK4 = true>
 __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__restrict__ x, const float *__restrict__ g_deform,
                                                                  const float *__restrict__ g_topo, const f32x4 *__restrict__ w3T_d,
                                                                  const f32x4 *__restrict__ w3T_t, int n_bands,
@@ -647,11 +651,14 @@ __global__ __launch_bounds__(NW * 64, 2) void warp_bwd_b3_kernel(const float *__
         b3_stage_issue<B3_LH_F4, NW * 64>(wt);
         b3_dma_fence();
         // dPre_4 from T5's output (the short first stage: nothing to hide it under)
-        b3_epilogue_bwd(acc, msk[4], dt + 4 * 128 * TILE, pt, h, bh, bm, bl);
+        b3_epilogue_bwd<PARK4>(acc, msk[4], dt + 4 * 128 * TILE, pt, h, bh, bm, bl);
         for (int l = 4; l >= 1; l--) {
             // dH_l = W_l^T dPre_l in quarters (see the forward kernel): tiles 0, 1 are complete after the third quarter and
             // their half of dPre_{l-1} (mask by H_l's ReLU bits, park, slice) runs under the fourth quarter's MFMAs
-            b3_stage_wait_keep<B3_KEEP_BWD>();               // behind the DMA: the 32 parking stores of tiles 2, 3
+            if (!PARK4 && l == 4)
+                b3_stage_wait();                             // no parking stores behind this DMA: vmcnt(KEEP) would not cover it
+            else
+                b3_stage_wait_keep<B3_KEEP_BWD>();           // behind the DMA: the 32 parking stores of tiles 2, 3
             acc_zero<4>(acc);
             b3_quarter<0, 0>(lds_b3, bh, bm, bl, acc, lane);
             b3_quarter<2, 0>(lds_b3, bh, bm, bl, acc, lane);
@@ -993,6 +1000,8 @@ static int b3_lds_opt_in() {
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
+            hipFuncSetAttribute((const void *)(warp_bwd_b3_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
+                hipSuccess ||
             hipFuncSetAttribute((const void *)warp_fwd_b3_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
                 hipSuccess ||
             hipFuncSetAttribute((const void *)warp_bwd_b3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, B3_LDS_BYTES) !=
@@ -1038,10 +1047,12 @@ extern "C" int64_t mh_warp_w3T_bytes(void) { return (int64_t)B3_NETT_F4 * 16; }
 static inline bool b3_small_batch(int64_t M) { return M <= (int64_t)BLOCK_PTS * mh_cu_count(); }
 
 extern "C" int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const float *g_topo, const void *w3T_d, const void *w3T_t,
-                                   int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, void *stream) {
+                                   int32_t n_bands, const float *acts, float *dpre, float *g_x, int64_t M, int32_t skip_dpre4,
+                                   void *stream) {
     if (M == 0) return MH_OK;
     if (M < 0 || !x || !w3T_d || !w3T_t || !acts || !dpre || n_bands < 0 || n_bands > 6) return MH_ERR_ARG;
     const bool small = b3_small_batch(M);
+    if (skip_dpre4 && small) return MH_ERR_ARG;       // (mh_warp_regen_dpre4(M) is never set for such a batch)
     const int64_t blocks = small ? (M + BLOCK_PTS - 1) / BLOCK_PTS : (M + B3_BLOCK_PTS - 1) / B3_BLOCK_PTS;
     if (blocks > 0x7fffffffLL) return MH_ERR_ARG;
     if (b3_lds_opt_in() != MH_OK) return MH_ERR_LAUNCH;
@@ -1049,6 +1060,10 @@ extern "C" int mh_warp_bwd_data_b3(const float *x, const float *g_deform, const 
         hipLaunchKernelGGL(warp_bwd_b3_kernel<4>, dim3((unsigned)blocks), dim3(256), B3_LDS_BYTES, mh_stream(stream), x, g_deform,
                            g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t), (int)n_bands,
                            acts, dpre, g_x, M, mh_mlp_tiles(M));
+    else if (skip_dpre4)
+        hipLaunchKernelGGL((warp_bwd_b3_kernel<8, false>), dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
+                           g_deform, g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t),
+                           (int)n_bands, acts, dpre, g_x, M, mh_mlp_tiles(M));
     else
         hipLaunchKernelGGL(warp_bwd_b3_kernel<8>, dim3((unsigned)blocks), dim3(B3_THREADS), B3_LDS_BYTES, mh_stream(stream), x,
                            g_deform, g_topo, reinterpret_cast<const f32x4 *>(w3T_d), reinterpret_cast<const f32x4 *>(w3T_t),

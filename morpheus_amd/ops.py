@@ -691,6 +691,8 @@ def sample_positions(rays_o, rays_d, ray_idx, t_starts, t_ends, ray_start, ray_c
 # A/B switch (tools/gpu/r6_pad_ab.sh): 0 = the weight-gradient kernels read every row of the padded tiles (needs a library built with
 # -DMH_PARK_PAD_ROWS, whose forward / backward-data kernels write them)
 WGRAD_LIVE_ROWS = os.environ.get("MORPHEUS_WGRAD_LIVE", "1") != "0"
+# A/B and test switch: 0 = dPre4 of the warp nets is parked by backward-data and read by the weight gradients (the round-5 form)
+REGEN_DPRE4 = os.environ.get("MORPHEUS_REGEN_DPRE4", "1") != "0"
 
 
 def _wgrad(lib, acts, dpre, acts_tile, dpre_tile, act_off, dpre_off, in_pad, out_pad, n_tiles, dev, tag, b3=False, in_live=None,
@@ -951,12 +953,31 @@ class _WarpMLP(torch.autograd.Function):
         g_x = torch.empty(M, 3, device=dev) if ctx.needs_input_grad[0] else None   # NULL -> the kernel skips the W0^T stage
         c = lambda t: None if t is None else t.contiguous()
         _e = TIMER.start()
-        bwd_data = lib.mh_warp_bwd_data_b3 if ctx.b3 else lib.mh_warp_bwd_data
-        check(bwd_data(ptr(x), ptr(c(g_deform)), ptr(c(g_topo)), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
-                       stream()), "mh_warp_bwd_data")
+        gd, gt = c(g_deform), c(g_topo)
+        # b3, large batches: dPre4 (16 KB of a tile's 172) is not parked, the layer-4 weight-gradient launches make it again from
+        # the incoming gradient, the ReLU sign words and the T5 slices -- the same bits (include/morpheus_hip.h: mh_warp_wgrad_b3)
+        regen = bool(ctx.b3 and REGEN_DPRE4 and lib.mh_warp_regen_dpre4(M))
+        if ctx.b3:
+            check(lib.mh_warp_bwd_data_b3(ptr(x), ptr(gd), ptr(gt), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
+                                          int(regen), stream()), "mh_warp_bwd_data")
+        else:
+            check(lib.mh_warp_bwd_data(ptr(x), ptr(gd), ptr(gt), ptr(wdT), ptr(wtT), ctx.n_bands, ptr(acts), ptr(dpre), ptr(g_x), M,
+                                       stream()), "mh_warp_bwd_data")
         TIMER.stop("mh_warp_bwd_data", _e)
-        raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
-                     _WARP_WG[3], n_tiles, dev, "warp", b3=ctx.b3, in_live=_WARP_WG[4], out_live=_WARP_WG[5])
+        if ctx.b3:
+            jp = ctx.jp
+            ws = torch.empty(max(lib.mh_warp_wgrad_workspace_floats(M), 1), device=dev)
+            dw_len = sum(i * o for i, o in zip(_WARP_WG[2], _WARP_WG[3]))
+            raw_len = dw_len + sum(_WARP_WG[3])
+            assert raw_len == jp.raw_len
+            raw = torch.empty(raw_len, device=dev) if M > 0 else torch.zeros(raw_len, device=dev)      # (an empty call writes nothing)
+            _e = TIMER.start()
+            check(lib.mh_warp_wgrad_b3(ptr(acts), ptr(dpre), ptr(gd), ptr(gt), ptr(wdT), ptr(wtT), int(regen), ptr(ws), ptr(raw[:dw_len]),
+                                       ptr(raw[dw_len:]), M, stream()), "mh_warp_wgrad_b3")
+            TIMER.stop("mh_mlp_wgrad[warp]", _e)
+        else:
+            raw = _wgrad(lib, acts, dpre, WARP_ACT_ROWS * 32, WARP_DPRE_ROWS * 32, _WARP_WG[0], _WARP_WG[1], _WARP_WG[2],
+                         _WARP_WG[3], n_tiles, dev, "warp", b3=False, in_live=_WARP_WG[4], out_live=_WARP_WG[5])
         # per-slot first-layer bias gradient: sum of dPre0 over the points of each slot
         if ctx.n_slots == 1:
             (od, ot) = ctx.jp.bias0_raw

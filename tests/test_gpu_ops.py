@@ -869,6 +869,27 @@ def test_warp_large_batch_weight_gradients(mlp, monkeypatch):
     for ga, gb in zip(big[3], small[3]):
         scale = float(gb.abs().max()) + 1e-20
         assert float((ga - gb).abs().max()) / scale <= 2e-5, (tuple(gb.shape), float((ga - gb).abs().max()) / scale)
+    if mlp == "b3":
+        # round 6: at this size backward-data does not park dPre4 and the layer-4 weight-gradient launches regenerate it from the
+        # incoming gradient, the ReLU sign words and the T5 slices (mh_warp_wgrad_b3) -- the SAME BITS as reading the parked rows,
+        # also when one net has no incoming gradient at all
+        assert ops.REGEN_DPRE4 and ops._lib.load().mh_warp_regen_dpre4(M) == 1 and ops._lib.load().mh_warp_regen_dpre4(CH) == 0
+        monkeypatch.setattr(ops, "REGEN_DPRE4", False)
+        parked = run(M)
+        assert torch.equal(parked[2], big[2])
+        for ga, gb in zip(big[3], parked[3]):
+            assert torch.equal(ga, gb), (tuple(gb.shape), float((ga - gb).abs().max()))
+
+        def run_deform_only(regen):
+            monkeypatch.setattr(ops, "REGEN_DPRE4", regen)
+            ps = [[p.clone().requires_grad_(True) for p in net] for net in nets]
+            bb = [t.clone().requires_grad_(True) for t in b0]
+            d, _ = ops.warp_mlp(x, None, bb[0], bb[1], 6, ops.prepare_warp_operands(ps[0], ps[1]))
+            (d * wd_).sum().backward()
+            return [p.grad for net in ps for p in net] + [t.grad for t in bb]
+
+        for ga, gb in zip(run_deform_only(True), run_deform_only(False)):
+            assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb))
 
 
 @pytest.mark.parametrize("with_color", [True, False])

@@ -125,7 +125,7 @@ def build_cases(M, dev):
                                      ptr(topo), ptr(acts), M, stream()), "fwd")
 
     def warp_bwd():
-        ops.check(lib.mh_warp_bwd_data_b3(ptr(x), ptr(g_d), ptr(g_t), ptr(wop.wT3[0]), ptr(wop.wT3[1]), 6, ptr(acts), ptr(dpre), ptr(g_x), M,
+        ops.check(lib.mh_warp_bwd_data_b3(ptr(x), ptr(g_d), ptr(g_t), ptr(wop.wT3[0]), ptr(wop.wT3[1]), 6, ptr(acts), ptr(dpre), ptr(g_x), M, 0,
                                           stream()), "bwd")
 
     def warp_wgrad():
