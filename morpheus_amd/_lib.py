@@ -136,7 +136,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+# torch.cuda.current_stream() builds a Stream object through three Python layers (device-index resolution, an availability check
+# that reads os.environ, Stream.__new__): ~7 us, once per C-ABI call, ~100 calls per eager real-view step whose host time IS the
+# step time (tools/gpu/host_profile.py).  The raw handle of the same stream, when this torch has the accessor:
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return _RAW_STREAM(_CUR_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -93,6 +93,10 @@ class GradBucket:
         self._early_work = []     # outstanding async collectives of this step
         self._side = None         # side stream the early exchange is queued on (GPU only)
         self.missing = set()      # layout indices without gradient at the last collect() (on every rank, once exchanged)
+        # the parameters' gradient views of `flat`, made once (two tensor operations per parameter: collect() runs twice per step
+        # over ~60 parameters, and an eager training step is host-bound)
+        self._gviews = [self.flat[o:o + k].view(p.shape) for p, o, k in layout]
+        self._gptrs = [v.data_ptr() for v in self._gviews]
         self.rebind(force=True)
 
     # ---- overlap of the exchange with the tail of backward -----------------------------------------------
@@ -192,28 +196,28 @@ class GradBucket:
     def collect(self):
         """Gather the gradients autograd produced into the flat bucket and re-bind `p.grad` to its views."""
         dst, src = [], []
-        for i, (p, o, k) in enumerate(self._layout):
+        views, ptrs, landed = self._gviews, self._gptrs, self._landed
+        for i, p in enumerate(self.params):
             g = p.grad
-            view = self.flat[o:o + k].view(p.shape)
             if g is None:
-                if i not in self._landed:
+                if i not in landed:
                     self.missing.add(i)                         # no gradient this step: the zeros of zero()
-                p.grad = view
-            elif g.data_ptr() != view.data_ptr():
-                if i in self._landed:                           # landed early, then another (un-hooked) accumulation
-                    view.add_(g)
+                p.grad = views[i]
+            elif g.data_ptr() != ptrs[i]:
+                if i in landed:                                 # landed early, then another (un-hooked) accumulation
+                    views[i].add_(g)
                 else:
-                    dst.append(view)
+                    dst.append(views[i])
                     src.append(g)
-                p.grad = view
+                p.grad = views[i]
         if dst:
             torch._foreach_copy_(dst, src)
 
     def rebind(self, force: bool = False):
         """Re-attach views (call if something replaced p.grad, e.g. zero_grad(set_to_none=True))."""
-        for p, o, k in self._layout:
-            if force or p.grad is None or p.grad.data_ptr() != self.flat[o:o + k].data_ptr():
-                p.grad = self.flat[o:o + k].view(p.shape)
+        for i, p in enumerate(self.params):
+            if force or p.grad is None or p.grad.data_ptr() != self._gptrs[i]:
+                p.grad = self._gviews[i]
 
     def allreduce_mean(self):
         self.collect()

@@ -220,6 +220,19 @@ def _freq_encode_torch(x, n_freqs=6, max_level=None):
 
 # ------------------------------------------------------------------------------------ the model
 IMPLICIT_OPERANDS = os.environ.get("MORPHEUS_IMPLICIT_OPERANDS", "1") != "0"
+_RAW_CAPTURING = getattr(torch._C, "_cuda_isCurrentStreamCapturing", None)
+_HAS_GPU = None
+
+
+def _capturing() -> bool:
+    """is the current stream being captured into a graph?  (torch.cuda.is_available() re-reads the environment on every call and
+    the step cache asks per model call: the answer to "is there a GPU" is taken once)"""
+    global _HAS_GPU
+    if _HAS_GPU is None:
+        _HAS_GPU = bool(torch.cuda.is_available())
+    if not _HAS_GPU or not torch.cuda.is_initialized():
+        return False
+    return bool(_RAW_CAPTURING()) if _RAW_CAPTURING is not None else torch.cuda.is_current_stream_capturing()
 
 
 class _StepCache:
@@ -392,7 +405,7 @@ class scene_representation(nn.Module):
         """-> the live _StepCache of this training forward (created if the last one has ended), or None when nothing may be kept"""
         if not (IMPLICIT_OPERANDS and self.training and torch.is_grad_enabled()):
             return None
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        if _capturing():
             return None           # operands prepared inside a capture belong to the graph; operands from outside would freeze in it
         ps = self._step_params
         if ps is None:

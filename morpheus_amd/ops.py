@@ -73,8 +73,23 @@ def _i32arr(a):
     by value -- a training step makes ~150 of these calls."""
     # one key form for every source kind: (length, values...) of Python ints -- a list [3, 1, 2, 3] and the array [1, 2, 3] must
     # not meet in one entry
-    if isinstance(a, (list, tuple)) and all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in a):
-        key = (len(a),) + tuple(int(v) for v in a)
+    if type(a) is tuple or type(a) is list:
+        # fast path: the tuple of the values themselves (hash-equal to the canonical key's tail for Python and numpy ints alike);
+        # the element types are checked once, when the entry is made
+        k2 = ("seq", tuple(a))
+        hit = _I32_CACHE.get(k2)
+        if hit is not None:
+            return hit
+        if all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in a):
+            key = (len(a),) + tuple(int(v) for v in a)
+            hit = _I32_CACHE.get(key)
+            if hit is None:
+                arr = np.ascontiguousarray(a, dtype=np.int32)
+                arr.setflags(write=False)
+                hit = _I32_CACHE[key] = (arr, arr.ctypes.data_as(ctypes.c_void_p))
+            _I32_CACHE[k2] = hit
+            return hit
+        key = None
     elif isinstance(a, np.ndarray) and a.dtype == np.int32 and a.ndim == 1 and a.size <= 64:
         key = (a.size,) + tuple(a.tolist())
     else:
