@@ -518,9 +518,12 @@ PIPE = {"f32": ("fp32 MFMA (v_mfma_f32_32x32x2_f32)", FP32_MFMA_PEAK_TFLOPS),
 # kernel symbols (rocprofv3 names, profiles/*_pmc_summary.csv) behind each timed C-ABI entry, per arithmetic mode
 SYMBOLS = {
     "mh_warp_fwd": {"f32": ["warp_fwd_kernel"], "b3": ["warp_fwd_b3_kernel<8, true>"]},
-    "mh_warp_bwd_data": {"f32": ["warp_bwd_kernel"], "b3": ["warp_bwd_b3_kernel<8>"]},
+    # (round 6: at cfg3's size backward-data does not park dPre4 -- <8, false> -- and the two layer-4 weight-gradient launches
+    #  regenerate it: wgrad_regen_b3_kernel)
+    "mh_warp_bwd_data": {"f32": ["warp_bwd_kernel"], "b3": ["warp_bwd_b3_kernel<8, false>"]},
     "mh_mlp_wgrad[warp]": {"f32": ["wgrad_kernel<4, false>", "wgrad_kernel<2, false>", "wgrad_reduce_kernel"],
-                           "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>", "wgrad_reduce_kernel"]},
+                           "b3": ["wgrad_regs_b3_kernel<4>", "wgrad_regen_b3_kernel", "wgrad_regs_b3_kernel<2>", "wgrad_kernel<4, true>",
+                                  "wgrad_reduce_kernel"]},
     "mh_field_fwd": {"f32": ["field_fwd_kernel"], "b3": ["field_fwd_b3_kernel"]},
     # (the b3 mode runs the bf16x3 form of the fused kernels, the f32 mode the fp32-MFMA form; ops.FIELD_BWD)
     "mh_field_bwd_fused": {"f32": ["field_fused_color_kernel<false>", "field_fused_sdf_kernel<true, false>"],
@@ -530,9 +533,12 @@ SYMBOLS = {
 # inputs in, results out); "parked" = what THIS design moves by construction (activations / pre-activation gradients parked
 # in HBM between the forward, backward-data and weight-gradient kernels, csrc/mlp_dev.h)
 IO_BYTES = {
-    "mh_warp_fwd": dict(algorithmic=12 + 20, parked=4 * (64 + 2 * 640) + 4 * 40 + 12 + 20),
-    "mh_warp_bwd_data": dict(algorithmic=12 + 20, parked=4 * 2 * 672 + 4 * 40 + 12 + 20),
-    "mh_mlp_wgrad[warp]": dict(algorithmic=12 + 20, parked=4 * (2 * 64 + 2 * 5 * 128 + 2 * (5 * 128 + 32))),
+    # round 6 (b3 at this size): H0's 24 pad rows and dPre5's 29 | 30 are not written or read, dPre4 (2 x 128 rows) is not parked
+    # (parked_f32: the fp32-MFMA kernels keep the round-5 tiles -- every row written, dPre4 parked; their weight gradients skip the pad rows)
+    "mh_warp_fwd": dict(algorithmic=12 + 20, parked=4 * (40 + 2 * 640) + 4 * 40 + 12 + 20, parked_f32=4 * (64 + 2 * 640) + 4 * 40 + 12 + 20),
+    "mh_warp_bwd_data": dict(algorithmic=12 + 20, parked=4 * (2 * 4 * 128 + 5) + 4 * 40 + 12 + 20, parked_f32=4 * 2 * 672 + 4 * 40 + 12 + 20),
+    "mh_mlp_wgrad[warp]": dict(algorithmic=12 + 20, parked=4 * (2 * 40 + 2 * 5 * 128 + 2 * 4 * 128 + 5) + 2 * 8 + 20,
+                               parked_f32=4 * (2 * 40 + 2 * 5 * 128 + 2 * 5 * 128 + 5)),
     "mh_field_fwd": dict(algorithmic=12 + 2 * 128 + 8 + 4 + 4 + 12, parked=4 * (96 + 64 * 5) + 4 * 8 + 12 + 2 * 128 + 8 + 20),
     "mh_field_bwd_fused": dict(algorithmic=12 + 20 + 2 * 128 + 8 + 12, parked=4 * (96 + 64 * 5) + 4 * 8 + 64 + 20 + 2 * 128 + 8 + 12),
 }
@@ -581,7 +587,7 @@ def _kernel_roofline(name, e, flops_per_call, mode, M, workload, full_size):
     alg_tflops = per_step_flops / secs / 1e12
     peak = unit_peak / prod
     io = IO_BYTES[name]
-    parked, algb = io["parked"] * M, io["algorithmic"] * M
+    parked, algb = (io.get("parked_f32", io["parked"]) if kmode == "f32" else io["parked"]) * M, io["algorithmic"] * M
     hbm_gbs = parked / secs / 1e9
     traffic, src, complete = (pmc_step_bytes(SYMBOLS[name][mode], mode)
                               if (full_size and workload == "cfg3") else (None, None, False))

@@ -16,6 +16,7 @@
 //   * both tables (3.2 MB each) are L2-resident per XCD; gathers are 8-byte float2 loads.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 // explicit fmaf where the reference kernel (nvcc -fmad=true) fuses, nothing else contracted:
 // the CPU oracle does the same, so features agree to the last bit of the interpolation.
@@ -882,11 +883,13 @@ extern "C" int32_t mh_grid_bin_bricks(void) { return NBRK; }
 extern "C" int32_t mh_grid_bin_index_ints(void) { return 2 * NBRK + 8; }  // brick_start | work_start | scratch
 
 // calls of at least this many points take the staged forms (grid_fwd_brick_kernel, the d/dx forms of grid_bwd_brick_kernel) and
-// the larger work items; a process-wide tuning knob
-static int64_t g_stage_min_points = BRK_STAGE_MIN_POINTS;
+// the larger work items; a process-wide tuning knob.  It only chooses between forms that give the same feature values and d/dx bits
+// (table gradients: equal to the fixed-point resolution); an atomic, so that a thread setting it while others launch is a data race in
+// no sense of the word
+static std::atomic<int64_t> g_stage_min_points{BRK_STAGE_MIN_POINTS};
 extern "C" int64_t mh_grid_stage_min_points(int64_t set) {
-    if (set >= 0) g_stage_min_points = set;
-    return g_stage_min_points;
+    if (set >= 0) g_stage_min_points.store(set, std::memory_order_relaxed);
+    return g_stage_min_points.load(std::memory_order_relaxed);
 }
 
 extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_t *workspace, int32_t *perm,
@@ -905,7 +908,7 @@ extern "C" int mh_grid_bin_points(const float *x, int64_t M, float bound, int32_
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((NBRK + 1 + 255) / 256), dim3(256), 0, mh_stream(stream), block_hist,
                        (int)G, brick_cnt);
     hipLaunchKernelGGL(bin_rowscan_kernel, dim3(1), dim3(1024), 0, mh_stream(stream), brick_cnt, brick_start,
-                       M >= g_stage_min_points ? BRK_CHUNK_LARGE : BRK_CHUNK_SMALL);
+                       M >= g_stage_min_points.load(std::memory_order_relaxed) ? BRK_CHUNK_LARGE : BRK_CHUNK_SMALL);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)G), dim3(256), 0, mh_stream(stream), x, M, chunk, bound,
                        2.0f * bound, block_hist, brick_start, perm);
     MH_CHECK_LAUNCH();
@@ -973,7 +976,7 @@ extern "C" int mh_grid_encode_bwd_binned(const float *grad, const float *x, cons
     hipLaunchKernelGGL((grid_bwd_brick_kernel<DXMODE, STG>), dim3(work_items), dim3(BRK_THREADS), 0, mh_stream(stream),       \
                        reinterpret_cast<const float2 *>(grad), x, reinterpret_cast<const float2 *>(emb), meta, bm, perm,     \
                        brick_start, grad_emb, grad_x, (int)L, (int)n_levels, bound, 2.0f * bound, gmax)
-    const bool staged = BRK_STAGE && M >= g_stage_min_points;
+    const bool staged = BRK_STAGE && M >= g_stage_min_points.load(std::memory_order_relaxed);
     if (grad_x && accumulate_dx) {
         // grad_x already holds a gradient of the same points (the field nets' d/dx): each visited point adds to its own row
         if (staged) BRK_LAUNCH(2, true); else BRK_LAUNCH(2, false);

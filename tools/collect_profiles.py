@@ -133,12 +133,41 @@ def main():
                       ("bench_grid.log", "micro_hashgrid.txt"), ("gpu_tests.log", "gpu_tests.txt"),
                       ("precision_report.jsonl", "precision_report.jsonl"),
                       ("timeline_train_real_graph.txt", "timeline_train_real_hip_graph.txt"),
-                      ("graph_memset_probe.txt", "graph_memset_probe.txt")):
+                      ("graph_memset_probe.txt", "graph_memset_probe.txt"), ("glue_ab.log", "ab_step_cache.txt"),
+                      ("host_profile.log", "host_profile_train_real.txt")):
         src = os.path.join(OUT, log)
         if fresh(src):
             shutil.copy(src, os.path.join(PROF, f"{tag}_{name}"))
             print("copied", name)
     print("pmc summary", pmc_summary(tag), [pmc_summary(tag, "_" + m) for m in ("f32",)])
+    parked = hbm_bytes_of("_parked")
+    shipped = hbm_bytes_of("")
+    if parked and shipped:        # the step's HBM bytes with dPre4 parked (MORPHEUS_REGEN_DPRE4=0) against the shipped form, same box
+        with open(os.path.join(PROF, f"{tag}_pmc_hbm_bytes_per_step.txt"), "w") as fo:
+            fo.write("# HBM bytes per cfg3 step (b3; rocprofv3 --pmc FETCH_SIZE x 2 (gfx950) / WRITE_SIZE, KB units, own passes; 3 steps per run)\n")
+            fo.write("# kernel                                  shipped: read MB  write MB      dPre4 parked (MORPHEUS_REGEN_DPRE4=0): read MB  write MB\n")
+            for k in sorted(set(parked) | set(shipped), key=lambda k: -(sum(shipped.get(k, (0, 0))) + sum(parked.get(k, (0, 0))))):
+                a, b = shipped.get(k, (0.0, 0.0)), parked.get(k, (0.0, 0.0))
+                if max(a + b) < 5.0:
+                    continue
+                fo.write(f"{k[:40]:40s} {a[0]:16.1f} {a[1]:9.1f} {b[0]:46.1f} {b[1]:9.1f}\n")
+            ts, tp = [sum(v[i] for v in shipped.values()) for i in (0, 1)], [sum(v[i] for v in parked.values()) for i in (0, 1)]
+            fo.write(f"{'TOTAL (every kernel of the step)':40s} {ts[0]:16.1f} {ts[1]:9.1f} {tp[0]:46.1f} {tp[1]:9.1f}\n")
+            fo.write(f"# per step: shipped {sum(ts) / 1024:.2f} GB, dPre4 parked {sum(tp) / 1024:.2f} GB\n")
+        print("hbm bytes per step: shipped %.2f GB, parked %.2f GB" % (sum(ts) / 1024, sum(tp) / 1024))
+
+
+def hbm_bytes_of(suffix, steps_in_run=3):
+    """kernel -> (read MB, write MB) per STEP from gpurun_out/pmc_fetch<suffix>, pmc_write<suffix>"""
+    out = defaultdict(lambda: [0.0, 0.0])
+    for d, col, idx, mul in (("pmc_fetch", "FETCH_SIZE", 0, 2.0), ("pmc_write", "WRITE_SIZE", 1, 1.0)):
+        f = latest(f"{d}{suffix}/*/*_counter_collection.csv")
+        if not f:
+            return None
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == col:
+                out[short(row["Kernel_Name"])][idx] += mul * float(row["Counter_Value"]) / 1024.0 / steps_in_run
+    return {k: tuple(v) for k, v in out.items()}
 
 
 if __name__ == "__main__":
