@@ -42,18 +42,28 @@ class KernelTimer:
         self._used += 1
         return e
 
+    @staticmethod
+    def _stream():
+        """the current stream as a torch Stream object, one object per raw handle (Event.record() without a stream argument
+        resolves torch.cuda.current_stream() through three Python layers: 5.4 us against 1.5 -- twice per timed call)"""
+        raw = stream()
+        s = _STREAM_OBJECTS.get(raw)
+        if s is None:
+            s = _STREAM_OBJECTS[raw] = torch.cuda.current_stream()
+        return s
+
     def start(self):
         if not self.enabled:
             return None
         e = self._event()
-        e.record()
+        e.record(self._stream())
         return e
 
     def stop(self, name: str, e0):
         if e0 is None:
             return
         e1 = self._event()
-        e1.record()
+        e1.record(self._stream())
         self.records.setdefault(name, []).append((e0, e1))
 
     def summary(self):
@@ -61,6 +71,7 @@ class KernelTimer:
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.records.items()}
 
 
+_STREAM_OBJECTS: dict = {}
 TIMER = KernelTimer()
 
 
