@@ -19,12 +19,16 @@ def main():
     ap.add_argument("--glue", default="fused")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--timers", action="store_true", help="with the per-kernel HIP-event timers on (bench.py's kernel tables)")
     a = ap.parse_args()
     import bench
     args = bench.parse_args(["--workload", "train_real", "--glue", a.glue, "--no-cpu-baseline", "--no-kernel-timers"])
     args.rays = args.rays or 2048
     wl = bench.build_train_real(args, 0, 1, torch.device("cuda", 0))
     step = wl["step"]
+    if a.timers:
+        from morpheus_amd import ops
+        ops.TIMER.reset(True)
     for _ in range(8):
         step()
     torch.cuda.synchronize()
