@@ -637,6 +637,57 @@ def gen_round4():
 
 
 # ----------------------------------------------------------------------------- round-5 fixture (round5.npz)
+def _virtual_step_in_double(g, hw, S, tag):
+    """One virtual-view TRAINING step of the imported reference, run in fp32 AND in float64 on the same inputs with its backward
+    (hw x hw rays x S samples; lambertian through finite-difference normals, orientation loss, normal_smooth_3d with its draws
+    injected, code_reg; normal_smoothness off: its angle draw depends on a boolean index), so that the HIP path's gradients can be held
+    to "within k x the reference's own fp32 error" instead of a fitted 1-3e-2.  Writes `tag|f32|...` and `tag|f64|...` into g."""
+    import morpheus as ref_morpheus
+    from bench_support import trainstep
+    o, d = synth.camera_rays(hw, hw, synth.look_at_pose(70.0, 35.0, 1.5))
+    N = o.shape[0]
+    o, d = o[None], d[None]
+    t = torch.full((1, N, 1), 140 / 200)
+    rid = torch.full((1, N, 1), 140, dtype=torch.int64)
+    smp = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
+    light = ofield.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
+    bg = torch.tensor([0.2, 0.5, 0.7])
+    for prec in ("f32", "f64"):
+        if prec == "f32":
+            m, cfg = build_ref_model(synth.make_state("b"), 0.75)
+        else:
+            m, cfg = build_ref_model_f64(synth.make_state("b"), 0.75)
+            m.encoder.differentiable = m.encoder_c.differentiable = True
+        m.train()
+        cfg["train"]["normal_smoothness"] = 0.0
+        cast = (lambda v: v.double()) if prec == "f64" else (lambda v: v)
+        sampler = _PresetSampler()
+        sampler.samples = (smp[0], cast(smp[1]), cast(smp[2]))
+        fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg, dataset=types.SimpleNamespace(num_frames=200),
+                                     global_step=1000)
+        fake.get_ortho_normal_dir = types.MethodType(ref_morpheus.MorpheuS.get_ortho_normal_dir, fake)
+        with DrawInjector() as inj:
+            res = ref_morpheus.MorpheuS.render_rays(fake, cast(o), cast(d), cast(t), rid, hw, hw, bg_color=cast(bg), ambient_ratio=0.55,
+                                                    light_d=cast(light), shading="lambertian", real_view=False, cano=False)
+            n_draws = inj.k
+        pred_rgb, _, _, pred_normal, _ = ref_morpheus.MorpheuS.get_pred_from_outputs(fake, res, 1, hw, hw)
+        G = trainstep.InjectedGuidance(hw, hw, "cpu", scale=5e-3)
+        l_guid = (pred_rgb * cast(G.grad)).sum()
+        l_reg = ref_morpheus.MorpheuS.get_regularization_loss(fake, res, pred_normal, cano=False)
+        total = l_guid + l_reg
+        m.zero_grad()
+        total.backward()
+        key = tag + "|" + prec
+        g[key + "|n_draws"] = np.int32(n_draws)
+        for lk in ("loss_orient", "loss_normal_perturb", "loss_code"):
+            g[key + "|" + lk] = np.float64(float(res[lk]))
+        g[key + "|loss"] = np.float64(float(total))
+        g[key + "|image"] = res["image"].detach().double().numpy()
+        for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
+            g[key + "|grad|" + kk] = v if not isinstance(v, np.ndarray) else v.astype(np.float64) if prec == "f64" else v
+        print("virtual step in double:", tag, prec, "loss", float(total), "draws", n_draws)
+
+
 def gen_round5():
     """cfg4's STEP COMPOSITION (morpheus.py:1390-1424): one virtual-view backward and one real-view backward feeding torch.optim.Adam
     over model.get_params_all(lr) (:154-155), learning rates set by the reference's own update_learning_rate (:472-503) and, in the
@@ -774,55 +825,18 @@ def gen_round5():
             g[variant + "|delta|" + kk] = v
         moved = sum(int((v != 0).any()) for v in delta.values())
         print("round5:", variant, "virtual", float(lv), "real", float(lr_), "tensors moved", moved, "of", len(delta))
-    # ---- a virtual-view TRAINING step small enough to run in DOUBLE with its backward (24 x 24 rays x 24 samples; lambertian through
-    #      finite-difference normals, orientation loss, normal_smooth_3d with its draws injected, code_reg; normal_smoothness off: its
-    #      angle draw depends on a boolean index): the reference's fp32 result AND its float64 result on the same inputs, so that the
-    #      HIP path's gradients can be held to "within k x the reference's own fp32 error" instead of a fitted 1-3e-2
-    hw, S = 24, 24
-    o, d = synth.camera_rays(hw, hw, synth.look_at_pose(70.0, 35.0, 1.5))
-    N = o.shape[0]
-    o, d = o[None], d[None]
-    t = torch.full((1, N, 1), 140 / 200)
-    rid = torch.full((1, N, 1), 140, dtype=torch.int64)
-    smp = ofield.uniform_samples(o[0], d[0], synth.ray_jitter(N), S, 1.01)
-    light = ofield.safe_normalize(o[0] + torch.tensor([0.3, -0.2, 0.5]))
-    bg = torch.tensor([0.2, 0.5, 0.7])
-    for prec in ("f32", "f64"):
-        if prec == "f32":
-            m, cfg = build_ref_model(synth.make_state("b"), 0.75)
-        else:
-            m, cfg = build_ref_model_f64(synth.make_state("b"), 0.75)
-            m.encoder.differentiable = m.encoder_c.differentiable = True
-        m.train()
-        cfg["train"]["normal_smoothness"] = 0.0
-        cast = (lambda v: v.double()) if prec == "f64" else (lambda v: v)
-        sampler = _PresetSampler()
-        sampler.samples = (smp[0], cast(smp[1]), cast(smp[2]))
-        fake = types.SimpleNamespace(model=m, occupancy_grid=sampler, config=cfg, dataset=types.SimpleNamespace(num_frames=200),
-                                     global_step=1000)
-        fake.get_ortho_normal_dir = types.MethodType(ref_morpheus.MorpheuS.get_ortho_normal_dir, fake)
-        with DrawInjector() as inj:
-            res = ref_morpheus.MorpheuS.render_rays(fake, cast(o), cast(d), cast(t), rid, hw, hw, bg_color=cast(bg), ambient_ratio=0.55,
-                                                    light_d=cast(light), shading="lambertian", real_view=False, cano=False)
-            n_draws = inj.k
-        pred_rgb, _, _, pred_normal, _ = ref_morpheus.MorpheuS.get_pred_from_outputs(fake, res, 1, hw, hw)
-        G = trainstep.InjectedGuidance(hw, hw, "cpu", scale=5e-3)
-        l_guid = (pred_rgb * cast(G.grad)).sum()
-        l_reg = ref_morpheus.MorpheuS.get_regularization_loss(fake, res, pred_normal, cano=False)
-        total = l_guid + l_reg
-        m.zero_grad()
-        total.backward()
-        key = "virt24|" + prec
-        g[key + "|n_draws"] = np.int32(n_draws)
-        for lk in ("loss_orient", "loss_normal_perturb", "loss_code"):
-            g[key + "|" + lk] = np.float64(float(res[lk]))
-        g[key + "|loss"] = np.float64(float(total))
-        g[key + "|image"] = res["image"].detach().double().numpy()
-        for kk, v in grad_digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}).items():
-            g[key + "|grad|" + kk] = v if not isinstance(v, np.ndarray) else v.astype(np.float64) if prec == "f64" else v
-        print("round5: virt24", prec, "loss", float(total), "draws", n_draws)
+    _virtual_step_in_double(g, 24, 24, "virt24")
     np.savez_compressed(os.path.join(OUT, "round5.npz"), **g)
     print("round5.npz", len(g), "arrays")
+
+
+def gen_round6():
+    """Round 6: the double-precision yardstick of the virtual-view step's gradients at the size of the 72 x 72 fixture test (round 5
+    had it at 24 x 24 only; VERDICT r5 "nothing of that kind exists at 72^2"): 5 184 rays x 32 samples, fp32 and float64."""
+    g = {}
+    _virtual_step_in_double(g, 72, 32, "virt72d")
+    np.savez_compressed(os.path.join(OUT, "round6.npz"), **g)
+    print("round6.npz", len(g), "arrays")
 
 
 def main():
@@ -839,6 +853,9 @@ def main():
     if "--round5-only" in sys.argv:        # round 5: cfg4's step composition (two backwards -> Adam), the others are unchanged
         gen_round5()
         return
+    if "--round6-only" in sys.argv:        # round 6: the 72 x 72 virtual-view step in double (the others are unchanged)
+        gen_round6()
+        return
     if "--extras-only" not in sys.argv:
         gen_operators()
         gen_model()
@@ -847,6 +864,7 @@ def main():
     gen_variants()
     gen_round4()
     gen_round5()
+    gen_round6()
 
 
 if __name__ == "__main__":
