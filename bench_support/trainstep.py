@@ -625,6 +625,10 @@ class GraphedRealViewStep:
         lazy one-time setup -- kernel attributes, cached constants, index maps -- must not happen inside the capture)"""
         if self.grid.overflow is None:
             self.grid.overflow = torch.zeros((), dtype=torch.int32, device=self.index.device)
+        # a capture in the middle of a run: autograd graphs of earlier eager steps that nothing references any more must be gone
+        # (their AccumulateGrad nodes would take the capture's gradients on the eager stream), collected -- not waiting for a cycle sweep
+        import gc
+        gc.collect()
         torch.cuda.synchronize()
         keep = self.grid.overflow.clone()
         side = torch.cuda.Stream()

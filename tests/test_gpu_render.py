@@ -977,16 +977,17 @@ def test_in_place_gradient_sums_under_other_autograd_entry_points():
         ops.ACCUMULATE_IN_PLACE = saved
 
 
-def virt24_errors():
-    """-> rows (tensor, |grad|, reference-fp32 error, HIP error), both as max |sample - f64 sample| / max |f64 sample| over the 64
-    strided samples of the fixture's digests, plus (loss_f64, loss_ref32, loss_hip).  The 24 x 24 virtual-view training step of
-    round5.npz: the reference ran it in fp32 AND in double (oracle/make_golden.py:gen_round5)."""
+def virt24_errors(hw=24, S=24, fixture="round5.npz", tag="virt24"):
+    """-> rows (tensor, |grad|, reference-fp32 error, HIP error, HIP error without its worst sample), the errors as max |sample - f64
+    sample| / max |f64 sample| over the 64 strided samples of the fixture's digests, plus (loss_f64, loss_ref32, loss_hip).  The 24 x 24 virtual-view training step of
+    round5.npz / the 72 x 72 x 32-sample one of round6.npz: the reference ran them in fp32 AND in double
+    (oracle/make_golden.py:_virtual_step_in_double)."""
     import numpy as np
     from morpheus_amd import harness
     from bench_support import trainstep
     from tests.util import DrawInjector
-    g = load_golden("round5.npz")
-    hw, S, frame = 24, 24, 140
+    g = load_golden(fixture)
+    frame = 140
     o, d = synth.camera_rays(hw, hw, synth.look_at_pose(70.0, 35.0, 1.5))
     N = o.shape[0]
     smp = of.uniform_samples(o, d, synth.ray_jitter(N), S, 1.01)
@@ -1001,22 +1002,23 @@ def virt24_errors():
     model.zero_grad()
     with DrawInjector() as inj:
         loss = ts(data=data, shading="lambertian", ambient_ratio=0.55, bg_color=torch.tensor([0.2, 0.5, 0.7], device=DEV), light_d=light)
-        assert inj.k == int(g["virt24|f32|n_draws"]) == int(g["virt24|f64|n_draws"])
+        assert inj.k == int(g[tag + "|f32|n_draws"]) == int(g[tag + "|f64|n_draws"])
     loss.backward()
     rows = []
     for k, p in model.named_parameters():
-        k64 = "virt24|f64|grad|" + k
+        k64 = tag + "|f64|grad|" + k
         if p.grad is None or k64 + "|samples" not in g:
             continue
         s64 = torch.from_numpy(g[k64 + "|samples"]).double()
-        s32 = torch.from_numpy(g["virt24|f32|grad|" + k + "|samples"]).double()
+        s32 = torch.from_numpy(g[tag + "|f32|grad|" + k + "|samples"]).double()
         gr = p.grad.detach().reshape(-1).double().cpu()
         idx = torch.linspace(0, gr.numel() - 1, min(64, gr.numel())).long()
         scale = float(s64.abs().max())
         if scale == 0.0:
             continue
-        rows.append((k, float(g[k64 + "|norm"]), float((s32 - s64).abs().max()) / scale, float((gr[idx] - s64).abs().max()) / scale))
-    return rows, (float(g["virt24|f64|loss"]), float(g["virt24|f32|loss"]), float(loss.detach()))
+        e_hip = torch.sort((gr[idx] - s64).abs(), descending=True).values / scale
+        rows.append((k, float(g[k64 + "|norm"]), float((s32 - s64).abs().max()) / scale, float(e_hip[0]), float(e_hip[min(1, len(e_hip) - 1)])))
+    return rows, (float(g[tag + "|f64|loss"]), float(g[tag + "|f32|loss"]), float(loss.detach()))
 
 
 def test_virtual_view_gradients_against_the_reference_in_double():
@@ -1029,12 +1031,37 @@ def test_virtual_view_gradients_against_the_reference_in_double():
     assert len(rows) >= 45, len(rows)
     assert abs(lhip - l64) <= max(3 * abs(l32 - l64), 1e-5 * abs(l64)), (l64, l32, lhip)
     worst = []
-    for k, norm, e_ref, e_hip in rows:
+    for k, norm, e_ref, e_hip, _ in rows:
         if e_hip > max(3 * e_ref, 2e-4):
             worst.append((k, e_ref, e_hip))
     assert not worst, worst
     # and the derived allowance is tight: the median of the reference's own error over the tensors is 1e-3 (worst 1.3e-2)
     assert sorted(r[2] for r in rows)[len(rows) // 2] < 2e-3
+
+
+def test_virtual_view_gradients_72_against_the_reference_in_double():
+    """The same derived gate at the size of the 72 x 72 fixture test ("nothing of that kind exists at 72^2"): all 5 184 rays
+    of the novel view x 32 samples through lambertian shading on finite-difference normals, orientation loss, normal_smooth_3d,
+    code_reg and the injected guidance gradient; the reference's fp32 and float64 runs are tests/golden/round6.npz
+    (oracle/make_golden.py:gen_round6).  HIP <= 3 x the reference's own fp32 error per tensor, or 2e-4 of the tensor's largest sample."""
+    rows, (l64, l32, lhip) = virt24_errors(72, 32, "round6.npz", "virt72d")
+    assert len(rows) >= 45, len(rows)
+    assert abs(lhip - l64) <= max(3 * abs(l32 - l64), 1e-5 * abs(l64)), (l64, l32, lhip)
+    # A hash TABLE gradient is a sum over the points whose cell touches the row: a tap point whose canonical position differs by an ulp
+    # between two fp32 implementations can sit in the neighbouring cell of some level, and its contribution then lands on other rows --
+    # a discrete event, not round-off.  Measured (tools/gpu/virt_flip_diag.py, profiles/r06_virt72_gradients_vs_f64.txt): b3 against
+    # f32 on this step, 190 811 touched rows: median row difference 9.5e-8 of the largest entry, 104 rows beyond 1e-4 (up to 1.7e-3),
+    # one of them among the fixture's 64 strided samples.  So for the two tables ONE sample may be such an event (bounded at 2e-3);
+    # every other sample, and every other tensor, is held to the derived allowance.
+    worst = []
+    for k, norm, e_ref, e_hip, e_hip_2nd in rows:
+        allow = max(3 * e_ref, 2e-4)
+        if k.endswith("embeddings"):
+            if e_hip > 2e-3 or e_hip_2nd > allow:
+                worst.append((k, e_ref, e_hip, e_hip_2nd))
+        elif e_hip > allow:
+            worst.append((k, e_ref, e_hip))
+    assert not worst, worst
 
 
 def test_two_frames_vs_reference_golden():

@@ -194,3 +194,22 @@ def test_round5_fixture_facts():
             if np.abs(s64).max() > 0:
                 errs.append(float(np.abs(s32 - s64).max() / np.abs(s64).max()))
     assert len(errs) >= 45 and 5e-3 < max(errs) < 3e-2 and 2e-4 < sorted(errs)[len(errs) // 2] < 3e-3, (max(errs), sorted(errs)[len(errs) // 2])
+
+
+def test_round6_fixture_facts():
+    """tests/golden/round6.npz (oracle/make_golden.py:gen_round6): the 72 x 72 x 32-sample virtual-view training step that the reference
+    ran in fp32 AND in float64 -- the yardstick of test_virtual_view_gradients_72_against_the_reference_in_double.  On the CPU: both
+    precisions took the same number of injected draws, the float64 arrays are float64, the two losses agree to fp32 round-off, and the
+    reference's own fp32 gradients are up to 5.5e-3 (median 7e-4) off its double run on the 57 parameter tensors with a gradient."""
+    g = load_golden("round6.npz")
+    assert int(g["virt72d|f32|n_draws"]) == int(g["virt72d|f64|n_draws"]) >= 1
+    assert g["virt72d|f64|image"].dtype == np.float64 and g["virt72d|f64|image"].reshape(-1, 3).shape[0] == 72 * 72
+    l64, l32 = float(g["virt72d|f64|loss"]), float(g["virt72d|f32|loss"])
+    assert abs(l32 - l64) < 1e-5 * abs(l64), (l32, l64)
+    errs = []
+    for k in g.files:
+        if k.startswith("virt72d|f64|grad|") and k.endswith("|samples"):
+            s64, s32 = g[k].astype(np.float64), g[k.replace("|f64|", "|f32|")].astype(np.float64)
+            if np.abs(s64).max() > 0:
+                errs.append(float(np.abs(s32 - s64).max() / np.abs(s64).max()))
+    assert len(errs) >= 50 and 1e-3 < max(errs) < 2e-2 and 1e-4 < sorted(errs)[len(errs) // 2] < 3e-3, (max(errs), sorted(errs)[len(errs) // 2])
