@@ -42,4 +42,5 @@ def make_renderer(model, n_samples: int, jitter=None, config: Optional[dict] = N
 def bench_loss(res, timg, tdep):
     """loss = MSE(image) + MSE(depth) against fixed targets: gradients reach every
     parameter group on the path, both hash tables included."""
-    return ((res["image"][0] - timg) ** 2).mean() + ((res["depth"][0] - tdep) ** 2).mean()
+    mse = torch.nn.functional.mse_loss           # the reference's own loss operator (morpheus.py:954, 980): one launch each way
+    return mse(res["image"][0], timg) + mse(res["depth"][0], tdep)

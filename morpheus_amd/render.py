@@ -256,6 +256,13 @@ class HotPathRenderer:
                 bg_color = model.background(rays_d, rays_t)
             else:
                 bg_color = 1
+        if isinstance(bg_color, (int, float)) and rgb_acc.is_cuda:
+            # a constant background (the reference's white, `bg_color = 1`): one cached [N, 3] constant, the same blend launch
+            n_rays_ = rgb_acc.shape[0]
+            bg_color = self._const(("bg", float(bg_color), n_rays_), lambda: torch.full((n_rays_, 3), float(bg_color)), rgb_acc.device)
+        elif (torch.is_tensor(bg_color) and bg_color.is_cuda and not bg_color.requires_grad and bg_color.numel() == 3
+              and bg_color.shape != rgb_acc.shape):
+            bg_color = bg_color.reshape(1, 3).to(rgb_acc.dtype).expand(rgb_acc.shape[0], 3).contiguous()     # one colour for every ray
         if torch.is_tensor(bg_color) and bg_color.shape == rgb_acc.shape and bg_color.is_cuda:
             image = ops.bg_blend(rgb_acc, opacity, bg_color).view(*prefix, 3)       # the same three rounded operations, one launch
         else:
