@@ -512,3 +512,63 @@ def test_nerfacc_check_tool_says_what_it_needs():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_against_nerfacc.py")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "nerfacc is not installed" in r.stderr and "Traceback" not in r.stderr
+
+
+def test_graph_task_id_semantics_the_in_place_sums_rely_on():
+    """ops._QueryAccumulator keys its running gradient sums on the PRIVATE torch._C._current_graph_task_id ("a torch
+    upgrade can change its semantics silently; the fallback triggers only when the symbol is absent").  This pins what the code
+    relies on, on the CPU, so that a changed torch fails HERE and not as wrong gradients: -1 outside a backward pass; one id for every
+    node of one pass; a different id for the next pass; another one again for a reentrant (checkpoint-style) pass nested in it; the
+    outer id back afterwards; and the same under torch.autograd.grad."""
+    import torch
+    from morpheus_amd import ops
+    tid = getattr(torch._C, "_current_graph_task_id", None)
+    if tid is None:                                  # then the per-query form must be the one in use
+        assert ops.ACCUMULATE_IN_PLACE is False
+        return
+    assert tid() == -1
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, tag):
+            ctx.tag = tag
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append((ctx.tag, tid()))
+            return g, None
+
+    class Nested(torch.autograd.Function):           # a backward that runs ANOTHER backward inside itself (reentrant checkpointing)
+        @staticmethod
+        def forward(ctx, x):
+            ctx.x = x.detach()
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(("outer-before", tid()))
+            with torch.enable_grad():
+                xi = ctx.x.clone().requires_grad_(True)
+                (Probe.apply(xi, "inner") * 2.0).sum().backward()
+            seen.append(("outer-after", tid()))
+            return g * 2.0
+
+    x = torch.ones(3, requires_grad=True)
+    (Probe.apply(x, "a") + Probe.apply(x, "b")).sum().backward()
+    (Probe.apply(x, "c")).sum().backward()
+    ids = dict(seen)
+    assert ids["a"] == ids["b"] >= 0 and ids["c"] >= 0 and ids["c"] != ids["a"], seen
+    seen.clear()
+    (Nested.apply(Probe.apply(x, "tail")) + Probe.apply(x, "side")).sum().backward()
+    ids = {}
+    for k, v in seen:
+        ids.setdefault(k, v)
+    assert ids["outer-before"] == ids["outer-after"] == ids["tail"] == ids["side"] >= 0, seen
+    assert ids["inner"] >= 0 and ids["inner"] != ids["tail"], seen
+    seen.clear()
+    torch.autograd.grad((Probe.apply(x, "g1") + Probe.apply(x, "g2")).sum(), x)
+    ids = dict(seen)
+    assert ids["g1"] == ids["g2"] >= 0, seen
+    assert tid() == -1

@@ -126,6 +126,7 @@ def main():
             print("parity", len(lines), "records")
     for log, name in (("phase_trace_field_bwd.log", "phase_trace_field_bwd.txt"),
                       ("census_fused.log", "launch_census_train_real.txt"), ("census_ref.log", "launch_census_train_real_reference_glue.txt"),
+                      ("census_cfg3.log", "launch_census_cfg3.txt"),
                       ("hbm_rates.log", "micro_hbm_rates.txt"), ("mfma_power.log", "micro_mfma_power.txt"),
                       ("mfma_bf16_rate.log", "micro_mfma_bf16_rate.txt"), ("hbm_read.log", "micro_hbm_read.txt"),
                       ("mfma_valu_gap.log", "micro_mfma_valu_gap.txt"), ("phase_trace_b3.log", "phase_trace_warp_fwd_pair.txt"),

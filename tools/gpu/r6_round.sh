@@ -41,6 +41,7 @@ cd "$REPO"
 if [ -z "$R6_LIGHT" ]; then
   timeout 200 python tools/gpu/launch_census.py --top 60 2>&1 | grep -v "amdgpu\|Anomaly\|detect_anomaly" > gpurun_out/census_fused.log
   timeout 200 python tools/gpu/launch_census.py --glue reference --top 60 2>&1 | grep -v "amdgpu\|Anomaly\|detect_anomaly" > gpurun_out/census_ref.log
+  timeout 200 python tools/gpu/launch_census.py --cfg3 --top 60 2>&1 | grep -v "amdgpu\|Anomaly\|detect_anomaly" > gpurun_out/census_cfg3.log
   timeout 200 python tools/gpu/host_profile.py --top 25 2>&1 | grep -v amdgpu > gpurun_out/host_profile.log
   timeout 300 python tools/bench_grid.py 2>&1 | grep -v amdgpu > gpurun_out/bench_grid.log
 fi
