@@ -411,9 +411,7 @@ __global__ __launch_bounds__(FIELD_THREADS, 1) void field_fwd_kernel(const float
     bin0[36] = topo ? topo[pc * 2 + h] : 0.f;
     bin0[37] = bin0[38] = bin0[39] = 0.f;
     if (tile) {
-        store_kk_rows<40>(tile, bin0, pt, h);
-#pragma unroll
-        for (int k = 40; k < 48; k++) tile[(2 * k + h) * TILE + pt] = 0.f;  // pad rows 80..95
+        store_kk_rows<40>(tile, bin0, pt, h);      // rows 80..95 (padding of the 96-row k extent) are neither written nor read
     }
     const f32x4 *wp = lds_res;
     f32x16 acc[2];
@@ -1130,7 +1128,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 1) void field_fused_sdf_kernel(
             RowSl Bs[3];
             row_load_async(B[0], atile, 0 + i, h);
             row_load_async(B[1], atile, 32 + i, h);
-            row_load_async(B[2], atile, 64 + i, h);
+            row_load_async(B[2], atile, 64 + min(i, 15), h);     // rows 80..95 are unwritten padding: their lanes take row 79 (k-step 39: zeros)
             scr_put<2>(scr, dbin, pt, h);
             // d(inputs) = W0^T dP0: tile0 = enc kk 0..15, tile1 = enc kk 16..19 + topo at r=4, tile2 = hash (16h + r)
             f32x16 e[3];

