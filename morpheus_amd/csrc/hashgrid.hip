@@ -666,7 +666,6 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
     float to_fx, from_fx;
     fx_scales(*gmax_bits, to_fx, from_fx);
     const int l = threadIdx.x & 15, sub = threadIdx.x >> 4;
-    const int bxyz[3] = {brick % BRK, (brick / BRK) % BRK, brick / (BRK * BRK)};
     // this lane's level
     const bool lev_on = l < n_levels;
     const BrickLevel lv = brk_level(meta, bm, emb, l, brick);
@@ -676,6 +675,16 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
     const int lo[3] = {lv.lo[0], lv.lo[1], lv.lo[2]};
     const float2 *tab = lv.tab;
     if (staged && lev_on) brk_stage_rows<W, 2>(lv, sub, acc);
+    // per-level parameters of the flush (below), from the sixteen lanes that hold one level each: the flush walks the brick's 4558
+    // vertex slots in ONE flat loop, every lane looking its slot's level up here
+    static_assert(MH_MAX_LEVELS >= 16, "the brick kernels run on 16-level grids (L == 16 is checked by the launchers)");
+    __shared__ int flush_par[16][16];
+    if (threadIdx.x < 16) {
+        int *fp = flush_par[l];
+        fp[0] = nn, fp[1] = (65536 + nn - 1) / nn, fp[2] = base, fp[3] = lo[0], fp[4] = lo[1], fp[5] = lo[2];
+        fp[6] = (int)(res - 1), fp[7] = (int)lv.my, fp[8] = (int)lv.mz, fp[9] = (int)lv.mask, fp[10] = (int)lv.sel, fp[11] = (int)T;
+        fp[12] = (int)(!dense && !pow2), fp[13] = meta.offsets[l];
+    }
     __syncthreads();
     constexpr int PPI = BRK_THREADS / 16;  // points per iteration
     const int end_r = start + ((end - start + PPI - 1) / PPI) * PPI;
@@ -790,26 +799,34 @@ __global__ __launch_bounds__(BRK_THREADS, STAGED ? 4 : 8) void grid_bwd_brick_ke
         }
     }
     __syncthreads();
-    // flush touched vertices: one global atomic per (vertex, channel) instead of one per (point, corner, channel)
-    for (int lev = 0; lev < n_levels; lev++) {
-        const uint32_t r = (uint32_t)meta.res[lev];
-        const uint32_t Tl = (uint32_t)(meta.offsets[lev + 1] - meta.offsets[lev]);
-        const bool dn = (uint64_t)r * r * r <= (uint64_t)Tl;
-        const bool p2 = (Tl & (Tl - 1)) == 0;
-        const int n = bm.n[lev], b0 = bm.lds_off[lev];
-        int lo2[3];
-#pragma unroll
-        for (int d = 0; d < 3; d++)
-            lo2[d] = (int)floorf(fminf(fmaxf(fmaf((float)bxyz[d] / (float)BRK, (float)r, -0.5f), 0.0f), (float)(r - 1)));
-        float *ge = grad_emb + (size_t)meta.offsets[lev] * 2;
-        for (int j = threadIdx.x; j < n * n * n; j += BRK_THREADS) {
-            const long long qx = acc[W * (b0 + j)], qy = acc[W * (b0 + j) + 1];
+    // flush touched vertices: one global atomic per (vertex, channel) instead of one per (point, corner, channel).
+    // One flat loop over the brick's vertex slots (five rounds of the 1024 lanes) instead of one loop per level: eleven of the sixteen
+    // levels have fewer than 256 slots, their rounds ran with three quarters of the lanes idle -- and the flush is instruction time, not
+    // atomic throughput (round 6, same box, cfg3's two launches: shipped 1.08 ms, the same loop without its atomics 1.06, no flush 0.92;
+    // profiles/r06_ab_grid_flush.txt).  A slot's level: the number of level starts at or below it (scalar compares); the level's
+    // geometry: two 16-byte LDS reads of flush_par; j / n by multiply and shift (brk_div); the branch-free row index of grid_rows8.
+    {
+        const int n_last = bm.n[n_levels - 1];
+        const int total = n_levels > 0 ? bm.lds_off[n_levels - 1] + n_last * n_last * n_last : 0;
+        for (int j = threadIdx.x; j < total; j += BRK_THREADS) {
+            const long long qx = acc[W * j], qy = acc[W * j + 1];
             if (qx == 0 && qy == 0) continue;
-            const float2 v = make_float2((float)qx * from_fx, (float)qy * from_fx);
-            const int jx = j % n, jy = (j / n) % n, jz = j / (n * n);
-            const uint32_t row = grid_row((uint32_t)(lo2[0] + jx), (uint32_t)(lo2[1] + jy), (uint32_t)(lo2[2] + jz), r, Tl, dn, p2);
-            atomicAdd(ge + (size_t)row * 2 + 0, v.x);
-            atomicAdd(ge + (size_t)row * 2 + 1, v.y);
+            int lev = 0;
+#pragma unroll
+            for (int k = 1; k < 16; k++) lev += (k < n_levels && j >= bm.lds_off[k]) ? 1 : 0;
+            const int *fp = flush_par[lev];
+            const int n = fp[0], m = fp[1], jl = j - fp[2];
+            const int t = brk_div(jl, m), jz = brk_div(t, m);
+            const int jx = jl - t * n, jy = t - jz * n;
+            const uint32_t rmax = (uint32_t)fp[6];
+            const uint32_t cx = min((uint32_t)(fp[3] + jx), rmax), ym = min((uint32_t)(fp[4] + jy), rmax) * (uint32_t)fp[7],
+                           zm = min((uint32_t)(fp[5] + jz), rmax) * (uint32_t)fp[8];
+            const uint32_t sel = (uint32_t)fp[10];
+            uint32_t row = ((cx + ym + zm) & sel) | ((cx ^ ym ^ zm) & (uint32_t)fp[9] & ~sel);
+            if (__builtin_expect(fp[12] != 0, 0)) row %= (uint32_t)fp[11];
+            float *ge = grad_emb + ((size_t)fp[13] + row) * 2;
+            atomicAdd(ge + 0, (float)qx * from_fx);
+            atomicAdd(ge + 1, (float)qy * from_fx);
         }
     }
 }
