@@ -10,16 +10,33 @@ cd "$(dirname "$0")/.."
 python -c "import __graft_entry__ as g; g.build()"
 B=morpheus_amd/_build
 OBJS=$(ls $B/*.o | grep -v "/mlp_b3.o\|ab_\|fpark_")
-for name in nopad nohash; do
+for name in ${FPARK_VARIANTS:-nopad nohash samerow}; do
   src=morpheus_amd/csrc/_fpark_mlp_b3.hip
   python - "$name" "$src" <<'PY'
 import sys
 name, dst = sys.argv[1], sys.argv[2]
 s = open("morpheus_amd/csrc/mlp_b3.hip").read()
-a = "for (int k = 0; k < 48; k++) PARK_STORE(k < 40 ? bin0[k] : 0.f, &tile[(2 * k + h) * TILE + pt]);"
+a = "for (int k = 0; k < 40; k++) PARK_STORE(bin0[k], &tile[(2 * k + h) * TILE + pt]);"      # (the shipped form: no padding rows)
 assert a in s
-if name == "nopad":
-    s = s.replace(a, "for (int k = 0; k < 40; k++) PARK_STORE(bin0[k], &tile[(2 * k + h) * TILE + pt]);")
+if name == "samerow":
+    # WRONG results on purpose: every parking store of the field forward goes to rows 0 / 1 of its tile -- the same store INSTRUCTIONS,
+    # ~1 % of the bytes reaching HBM: is the forward bound by the bytes it parks or by issuing the stores?
+    import re
+    i0 = s.index("__device__ __forceinline__ void fb3_epilogue(")
+    i1 = s.index("// ---- fp32 fragments (b3 order")
+    seg = s[i0:i1]
+    seg = seg.replace("&ht[(32 * t + acc_row(r, h)) * TILE + pt]", "&ht[h * TILE + pt]")
+    seg = seg.replace("&tile[(2 * k + h) * TILE + pt]", "&tile[h * TILE + pt]").replace("&tile[(224 + 2 * k + h) * TILE + pt]", "&tile[h * TILE + pt]")
+    s = s[:i0] + seg + s[i1:]
+elif name == "wrap":
+    # WRONG results on purpose: the forward parks every tile into one of 256 tile slots (14 MB: stays in L2 / the memory-side cache), i.e.
+    # the same store instructions on distinct lines and ~no HBM writes: HBM bytes or the store path?
+    a2 = "float *tile = acts ? acts + tile_id * (int64_t)(FIELD_ACT_ROWS * TILE) : nullptr;"
+    i0 = s.index("void field_fwd_b3_kernel(")
+    assert a2 in s[i0:]
+    s = s[:i0] + s[i0:].replace(a2, "float *tile = acts ? acts + (tile_id & 255) * (int64_t)(FIELD_ACT_ROWS * TILE) : nullptr;", 1)
+elif name == "nopad":
+    pass                                                                                      # = HEAD since the padding rows went
 else:
     s = s.replace(a, "for (int k = 0; k < 40; k++) if (k < 20 || k >= 36) PARK_STORE(bin0[k], &tile[(2 * k + h) * TILE + pt]);")
     b = "for (int k = 0; k < 32; k++) PARK_STORE(binc[k], &tile[(224 + 2 * k + h) * TILE + pt]);"

@@ -3,7 +3,7 @@
 # virtual-view step, per-kernel HIP-event times; head = the in-tree library
 O=gpurun_out/r6fpark; mkdir -p $O; : > $O/summary.txt
 for rep in 1 2; do
-for v in head nopad nohash; do
+for v in ${FPARK_RUN:-head nopad nohash}; do
   unset MORPHEUS_HIP_LIB
   [ $v != head ] && export MORPHEUS_HIP_LIB=$PWD/morpheus_amd/_build/libmorpheus_fpark_$v.so
   timeout 300 python bench.py --mode b3 --no-cpu-baseline --no-extras --detail-out $O/${v}_b3_$rep.json > $O/${v}_b3_$rep.log 2>&1
