@@ -35,6 +35,30 @@ elif name == "wrap":
     i0 = s.index("void field_fwd_b3_kernel(")
     assert a2 in s[i0:]
     s = s[:i0] + s[i0:].replace(a2, "float *tile = acts ? acts + (tile_id & 255) * (int64_t)(FIELD_ACT_ROWS * TILE) : nullptr;", 1)
+elif name == "warpwrap":
+    # WRONG results on purpose: the WARP forward parks every tile into one of 2048 tile slots (2048 x 176 KB = 360 MB > the 256 MB
+    # memory-side cache: "warpwrap512" = 512 slots = 90 MB stays on chip): its store instructions on distinct lines without HBM writes
+    a2 = "float *tile = PARK ? acts + tile_id * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;"
+    assert a2 in s
+    s = s.replace(a2, "float *tile = PARK ? acts + (tile_id & 511) * (int64_t)(WARP_ACT_ROWS * TILE) : nullptr;")
+elif name == "warpx4":
+    # WRONG results on purpose: the WARP forward parks a lane's 16 accumulator values of an output tile as four dwordx4 stores in
+    # accumulator order ([tile t][lane][16] -- not the feature-major rows the weight-gradient kernels read): the same bytes, a quarter
+    # of the store instructions, whole 64-byte pieces per lane.  The upper bound of what a dwordx4-friendly parked layout could buy.
+    a2 = "#define B3_PARK_STORES_EIGHTH 8"
+    assert a2 in s
+    s = s.replace(a2, "#define B3_PARK_STORES_EIGHTH 2")
+    a3 = "        for (int r = 8 * s2; r < 8 * s2 + B3_PARK_STORES_EIGHTH; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);\n    }\n    uint32_t m = 0;"
+    b3 = ("        for (int one_ = 0; one_ < 1; one_++) { float *q_ = ht + (32 * t) * TILE + (pt + 32 * h) * 16 + 8 * s2;\n"
+          "          __builtin_nontemporal_store((f32x4){acc[t][8 * s2], acc[t][8 * s2 + 1], acc[t][8 * s2 + 2], acc[t][8 * s2 + 3]}, reinterpret_cast<f32x4 *>(q_));\n"
+          "          __builtin_nontemporal_store((f32x4){acc[t][8 * s2 + 4], acc[t][8 * s2 + 5], acc[t][8 * s2 + 6], acc[t][8 * s2 + 7]}, reinterpret_cast<f32x4 *>(q_ + 4)); }\n    }\n    uint32_t m = 0;")
+    assert a3 in s, "eighth"
+    s = s.replace(a3, b3, 1)
+    a4 = "            for (int r = 0; r < 16; r++) PARK_STORE(acc[t][r], &ht[(32 * t + acc_row(r, h)) * TILE + pt]);\n        }\n        uint32_t m = 0;"
+    b4 = ("            for (int j_ = 0; j_ < 4; j_++) __builtin_nontemporal_store((f32x4){acc[t][4 * j_], acc[t][4 * j_ + 1], acc[t][4 * j_ + 2], acc[t][4 * j_ + 3]},\n"
+          "                reinterpret_cast<f32x4 *>(ht + (32 * t) * TILE + (pt + 32 * h) * 16 + 4 * j_));\n        }\n        uint32_t m = 0;")
+    assert a4 in s, "half"
+    s = s.replace(a4, b4, 1)
 elif name == "nopad":
     pass                                                                                      # = HEAD since the padding rows went
 else:
