@@ -4,7 +4,10 @@
 #   nopad   rows 80..95 of the sdf net's input block (zeros nobody needs) not written               -> results unchanged
 #   nohash  ... and the hash-feature rows (40..71, 224..255) not written: the backward then reads stale rows -- WRONG gradients on
 #           purpose; only the forward's time is of interest (what reading the features from the encoder's output instead would save)
-# -> morpheus_amd/_build/libmorpheus_fpark_<name>.so (MORPHEUS_HIP_LIB)
+#   wrap / samerow   the field forward's stores into 256 tile slots (an L2-resident window) / onto two rows per tile: bytes or store path?
+#   warpwrap / warpx4   the same question for the WARP forward: 512 tile slots; dwordx4 stores in accumulator order
+#   (FPARK_VARIANTS="name ..." selects; every one of these except nopad computes WRONG results on purpose -- side libraries only)
+# -> morpheus_amd/_build/libmorpheus_fpark_<name>.so (MORPHEUS_HIP_LIB); records: profiles/r06_ab_field_park_rows.txt, r06_ab_warp_fwd_parking.txt
 set -e
 cd "$(dirname "$0")/.."
 python -c "import __graft_entry__ as g; g.build()"
